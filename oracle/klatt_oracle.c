@@ -1,0 +1,385 @@
+/*
+ * klatt_oracle.c -- CPU restatement of the NVSpeechPlayer Klatt hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity checker ("oracle") for the
+ * HIP engine in nvspeechplayer_amd/csrc.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it; the product library never links
+ * or calls it.
+ *
+ * It restates, in plain C and double precision, what the reference computes in
+ *   src/frame.cpp:41-80      (per-sample frame state machine: fade, dequeue, glide)
+ *   src/frame.cpp:90-115     (queueFrame incl. purge)
+ *   src/utils.h:20-23        (NaN-holding linear interpolation)
+ *   src/speechWaveGenerator.cpp:32-44   (noise source)
+ *   src/speechWaveGenerator.cpp:46-60   (phase accumulator)
+ *   src/speechWaveGenerator.cpp:62-88   (glottal source)
+ *   src/speechWaveGenerator.cpp:90-137  (second-order resonator / anti-resonator)
+ *   src/speechWaveGenerator.cpp:139-182 (cascade and parallel banks)
+ *   src/speechWaveGenerator.cpp:197-214 (mix, gain, clip, int16 store)
+ *   src/speechPlayer.cpp:25-53          (C-ABI shim, fade clamp >= 1)
+ *
+ * Pinning: tests/test_oracle_pin.py checks this file against the known-answer
+ * values SURVEY.md section 8(c) recorded from the compiled reference (cfg0 SHA-1,
+ * first samples, min/max; the eight sampleIpa.txt lines' lengths and SHA-1
+ * prefixes under glibc rand() after srand(1)).  The reference itself needs
+ * <windows.h> and MSVC extensions, so it is not built here.
+ *
+ * Noise: the reference draws from libc rand().  ORACLE_NOISE_LIBC reproduces that
+ * (used only for the pin above).  ORACLE_NOISE_COUNTER is the engine's defined
+ * per-utterance stream: value k of stream `seed` is klatt_noise31(seed, k), and a
+ * produced sample n consumes k = 2n (aspiration) then k = 2n+1 (frication),
+ * exactly the order of the two rand() calls at speechWaveGenerator.cpp:75,205.
+ *
+ * Build with contraction off so that every multiply and add rounds separately,
+ * as the reference binary (x86 without FMA) does.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define NP 47 /* frame.h:24-42: 47 doubles per frame */
+
+enum { ORACLE_NOISE_LIBC = 0, ORACLE_NOISE_COUNTER = 1 };
+
+/* parameter indices, frame.h:24-42 / speechPlayer.py:22-39 */
+enum {
+    P_VOICEPITCH = 0, P_VIBOFFSET = 1, P_VIBSPEED = 2, P_TURB = 3, P_OPENQ = 4,
+    P_VOICEAMP = 5, P_ASPAMP = 6,
+    P_CF1 = 7, /* cf1..cf6, cfN0=13, cfNP=14 */
+    P_CFN0 = 13, P_CFNP = 14,
+    P_CB1 = 15, /* cb1..cb6, cbN0=21, cbNP=22 */
+    P_CBN0 = 21, P_CBNP = 22,
+    P_CANP = 23, P_FRICAMP = 24,
+    P_PF1 = 25, P_PB1 = 31, P_PA1 = 37,
+    P_BYPASS = 43, P_PREGAIN = 44, P_OUTGAIN = 45, P_ENDPITCH = 46
+};
+
+typedef struct {
+    unsigned minSamples;  /* frame.cpp:22 */
+    unsigned fadeSamples; /* frame.cpp:23 */
+    int isNull;           /* frame.cpp:24 */
+    double p[NP];         /* frame.cpp:25 */
+    double pitchInc;      /* frame.cpp:26 */
+    int userIndex;        /* frame.cpp:27 */
+} request_t;
+
+typedef struct {
+    double a, b, c;   /* coefficients, speechWaveGenerator.cpp:100 */
+    double f, bw;     /* cached raw parameters, :95-96 */
+    double z1, z2;    /* memories, :102 */
+    int anti;         /* :97 */
+    int everSet;      /* :99 */
+} reso_t;
+
+/* 14 resonators: cascade order of evaluation is N0(anti), NP, 6,5,4,3,2,1 (:149-156);
+ * parallel 1..6 (:173-178). */
+enum { R_N0 = 0, R_NP = 1, R_C6 = 2, R_C5 = 3, R_C4 = 4, R_C3 = 5, R_C2 = 6, R_C1 = 7,
+       R_P1 = 8, NRES = 14 };
+
+typedef struct oracle_player {
+    int sampleRate;
+    /* frame manager, frame.cpp:32-39,85-88 */
+    request_t *queue;
+    size_t qHead, qCount, qCap;
+    request_t oldReq, newReq;
+    int hasNew;
+    double cur[NP];
+    int curIsNull;
+    unsigned counter;
+    int lastIndex;
+    /* wave generator state, speechWaveGenerator.cpp:184-191 */
+    double pitchPhase, vibPhase;
+    double aspNoise, fricNoise;
+    reso_t res[NRES];
+    /* noise source selection */
+    int noiseMode;
+    uint32_t noiseSeed;
+    uint32_t noiseIndex;
+} oracle_player;
+
+/* ---- counter-based noise (the engine's definition; the HIP kernel restates it) ---- */
+uint32_t klatt_noise31(uint32_t seed, uint32_t k)
+{
+    /* key: one avalanche of the seed; stream: multiply-xorshift hash of the index */
+    uint32_t key = seed ^ 0x9E3779B9u;
+    key ^= key >> 16; key *= 0x7FEB352Du; key ^= key >> 15; key *= 0x846CA68Bu; key ^= key >> 16;
+    uint32_t x = (k * 0x9E3779B1u) ^ key;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x >> 1; /* 0 .. 2^31-1, the range of glibc rand() */
+}
+
+static double next_uniform(oracle_player *s)
+{
+    /* speechWaveGenerator.cpp:40: (double)rand()/RAND_MAX with glibc RAND_MAX = 2^31-1 */
+    double r;
+    if (s->noiseMode == ORACLE_NOISE_LIBC)
+        r = (double)rand();
+    else
+        r = (double)klatt_noise31(s->noiseSeed, s->noiseIndex++);
+    return r / 2147483647.0;
+}
+
+/* utils.h:20-23 */
+static inline double fade_value(double from, double to, double ratio)
+{
+    if (isnan(to)) return from;
+    return from + ((to - from) * ratio);
+}
+
+/* ---- frame manager ---- */
+
+/* frame.cpp:41-80; returns 1 if a current frame exists after the update */
+static int advance_frame(oracle_player *s)
+{
+    s->counter++;
+    if (s->hasNew) {
+        if (s->counter > s->newReq.fadeSamples) { /* :44-47 fade finished */
+            s->oldReq = s->newReq;
+            s->hasNew = 0;
+        } else { /* :48-53 interpolate all parameters */
+            double ratio = (double)s->counter / s->newReq.fadeSamples;
+            for (int i = 0; i < NP; ++i)
+                s->cur[i] = fade_value(s->oldReq.p[i], s->newReq.p[i], ratio);
+        }
+    } else if (s->counter > s->oldReq.minSamples) { /* :54 */
+        if (s->qCount) { /* :55-72 take the next request */
+            s->curIsNull = 0;
+            s->newReq = s->queue[s->qHead];
+            s->qHead = (s->qHead + 1) % s->qCap;
+            s->qCount--;
+            s->hasNew = 1;
+            if (s->newReq.isNull) { /* :59-63 silence: keep the old shape, gate it off */
+                memcpy(s->newReq.p, s->oldReq.p, sizeof s->newReq.p);
+                s->newReq.p[P_PREGAIN] = 0;
+                s->newReq.p[P_VOICEPITCH] = s->cur[P_VOICEPITCH];
+                s->newReq.pitchInc = 0;
+            } else if (s->oldReq.isNull) { /* :64-67 coming out of silence */
+                memcpy(s->oldReq.p, s->newReq.p, sizeof s->oldReq.p);
+                s->oldReq.p[P_PREGAIN] = 0;
+            }
+            if (s->newReq.userIndex != -1) s->lastIndex = s->newReq.userIndex; /* :69 */
+            s->counter = 0;                                                    /* :70 */
+            s->newReq.p[P_VOICEPITCH] += s->newReq.pitchInc * s->newReq.fadeSamples; /* :71 */
+        } else {
+            s->curIsNull = 1; /* :74 */
+        }
+    } else { /* :76-79 steady state: glide the pitch */
+        s->cur[P_VOICEPITCH] += s->oldReq.pitchInc;
+        s->oldReq.p[P_VOICEPITCH] = s->cur[P_VOICEPITCH];
+    }
+    return !s->curIsNull;
+}
+
+static void queue_push(oracle_player *s, const request_t *r)
+{
+    if (s->qCount == s->qCap) {
+        size_t ncap = s->qCap ? s->qCap * 2 : 64;
+        request_t *nq = (request_t *)malloc(ncap * sizeof *nq);
+        for (size_t i = 0; i < s->qCount; ++i) nq[i] = s->queue[(s->qHead + i) % s->qCap];
+        free(s->queue);
+        s->queue = nq; s->qHead = 0; s->qCap = ncap;
+    }
+    s->queue[(s->qHead + s->qCount) % s->qCap] = *r;
+    s->qCount++;
+}
+
+/* ---- DSP ---- */
+
+/* speechWaveGenerator.cpp:112-127 */
+static void reso_set(reso_t *r, int sampleRate, double f, double bw)
+{
+    if (!r->everSet || f != r->f || bw != r->bw) {
+        r->f = f; r->bw = bw;
+        double rad = exp(-M_PI / sampleRate * bw);
+        r->c = -(rad * rad);
+        r->b = rad * cos((M_PI * 2) / sampleRate * -f) * 2.0;
+        r->a = 1.0 - r->b - r->c;
+        if (r->anti && f != 0) {
+            r->a = 1.0 / r->a;
+            r->c *= -r->a;
+            r->b *= -r->a;
+        }
+    }
+    r->everSet = 1;
+}
+
+/* speechWaveGenerator.cpp:129-135 */
+static inline double reso_run(reso_t *r, int sampleRate, double in, double f, double bw)
+{
+    reso_set(r, sampleRate, f, bw);
+    double out = r->a * in + r->b * r->z1 + r->c * r->z2;
+    r->z2 = r->z1;
+    r->z1 = r->anti ? in : out;
+    return out;
+}
+
+/* speechWaveGenerator.cpp:54-58 */
+static inline double phase_step(double *phase, int sampleRate, double hz)
+{
+    double pos = fmod((hz / sampleRate) + *phase, 1);
+    *phase = pos;
+    return pos;
+}
+
+/* one output sample from the current frame; speechWaveGenerator.cpp:203-208 */
+static short render_sample(oracle_player *s)
+{
+    const double *p = s->cur;
+    const int sr = s->sampleRate;
+    /* voice source, :72-86 */
+    double vib = (sin(phase_step(&s->vibPhase, sr, p[P_VIBSPEED]) * (M_PI * 2)) * 0.06 * p[P_VIBOFFSET]) + 1;
+    double voice = phase_step(&s->pitchPhase, sr, p[P_VOICEPITCH] * vib);
+    s->aspNoise = next_uniform(s) + 0.75 * s->aspNoise; /* :40 */
+    double asp = s->aspNoise * 0.2;
+    double turb = asp * p[P_TURB];
+    int open = voice >= p[P_OPENQ];
+    if (!open) turb *= 0.01;
+    voice = (voice * 2) - 1;
+    voice += turb;
+    voice *= p[P_VOICEAMP];
+    asp *= p[P_ASPAMP];
+    double src = asp + voice;
+    /* cascade, :147-158 */
+    double x = (src * p[P_PREGAIN]) / 2.0;
+    double n0 = reso_run(&s->res[R_N0], sr, x, p[P_CFN0], p[P_CBN0]);
+    double np = reso_run(&s->res[R_NP], sr, n0, p[P_CFNP], p[P_CBNP]);
+    double o = fade_value(x, np, p[P_CANP]);
+    for (int k = 0; k < 6; ++k) /* r6 .. r1 */
+        o = reso_run(&s->res[R_C6 + k], sr, o, p[P_CF1 + 5 - k], p[P_CB1 + 5 - k]);
+    /* frication + parallel bank, :205-206,170-180 */
+    s->fricNoise = next_uniform(s) + 0.75 * s->fricNoise;
+    double fric = s->fricNoise * 0.3 * p[P_FRICAMP];
+    double y = (fric * p[P_PREGAIN]) / 2.0;
+    double par = 0;
+    for (int k = 0; k < 6; ++k)
+        par += (reso_run(&s->res[R_P1 + k], sr, y, p[P_PF1 + k], p[P_PB1 + k]) - y) * p[P_PA1 + k];
+    par = fade_value(par, y, p[P_BYPASS]);
+    double out = (o + par) * p[P_OUTGAIN];
+    /* :208 with the windows.h min/max macros: ((a)<(b)?(a):(b)), ((a)>(b)?(a):(b)) */
+    double v = out * 4000;
+    double lo = (v < 32000) ? v : 32000;
+    double cl = (lo > -32000) ? lo : -32000;
+    return (short)(int)cl;
+}
+
+/* ---- public C surface (names differ from the product ABI on purpose) ---- */
+
+oracle_player *oracle_initialize(int sampleRate)
+{
+    oracle_player *s = (oracle_player *)calloc(1, sizeof *s);
+    s->sampleRate = sampleRate;
+    s->oldReq.isNull = 1; /* frame.cpp:85-88 */
+    s->curIsNull = 1;
+    s->lastIndex = -1;
+    s->res[R_N0].anti = 1; /* speechWaveGenerator.cpp:145 */
+    s->noiseMode = ORACLE_NOISE_LIBC;
+    return s;
+}
+
+void oracle_setNoise(oracle_player *s, int mode, uint32_t seed)
+{
+    s->noiseMode = mode;
+    s->noiseSeed = seed;
+    s->noiseIndex = 0;
+}
+
+/* speechPlayer.cpp:34-37 + frame.cpp:90-115 */
+void oracle_queueFrame(oracle_player *s, const double *frame, unsigned minDur, unsigned fadeDur,
+                       int userIndex, int purge)
+{
+    request_t r;
+    memset(&r, 0, sizeof r);
+    r.minSamples = minDur;
+    r.fadeSamples = fadeDur > 1 ? fadeDur : 1; /* speechPlayer.cpp:36 */
+    if (frame) {
+        r.isNull = 0;
+        memcpy(r.p, frame, sizeof r.p);
+        r.pitchInc = (frame[P_ENDPITCH] - frame[P_VOICEPITCH]) / r.minSamples; /* frame.cpp:98 */
+    } else {
+        r.isNull = 1;
+    }
+    r.userIndex = userIndex;
+    if (purge) { /* frame.cpp:103-112 */
+        s->qCount = 0; s->qHead = 0;
+        s->counter = s->oldReq.minSamples;
+        if (s->hasNew) {
+            s->oldReq.isNull = s->newReq.isNull;
+            memcpy(s->oldReq.p, s->cur, sizeof s->oldReq.p);
+            s->hasNew = 0;
+        }
+    }
+    queue_push(s, &r);
+}
+
+/* speechWaveGenerator.cpp:197-214 */
+int oracle_synthesize(oracle_player *s, unsigned count, short *out)
+{
+    for (unsigned i = 0; i < count; ++i) {
+        if (!advance_frame(s)) return (int)i;
+        out[i] = render_sample(s);
+    }
+    return (int)count;
+}
+
+int oracle_getLastIndex(oracle_player *s) { return s->lastIndex; }
+
+void oracle_terminate(oracle_player *s)
+{
+    if (!s) return;
+    free(s->queue);
+    free(s);
+}
+
+/* Closed-form length of an utterance: each request spans max(M, F+1)+1 samples
+ * (follows from frame.cpp:41-80; checked by tests against oracle_synthesize). */
+long long oracle_utteranceLength(const unsigned *minDur, const unsigned *fadeDur, unsigned nFrames)
+{
+    long long total = 0;
+    for (unsigned k = 0; k < nFrames; ++k) {
+        long long m = minDur[k];
+        long long f = fadeDur[k] > 1 ? fadeDur[k] : 1;
+        total += (m > f + 1 ? m : f + 1) + 1;
+    }
+    return total;
+}
+
+/*
+ * Batch helper used by the parity tests and by bench.py's cpu_baseline leg:
+ * synthesise utterances [first, first+count) of a packed batch, each with its
+ * own player and counter noise stream.  Layout matches the product batch ABI
+ * (include/speechPlayer_batch.h): frames[nFramesTotal][47], per-frame minDur /
+ * fadeDur / userIndex / isNull, frameStart[nUtt+1], seeds[nUtt], and
+ * outStart[nUtt+1] sample offsets into `pcm`.  Returns total samples written.
+ * `threads` > 1 uses OpenMP when compiled with it.
+ */
+long long oracle_batchSynthesize(int sampleRate, const double *frames, const unsigned *minDur,
+                                 const unsigned *fadeDur, const int *userIndex,
+                                 const unsigned char *isNull, const long long *frameStart,
+                                 const unsigned *seeds, const long long *outStart, short *pcm,
+                                 long long first, long long count, int threads)
+{
+    long long total = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (long long u = first; u < first + count; ++u) {
+        oracle_player *s = oracle_initialize(sampleRate);
+        oracle_setNoise(s, ORACLE_NOISE_COUNTER, seeds ? seeds[u] : (uint32_t)u);
+        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k)
+            oracle_queueFrame(s, isNull[k] ? NULL : frames + (size_t)k * NP, minDur[k], fadeDur[k],
+                              userIndex ? userIndex[k] : -1, 0);
+        long long cap = outStart[u + 1] - outStart[u];
+        long long done = 0;
+        while (done < cap) {
+            unsigned want = (unsigned)((cap - done) > 8192 ? 8192 : (cap - done));
+            int got = oracle_synthesize(s, want, pcm + outStart[u] + done);
+            done += got;
+            if ((unsigned)got < want) break;
+        }
+        total += done;
+        oracle_terminate(s);
+    }
+    (void)threads;
+    return total;
+}

@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under tests/golden/.
+
+Runs ONLY in the build container, where the Python part of the reference
+(/root/reference: ipa.py, data.py, speechPlayer.py -- the frame *producer* that
+sits above the hot path) can be imported.  Nothing here travels as source: the
+outputs are plain data (frame parameter vectors, durations, expected PCM).
+
+  ref_frames.npz   frame streams produced by the reference's own
+                   ipa.generateFramesAndTiming / ipa.setFrame (inputs of the path)
+  pcm_*.npz        expected PCM for those inputs from oracle/klatt_oracle.c, which
+                   tests/test_oracle_pin.py pins to the known answers SURVEY.md
+                   section 8(c) recorded from the compiled reference.
+
+Usage:  python tests/golden/make_golden.py   (from the repo root)
+"""
+import codecs
+import ctypes
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+SR = 22050
+
+
+def import_reference():
+    """ipa.py does `from . import speechPlayer`, so it must be imported as a package
+    member; build a throw-away package of symlinks outside the repo."""
+    tmp = tempfile.mkdtemp(prefix="nvsp_ref_")
+    pkg = os.path.join(tmp, "nvsp_ref")
+    os.mkdir(pkg)
+    open(os.path.join(pkg, "__init__.py"), "w").close()
+    for name in ("ipa.py", "speechPlayer.py", "data.py"):
+        os.symlink(os.path.join(REF, name), os.path.join(pkg, name))
+    sys.path.insert(0, tmp)
+    from nvsp_ref import ipa, speechPlayer  # noqa
+    return ipa, speechPlayer
+
+
+def frame_to_vec(frame):
+    return np.frombuffer(bytes(frame), dtype=np.float64).copy()
+
+
+def ms_to_samples(ms, sr=SR):
+    # speechPlayer.py:53
+    return int(ms * (sr / 1000.0))
+
+
+def main():
+    ipa, speechPlayer = import_reference()
+    assert ctypes.sizeof(speechPlayer.Frame) == 47 * 8
+    out = {}
+
+    # --- phoneme table as frames (ipa.setFrame on a zeroed Frame) -----------------
+    names = sorted(ipa.data.keys())
+    ph = np.zeros((len(names), 47))
+    mask = np.zeros((len(names), 47), dtype=np.uint8)  # which fields the phoneme entry sets
+    field_names = [n for n, _ in speechPlayer.Frame._fields_]
+    flags = {}
+    flag_names = ["_isVowel", "_isVoiced", "_isNasal", "_isStop", "_isLiquid", "_isSemivowel",
+                  "_isAfricate", "_copyAdjacent"]
+    for i, name in enumerate(names):
+        f = speechPlayer.Frame()
+        # ipa.setFrame sets every key, including the '_' class flags, which ctypes
+        # accepts as plain python attributes; only struct fields land in the bytes.
+        ipa.setFrame(f, name)
+        ph[i] = frame_to_vec(f)
+        for k in ipa.data[name]:
+            if k in field_names:
+                mask[i, field_names.index(k)] = 1
+    for fl in flag_names:
+        flags[fl] = np.array([bool(ipa.data[n].get(fl)) for n in names], dtype=np.uint8)
+    out["phoneme_names"] = np.array([n.encode("utf8") for n in names])
+    out["phoneme_frames"] = ph
+    out["phoneme_mask"] = mask
+    out["field_names"] = np.array([n.encode() for n in field_names])
+    for fl in flag_names:
+        out["phoneme" + fl] = flags[fl]
+    # iteration order of ipa.iterPhonemes(_isVoiced=True) (test_playVowelchart.py:31)
+    out["voiced_order"] = np.array([names.index(n) for n in ipa.iterPhonemes(_isVoiced=True)], dtype=np.int32)
+
+    # --- sampleIpa.txt through generateFramesAndTiming -----------------------------
+    text = codecs.open(os.path.join(REF, "sampleIpa.txt"), "r", "utf8").read()
+    lines = [l.strip() for l in text.splitlines()]
+    out["ipa_lines"] = np.array([l.encode("utf8") for l in lines])
+    cases = []
+    for speed in (1.0, 0.6):
+        for clause in (".", ",", "?", "!", None):
+            for li, line in enumerate(lines):
+                cases.append((li, speed, clause, 100.0, 0.5))
+    # pitch / inflection variants on the '.' clause
+    for li, line in enumerate(lines):
+        cases.append((li, 1.0, ".", 140.0, 0.5))
+        cases.append((li, 1.0, ".", 70.0, 1.0))
+    fr_all, dur_all, fade_all, null_all, start = [], [], [], [], [0]
+    meta = []
+    for (li, speed, clause, pitch, infl) in cases:
+        n = 0
+        for frame, dur, fade in ipa.generateFramesAndTiming(lines[li], speed=speed, basePitch=pitch,
+                                                            inflection=infl, clauseType=clause):
+            if frame is None:
+                fr_all.append(np.zeros(47)); null_all.append(1)
+            else:
+                fr_all.append(frame_to_vec(frame)); null_all.append(0)
+            dur_all.append(dur); fade_all.append(fade); n += 1
+        start.append(start[-1] + n)
+        meta.append((li, speed, {".": 0, ",": 1, "?": 2, "!": 3, None: 4}[clause], pitch, infl))
+    out["ipa_case_meta"] = np.array(meta, dtype=np.float64)  # line, speed, clause code, basePitch, inflection
+    out["ipa_frames"] = np.array(fr_all)
+    out["ipa_isnull"] = np.array(null_all, dtype=np.uint8)
+    out["ipa_dur_ms"] = np.array(dur_all)
+    out["ipa_fade_ms"] = np.array(fade_all)
+    out["ipa_start"] = np.array(start, dtype=np.int64)
+
+    np.savez_compressed(os.path.join(HERE, "ref_frames.npz"), **out)
+    print("ref_frames.npz: %d phonemes, %d ipa cases, %d frames" % (len(names), len(cases), len(fr_all)))
+
+    # --- expected PCM from the pinned oracle ---------------------------------------
+    sys.path.insert(0, ROOT)
+    from tests import scenarios
+    scenarios.write_expected_pcm(os.path.join(HERE, "ref_frames.npz"), HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,90 @@
+"""The oracle against the committed golden fixtures (regression lock) and its own invariants."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+from tests import oracle, scenarios
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return scenarios.Ref()
+
+
+@pytest.fixture(scope="module")
+def all_scenarios(ref):
+    return scenarios.build_scenarios(ref)
+
+
+def test_expected_table_matches_oracle(all_scenarios):
+    table = json.load(open(os.path.join(scenarios.GOLDEN, "expected.json")))
+    stored = np.load(os.path.join(scenarios.GOLDEN, "expected_pcm.npz"))
+    assert set(table) == {s.name for s in all_scenarios}
+    for scn in all_scenarios:
+        pcm, marks = scenarios.play_oracle(scn)
+        flat = np.concatenate(pcm)
+        exp = table[scn.name]
+        assert [len(x) for x in pcm] == exp["calls"], scn.name
+        assert marks == exp["marks"], scn.name
+        assert hashlib.sha1(flat.tobytes()).hexdigest() == exp["sha1"], scn.name
+        if scn.name in stored.files:
+            assert np.array_equal(stored[scn.name], flat), scn.name
+
+
+def test_closed_form_length(all_scenarios):
+    """sum over requests of max(M, F+1)+1 equals what synthesize produces."""
+    for scn in all_scenarios:
+        if not scn.batchable:
+            continue
+        fr, m, f, ix, nu = scn.frames()
+        pcm, _ = scenarios.play_oracle(scn)
+        assert oracle.utterance_length(m, f) == sum(len(x) for x in pcm), scn.name
+
+
+def test_chunking_invariance(ref):
+    """Streaming contract: the PCM does not depend on how synthesize calls cut it."""
+    case = ref.find_ipa(4)
+    def run(chunks):
+        p = oracle.OraclePlayer(22050, seed=99)
+        for fr, m, f in ref.ipa_case(case):
+            p.queue(fr, m, f)
+        parts = [p.synthesize(n) for n in chunks]
+        parts.append(p.drain())
+        return np.concatenate(parts)
+    a = run([])
+    b = run([1, 2, 3, 500, 8192, 17])
+    assert np.array_equal(a, b)
+
+
+def test_noise_function_reference_values():
+    """The counter noise definition is part of the engine's contract; lock a few values."""
+    L = oracle.lib()
+    vals = [L.klatt_noise31(s, k) for s, k in ((0, 0), (0, 1), (1, 0), (12345, 678), (0xFFFFFFFF, 0xFFFFFFFF))]
+    assert all(0 <= v < 2 ** 31 for v in vals)
+    assert len(set(vals)) == len(vals)
+    # uniformity smoke: mean of 1e5 draws within 1% of 0.5
+    xs = np.array([L.klatt_noise31(7, k) for k in range(100000)], dtype=np.float64) / 2147483647.0
+    assert abs(xs.mean() - 0.5) < 0.005
+    # lag-1 correlation small
+    c = np.corrcoef(xs[:-1], xs[1:])[0, 1]
+    assert abs(c) < 0.01
+
+
+def test_batch_helper_matches_streaming(ref, all_scenarios):
+    sel = [s for s in all_scenarios if s.batchable][:12]
+    frames, mins, fades, idx, nul, start, seeds = [], [], [], [], [], [0], []
+    for s in sel:
+        fr, m, f, ix, nu = s.frames()
+        frames.append(fr); mins.append(m); fades.append(f); idx.append(ix); nul.append(nu)
+        start.append(start[-1] + len(m)); seeds.append(s.seed)
+    batch = dict(frames=np.concatenate(frames), min=np.concatenate(mins), fade=np.concatenate(fades),
+                 index=np.concatenate(idx), isnull=np.concatenate(nul), frame_start=np.array(start),
+                 seeds=np.array(seeds))
+    pcm, out_start, total = oracle.batch_synthesize(22050, batch, threads=2)
+    assert total == out_start[-1]
+    for i, s in enumerate(sel):
+        exp = np.concatenate(scenarios.play_oracle(s)[0])
+        assert np.array_equal(pcm[out_start[i]:out_start[i + 1]], exp), s.name

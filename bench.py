@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""bench.py -- throughput of the Klatt hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3] [--mode 0]
+
+A step is one pass of the synthesis kernel over one batch of synthetic frame streams
+that is already resident in HBM (frames in, int16 PCM out, both in HBM).  At N = 1 the
+workload is BASELINE.json configs[1] (4096 steady vowels x 1 s); with N > 1 every rank
+(one process per GPU, launched by torch.distributed.run) synthesises its own batch of
+the same shape with different utterance numbers (weak scaling, no collective on the
+data path -- utterances are independent).  Rank 0 prints ONE JSON line.
+
+The K timed launches are individually bracketed by HIP events on the engine's stream
+(speechPlayer_batch_time); their mean is the kernel duration the roofline uses, the
+wall clock around all K (barrier + device synchronize on both sides, max over ranks)
+gives `value`.  The CPU baseline is the oracle (oracle/klatt_oracle.c, "port") timed
+on this box's host cores on the same workload, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg2", "cfg3"])
+    ap.add_argument("--utterances", type=int, default=0, help="override the batch size per GPU")
+    ap.add_argument("--mode", type=int, default=0, help="arithmetic mode (include/speechPlayer_batch.h)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="target CPU-baseline work")
+    return ap.parse_args()
+
+
+def cpu_baseline(batch, target_seconds):
+    """Oracle on the host cores: all cores (OpenMP) on a bounded sample of the same workload."""
+    import numpy as np
+    from tests import oracle
+    cores = os.cpu_count() or 1
+    counts = batch.sample_counts()
+    # calibrate on a few utterances, single thread
+    probe = batch.slice(0, min(8, batch.n_utt))
+    t0 = time.perf_counter()
+    _, _, total = oracle.batch_synthesize(batch["sr"], probe, threads=1)
+    t1 = time.perf_counter() - t0
+    one_core = total / t1
+    want = one_core * cores * target_seconds * 0.7
+    n = int(min(batch.n_utt, max(cores, np.searchsorted(np.cumsum(counts), want) + 1)))
+    sample = batch.slice(0, n)
+    t0 = time.perf_counter()
+    _, _, total = oracle.batch_synthesize(batch["sr"], sample, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": total / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "first %d utterances of the workload (%d samples) on %d OpenMP threads, %.1f s; "
+                      "1 thread: %.3g samples/s" % (n, total, cores, dt, one_core)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch  # first: its HIP runtime is then the one the engine library binds to
+    import numpy as np
+    from nvspeechplayer_amd import BatchPlayer, workloads
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    n_utt = args.utterances or {"cfg1": 4096, "cfg2": 65536, "cfg3": 131072}[args.workload]
+    batch = workloads.make(args.workload, n_utt, first=rank * n_utt)
+    bp = BatchPlayer(batch["sr"], device=local_rank, mode=args.mode)
+    bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                     batch["isnull"], batch["seeds"])
+    samples = bp.totalSamples
+    assert samples == int(batch.sample_counts().sum())
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if args.warmup > 0:
+        bp.time(args.warmup)
+    barrier()
+    t0 = time.perf_counter()
+    kernel_ms = bp.time(args.steps)          # K launches, each between two HIP events on the launch stream
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tot = torch.tensor([float(samples)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        total_samples = float(tot.item())
+    else:
+        total_samples = float(samples)
+
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        alg_bytes = batch.algorithmic_bytes()
+        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        info = bp.kernelInfo()
+        out = {
+            "metric": "audio samples/sec (whole node) at 22.05 kHz Klatt synth, batch-N utterances",
+            "value": total_samples * args.steps / elapsed,
+            "unit": "samples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": batch["name"], "utterances_per_gpu": n_utt, "samples_per_gpu": int(samples),
+                       "frames_per_gpu": int(bp.totalFrames), "sample_rate": batch["sr"], "mode": args.mode,
+                       "parallelism": "utterances sharded over %d GPU(s), no collective" % world},
+            "realtime_factor": total_samples * args.steps / elapsed / batch["sr"],
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "kernel": "klatt_synthesize", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
+                         "note": "f64 VALU issue binds before HBM; see DESIGN.md"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    bp.close()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

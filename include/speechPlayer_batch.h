@@ -1,0 +1,88 @@
+/*
+ * speechPlayer_batch.h -- additive batch entry points of the MI355X Klatt engine.
+ *
+ * The reference has no batch interface: one handle is one stream
+ * (reference src/speechPlayer.cpp:19-23) and a caller loops
+ * speechPlayer_queueFrame / speechPlayer_synthesize per stream
+ * (test_speakIpa.py:24-27, nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:62-81,222-233).
+ * A batch replaces N such loops: N frame streams in, N int16 PCM streams out, one
+ * utterance per wavefront lane on the GPU.  Every utterance behaves exactly like a
+ * fresh handle that had all its frames queued (no purge) and was drained.
+ *
+ * Plain C: host pointers and sizes only.  All functions return 0 on success and a
+ * negative value on failure unless stated; speechPlayer_lastError() describes it.
+ */
+#ifndef NVSP_AMD_SPEECHPLAYER_BATCH_H
+#define NVSP_AMD_SPEECHPLAYER_BATCH_H
+
+#include "speechPlayer.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* speechPlayer_batch_t;
+
+/* Arithmetic modes (speechPlayer_batch_setOption(b, "mode", ...)). */
+#define SPEECHPLAYER_MODE_EXACT 0 /* f64, separate rounding of every operation, libm-grade coefficients */
+#define SPEECHPLAYER_MODE_FAST 1  /* f64 state, fused multiply-add, coefficient recurrences inside fades */
+
+/* Bind a batch engine to HIP device `device` (-1: the current device). NULL on failure. */
+speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device);
+void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
+
+/* Options: "mode" (see above), "sort" (1: pack wavefronts by utterance length, default 1). */
+int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value);
+
+/*
+ * Describe the batch and make it resident in HBM (host arrays are copied).
+ *   frameStart[nUtterances+1]  utterance u owns frames frameStart[u] .. frameStart[u+1]-1
+ *   frames[nFrames]            what each speechPlayer_queueFrame call would have been given
+ *   minFrameDuration/fadeDuration[nFrames]  in samples, as in speechPlayer_queueFrame
+ *   userIndex[nFrames]         may be NULL (all -1)
+ *   isNull[nFrames]            may be NULL (none); nonzero = the call passed framePtr==NULL
+ *   noiseSeed[nUtterances]     may be NULL (seed = utterance number); selects the utterance's
+ *                              noise stream (the reference's rand() is process-global,
+ *                              src/speechWaveGenerator.cpp:40; the engine defines one stream per
+ *                              utterance instead -- see DESIGN.md "Noise")
+ */
+int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
+	const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration, const unsigned int* fadeDuration,
+	const int* userIndex, const unsigned char* isNull, const unsigned int* noiseSeed);
+
+/* Number of samples utterance u produces: sum over its frames of max(M, F+1)+1. */
+long long speechPlayer_batch_utteranceSamples(speechPlayer_batch_t batch, long long utterance);
+long long speechPlayer_batch_totalSamples(speechPlayer_batch_t batch);
+long long speechPlayer_batch_totalFrames(speechPlayer_batch_t batch);
+
+/* Launch the synthesis kernel on the batch's stream (asynchronous), and wait for it. */
+int speechPlayer_batch_synthesize(speechPlayer_batch_t batch);
+int speechPlayer_batch_wait(speechPlayer_batch_t batch);
+
+/* Copy utterance u's PCM to the host (after wait). Returns samples copied (<= capacity). */
+long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long utterance, sample* sampleBuf, long long capacity);
+/* Copy every utterance's PCM, concatenated in utterance order; outStart[nUtterances+1] receives
+ * the offsets. Returns total samples. */
+long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart);
+/* speechPlayer_getLastIndex for utterance u after the run. */
+int speechPlayer_batch_getLastIndex(speechPlayer_batch_t batch, long long utterance);
+
+/* Zero-copy access for GPU consumers: device pointer of the PCM pool and the sample offset of
+ * utterance u in it (offsets are padded to 64-sample boundaries). */
+const sample* speechPlayer_batch_devicePcm(speechPlayer_batch_t batch);
+long long speechPlayer_batch_deviceOffset(speechPlayer_batch_t batch, long long utterance);
+
+/* Measurement: run `launches` synthesis launches back to back on the batch's stream and report
+ * each launch's duration in milliseconds from HIP events recorded on that stream. */
+int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msPerLaunch);
+
+/* Kernel resource facts for reports: fills vgprs, ldsBytes, wavefronts launched, workgroups per CU. */
+int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo);
+
+const char* speechPlayer_lastError(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif

@@ -1,0 +1,591 @@
+// klatt_engine.hip -- host side of the MI355X Klatt engine and its C-ABI.
+//
+// Exports (include/speechPlayer.h, include/speechPlayer_batch.h):
+//   the reference's five entry points  (reference src/speechPlayer.cpp:25-53)
+//     -- each handle is a GPU-resident stream: queueFrame keeps the producer-side queue on the
+//        host (as reference src/frame.cpp:90-115 does), synthesize runs the kernel for that one
+//        stream from its saved state and copies the PCM back;
+//   the additive batch entry points    (N independent streams per launch).
+// There is no CPU synthesis path in this library: without a HIP device every entry point fails.
+#include "klatt_device.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <numeric>
+#include <string>
+#include <vector>
+
+#include "../../include/speechPlayer_batch.h"
+
+using namespace klatt;
+
+namespace {
+
+thread_local std::string g_lastError;
+
+void set_error(const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_lastError = buf;
+    fprintf(stderr, "[speechPlayer/hip] %s\n", buf);
+}
+
+#define HIP_TRY(expr)                                                                       \
+    do {                                                                                    \
+        hipError_t e_ = (expr);                                                             \
+        if (e_ != hipSuccess) {                                                             \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return -1;                                                                      \
+        }                                                                                   \
+    } while (0)
+
+template <typename T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T)));
+        cap = n;
+        return 0;
+    }
+    void release()
+    {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr; cap = 0;
+    }
+};
+
+KernelArgs base_args(int sampleRate)
+{
+    KernelArgs a;
+    memset(&a, 0, sizeof a);
+    a.sampleRate = sampleRate;
+    a.invSampleRate = 1.0 / (double)sampleRate;
+    a.negPiOverSr = -M_PI / sampleRate;          // reference src/speechWaveGenerator.cpp:116
+    a.twoPiOverSr = (M_PI * 2) / sampleRate;     // reference src/speechWaveGenerator.cpp:31,118
+    a.maxSamples = 0xFFFFFFFFu;
+    return a;
+}
+
+template <bool STREAM>
+int launch(const KernelArgs& a, int mode, long long nWaves, hipStream_t stream)
+{
+    if (nWaves <= 0) return 0;
+    if (nWaves > 0x7FFFFFFF) { set_error("too many wavefronts: %lld", nWaves); return -1; }
+    constexpr int ldsBytes = LdsLayout<STREAM>::kBytes;
+    switch (mode) {
+    case MODE_EXACT: {
+        auto k = klatt_synthesize<MODE_EXACT, STREAM>;
+        static bool attrSet = false;
+        if (!attrSet) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+            attrSet = true;
+        }
+        hipLaunchKernelGGL(k, dim3((unsigned)nWaves), dim3(kLanes), ldsBytes, stream, a);
+        break;
+    }
+    default:
+        set_error("unknown arithmetic mode %d", mode);
+        return -1;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int pick_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+        set_error("no HIP device available (%s); this engine has no CPU path", e == hipSuccess ? "count 0" : hipGetErrorString(e));
+        return -1;
+    }
+    if (device < 0) {
+        const char* env = getenv("SPEECHPLAYER_DEVICE");
+        if (env) device = atoi(env);
+        else if (hipGetDevice(&device) != hipSuccess) device = 0;
+    }
+    if (device >= n) { set_error("device %d out of range (%d devices)", device, n); return -1; }
+    return device;
+}
+
+// ------------------------------------------------------------------------------------------
+// Batch
+// ------------------------------------------------------------------------------------------
+struct Batch {
+    int sampleRate = 0;
+    int device = 0;
+    int mode = MODE_EXACT;
+    int sortByLength = 1;
+    hipStream_t stream = nullptr;
+    long long nUtt = 0, nFrames = 0, nSlots = 0;
+    long long totalSamples = 0, poolSamples = 0;
+    std::vector<uint32_t> lens;
+    std::vector<long long> outStart;   // padded offsets in the device pool
+    std::vector<UttResult> results;
+    bool resultsFresh = false;
+    DeviceBuffer<double> dFrames;
+    DeviceBuffer<FrameMeta> dMeta;
+    DeviceBuffer<UttDesc> dUtt;
+    DeviceBuffer<uint32_t> dOrder;
+    DeviceBuffer<int16_t> dPcm;
+    DeviceBuffer<UttResult> dResult;
+};
+
+int batch_launch(Batch* b)
+{
+    KernelArgs a = base_args(b->sampleRate);
+    a.frames = b->dFrames.ptr; a.meta = b->dMeta.ptr; a.utt = b->dUtt.ptr; a.order = b->dOrder.ptr;
+    a.pcm = b->dPcm.ptr; a.result = b->dResult.ptr; a.state = nullptr; a.control = nullptr;
+    a.nSlots = b->nSlots;
+    b->resultsFresh = false;
+    return launch<false>(a, b->mode, (b->nSlots + kLanes - 1) / kLanes, b->stream);
+}
+
+// ------------------------------------------------------------------------------------------
+// Streams behind the reference's five entry points
+// ------------------------------------------------------------------------------------------
+struct PendingFrame {
+    double p[kNumParams];
+    FrameMeta meta;
+};
+
+struct Stream {
+    int sampleRate = 0;
+    int device = 0;
+    int mode = MODE_EXACT;
+    uint32_t seed = 0;
+    std::mutex mu;                       // per call, not per sample (reference locks per sample: src/frame.cpp:122)
+    std::vector<PendingFrame> pending;   // queued, not yet taken by the kernel
+    bool purgePending = false;
+    int lastIndex = -1;
+    hipStream_t stream = nullptr;
+    DeviceBuffer<double> dFrames;
+    DeviceBuffer<FrameMeta> dMeta;
+    DeviceBuffer<UttDesc> dUtt;
+    DeviceBuffer<uint32_t> dOrder;
+    DeviceBuffer<uint32_t> dControl;
+    DeviceBuffer<int16_t> dPcm;
+    DeviceBuffer<UttResult> dResult;
+    DeviceBuffer<double> dState;
+    std::vector<double> hFrames;
+    std::vector<FrameMeta> hMeta;
+};
+
+std::mutex g_tableMutex;
+std::vector<Stream*> g_streams;   // handle = index + 1
+
+Stream* lookup(speechPlayer_handle_t h)
+{
+    uintptr_t id = reinterpret_cast<uintptr_t>(h);
+    // a prototype-less 32-bit ctypes call hands the id back sign-/zero-extended; ids are small
+    id &= 0xFFFFFFFFu;
+    std::lock_guard<std::mutex> g(g_tableMutex);
+    if (id == 0 || id > g_streams.size()) return nullptr;
+    return g_streams[id - 1];
+}
+
+int stream_init_device(Stream* s)
+{
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+    if (s->dUtt.reserve(1) || s->dOrder.reserve(1) || s->dControl.reserve(1) || s->dResult.reserve(1) ||
+        s->dState.reserve(kStateDoubles))
+        return -1;
+    HIP_TRY(hipMemsetAsync(s->dState.ptr, 0, kStateDoubles * sizeof(double), s->stream));
+    const uint32_t zero = 0;
+    HIP_TRY(hipMemcpyAsync(s->dOrder.ptr, &zero, sizeof zero, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return 0;
+}
+
+int stream_synthesize(Stream* s, unsigned int count, sample* out)
+{
+    if (count == 0) return 0;
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t nf = s->pending.size();
+    if (nf) {
+        s->hFrames.resize(nf * kNumParams);
+        s->hMeta.resize(nf);
+        for (size_t k = 0; k < nf; ++k) {
+            memcpy(&s->hFrames[k * kNumParams], s->pending[k].p, sizeof(double) * kNumParams);
+            s->hMeta[k] = s->pending[k].meta;
+        }
+        if (s->dFrames.reserve(std::max<size_t>(nf, 64) * kNumParams) || s->dMeta.reserve(std::max<size_t>(nf, 64))) return -1;
+        HIP_TRY(hipMemcpyAsync(s->dFrames.ptr, s->hFrames.data(), nf * kNumParams * sizeof(double), hipMemcpyHostToDevice, s->stream));
+        HIP_TRY(hipMemcpyAsync(s->dMeta.ptr, s->hMeta.data(), nf * sizeof(FrameMeta), hipMemcpyHostToDevice, s->stream));
+    } else if (!s->dFrames.ptr) {
+        if (s->dFrames.reserve(64 * kNumParams) || s->dMeta.reserve(64)) return -1;
+    }
+    const size_t padded = ((size_t)count + kTile - 1) / kTile * kTile;
+    if (s->dPcm.reserve(padded)) return -1;
+    UttDesc d;
+    memset(&d, 0, sizeof d);
+    d.frameStart = 0; d.outStart = 0; d.nFrames = (uint32_t)nf; d.seed = s->seed;
+    const uint32_t control = s->purgePending ? 1u : 0u;
+    HIP_TRY(hipMemcpyAsync(s->dUtt.ptr, &d, sizeof d, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->dControl.ptr, &control, sizeof control, hipMemcpyHostToDevice, s->stream));
+
+    KernelArgs a = base_args(s->sampleRate);
+    a.frames = s->dFrames.ptr; a.meta = s->dMeta.ptr; a.utt = s->dUtt.ptr; a.order = s->dOrder.ptr;
+    a.pcm = s->dPcm.ptr; a.result = s->dResult.ptr; a.state = s->dState.ptr; a.control = s->dControl.ptr;
+    a.nSlots = 1;
+    a.maxSamples = count;
+    if (launch<true>(a, s->mode, 1, s->stream)) return -1;
+
+    UttResult r;
+    HIP_TRY(hipMemcpyAsync(&r, s->dResult.ptr, sizeof r, hipMemcpyDeviceToHost, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (r.produced > count) { set_error("kernel produced %u > %u", r.produced, count); return -1; }
+    if (r.produced) HIP_TRY(hipMemcpy(out, s->dPcm.ptr, (size_t)r.produced * sizeof(int16_t), hipMemcpyDeviceToHost));
+    s->purgePending = false;
+    s->pending.erase(s->pending.begin(), s->pending.begin() + std::min<size_t>(r.framesTaken, nf));
+    s->lastIndex = r.lastIndex;
+    return (int)r.produced;
+}
+
+}  // namespace
+
+// ==========================================================================================
+// C-ABI: the reference's five entry points
+// ==========================================================================================
+extern "C" {
+
+const char* speechPlayer_lastError(void) { return g_lastError.c_str(); }
+
+speechPlayer_handle_t speechPlayer_initialize(int sampleRate)
+{
+    int dev = pick_device(-1);
+    if (dev < 0) return nullptr;
+    Stream* s = new Stream;
+    s->sampleRate = sampleRate;
+    s->device = dev;
+    if (stream_init_device(s)) { delete s; return nullptr; }
+    std::lock_guard<std::mutex> g(g_tableMutex);
+    for (size_t i = 0; i < g_streams.size(); ++i)
+        if (!g_streams[i]) { g_streams[i] = s; return reinterpret_cast<speechPlayer_handle_t>(i + 1); }
+    g_streams.push_back(s);
+    return reinterpret_cast<speechPlayer_handle_t>(g_streams.size());
+}
+
+void speechPlayer_queueFrame(speechPlayer_handle_t playerHandle, speechPlayer_frame_t* framePtr, unsigned int minFrameDuration,
+                             unsigned int fadeDuration, int userIndex, bool purgeQueue)
+{
+    Stream* s = lookup(playerHandle);
+    if (!s) { set_error("speechPlayer_queueFrame: invalid handle"); return; }
+    PendingFrame f;
+    memset(&f, 0, sizeof f);
+    f.meta.minSamples = minFrameDuration;
+    f.meta.fadeSamples = std::max(fadeDuration, 1u);     // reference src/speechPlayer.cpp:36
+    f.meta.userIndex = userIndex;
+    f.meta.flags = framePtr ? 0u : FRAME_NULL;
+    if (framePtr) memcpy(f.p, framePtr, sizeof f.p);     // copied: caller may reuse it (reference src/frame.cpp:97)
+    std::lock_guard<std::mutex> g(s->mu);
+    if (purgeQueue) {                                    // reference src/frame.cpp:103-112; the state half of
+        s->pending.clear();                              // the purge runs in the kernel before the next sample
+        s->purgePending = true;
+    }
+    s->pending.push_back(f);
+}
+
+int speechPlayer_synthesize(speechPlayer_handle_t playerHandle, unsigned int sampleCount, sample* sampleBuf)
+{
+    Stream* s = lookup(playerHandle);
+    if (!s) { set_error("speechPlayer_synthesize: invalid handle"); return 0; }
+    std::lock_guard<std::mutex> g(s->mu);
+    int n = stream_synthesize(s, sampleCount, sampleBuf);
+    return n < 0 ? 0 : n;
+}
+
+int speechPlayer_getLastIndex(speechPlayer_handle_t playerHandle)
+{
+    Stream* s = lookup(playerHandle);
+    if (!s) return -1;
+    return s->lastIndex;   // unlocked, as reference src/frame.cpp:117-119
+}
+
+void speechPlayer_terminate(speechPlayer_handle_t playerHandle)
+{
+    Stream* s = nullptr;
+    {
+        uintptr_t id = reinterpret_cast<uintptr_t>(playerHandle) & 0xFFFFFFFFu;
+        std::lock_guard<std::mutex> g(g_tableMutex);
+        if (id == 0 || id > g_streams.size()) return;
+        s = g_streams[id - 1];
+        g_streams[id - 1] = nullptr;
+    }
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
+    s->dFrames.release(); s->dMeta.release(); s->dUtt.release(); s->dOrder.release(); s->dControl.release();
+    s->dPcm.release(); s->dResult.release(); s->dState.release();
+    delete s;
+}
+
+// Additive: choose the handle's noise stream (default 0) and arithmetic mode.
+int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int seed)
+{
+    Stream* s = lookup(playerHandle);
+    if (!s) return -1;
+    std::lock_guard<std::mutex> g(s->mu);
+    s->seed = seed;
+    return 0;
+}
+
+// ==========================================================================================
+// C-ABI: batch
+// ==========================================================================================
+speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
+{
+    int dev = pick_device(device);
+    if (dev < 0) return nullptr;
+    Batch* b = new Batch;
+    b->sampleRate = sampleRate;
+    b->device = dev;
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+        set_error("cannot create a stream on device %d", dev);
+        delete b;
+        return nullptr;
+    }
+    return b;
+}
+
+void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b) return;
+    (void)hipSetDevice(b->device);
+    if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
+    delete b;
+}
+
+int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || !name) return -1;
+    if (!strcmp(name, "mode")) {
+        if (value != MODE_EXACT) { set_error("mode %d not available", value); return -1; }
+        b->mode = value;
+        return 0;
+    }
+    if (!strcmp(name, "sort")) { b->sortByLength = value ? 1 : 0; return 0; }
+    set_error("unknown option %s", name);
+    return -1;
+}
+
+int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
+                                     const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
+                                     const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
+                                     const unsigned int* noiseSeed)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || nUtterances < 0 || !frameStart) { set_error("setUtterances: bad arguments"); return -1; }
+    if (nUtterances >= 0xFFFFFFFFll) { set_error("setUtterances: too many utterances"); return -1; }
+    HIP_TRY(hipSetDevice(b->device));
+    const long long nF = frameStart[nUtterances];
+    if (frameStart[0] != 0 || nF < 0 || (nF > 0 && (!frames || !minFrameDuration || !fadeDuration))) {
+        set_error("setUtterances: bad frame arrays");
+        return -1;
+    }
+    b->nUtt = nUtterances;
+    b->nFrames = nF;
+    b->lens.assign((size_t)nUtterances, 0);
+    b->outStart.assign((size_t)nUtterances + 1, 0);
+    std::vector<FrameMeta> meta((size_t)nF);
+    for (long long k = 0; k < nF; ++k) {
+        meta[k].minSamples = minFrameDuration[k];
+        meta[k].fadeSamples = std::max(fadeDuration[k], 1u);   // reference src/speechPlayer.cpp:36
+        meta[k].userIndex = userIndex ? userIndex[k] : -1;
+        meta[k].flags = (isNull && isNull[k]) ? FRAME_NULL : 0u;
+    }
+    std::vector<UttDesc> utt((size_t)nUtterances);
+    long long total = 0, pool = 0;
+    for (long long u = 0; u < nUtterances; ++u) {
+        if (frameStart[u + 1] < frameStart[u]) { set_error("setUtterances: frameStart not monotone at %lld", u); return -1; }
+        unsigned long long len = 0;
+        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+            const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
+            len += std::max(m, f + 1) + 1;   // samples one request spans (follows from reference src/frame.cpp:41-80)
+        }
+        if (len >= 0xFFFFFFFFull) { set_error("utterance %lld too long (%llu samples)", u, len); return -1; }
+        b->lens[u] = (uint32_t)len;
+        b->outStart[u] = pool;
+        memset(&utt[u], 0, sizeof(UttDesc));
+        utt[u].frameStart = frameStart[u];
+        utt[u].outStart = pool;
+        utt[u].nFrames = (uint32_t)(frameStart[u + 1] - frameStart[u]);
+        utt[u].seed = noiseSeed ? noiseSeed[u] : (uint32_t)u;
+        total += (long long)len;
+        pool += ((long long)len + kTile - 1) / kTile * kTile;
+    }
+    b->outStart[nUtterances] = pool;
+    b->totalSamples = total;
+    b->poolSamples = pool;
+    // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
+    std::vector<uint32_t> order((size_t)nUtterances);
+    std::iota(order.begin(), order.end(), 0u);
+    if (b->sortByLength)
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b->lens[x] > b->lens[y]; });
+    b->nSlots = nUtterances;
+
+    if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>(nF, 1)) ||
+        b->dUtt.reserve(std::max<size_t>(nUtterances, 1)) || b->dOrder.reserve(std::max<size_t>(nUtterances, 1)) ||
+        b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
+        return -1;
+    if (nF) {
+        HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->dMeta.ptr, meta.data(), (size_t)nF * sizeof(FrameMeta), hipMemcpyHostToDevice, b->stream));
+    }
+    if (nUtterances) {
+        HIP_TRY(hipMemcpyAsync(b->dUtt.ptr, utt.data(), (size_t)nUtterances * sizeof(UttDesc), hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemcpyAsync(b->dOrder.ptr, order.data(), (size_t)nUtterances * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+        HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nUtterances * sizeof(UttResult), b->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->results.clear();
+    b->resultsFresh = false;
+    return 0;
+}
+
+long long speechPlayer_batch_utteranceSamples(speechPlayer_batch_t batch, long long u)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || u < 0 || u >= b->nUtt) return -1;
+    return b->lens[u];
+}
+long long speechPlayer_batch_totalSamples(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->totalSamples : -1; }
+long long speechPlayer_batch_totalFrames(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->nFrames : -1; }
+
+int speechPlayer_batch_synthesize(speechPlayer_batch_t batch)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    return batch_launch(b);
+}
+
+int speechPlayer_batch_wait(speechPlayer_batch_t batch)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    return 0;
+}
+
+static int fetch_results(Batch* b)
+{
+    if (b->resultsFresh) return 0;
+    b->results.resize((size_t)b->nUtt);
+    if (b->nUtt) HIP_TRY(hipMemcpy(b->results.data(), b->dResult.ptr, (size_t)b->nUtt * sizeof(UttResult), hipMemcpyDeviceToHost));
+    b->resultsFresh = true;
+    return 0;
+}
+
+long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long u, sample* sampleBuf, long long capacity)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || u < 0 || u >= b->nUtt || !sampleBuf) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (fetch_results(b)) return -1;
+    long long n = std::min<long long>(b->results[u].produced, capacity);
+    if (n > 0) HIP_TRY(hipMemcpy(sampleBuf, b->dPcm.ptr + b->outStart[u], (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost));
+    return n;
+}
+
+long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || !sampleBuf) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (fetch_results(b)) return -1;
+    std::vector<int16_t> pool((size_t)b->poolSamples);
+    if (b->poolSamples) HIP_TRY(hipMemcpy(pool.data(), b->dPcm.ptr, (size_t)b->poolSamples * sizeof(int16_t), hipMemcpyDeviceToHost));
+    long long pos = 0;
+    for (long long u = 0; u < b->nUtt; ++u) {
+        if (outStart) outStart[u] = pos;
+        long long n = b->results[u].produced;
+        if (pos + n > capacity) { set_error("readAll: capacity %lld too small", capacity); return -1; }
+        memcpy(reinterpret_cast<int16_t*>(sampleBuf) + pos, pool.data() + b->outStart[u], (size_t)n * sizeof(int16_t));
+        pos += n;
+    }
+    if (outStart) outStart[b->nUtt] = pos;
+    return pos;
+}
+
+int speechPlayer_batch_getLastIndex(speechPlayer_batch_t batch, long long u)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || u < 0 || u >= b->nUtt) return -1;
+    if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) return -1;
+    if (fetch_results(b)) return -1;
+    return b->results[u].lastIndex;
+}
+
+const sample* speechPlayer_batch_devicePcm(speechPlayer_batch_t batch)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    return b ? reinterpret_cast<const sample*>(b->dPcm.ptr) : nullptr;
+}
+
+long long speechPlayer_batch_deviceOffset(speechPlayer_batch_t batch, long long u)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || u < 0 || u > b->nUtt) return -1;
+    return b->outStart[u];
+}
+
+int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msPerLaunch)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || launches <= 0 || !msPerLaunch) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    std::vector<hipEvent_t> ev((size_t)launches * 2);
+    for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+    int rc = 0;
+    for (int i = 0; i < launches && !rc; ++i) {
+        HIP_TRY(hipEventRecord(ev[2 * i], b->stream));
+        rc = batch_launch(b);
+        HIP_TRY(hipEventRecord(ev[2 * i + 1], b->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    for (int i = 0; i < launches && !rc; ++i) HIP_TRY(hipEventElapsedTime(&msPerLaunch[i], ev[2 * i], ev[2 * i + 1]));
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || !info || nInfo < 6) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    hipFuncAttributes fa;
+    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false>)));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, b->device));
+    info[0] = fa.numRegs;
+    info[1] = LdsLayout<false>::kBytes;
+    info[2] = (int)((b->nSlots + kLanes - 1) / kLanes);
+    info[3] = prop.multiProcessorCount;
+    info[4] = (int)(prop.sharedMemPerMultiprocessor / LdsLayout<false>::kBytes);
+    info[5] = (int)fa.localSizeBytes;   // scratch; must be 0
+    return 0;
+}
+
+}  // extern "C"

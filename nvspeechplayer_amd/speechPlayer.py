@@ -1,0 +1,198 @@
+"""Host-side mirror of the reference's ctypes wrapper, over the MI355X engine.
+
+`Frame` and `SpeechPlayer` keep the reference wrapper's names, arguments and
+behaviour (reference speechPlayer.py:20-68): durations in milliseconds converted
+with the same truncation, `synthesize` returning a ctypes short array carrying
+`.length`, or None when nothing was produced.  `BatchPlayer` is the additive batch
+interface (include/speechPlayer_batch.h): many frame streams, one kernel launch.
+
+Everything here calls the HIP library through its C-ABI; there is no CPU path.
+"""
+from ctypes import Structure, byref, c_double, c_short
+
+import numpy as np
+
+from . import _native
+
+speechPlayer_frameParam_t = c_double
+
+FRAME_FIELDS = [
+    'voicePitch',
+    'vibratoPitchOffset',
+    'vibratoSpeed',
+    'voiceTurbulenceAmplitude',
+    'glottalOpenQuotient',
+    'voiceAmplitude',
+    'aspirationAmplitude',
+    'cf1', 'cf2', 'cf3', 'cf4', 'cf5', 'cf6', 'cfN0', 'cfNP',
+    'cb1', 'cb2', 'cb3', 'cb4', 'cb5', 'cb6', 'cbN0', 'cbNP',
+    'caNP',
+    'fricationAmplitude',
+    'pf1', 'pf2', 'pf3', 'pf4', 'pf5', 'pf6',
+    'pb1', 'pb2', 'pb3', 'pb4', 'pb5', 'pb6',
+    'pa1', 'pa2', 'pa3', 'pa4', 'pa5', 'pa6',
+    'parallelBypass',
+    'preFormantGain',
+    'outputGain',
+    'endVoicePitch',
+]
+
+
+class Frame(Structure):
+    """47 doubles, field order = the C struct (include/speechPlayer.h; reference speechPlayer.py:20-40)."""
+    _fields_ = [(name, speechPlayer_frameParam_t) for name in FRAME_FIELDS]
+
+    def as_array(self):
+        return np.frombuffer(bytes(self), dtype=np.float64).copy()
+
+    @classmethod
+    def from_array(cls, values):
+        f = cls()
+        for name, v in zip(FRAME_FIELDS, values):
+            setattr(f, name, float(v))
+        return f
+
+
+class SpeechPlayer(object):
+    """One live stream (reference speechPlayer.py:44-68)."""
+
+    def __init__(self, sampleRate, noiseSeed=None):
+        self.sampleRate = sampleRate
+        self._dll = _native.load()
+        self._speechHandle = self._dll.speechPlayer_initialize(sampleRate)
+        if not self._speechHandle:
+            raise RuntimeError("speechPlayer_initialize failed: %s" % _native.last_error())
+        if noiseSeed is not None:
+            self._dll.speechPlayer_setNoiseSeed(self._speechHandle, int(noiseSeed))
+
+    def queueFrame(self, frame, minFrameDuration, fadeDuration, userIndex=-1, purgeQueue=False):
+        frame = byref(frame) if frame else None
+        self._dll.speechPlayer_queueFrame(self._speechHandle, frame,
+                                          int(minFrameDuration * (self.sampleRate / 1000.0)),
+                                          int(fadeDuration * (self.sampleRate / 1000.0)), userIndex, purgeQueue)
+
+    def queueFrameSamples(self, frame, minSamples, fadeSamples, userIndex=-1, purgeQueue=False):
+        """Same call with durations already in samples (the C-ABI unit)."""
+        frame = byref(frame) if frame else None
+        self._dll.speechPlayer_queueFrame(self._speechHandle, frame, int(minSamples), int(fadeSamples), userIndex, purgeQueue)
+
+    def synthesize(self, numSamples):
+        buf = (c_short * numSamples)()
+        res = self._dll.speechPlayer_synthesize(self._speechHandle, numSamples, buf)
+        if res > 0:
+            buf.length = min(res, len(buf))
+            return buf
+        else:
+            return None
+
+    def getLastIndex(self):
+        return self._dll.speechPlayer_getLastIndex(self._speechHandle)
+
+    def close(self):
+        if getattr(self, "_speechHandle", None):
+            self._dll.speechPlayer_terminate(self._speechHandle)
+            self._speechHandle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchPlayer(object):
+    """N independent utterances per launch (include/speechPlayer_batch.h)."""
+
+    def __init__(self, sampleRate, device=-1, mode=0):
+        self.sampleRate = sampleRate
+        self._dll = _native.load()
+        self._h = self._dll.speechPlayer_batch_create(sampleRate, device)
+        if not self._h:
+            raise RuntimeError("speechPlayer_batch_create failed: %s" % _native.last_error())
+        self._check(self._dll.speechPlayer_batch_setOption(self._h, b"mode", mode))
+        self.nUtterances = 0
+
+    def _check(self, rc):
+        if rc is None or rc < 0:
+            raise RuntimeError("speechPlayer batch call failed: %s" % _native.last_error())
+        return rc
+
+    def setOption(self, name, value):
+        self._check(self._dll.speechPlayer_batch_setOption(self._h, name.encode(), int(value)))
+
+    def setUtterances(self, frameStart, frames, minSamples, fadeSamples, userIndex=None, isNull=None, noiseSeed=None):
+        fs = np.ascontiguousarray(frameStart, dtype=np.int64)
+        fr = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 47)
+        m = np.ascontiguousarray(minSamples, dtype=np.uint32)
+        f = np.ascontiguousarray(fadeSamples, dtype=np.uint32)
+        n_utt = len(fs) - 1
+        assert fs[-1] == len(fr) == len(m) == len(f)
+        ix = None if userIndex is None else np.ascontiguousarray(userIndex, dtype=np.int32)
+        nu = None if isNull is None else np.ascontiguousarray(isNull, dtype=np.uint8)
+        sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
+        p = lambda a: None if a is None else a.ctypes.data
+        self._check(self._dll.speechPlayer_batch_setUtterances(self._h, n_utt, p(fs), p(fr), p(m), p(f), p(ix), p(nu), p(sd)))
+        self.nUtterances = n_utt
+
+    @property
+    def totalSamples(self):
+        return self._dll.speechPlayer_batch_totalSamples(self._h)
+
+    @property
+    def totalFrames(self):
+        return self._dll.speechPlayer_batch_totalFrames(self._h)
+
+    def utteranceSamples(self, u):
+        return self._dll.speechPlayer_batch_utteranceSamples(self._h, u)
+
+    def synthesize(self, wait=True):
+        self._check(self._dll.speechPlayer_batch_synthesize(self._h))
+        if wait:
+            self._check(self._dll.speechPlayer_batch_wait(self._h))
+
+    def wait(self):
+        self._check(self._dll.speechPlayer_batch_wait(self._h))
+
+    def read(self, u):
+        n = self.utteranceSamples(u)
+        buf = np.zeros(max(n, 1), dtype=np.int16)
+        got = self._check(self._dll.speechPlayer_batch_read(self._h, u, buf.ctypes.data, n))
+        return buf[:got]
+
+    def readAll(self):
+        total = self.totalSamples
+        buf = np.zeros(max(total, 1), dtype=np.int16)
+        starts = np.zeros(self.nUtterances + 1, dtype=np.int64)
+        got = self._check(self._dll.speechPlayer_batch_readAll(self._h, buf.ctypes.data, total, starts.ctypes.data))
+        return buf[:got], starts
+
+    def getLastIndex(self, u):
+        return self._dll.speechPlayer_batch_getLastIndex(self._h, u)
+
+    def time(self, launches):
+        ms = np.zeros(launches, dtype=np.float32)
+        self._check(self._dll.speechPlayer_batch_time(self._h, launches, ms.ctypes.data))
+        return ms
+
+    def kernelInfo(self):
+        info = np.zeros(8, dtype=np.int32)
+        self._check(self._dll.speechPlayer_batch_kernelInfo(self._h, info.ctypes.data, len(info)))
+        return dict(vgprs=int(info[0]), lds_bytes=int(info[1]), wavefronts=int(info[2]), cus=int(info[3]),
+                    workgroups_per_cu_by_lds=int(info[4]), scratch_bytes=int(info[5]))
+
+    def devicePcm(self):
+        return self._dll.speechPlayer_batch_devicePcm(self._h)
+
+    def deviceOffset(self, u):
+        return self._dll.speechPlayer_batch_deviceOffset(self._h, u)
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._dll.speechPlayer_batch_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,132 @@
+"""Synthetic frame-stream batches for BASELINE.json's configurations.
+
+The phoneme parameter vectors and the sampleIpa.txt frame streams are the ones the
+reference's own frame producer emits (captured as data in tests/golden/ref_frames.npz
+by tests/golden/make_golden.py); this module only instances them into batches, following
+the recipes of SURVEY.md section 8(d).
+"""
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF_FRAMES = os.path.join(ROOT, "tests", "golden", "ref_frames.npz")
+SR = 22050
+
+VOICEPITCH, VOICEAMP, PREGAIN, OUTGAIN, ENDPITCH = 0, 5, 44, 45, 46
+
+
+def ms(x, sr=SR):
+    """reference speechPlayer.py:53"""
+    return int(x * (sr / 1000.0))
+
+
+class Batch(dict):
+    """frames[nF,47] f64, min[nF] u32, fade[nF] u32, index[nF] i32, isnull[nF] u8,
+    frame_start[nU+1] i64, seeds[nU] u32, name, sr"""
+
+    @property
+    def n_utt(self):
+        return len(self["frame_start"]) - 1
+
+    def sample_counts(self):
+        m = self["min"].astype(np.int64)
+        f = np.maximum(self["fade"].astype(np.int64), 1)
+        per = np.maximum(m, f + 1) + 1
+        c = np.concatenate([[0], np.cumsum(per)])
+        fs = self["frame_start"]
+        return c[fs[1:]] - c[fs[:-1]]
+
+    def algorithmic_bytes(self):
+        """2 B per output sample + 388 B per frame read."""
+        return 2 * int(self.sample_counts().sum()) + 388 * int(len(self["min"]))
+
+    def slice(self, first, count):
+        fs = self["frame_start"]
+        a, b = int(fs[first]), int(fs[first + count])
+        out = Batch(frames=self["frames"][a:b], min=self["min"][a:b], fade=self["fade"][a:b], index=self["index"][a:b],
+                    isnull=self["isnull"][a:b], frame_start=(fs[first:first + count + 1] - a).astype(np.int64),
+                    seeds=self["seeds"][first:first + count], name=self["name"], sr=self["sr"])
+        return out
+
+
+def _load():
+    return np.load(REF_FRAMES)
+
+
+def cfg1_steady_vowels(n_utt=4096, seconds=1.0, first=0, sr=SR):
+    """BASELINE configs[1]: steady vowels, full vowel-chart sweep, `seconds` each.
+    Utterance u: vowel = sorted(_isVowel phonemes)[u mod 20]; frame = zero + preFormantGain =
+    voiceAmplitude = outputGain = 1 (reference test_playVowelchart.py:27-30) + the phoneme's fields;
+    pitch 80..320 Hz over (u div 20); one frame (M = seconds, F = 50 ms) + NULL(50 ms, 50 ms)."""
+    z = _load()
+    names = [b.decode("utf8") for b in z["phoneme_names"]]
+    vowels = [i for i in range(len(names)) if z["phoneme_isVowel"][i]]
+    frames = np.zeros((n_utt * 2, 47))
+    for k in range(n_utt):
+        u = first + k
+        i = vowels[u % len(vowels)]
+        f = np.zeros(47)
+        f[PREGAIN] = 1.0; f[VOICEAMP] = 1.0; f[OUTGAIN] = 1.0
+        mask = z["phoneme_mask"][i].astype(bool)
+        f[mask] = z["phoneme_frames"][i][mask]
+        pitch = 80.0 * 2.0 ** (((u // len(vowels)) % 205) / 205.0 * 2.0)
+        f[VOICEPITCH] = pitch; f[ENDPITCH] = pitch
+        frames[2 * k] = f
+    M, F = ms(1000 * seconds, sr), ms(50, sr)
+    return Batch(frames=frames, min=np.tile(np.array([M, F], np.uint32), n_utt),
+                 fade=np.tile(np.array([F, F], np.uint32), n_utt), index=np.full(n_utt * 2, -1, np.int32),
+                 isnull=np.tile(np.array([0, 1], np.uint8), n_utt),
+                 frame_start=np.arange(n_utt + 1, dtype=np.int64) * 2,
+                 seeds=(np.arange(n_utt) + first).astype(np.uint32),
+                 name="cfg1: %d steady vowels x %.3g s (vowel-chart sweep)" % (n_utt, seconds), sr=sr)
+
+
+def cfg2_ipa_utterances(n_utt=65536, first=0, max_seconds=None, sr=SR):
+    """BASELINE configs[2] (and configs[3] with max_seconds=0.5): utterance u = sampleIpa.txt line
+    (u mod 8) through the reference frame producer (speed 1, inflection 0.5, clause '.'), base pitch
+    100*2^(((u div 8) mod 64 - 32)/64) Hz applied by scaling the captured 100 Hz stream's voicePitch /
+    endVoicePitch, + NULL(150 ms, 0) (reference test_speakIpa.py:25-27); noise seed = u."""
+    z = _load()
+    meta = z["ipa_case_meta"]
+    start = z["ipa_start"]
+    base = {}
+    for i, m in enumerate(meta):
+        if m[1] == 1.0 and int(m[2]) == 0 and m[3] == 100.0 and m[4] == 0.5:
+            a, b = start[i], start[i + 1]
+            fr = z["ipa_frames"][a:b].copy()
+            nu = z["ipa_isnull"][a:b].copy()
+            M = np.array([ms(d, sr) for d in z["ipa_dur_ms"][a:b]], np.uint32)
+            F = np.array([ms(d, sr) for d in z["ipa_fade_ms"][a:b]], np.uint32)
+            fr = np.concatenate([fr, np.zeros((1, 47))]); nu = np.concatenate([nu, [1]]).astype(np.uint8)
+            M = np.concatenate([M, [ms(150, sr)]]).astype(np.uint32); F = np.concatenate([F, [0]]).astype(np.uint32)
+            if max_seconds is not None:
+                per = np.maximum(M.astype(np.int64), np.maximum(F.astype(np.int64), 1) + 1) + 1
+                keep = max(1, int(np.searchsorted(np.cumsum(per), max_seconds * sr, side="right")))
+                fr, nu, M, F = fr[:keep], nu[:keep], M[:keep], F[:keep]
+            base[int(m[0])] = (fr, nu, M, F)
+    frames, mins, fades, nul, fs = [], [], [], [], [0]
+    for k in range(n_utt):
+        u = first + k
+        fr, nu, M, F = base[u % 8]
+        scale = 2.0 ** ((((u // 8) % 64) - 32) / 64.0)
+        g = fr.copy()
+        g[:, VOICEPITCH] *= scale; g[:, ENDPITCH] *= scale
+        frames.append(g); mins.append(M); fades.append(F); nul.append(nu)
+        fs.append(fs[-1] + len(M))
+    nF = fs[-1]
+    tag = "cfg2" if max_seconds is None else "cfg3-slice(<=%.2gs)" % max_seconds
+    return Batch(frames=np.concatenate(frames), min=np.concatenate(mins), fade=np.concatenate(fades),
+                 index=np.full(nF, -1, np.int32), isnull=np.concatenate(nul), frame_start=np.array(fs, np.int64),
+                 seeds=(np.arange(n_utt) + first).astype(np.uint32),
+                 name="%s: %d sampleIpa utterances, 64 pitch variants" % (tag, n_utt), sr=sr)
+
+
+def make(workload, n_utt=None, first=0):
+    if workload == "cfg1":
+        return cfg1_steady_vowels(n_utt or 4096, first=first)
+    if workload == "cfg2":
+        return cfg2_ipa_utterances(n_utt or 65536, first=first)
+    if workload == "cfg3":
+        return cfg2_ipa_utterances(n_utt or 131072, first=first, max_seconds=0.5)
+    raise ValueError(workload)

@@ -1,0 +1,156 @@
+"""Parity of the HIP engine (through its C-ABI) against the CPU oracle.  Needs a GPU.
+
+Bar (BASELINE.json north_star): per-sample RMS error < 1e-5 of full scale (int16/32768).
+MODE_EXACT computes in IEEE double with the reference's operation order, so these tests
+ask for more: identical int16 PCM, identical call lengths and index marks.  The only
+tolerated difference is a last-place difference between the device's exp/cos/sin and
+glibc's, which can move a sample by one LSB when a value sits on a truncation boundary;
+the tests therefore allow at most MAX_FLIPS one-LSB differences per million samples
+and print what they saw.
+"""
+import numpy as np
+import pytest
+
+from tests import oracle, scenarios
+
+pytestmark = pytest.mark.gpu
+
+RMS_TOL = 1e-5          # north_star tolerance, full-scale units
+MAX_FLIPS_PER_M = 5     # one-LSB differences tolerated per million samples in MODE_EXACT
+
+
+def compare(got, exp, name):
+    assert len(got) == len(exp), "%s: length %d != %d" % (name, len(got), len(exp))
+    if len(exp) == 0:
+        return 0
+    d = got.astype(np.int32) - exp.astype(np.int32)
+    nbad = int(np.count_nonzero(d))
+    rms = float(np.sqrt(np.mean((d / 32768.0) ** 2)))
+    mx = int(np.abs(d).max())
+    assert rms < RMS_TOL, "%s: rms %.3g" % (name, rms)
+    assert mx <= 1, "%s: max |diff| %d LSB (%d samples differ)" % (name, mx, nbad)
+    assert nbad <= max(1, MAX_FLIPS_PER_M * len(exp) // 1000000 + 1), "%s: %d samples differ" % (name, nbad)
+    return nbad
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return scenarios.Ref()
+
+
+@pytest.fixture(scope="module")
+def all_scenarios(ref):
+    return scenarios.build_scenarios(ref)
+
+
+def play_engine(scn):
+    import nvspeechplayer_amd as eng
+    p = eng.SpeechPlayer(scn.sr, noiseSeed=scn.seed)
+    pcm, marks = [], []
+
+    def synth(n):
+        buf = p.synthesize(n)
+        if buf is None:
+            return np.zeros(0, np.int16)
+        return np.frombuffer(buf, dtype=np.int16)[:buf.length].copy()
+
+    for op in scn.ops:
+        if op[0] == "q":
+            fr = None if op[1] is None else eng.Frame.from_array(op[1])
+            p.queueFrameSamples(fr, op[2], op[3], op[4], op[5])
+        elif op[0] == "s":
+            pcm.append(synth(op[1])); marks.append(p.getLastIndex())
+        else:
+            parts = []
+            while True:
+                x = synth(8192)
+                parts.append(x)
+                if len(x) < 8192:
+                    break
+            pcm.append(np.concatenate(parts)); marks.append(p.getLastIndex())
+    p.close()
+    return pcm, marks
+
+
+def test_streaming_abi_scenarios(all_scenarios):
+    """The five reference entry points, call by call: chunked pulls, purge, marks, drain/resume."""
+    names = ("cfg0_a_1s", "stream_chunks", "purge_resume", "vowelchart_pairs", "hannah_vibrato", "nan_hold",
+             "duration_edges", "ipa_l0_16k")
+    flips = 0
+    for scn in all_scenarios:
+        if scn.name not in names and not scn.name.endswith("_s10_c0_p100_i05"):
+            continue
+        exp_pcm, exp_marks = scenarios.play_oracle(scn)
+        got_pcm, got_marks = play_engine(scn)
+        assert [len(x) for x in got_pcm] == [len(x) for x in exp_pcm], scn.name
+        assert got_marks == exp_marks, scn.name
+        flips += compare(np.concatenate(got_pcm), np.concatenate(exp_pcm), scn.name)
+    print("streaming scenarios: %d one-LSB differences in total" % flips)
+
+
+def make_batch(sel):
+    frames, mins, fades, idx, nul, start, seeds = [], [], [], [], [], [0], []
+    for s in sel:
+        fr, m, f, ix, nu = s.frames()
+        frames.append(fr); mins.append(m); fades.append(f); idx.append(ix); nul.append(nu)
+        start.append(start[-1] + len(m)); seeds.append(s.seed)
+    return dict(frames=np.concatenate(frames), min=np.concatenate(mins), fade=np.concatenate(fades),
+                index=np.concatenate(idx), isnull=np.concatenate(nul), frame_start=np.array(start, np.int64),
+                seeds=np.array(seeds, np.uint32))
+
+
+def test_batch_all_scenarios(all_scenarios):
+    """Every batchable scenario (vowels, all sampleIpa cases, vibrato, NaN hold, duration edges)
+    as ONE ragged batch through speechPlayer_batch_*; each utterance must equal a fresh oracle player."""
+    import nvspeechplayer_amd as eng
+    sel = [s for s in all_scenarios if s.batchable and s.sr == 22050]
+    batch = make_batch(sel)
+    bp = eng.BatchPlayer(22050)
+    bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                     batch["isnull"], batch["seeds"])
+    exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=4)
+    assert bp.totalSamples == total
+    bp.synthesize()
+    got, got_start = bp.readAll()
+    assert np.array_equal(got_start, exp_start)
+    flips = 0
+    for i, s in enumerate(sel):
+        flips += compare(got[got_start[i]:got_start[i + 1]], exp[exp_start[i]:exp_start[i + 1]], s.name)
+        assert np.array_equal(bp.read(i), got[got_start[i]:got_start[i + 1]])
+    print("batch of %d utterances, %d samples: %d one-LSB differences" % (len(sel), total, flips))
+    # unsorted lane packing gives the same PCM
+    bp.setOption("sort", 0)
+    bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                     batch["isnull"], batch["seeds"])
+    bp.synthesize()
+    got2, _ = bp.readAll()
+    assert np.array_equal(got, got2)
+    bp.close()
+
+
+def test_batch_edge_shapes(ref):
+    """Empty batch, empty utterances, a single utterance, 65 utterances (one lane in the 2nd wavefront)."""
+    import nvspeechplayer_amd as eng
+    bp = eng.BatchPlayer(22050)
+    bp.setUtterances(np.array([0]), np.zeros((0, 47)), [], [])
+    bp.synthesize()
+    assert bp.totalSamples == 0
+    fa = scenarios.vowel_frame(ref, "a", 120.0)
+    # utterances 0 and 2 are empty
+    bp.setUtterances(np.array([0, 0, 2, 2]), np.stack([fa, fa]), [300, 10], [40, 10], None, [0, 1], [5, 6, 7])
+    bp.synthesize()
+    assert bp.utteranceSamples(0) == 0 and bp.utteranceSamples(2) == 0
+    assert len(bp.read(0)) == 0 and len(bp.read(2)) == 0
+    p = oracle.OraclePlayer(22050, seed=6)
+    p.queue(fa, 300, 40); p.queue(None, 10, 10)
+    compare(bp.read(1), p.drain(), "middle")
+    # 65 identical-shape utterances with different pitches
+    n = 65
+    frames = np.stack([scenarios.vowel_frame(ref, "i", 80.0 + 3 * k, 100.0 + k) for k in range(n)])
+    bp.setUtterances(np.arange(n + 1), frames, [1500] * n, [200] * n)
+    bp.synthesize()
+    for k in (0, 1, 63, 64):
+        p = oracle.OraclePlayer(22050, seed=k)
+        p.queue(frames[k], 1500, 200)
+        compare(bp.read(k), p.drain(), "u%d" % k)
+    bp.close()

@@ -8,35 +8,47 @@
 //   resonators                 reference src/speechWaveGenerator.cpp:90-137
 //   cascade / parallel banks   reference src/speechWaveGenerator.cpp:139-182
 //   mix, clip, int16           reference src/speechWaveGenerator.cpp:203-208
-// each lane does here for its own utterance, with
-//   * the "old" and "new" frame of the running fade staged in LDS ([param][lane],
-//     conflict-free ds_read_b64), the per-sample working set in VGPRs;
-//   * resonator coefficients recomputed only on samples where a fade moved them;
-//   * PCM packed 8 samples per lane in registers, transposed through an XOR-swizzled
-//     LDS tile and written to HBM as full 16-byte-per-lane row segments.
+// each lane does here for its own utterance:
+//   * the "old" and "new" frame of the running fade are staged in LDS ([param][lane],
+//     conflict-free ds_read_b64); the per-sample working set (filter memories,
+//     coefficients, the parameters the DSP reads) lives in VGPRs;
+//   * a request is E F..F E S..S: an event sample (dequeue), F fade samples, an event
+//     sample (fade end), then steady samples.  The wavefront runs 8-sample blocks of
+//     branch-free steady or fade code whenever every live lane is inside such a stretch,
+//     and single general steps around events;
+//   * resonator coefficients are recomputed only on fade samples that can move them;
+//   * branches that provably contribute nothing (noise sources and the parallel bank of an
+//     utterance whose frames have zero noise gains; vibrato at zero depth) are skipped;
+//   * PCM goes to a padded LDS tile (ds_write_b16, conflict-free) and leaves as 16 B per
+//     lane, whole 64-byte row segments per utterance.
 //
-// Arithmetic is IEEE double.  This translation unit is compiled with
-// -ffp-contract=off: in MODE_EXACT every multiply and add rounds separately, as in
-// the reference binary; fused operations appear only where written as fma().
+// Arithmetic is IEEE double.  This translation unit is compiled with -ffp-contract=off.
+// MODE_EXACT rounds every multiply and add separately, as the reference binary does, and
+// uses the device library's exp/cos.  MODE_FAST fuses multiply-adds and uses klatt_math.h.
 #pragma once
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
+
+#include "klatt_math.h"
 
 namespace klatt {
 
 constexpr int kNumParams = 47;
 constexpr int kLanes = 64;
 constexpr int kTile = 32;                 // samples per lane per output tile (64-byte row segments)
+constexpr int kTileStride = kTile * 2 + 8; // bytes per tile row; the pad keeps ds_write_b16 conflict-free
 constexpr int kSlots = 45;                // parameters 1..45 live in LDS slots 0..44
 constexpr int kNumRes = 14;
+constexpr int kBlock = 16;                // samples per specialised block (two per tile)
 constexpr int kStateDoubles = 240;        // per-stream saved state (streaming path)
 
 constexpr int MODE_EXACT = 0;
 constexpr int MODE_FAST = 1;
 
-// frame flags
-constexpr uint32_t FRAME_NULL = 1u;
+constexpr uint32_t FRAME_NULL = 1u;       // FrameMeta.flags
+constexpr uint32_t UTT_NEEDS_NOISE = 1u;  // UttDesc.flags
 
 struct FrameMeta {           // 16 B per frame; with the 376-B parameter vector: 392 B/frame read
     uint32_t minSamples;
@@ -50,7 +62,8 @@ struct UttDesc {             // 32 B per utterance
     long long outStart;      // sample offset in the PCM pool, multiple of kTile
     uint32_t nFrames;
     uint32_t seed;
-    uint32_t pad0, pad1;
+    uint32_t flags;          // UTT_NEEDS_NOISE: some frame has a non-zero (or non-finite) noise gain
+    uint32_t pad;
 };
 
 struct UttResult {           // written by the kernel
@@ -72,6 +85,7 @@ struct KernelArgs {
     long long nSlots;
     uint32_t maxSamples;         // per launch and utterance; 0xFFFFFFFF = until drained
     int sampleRate;
+    double sampleRateF;          // (double)sampleRate
     double invSampleRate;        // RN(1/sr)
     double negPiOverSr;          // -pi/sr     (reference src/speechWaveGenerator.cpp:116)
     double twoPiOverSr;          // (2*pi)/sr  (reference src/speechWaveGenerator.cpp:118)
@@ -82,12 +96,13 @@ struct KernelArgs {
 __device__ constexpr int kResF[kNumRes] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
 __device__ constexpr int kResB[kNumRes] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
 // parameters the per-sample DSP reads directly (everything except 0, the f/bw pairs and 46)
-__device__ constexpr int kHot[17] = {1, 2, 3, 4, 5, 6, 23, 24, 37, 38, 39, 40, 41, 42, 43, 44, 45};
+constexpr int kNumHot = 17;
+__device__ constexpr int kHot[kNumHot] = {1, 2, 3, 4, 5, 6, 23, 24, 37, 38, 39, 40, 41, 42, 43, 44, 45};
 
 // ---- arithmetic helpers -------------------------------------------------------------------
 
 // Correctly rounded x / b from y = RN(1/b) (Markstein): 3 instructions instead of a division
-// sequence.  tests/test_host_logic.py checks the identity against true division.
+// sequence.  tests/native/check_math.cpp checks the identity against the '/' operator.
 __device__ __forceinline__ double div_by(double x, double b, double y)
 {
     double q = x * y;
@@ -113,43 +128,263 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 // the engine's noise definition (restated by oracle/klatt_oracle.c klatt_noise31)
 __device__ __forceinline__ uint32_t noise_key(uint32_t seed) { return mix32(seed ^ 0x9E3779B9u); }
 __device__ __forceinline__ uint32_t noise31(uint32_t key, uint32_t k) { return mix32((k * 0x9E3779B1u) ^ key) >> 1; }
+// (double)rand()/RAND_MAX with RAND_MAX = 2^31-1 (reference src/speechWaveGenerator.cpp:40)
+__device__ __forceinline__ double noise_uniform(uint32_t key, uint32_t k)
+{
+    return div_by((double)noise31(key, k), 2147483647.0, 0x1.00000002p-31);
+}
+
+// a*x + b*y + c*z in the reference's order: ((a*x) + (b*y)) + (c*z)
+template <int MODE>
+__device__ __forceinline__ double dot3(double a, double x, double b, double y, double c, double z)
+{
+    if (MODE == MODE_FAST) return __builtin_fma(c, z, __builtin_fma(b, y, a * x));
+    return a * x + b * y + c * z;
+}
 
 // reference src/speechWaveGenerator.cpp:112-127
+struct Coef { double a, b, c; };
 template <int MODE>
-__device__ __forceinline__ void resonator_coefficients(double f, double bw, bool anti, const KernelArgs& A,
-                                                       double& a, double& b, double& c)
+__device__ __attribute__((noinline)) Coef resonator_coefficients(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr)
 {
-    double rad = exp(A.negPiOverSr * bw);
+    const double ex = negPiOverSr * bw;
+    const double th = twoPiOverSr * -f;
+    double rad, cs;
+    if (MODE == MODE_FAST) {
+        // straight-line versions; arguments outside their range take the library path
+        if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
+        else { rad = exp(ex); cs = cos(th); }
+    } else {
+        rad = exp(ex);
+        cs = cos(th);
+    }
     double cc = -(rad * rad);
-    double bb = rad * cos(A.twoPiOverSr * -f) * 2.0;
+    double bb = rad * cs * 2.0;
     double aa = 1.0 - bb - cc;
     if (anti && f != 0) {
         aa = 1.0 / aa;
         cc *= -aa;
         bb *= -aa;
     }
-    a = aa; b = bb; c = cc;
+    Coef k; k.a = aa; k.b = bb; k.c = cc;
+    return k;
 }
-
-// ---- the kernel ---------------------------------------------------------------------------
 
 // LDS per workgroup (one wavefront):
 //   oldP[kSlots][64] f64, newP[kSlots][64] f64          46,080 B
 //   curFB[28][64] f64 (STREAM only: current f/bw)        14,336 B
-//   tile[64 rows][kTile] i16, 16-byte chunks swizzled     4,096 B
-//   rowBase[64] i64, rowCount[64] u32                       768 B
+//   tile[64 rows][kTileStride B]                           4,608 B
+//   rowBase[64] i64, rowCount[64] u32                        768 B
 template <bool STREAM>
 struct LdsLayout {
     static constexpr int kOld = 0;
     static constexpr int kNew = kOld + kSlots * kLanes * 8;
     static constexpr int kCurFB = kNew + kSlots * kLanes * 8;
     static constexpr int kTileOff = kCurFB + (STREAM ? 28 * kLanes * 8 : 0);
-    static constexpr int kRowBase = kTileOff + kLanes * kTile * 2;
+    static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kBytes = kRowCount + kLanes * 4;
 };
 
-template <int MODE, bool STREAM>
+// ---- per-lane state ------------------------------------------------------------------------
+struct Lane {
+    double cur[kNumParams];    // only cur[0] and the kHot entries are ever touched (registers)
+    double old0, new0, oldInc, newInc, invFade;
+    double ra[kNumRes], rb[kNumRes], rc[kNumRes], z1[kNumRes], z2[kNumRes];
+    double pitchPhase, vibPhase, aspNoise, fricNoise;
+    uint32_t cnt, oldMin, newMin, newFade;
+    uint32_t resMask, nextFrame, noiseIdx, produced;
+    int32_t lastIndex;
+    bool hasNew, oldNull, newNull, done, drained;
+    bool vibFrames;            // the old or new frame has a non-zero (or NaN) vibrato depth/speed
+};
+
+// ---- one output sample from the lane's current parameters (reference :72-86, :147-180, :203-208)
+// NOISE: the wavefront holds an utterance with non-zero noise gains; waveVib: some lane may have vibrato.
+template <int MODE, bool NOISE>
+__device__ __forceinline__ uint32_t dsp_sample(Lane& s, const KernelArgs& A, uint32_t nkey, bool waveVib)
+{
+    double vib = 1.0;
+    if (waveVib) {   // wave-uniform
+        // vibrato phase advances even at zero depth; fmod(0 + p, 1) == p so zero speed is a no-op
+        const double vs = s.cur[2];
+        const double adv = frac_toward_zero(div_by(vs, A.sampleRateF, A.invSampleRate) + s.vibPhase);
+        s.vibPhase = (vs != 0.0) ? adv : s.vibPhase;
+        vib = (sin(s.vibPhase * 6.283185307179586) * 0.06 * s.cur[1]) + 1.0;
+    }
+    s.pitchPhase = frac_toward_zero(div_by(s.cur[0] * vib, A.sampleRateF, A.invSampleRate) + s.pitchPhase);
+    double voice = (s.pitchPhase * 2.0) - 1.0;
+    double src;
+    if (NOISE) {
+        s.aspNoise = noise_uniform(nkey, s.noiseIdx) + 0.75 * s.aspNoise;     // :40
+        double asp = s.aspNoise * 0.2;
+        double turb = asp * s.cur[3];
+        turb = (s.pitchPhase >= s.cur[4]) ? turb : turb * 0.01;               // glottis closed
+        voice += turb;
+        voice *= s.cur[5];
+        asp *= s.cur[6];
+        src = asp + voice;
+    } else {
+        // all noise gains are zero: turbulence and aspiration terms are exactly +0
+        src = voice * s.cur[5];
+    }
+
+    // cascade (:147-158): N0 anti-resonator (memory takes the INPUT, :133), NP mixed in by caNP, r6..r1
+    const double x = (src * s.cur[44]) * 0.5;
+    double o;
+    {
+        const double n0 = dot3<MODE>(s.ra[0], x, s.rb[0], s.z1[0], s.rc[0], s.z2[0]);
+        s.z2[0] = s.z1[0]; s.z1[0] = x;
+        const double np = dot3<MODE>(s.ra[1], n0, s.rb[1], s.z1[1], s.rc[1], s.z2[1]);
+        s.z2[1] = s.z1[1]; s.z1[1] = np;
+        o = fade_value(x, np, s.cur[23]);
+    }
+#pragma unroll
+    for (int r = 2; r < 8; ++r) {
+        const double y = dot3<MODE>(s.ra[r], o, s.rb[r], s.z1[r], s.rc[r], s.z2[r]);
+        s.z2[r] = s.z1[r]; s.z1[r] = y;
+        o = y;
+    }
+
+    double mix = o;
+    if (NOISE) {
+        // frication + parallel bank (:205-206, :170-180)
+        s.fricNoise = noise_uniform(nkey, s.noiseIdx + 1u) + 0.75 * s.fricNoise;
+        s.noiseIdx += 2u;
+        const double fric = s.fricNoise * 0.3 * s.cur[24];
+        const double y = (fric * s.cur[44]) * 0.5;
+        double par = 0.0;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            const int r = 8 + k;
+            const double w = dot3<MODE>(s.ra[r], y, s.rb[r], s.z1[r], s.rc[r], s.z2[r]);
+            s.z2[r] = s.z1[r]; s.z1[r] = w;
+            par += (w - y) * s.cur[37 + k];
+        }
+        par = fade_value(par, y, s.cur[43]);
+        mix = o + par;
+    }
+    // else: frication gain 0 => the bank's input, memories and output stay exactly 0
+
+    const double v = (mix * s.cur[45]) * 4000.0;
+    const double lo = (v < 32000.0) ? v : 32000.0;       // windows.h min(): NaN -> 32000
+    const double cl = (lo > -32000.0) ? lo : -32000.0;
+    return (uint32_t)(int)cl;                             // (int) truncates toward zero (:208)
+}
+
+// ---- one fade sample's parameter update (reference src/frame.cpp:48-53) ----------------------
+template <int MODE, bool STREAM, int NRES>
+__device__ __forceinline__ void fade_update(Lane& s, const KernelArgs& A, const double* oldP, const double* newP,
+                                            double* curFB, int lane)
+{
+    // ratio = (double)counter / numFadeSamples, correctly rounded
+    const double ratio = div_by((double)s.cnt, (double)s.newFade, s.invFade);
+    s.cur[0] = fade_value(s.old0, s.new0, ratio);
+#pragma unroll
+    for (int h = 0; h < kNumHot; ++h) {
+        const int sl = kHot[h] - 1;
+        s.cur[kHot[h]] = fade_value(oldP[sl * kLanes + lane], newP[sl * kLanes + lane], ratio);
+    }
+    // Coefficients are a pure function of (f, bw) (reference :112-127), so recomputing them whenever
+    // the pair MAY have moved equals the reference's recompute-on-change: on the first fade sample
+    // (the previous fade's last interpolated value need not equal the frame value), and afterwards
+    // for resonators whose old and new (f, bw) differ.
+    const uint32_t need = (s.cnt == 1) ? 0x3FFFu : s.resMask;
+#pragma unroll
+    for (int r = 0; r < NRES; ++r) {      // a quiet launch never runs the parallel bank (r >= 8)
+        if (need & (1u << r)) {
+            const int sf = kResF[r] - 1, sb = kResB[r] - 1;
+            const double f = fade_value(oldP[sf * kLanes + lane], newP[sf * kLanes + lane], ratio);
+            const double bw = fade_value(oldP[sb * kLanes + lane], newP[sb * kLanes + lane], ratio);
+            if (STREAM) { curFB[(2 * r) * kLanes + lane] = f; curFB[(2 * r + 1) * kLanes + lane] = bw; }
+            const Coef k = resonator_coefficients<MODE>(f, bw, r == 0, A.negPiOverSr, A.twoPiOverSr);
+            s.ra[r] = k.a; s.rb[r] = k.b; s.rc[r] = k.c;
+        }
+    }
+}
+
+// may the lane's vibrato path be live?  (frames' parameters 1 and 2; NaN compares as non-zero)
+__device__ __forceinline__ bool vib_in_frames(const double* oldP, const double* newP, int lane)
+{
+    return oldP[0 * kLanes + lane] != 0.0 || oldP[1 * kLanes + lane] != 0.0 ||
+           newP[0 * kLanes + lane] != 0.0 || newP[1 * kLanes + lane] != 0.0;
+}
+__device__ __forceinline__ bool vib_live(const Lane& s)
+{
+    return s.vibFrames || s.cur[1] != 0.0 || s.cur[2] != 0.0 || s.vibPhase != s.vibPhase;
+}
+
+// ---- an event sample: fade end, dequeue, or end of queue (reference src/frame.cpp:44-47, :54-75)
+// Called with counter already incremented.  Returns true when a sample is emitted.
+__device__ __forceinline__ bool event_step(Lane& s, const UttDesc& d, const double* myFrames, const FrameMeta* myMeta,
+                                           double* oldP, double* newP, int lane)
+{
+    if (s.hasNew) {
+        // fade finished: the new request becomes the old one (:44-47)
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) oldP[k * kLanes + lane] = newP[k * kLanes + lane];
+        s.old0 = s.new0; s.oldMin = s.newMin; s.oldInc = s.newInc; s.oldNull = s.newNull;
+        s.hasNew = false;
+        return true;
+    }
+    if (s.nextFrame >= d.nFrames) {
+        // queue empty: no current frame, generate() returns early (:74, wavegen :209-211)
+        s.done = true;
+        s.drained = true;
+        return false;
+    }
+    // dequeue (:55-72)
+    const FrameMeta m = myMeta[s.nextFrame];
+    const double* g = myFrames + (size_t)s.nextFrame * kNumParams;
+    s.nextFrame++;
+    s.newMin = m.minSamples; s.newFade = m.fadeSamples; s.newNull = (m.flags & FRAME_NULL) != 0;
+    if (s.newNull) {
+        // silence keeps the old shape with the gain gated off (:59-63)
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) newP[k * kLanes + lane] = oldP[k * kLanes + lane];
+        newP[(44 - 1) * kLanes + lane] = 0.0;
+        s.new0 = s.cur[0];
+        s.newInc = 0.0;
+        s.resMask = 0;
+    } else {
+        const double g0 = g[0];
+        const double g46 = g[46];
+#pragma unroll
+        for (int k = 0; k < kSlots; ++k) newP[k * kLanes + lane] = g[k + 1];
+        s.new0 = g0;
+        s.newInc = (g46 - g0) / (double)s.newMin;   // reference src/frame.cpp:98
+        if (s.oldNull) {
+            // coming out of silence: start from the new shape, gain 0 (:64-67)
+#pragma unroll
+            for (int k = 0; k < kSlots; ++k) oldP[k * kLanes + lane] = g[k + 1];
+            oldP[(44 - 1) * kLanes + lane] = 0.0;
+            s.old0 = g0;
+            s.resMask = 0;
+        } else {
+            uint32_t mk = 0;
+#pragma unroll
+            for (int r = 0; r < kNumRes; ++r) {
+                const double of = oldP[(kResF[r] - 1) * kLanes + lane];
+                const double ob = oldP[(kResB[r] - 1) * kLanes + lane];
+                const bool same = (g[kResF[r]] == of) && (g[kResB[r]] == ob);
+                mk |= same ? 0u : (1u << r);
+            }
+            s.resMask = mk;
+        }
+    }
+    if (m.userIndex != -1) s.lastIndex = m.userIndex;     // :69
+    s.cnt = 0;                                            // :70
+    s.new0 += s.newInc * (double)s.newFade;               // :71
+    s.invFade = 1.0 / (double)s.newFade;
+    s.hasNew = true;
+    s.vibFrames = vib_in_frames(oldP, newP, lane);
+    return true;
+}
+
+// ---- the kernel ---------------------------------------------------------------------------
+// NOISE: the launch's utterances use their noise sources and parallel bank (host splits a batch into
+// a quiet and a noisy group of wavefronts and launches each with its own instantiation).
+template <int MODE, bool STREAM, bool NOISE>
 __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
 {
     using L = LdsLayout<STREAM>;
@@ -157,7 +392,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
     double* const oldP = reinterpret_cast<double*>(lds + L::kOld);
     double* const newP = reinterpret_cast<double*>(lds + L::kNew);
     double* const curFB = reinterpret_cast<double*>(lds + L::kCurFB);
-    uint4* const tile = reinterpret_cast<uint4*>(lds + L::kTileOff);
+    unsigned char* const tile = lds + L::kTileOff;
     long long* const rowBase = reinterpret_cast<long long*>(lds + L::kRowBase);
     uint32_t* const rowCount = reinterpret_cast<uint32_t*>(lds + L::kRowCount);
 
@@ -167,306 +402,84 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
     const bool live = (u != 0xFFFFFFFFu);
 
     UttDesc d;
-    d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0;
+    d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.pad = 0;
     if (live) d = A.utt[u];
     const double* const myFrames = A.frames + d.frameStart * kNumParams;
     const FrameMeta* const myMeta = A.meta + d.frameStart;
     const uint32_t nkey = noise_key(d.seed);
 
-    // ---- per-lane state (fresh-handle values: reference src/frame.cpp:85-88,
-    //      src/speechWaveGenerator.cpp:37,52,108-109) ----
-    double cur[kNumParams];           // only cur[0] and the kHot entries are live registers
+    // ---- fresh-handle state (reference src/frame.cpp:85-88, src/speechWaveGenerator.cpp:37,52,108-109)
+    Lane s;
 #pragma unroll
-    for (int i = 0; i < kNumParams; ++i) cur[i] = 0.0;
-    double old0 = 0.0, new0 = 0.0;
-    double oldInc = 0.0, newInc = 0.0, invFade = 1.0;
-    uint32_t cnt = 0, oldMin = 0, newMin = 0, newFade = 1;
-    bool hasNew = false, oldNull = true, newNull = false;
-    int32_t lastIndex = -1;
-    uint32_t resMask = 0;
-    uint32_t nextFrame = 0;
-    uint32_t noiseIdx = 0;
-    double ra[kNumRes], rb[kNumRes], rc[kNumRes], z1[kNumRes], z2[kNumRes];
+    for (int i = 0; i < kNumParams; ++i) s.cur[i] = 0.0;
+    s.old0 = 0.0; s.new0 = 0.0; s.oldInc = 0.0; s.newInc = 0.0; s.invFade = 1.0;
+    s.cnt = 0; s.oldMin = 0; s.newMin = 0; s.newFade = 1;
+    s.hasNew = false; s.oldNull = true; s.newNull = false;
+    s.lastIndex = -1; s.resMask = 0; s.nextFrame = 0; s.noiseIdx = 0; s.produced = 0;
+    s.done = !live; s.drained = false; s.vibFrames = false;
 #pragma unroll
-    for (int r = 0; r < kNumRes; ++r) { ra[r] = 0.0; rb[r] = 2.0; rc[r] = -1.0; z1[r] = 0.0; z2[r] = 0.0; }
-    double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, fricNoise = 0.0;
+    for (int r = 0; r < kNumRes; ++r) { s.ra[r] = 0.0; s.rb[r] = 2.0; s.rc[r] = -1.0; s.z1[r] = 0.0; s.z2[r] = 0.0; }
+    s.pitchPhase = 0.0; s.vibPhase = 0.0; s.aspNoise = 0.0; s.fricNoise = 0.0;
 
 #pragma unroll
-    for (int s = 0; s < kSlots; ++s) { oldP[s * kLanes + lane] = 0.0; newP[s * kLanes + lane] = 0.0; }
+    for (int k = 0; k < kSlots; ++k) { oldP[k * kLanes + lane] = 0.0; newP[k * kLanes + lane] = 0.0; }
     if (STREAM) {
 #pragma unroll
-        for (int s = 0; s < 28; ++s) curFB[s * kLanes + lane] = 0.0;
+        for (int k = 0; k < 28; ++k) curFB[k * kLanes + lane] = 0.0;
     }
 
     if (STREAM && live && A.state) {
-        // ---- resume a stream: see save block at the end for the layout ----
+        // ---- resume a stream (layout: see the save block at the end) ----
         const double* S = A.state + (size_t)u * kStateDoubles;
-        if (S[239] != 0.0) {  // state valid
+        if (S[239] != 0.0) {
 #pragma unroll
-            for (int s = 0; s < kSlots; ++s) { oldP[s * kLanes + lane] = S[s]; newP[s * kLanes + lane] = S[45 + s]; }
+            for (int k = 0; k < kSlots; ++k) { oldP[k * kLanes + lane] = S[k]; newP[k * kLanes + lane] = S[45 + k]; }
 #pragma unroll
-            for (int s = 0; s < 28; ++s) curFB[s * kLanes + lane] = S[90 + s];
+            for (int k = 0; k < 28; ++k) curFB[k * kLanes + lane] = S[90 + k];
 #pragma unroll
-            for (int h = 0; h < 17; ++h) cur[kHot[h]] = S[118 + h];
-            old0 = S[135]; new0 = S[136]; cur[0] = S[137];
+            for (int h = 0; h < kNumHot; ++h) s.cur[kHot[h]] = S[118 + h];
+            s.old0 = S[135]; s.new0 = S[136]; s.cur[0] = S[137];
 #pragma unroll
             for (int r = 0; r < kNumRes; ++r) {
-                ra[r] = S[138 + r]; rb[r] = S[152 + r]; rc[r] = S[166 + r]; z1[r] = S[180 + r]; z2[r] = S[194 + r];
+                s.ra[r] = S[138 + r]; s.rb[r] = S[152 + r]; s.rc[r] = S[166 + r]; s.z1[r] = S[180 + r]; s.z2[r] = S[194 + r];
             }
-            pitchPhase = S[208]; vibPhase = S[209]; aspNoise = S[210]; fricNoise = S[211];
-            oldInc = S[212]; newInc = S[213]; invFade = S[214];
-            cnt = (uint32_t)S[215]; oldMin = (uint32_t)S[216]; newMin = (uint32_t)S[217]; newFade = (uint32_t)S[218];
-            uint32_t fl = (uint32_t)S[219];
-            hasNew = fl & 1; oldNull = fl & 2; newNull = fl & 4;
-            lastIndex = (int32_t)S[220]; noiseIdx = (uint32_t)S[221]; resMask = (uint32_t)S[222];
+            s.pitchPhase = S[208]; s.vibPhase = S[209]; s.aspNoise = S[210]; s.fricNoise = S[211];
+            s.oldInc = S[212]; s.newInc = S[213]; s.invFade = S[214];
+            s.cnt = (uint32_t)S[215]; s.oldMin = (uint32_t)S[216]; s.newMin = (uint32_t)S[217]; s.newFade = (uint32_t)S[218];
+            const uint32_t fl = (uint32_t)S[219];
+            s.hasNew = fl & 1; s.oldNull = fl & 2; s.newNull = fl & 4;
+            s.lastIndex = (int32_t)S[220]; s.noiseIdx = (uint32_t)S[221]; s.resMask = (uint32_t)S[222];
         }
         if (A.control && (A.control[u] & 1u)) {
             // purge (reference src/frame.cpp:103-112): cut over from the current interpolated frame
-            cnt = oldMin;
-            if (hasNew) {
-                oldNull = newNull;
-                old0 = cur[0];
+            s.cnt = s.oldMin;
+            if (s.hasNew) {
+                s.oldNull = s.newNull;
+                s.old0 = s.cur[0];
 #pragma unroll
-                for (int h = 0; h < 17; ++h) oldP[(kHot[h] - 1) * kLanes + lane] = cur[kHot[h]];
+                for (int h = 0; h < kNumHot; ++h) oldP[(kHot[h] - 1) * kLanes + lane] = s.cur[kHot[h]];
 #pragma unroll
                 for (int r = 0; r < kNumRes; ++r) {
                     oldP[(kResF[r] - 1) * kLanes + lane] = curFB[(2 * r) * kLanes + lane];
                     oldP[(kResB[r] - 1) * kLanes + lane] = curFB[(2 * r + 1) * kLanes + lane];
                 }
-                hasNew = false;
+                s.hasNew = false;
             }
         }
     }
+
+    if (STREAM) s.vibFrames = vib_in_frames(oldP, newP, lane);
 
     rowBase[lane] = d.outStart;
     rowCount[lane] = 0;
     __syncthreads();
 
-    bool done = !live;
-    bool drained = false;
-    uint32_t produced = 0;
-    uint32_t pk0 = 0, pk1 = 0, pk2 = 0, pk3 = 0;   // 8 packed samples
-    uint32_t it = 0;                               // wave-uniform sample counter of this launch
+    int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
+    uint32_t it = 0;    // wave-uniform: samples stepped by this launch (position in the output rows)
 
-    while (true) {
-        if (!done && produced >= A.maxSamples) done = true;
-        if (!__any(!done)) break;
-
-        bool emit = false;
-        if (!done) {
-            // ================= frame manager, reference src/frame.cpp:41-80 =================
-            cnt++;
-            bool fading = false;
-            if (hasNew) {
-                if (cnt > newFade) {
-                    // fade finished: the new request becomes the old one (:44-47)
-#pragma unroll
-                    for (int s = 0; s < kSlots; ++s) oldP[s * kLanes + lane] = newP[s * kLanes + lane];
-                    old0 = new0; oldMin = newMin; oldInc = newInc; oldNull = newNull;
-                    hasNew = false;
-                } else {
-                    fading = true;
-                }
-                emit = true;
-            } else if (cnt > oldMin) {
-                if (nextFrame < d.nFrames) {
-                    // dequeue (:55-72)
-                    const FrameMeta m = myMeta[nextFrame];
-                    const double* g = myFrames + (size_t)nextFrame * kNumParams;
-                    nextFrame++;
-                    newMin = m.minSamples; newFade = m.fadeSamples; newNull = (m.flags & FRAME_NULL) != 0;
-                    if (newNull) {
-                        // silence keeps the old shape with the gain gated off (:59-63)
-#pragma unroll
-                        for (int s = 0; s < kSlots; ++s) newP[s * kLanes + lane] = oldP[s * kLanes + lane];
-                        newP[(44 - 1) * kLanes + lane] = 0.0;
-                        new0 = cur[0];
-                        newInc = 0.0;
-                        resMask = 0;
-                    } else {
-                        const double g0 = g[0];
-                        const double g46 = g[46];
-#pragma unroll
-                        for (int s = 0; s < kSlots; ++s) newP[s * kLanes + lane] = g[s + 1];
-                        new0 = g0;
-                        newInc = (g46 - g0) / (double)newMin;   // reference src/frame.cpp:98
-                        if (oldNull) {
-                            // coming out of silence: start from the new shape, gain 0 (:64-67)
-#pragma unroll
-                            for (int s = 0; s < kSlots; ++s) oldP[s * kLanes + lane] = g[s + 1];
-                            oldP[(44 - 1) * kLanes + lane] = 0.0;
-                            old0 = g0;
-                            resMask = 0;
-                        } else {
-                            uint32_t mk = 0;
-#pragma unroll
-                            for (int r = 0; r < kNumRes; ++r) {
-                                const double of = oldP[(kResF[r] - 1) * kLanes + lane];
-                                const double ob = oldP[(kResB[r] - 1) * kLanes + lane];
-                                const bool same = (g[kResF[r]] == of) && (g[kResB[r]] == ob);
-                                mk |= same ? 0u : (1u << r);
-                            }
-                            resMask = mk;
-                        }
-                    }
-                    if (m.userIndex != -1) lastIndex = m.userIndex;     // :69
-                    cnt = 0;                                            // :70
-                    new0 += newInc * (double)newFade;                   // :71
-                    invFade = 1.0 / (double)newFade;
-                    hasNew = true;
-                    emit = true;
-                } else {
-                    // queue empty: no current frame, generate() returns early (:74, wavegen :209-211)
-                    done = true;
-                    drained = true;
-                }
-            } else {
-                // steady state: glide the pitch (:76-79)
-                cur[0] += oldInc;
-                old0 = cur[0];
-                emit = true;
-            }
-
-            if (fading) {
-                // interpolate (:48-53).  ratio = (double)cnt / numFadeSamples, correctly rounded
-                const double ratio = div_by((double)cnt, (double)newFade, invFade);
-                cur[0] = fade_value(old0, new0, ratio);
-#pragma unroll
-                for (int h = 0; h < 17; ++h) {
-                    const int s = kHot[h] - 1;
-                    cur[kHot[h]] = fade_value(oldP[s * kLanes + lane], newP[s * kLanes + lane], ratio);
-                }
-                // Coefficients are a pure function of (f, bw) (reference :112-127), so recomputing
-                // them whenever the pair MAY have moved is equivalent to the reference's
-                // recompute-on-change: on the first fade sample, and afterwards for resonators
-                // whose old and new (f, bw) differ.
-                const uint32_t need = (cnt == 1) ? 0x3FFFu : resMask;
-#pragma unroll
-                for (int r = 0; r < kNumRes; ++r) {
-                    if (need & (1u << r)) {
-                        const int sf = kResF[r] - 1, sb = kResB[r] - 1;
-                        const double f = fade_value(oldP[sf * kLanes + lane], newP[sf * kLanes + lane], ratio);
-                        const double bw = fade_value(oldP[sb * kLanes + lane], newP[sb * kLanes + lane], ratio);
-                        if (STREAM) { curFB[(2 * r) * kLanes + lane] = f; curFB[(2 * r + 1) * kLanes + lane] = bw; }
-                        resonator_coefficients<MODE>(f, bw, r == 0, A, ra[r], rb[r], rc[r]);
-                    }
-                }
-            }
-        }
-
-        if (emit) {
-            // ================= sources, reference src/speechWaveGenerator.cpp:72-86 =================
-            double vib = 1.0;
-            {
-                // vibrato phase advances even when its depth is 0; fmod(0 + p, 1) == p
-                const double vs = cur[2];
-                if (vs != 0.0) vibPhase = frac_toward_zero(div_by(vs, (double)A.sampleRate, A.invSampleRate) + vibPhase);
-                const double vo = cur[1];
-                if (vo != 0.0 || vibPhase != vibPhase) vib = (sin(vibPhase * 6.283185307179586) * 0.06 * vo) + 1.0;
-            }
-            pitchPhase = frac_toward_zero(div_by(cur[0] * vib, (double)A.sampleRate, A.invSampleRate) + pitchPhase);
-            double voice = pitchPhase;
-            {
-                const double un = div_by((double)noise31(nkey, noiseIdx), 2147483647.0, 0x1.00000002p-31);
-                aspNoise = un + 0.75 * aspNoise;    // :40
-            }
-            double asp = aspNoise * 0.2;
-            double turb = asp * cur[3];
-            const bool glottisOpen = voice >= cur[4];
-            if (!glottisOpen) turb *= 0.01;
-            voice = (voice * 2.0) - 1.0;
-            voice += turb;
-            voice *= cur[5];
-            asp *= cur[6];
-            const double src = asp + voice;
-
-            // ================= cascade, :147-158 =================
-            const double x = (src * cur[44]) * 0.5;
-            double o;
-            {
-                // anti-resonator N0: memory takes the INPUT (:133)
-                const double n0 = ra[0] * x + rb[0] * z1[0] + rc[0] * z2[0];
-                z2[0] = z1[0]; z1[0] = x;
-                const double np = ra[1] * n0 + rb[1] * z1[1] + rc[1] * z2[1];
-                z2[1] = z1[1]; z1[1] = np;
-                o = fade_value(x, np, cur[23]);
-            }
-#pragma unroll
-            for (int r = 2; r < 8; ++r) {
-                const double y = ra[r] * o + rb[r] * z1[r] + rc[r] * z2[r];
-                z2[r] = z1[r]; z1[r] = y;
-                o = y;
-            }
-
-            // ================= frication + parallel bank, :205-206, :170-180 =================
-            {
-                const double un = div_by((double)noise31(nkey, noiseIdx + 1u), 2147483647.0, 0x1.00000002p-31);
-                fricNoise = un + 0.75 * fricNoise;
-            }
-            noiseIdx += 2u;
-            const double fric = fricNoise * 0.3 * cur[24];
-            const double y = (fric * cur[44]) * 0.5;
-            double par = 0.0;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int r = 8 + k;
-                const double w = ra[r] * y + rb[r] * z1[r] + rc[r] * z2[r];
-                z2[r] = z1[r]; z1[r] = w;
-                par += (w - y) * cur[37 + k];
-            }
-            par = fade_value(par, y, cur[43]);
-
-            // ================= mix, clip, quantise, :207-208 =================
-            const double v = ((o + par) * cur[45]) * 4000.0;
-            const double lo = (v < 32000.0) ? v : 32000.0;       // windows.h min(): NaN -> 32000
-            const double cl = (lo > -32000.0) ? lo : -32000.0;
-            const uint32_t s16 = (uint32_t)(int)cl & 0xFFFFu;
-            produced++;
-            // pack: sample (it % 8) -> half ((it%8)&1) of word (it%8)/2   (it is wave-uniform)
-            const uint32_t sh = (it & 1u) * 16u;
-            const uint32_t w4 = (it >> 1) & 3u;
-            const uint32_t bits = s16 << sh;
-            if (w4 == 0) pk0 = sh ? (pk0 | bits) : bits;
-            else if (w4 == 1) pk1 = sh ? (pk1 | bits) : bits;
-            else if (w4 == 2) pk2 = sh ? (pk2 | bits) : bits;
-            else pk3 = sh ? (pk3 | bits) : bits;
-        }
-
-        // ---- output staging: every 8th sample a 16-byte chunk goes to the LDS tile; every
-        //      kTile samples the tile is written out as 16 B per lane, whole row segments ----
-        if ((it & 7u) == 7u) {
-            const uint32_t chunk = (it % kTile) >> 3;
-            tile[lane * (kTile / 8) + (chunk ^ (lane & (kTile / 8 - 1)))] = make_uint4(pk0, pk1, pk2, pk3);
-        }
-        it++;
-        if ((it % kTile) == 0) {
-            rowCount[lane] = produced;
-            __syncthreads();
-            const uint32_t tileStart = it - kTile;
-            constexpr int kChunksPerRow = kTile / 8;
-            constexpr int kRowsPerPass = kLanes / kChunksPerRow;
-#pragma unroll
-            for (int p = 0; p < kLanes / kRowsPerPass; ++p) {
-                const int row = p * kRowsPerPass + lane / kChunksPerRow;
-                const int chunk = lane % kChunksPerRow;
-                const uint4 val = tile[row * kChunksPerRow + (chunk ^ (row & (kChunksPerRow - 1)))];
-                if (rowCount[row] > tileStart) {
-                    uint4* dst = reinterpret_cast<uint4*>(A.pcm + rowBase[row] + tileStart + chunk * 8);
-                    *dst = val;
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- flush the last, partial tile ----
-    if ((it % kTile) != 0) {
-        const uint32_t tileStart = it - (it % kTile);
-        if ((it & 7u) != 0u) {
-            const uint32_t chunk = (it % kTile) >> 3;
-            tile[lane * (kTile / 8) + (chunk ^ (lane & (kTile / 8 - 1)))] = make_uint4(pk0, pk1, pk2, pk3);
-        }
-        rowCount[lane] = produced;
+    // write out tile rows: 16 B per lane; lane -> (row, chunk), kTile/8 chunks per row
+    auto flush_tile = [&](uint32_t tileStart, uint32_t validTo) __attribute__((always_inline)) {
+        rowCount[lane] = s.produced;
         __syncthreads();
         constexpr int kChunksPerRow = kTile / 8;
         constexpr int kRowsPerPass = kLanes / kChunksPerRow;
@@ -474,38 +487,107 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
         for (int p = 0; p < kLanes / kRowsPerPass; ++p) {
             const int row = p * kRowsPerPass + lane / kChunksPerRow;
             const int chunk = lane % kChunksPerRow;
-            const uint4 val = tile[row * kChunksPerRow + (chunk ^ (row & (kChunksPerRow - 1)))];
-            if (rowCount[row] > tileStart + (uint32_t)chunk * 8u) {
-                uint4* dst = reinterpret_cast<uint4*>(A.pcm + rowBase[row] + tileStart + chunk * 8);
-                *dst = val;
+            const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
+            const uint2 lo = src[0], hi = src[1];
+            const uint32_t first = tileStart + (uint32_t)chunk * 8u;
+            if (rowCount[row] > first && first < validTo) {
+                uint4* dst = reinterpret_cast<uint4*>(A.pcm + rowBase[row] + first);
+                *dst = make_uint4(lo.x, lo.y, hi.x, hi.y);
             }
+        }
+        __syncthreads();
+    };
+
+    // one general step: per lane an event, fade or steady sample
+    auto general_step = [&]() __attribute__((always_inline)) {
+        bool emit = false;
+        if (!s.done) {
+            s.cnt++;
+            const bool fading = s.hasNew && s.cnt <= s.newFade;
+            const bool steady = !s.hasNew && s.cnt <= s.oldMin;
+            if (fading) {
+                fade_update<MODE, STREAM, (NOISE ? kNumRes : 8)>(s, A, oldP, newP, curFB, lane);
+                emit = true;
+            } else if (steady) {
+                s.cur[0] += s.oldInc;          // glide the pitch (reference src/frame.cpp:76-79)
+                s.old0 = s.cur[0];
+                emit = true;
+            } else {
+                emit = event_step(s, d, myFrames, myMeta, oldP, newP, lane);
+            }
+        }
+        const bool waveVib = __any(emit && vib_live(s));
+        if (emit) {
+            myRow[it % kTile] = (int16_t)dsp_sample<MODE, NOISE>(s, A, nkey, waveVib);
+            s.produced++;
+        }
+        it++;
+    };
+
+    // kBlock branch-free samples; KIND 0 = every live lane steady, 1 = every live lane fading
+    auto block_run = [&](auto kindTag) __attribute__((always_inline)) {
+        constexpr int KIND = decltype(kindTag)::value;
+        const uint32_t tpos = it % kTile;
+        if (!s.done) {
+#pragma nounroll
+            for (int i = 0; i < kBlock; ++i) {
+                s.cnt++;
+                if (KIND == 0) { s.cur[0] += s.oldInc; s.old0 = s.cur[0]; }
+                else fade_update<MODE, STREAM, (NOISE ? kNumRes : 8)>(s, A, oldP, newP, curFB, lane);
+                myRow[tpos + i] = (int16_t)dsp_sample<MODE, NOISE>(s, A, nkey, false);
+            }
+            s.produced += kBlock;
+        }
+        it += kBlock;
+    };
+
+    {
+        while (true) {
+            if (STREAM && !s.done && s.produced >= A.maxSamples) s.done = true;
+            if (!__any(!s.done)) break;
+            // samples left in the lane's current stretch (0 = the next sample is an event)
+            uint32_t rem = s.hasNew ? (s.newFade - s.cnt) : (s.oldMin > s.cnt ? s.oldMin - s.cnt : 0u);
+            if (STREAM) rem = min(rem, A.maxSamples - s.produced);
+            const bool roomy = s.done || rem >= (uint32_t)kBlock;
+            const bool fits = (it % kTile) + kBlock <= (uint32_t)kTile;
+            int kind = -1;
+            if (fits && __all(roomy) && !__any(!s.done && vib_live(s))) {
+                if (!__any(!s.done && s.hasNew)) kind = 0;
+                else if (!__any(!s.done && !s.hasNew)) kind = 1;
+            }
+            if (kind == 0) block_run(std::integral_constant<int, 0>());
+            else if (kind == 1) block_run(std::integral_constant<int, 1>());
+            else general_step();
+            if ((it % kTile) == 0) flush_tile(it - kTile, it);
         }
     }
 
+    if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
+
     if (live) {
         UttResult res;
-        res.produced = produced; res.framesTaken = nextFrame; res.lastIndex = lastIndex; res.drained = drained ? 1u : 0u;
+        res.produced = s.produced; res.framesTaken = s.nextFrame; res.lastIndex = s.lastIndex; res.drained = s.drained ? 1u : 0u;
         A.result[u] = res;
     }
 
     if (STREAM && live && A.state) {
         double* S = A.state + (size_t)u * kStateDoubles;
 #pragma unroll
-        for (int s = 0; s < kSlots; ++s) { S[s] = oldP[s * kLanes + lane]; S[45 + s] = newP[s * kLanes + lane]; }
+        for (int k = 0; k < kSlots; ++k) { S[k] = oldP[k * kLanes + lane]; S[45 + k] = newP[k * kLanes + lane]; }
 #pragma unroll
-        for (int s = 0; s < 28; ++s) S[90 + s] = curFB[s * kLanes + lane];
+        for (int k = 0; k < 28; ++k) S[90 + k] = curFB[k * kLanes + lane];
 #pragma unroll
-        for (int h = 0; h < 17; ++h) S[118 + h] = cur[kHot[h]];
-        S[135] = old0; S[136] = new0; S[137] = cur[0];
+        for (int h = 0; h < kNumHot; ++h) S[118 + h] = s.cur[kHot[h]];
+        S[135] = s.old0; S[136] = s.new0; S[137] = s.cur[0];
 #pragma unroll
         for (int r = 0; r < kNumRes; ++r) {
-            S[138 + r] = ra[r]; S[152 + r] = rb[r]; S[166 + r] = rc[r]; S[180 + r] = z1[r]; S[194 + r] = z2[r];
+            S[138 + r] = s.ra[r]; S[152 + r] = s.rb[r]; S[166 + r] = s.rc[r]; S[180 + r] = s.z1[r]; S[194 + r] = s.z2[r];
         }
-        S[208] = pitchPhase; S[209] = vibPhase; S[210] = aspNoise; S[211] = fricNoise;
-        S[212] = oldInc; S[213] = newInc; S[214] = invFade;
-        S[215] = (double)cnt; S[216] = (double)oldMin; S[217] = (double)newMin; S[218] = (double)newFade;
-        S[219] = (double)((hasNew ? 1u : 0u) | (oldNull ? 2u : 0u) | (newNull ? 4u : 0u));
-        S[220] = (double)lastIndex; S[221] = (double)noiseIdx; S[222] = (double)resMask;
+        S[208] = s.pitchPhase; S[209] = s.vibPhase; S[210] = s.aspNoise; S[211] = s.fricNoise;
+        S[212] = s.oldInc; S[213] = s.newInc; S[214] = s.invFade;
+        S[215] = (double)s.cnt; S[216] = (double)s.oldMin; S[217] = (double)s.newMin; S[218] = (double)s.newFade;
+        S[219] = (double)((s.hasNew ? 1u : 0u) | (s.oldNull ? 2u : 0u) | (s.newNull ? 4u : 0u));
+        S[220] = (double)s.lastIndex; S[221] = (double)s.noiseIdx; S[222] = (double)s.resMask;
         S[239] = 1.0;
     }
 }

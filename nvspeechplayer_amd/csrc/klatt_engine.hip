@@ -73,6 +73,7 @@ KernelArgs base_args(int sampleRate)
     KernelArgs a;
     memset(&a, 0, sizeof a);
     a.sampleRate = sampleRate;
+    a.sampleRateF = (double)sampleRate;
     a.invSampleRate = 1.0 / (double)sampleRate;
     a.negPiOverSr = -M_PI / sampleRate;          // reference src/speechWaveGenerator.cpp:116
     a.twoPiOverSr = (M_PI * 2) / sampleRate;     // reference src/speechWaveGenerator.cpp:31,118
@@ -80,27 +81,30 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool STREAM>
+template <bool STREAM, bool NOISE>
 int launch(const KernelArgs& a, int mode, long long nWaves, hipStream_t stream)
 {
     if (nWaves <= 0) return 0;
     if (nWaves > 0x7FFFFFFF) { set_error("too many wavefronts: %lld", nWaves); return -1; }
     constexpr int ldsBytes = LdsLayout<STREAM>::kBytes;
-    switch (mode) {
-    case MODE_EXACT: {
-        auto k = klatt_synthesize<MODE_EXACT, STREAM>;
-        static bool attrSet = false;
+    auto go = [&](auto kernel, bool& attrSet) -> int {
         if (!attrSet) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
             attrSet = true;
         }
-        hipLaunchKernelGGL(k, dim3((unsigned)nWaves), dim3(kLanes), ldsBytes, stream, a);
-        break;
-    }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nWaves), dim3(kLanes), ldsBytes, stream, a);
+        return 0;
+    };
+    static bool attrExact = false, attrFast = false;
+    int rc;
+    switch (mode) {
+    case MODE_EXACT: rc = go(klatt_synthesize<MODE_EXACT, STREAM, NOISE>, attrExact); break;
+    case MODE_FAST: rc = go(klatt_synthesize<MODE_FAST, STREAM, NOISE>, attrFast); break;
     default:
         set_error("unknown arithmetic mode %d", mode);
         return -1;
     }
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -131,7 +135,10 @@ struct Batch {
     int mode = MODE_EXACT;
     int sortByLength = 1;
     hipStream_t stream = nullptr;
+    hipStream_t sideStream = nullptr;      // the quiet group runs beside the noisy one
+    hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
     long long nUtt = 0, nFrames = 0, nSlots = 0;
+    long long nQuiet = 0;                  // order[0..nQuiet) = utterances without noise, the rest with
     long long totalSamples = 0, poolSamples = 0;
     std::vector<uint32_t> lens;
     std::vector<long long> outStart;   // padded offsets in the device pool
@@ -148,11 +155,29 @@ struct Batch {
 int batch_launch(Batch* b)
 {
     KernelArgs a = base_args(b->sampleRate);
-    a.frames = b->dFrames.ptr; a.meta = b->dMeta.ptr; a.utt = b->dUtt.ptr; a.order = b->dOrder.ptr;
+    a.frames = b->dFrames.ptr; a.meta = b->dMeta.ptr; a.utt = b->dUtt.ptr;
     a.pcm = b->dPcm.ptr; a.result = b->dResult.ptr; a.state = nullptr; a.control = nullptr;
-    a.nSlots = b->nSlots;
     b->resultsFresh = false;
-    return launch<false>(a, b->mode, (b->nSlots + kLanes - 1) / kLanes, b->stream);
+    const long long nNoisy = b->nSlots - b->nQuiet;
+    const bool both = b->nQuiet > 0 && nNoisy > 0;
+    if (b->nQuiet > 0) {
+        // quiet group: no noise sources, no parallel bank.  Beside a noisy group it runs on the side stream.
+        hipStream_t st = b->stream;
+        if (both) {
+            HIP_TRY(hipEventRecord(b->forkEvent, b->stream));
+            HIP_TRY(hipStreamWaitEvent(b->sideStream, b->forkEvent, 0));
+            st = b->sideStream;
+        }
+        a.order = b->dOrder.ptr; a.nSlots = b->nQuiet;
+        if (launch<false, false>(a, b->mode, (b->nQuiet + kLanes - 1) / kLanes, st)) return -1;
+        if (both) HIP_TRY(hipEventRecord(b->joinEvent, b->sideStream));
+    }
+    if (nNoisy > 0) {
+        a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
+        if (launch<false, true>(a, b->mode, (nNoisy + kLanes - 1) / kLanes, b->stream)) return -1;
+        if (both) HIP_TRY(hipStreamWaitEvent(b->stream, b->joinEvent, 0));
+    }
+    return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -244,7 +269,7 @@ int stream_synthesize(Stream* s, unsigned int count, sample* out)
     a.pcm = s->dPcm.ptr; a.result = s->dResult.ptr; a.state = s->dState.ptr; a.control = s->dControl.ptr;
     a.nSlots = 1;
     a.maxSamples = count;
-    if (launch<true>(a, s->mode, 1, s->stream)) return -1;
+    if (launch<true, true>(a, s->mode, 1, s->stream)) return -1;
 
     UttResult r;
     HIP_TRY(hipMemcpyAsync(&r, s->dResult.ptr, sizeof r, hipMemcpyDeviceToHost, s->stream));
@@ -355,7 +380,10 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     Batch* b = new Batch;
     b->sampleRate = sampleRate;
     b->device = dev;
-    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&b->sideStream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->joinEvent, hipEventDisableTiming) != hipSuccess) {
         set_error("cannot create a stream on device %d", dev);
         delete b;
         return nullptr;
@@ -369,6 +397,9 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
+    if (b->sideStream) { (void)hipStreamSynchronize(b->sideStream); (void)hipStreamDestroy(b->sideStream); }
+    if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
+    if (b->joinEvent) (void)hipEventDestroy(b->joinEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     delete b;
 }
@@ -378,7 +409,7 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     Batch* b = static_cast<Batch*>(batch);
     if (!b || !name) return -1;
     if (!strcmp(name, "mode")) {
-        if (value != MODE_EXACT) { set_error("mode %d not available", value); return -1; }
+        if (value != MODE_EXACT && value != MODE_FAST) { set_error("mode %d not available", value); return -1; }
         b->mode = value;
         return 0;
     }
@@ -429,6 +460,18 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         utt[u].outStart = pool;
         utt[u].nFrames = (uint32_t)(frameStart[u + 1] - frameStart[u]);
         utt[u].seed = noiseSeed ? noiseSeed[u] : (uint32_t)u;
+        // Noise sources and the parallel bank can be skipped for an utterance only if every frame has
+        // all three noise gains exactly zero (voiceTurbulenceAmplitude, aspirationAmplitude,
+        // fricationAmplitude) and no non-finite parameter that could turn 0*x into NaN.
+        bool needsNoise = false;
+        for (long long k = frameStart[u]; k < frameStart[u + 1] && !needsNoise; ++k) {
+            if (meta[k].flags & FRAME_NULL) continue;
+            const double* p = reinterpret_cast<const double*>(frames + k);
+            if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) needsNoise = true;
+            for (int i = 0; i < kNumParams && !needsNoise; ++i)
+                if (!std::isfinite(p[i])) needsNoise = true;
+        }
+        utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : 0u;
         total += (long long)len;
         pool += ((long long)len + kTile - 1) / kTile * kTile;
     }
@@ -436,10 +479,16 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     b->totalSamples = total;
     b->poolSamples = pool;
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
+    // (within the quiet group and within the noisy group, which are launched as separate kernels)
     std::vector<uint32_t> order((size_t)nUtterances);
     std::iota(order.begin(), order.end(), 0u);
-    if (b->sortByLength)
-        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return b->lens[x] > b->lens[y]; });
+    auto quietEnd = std::stable_partition(order.begin(), order.end(), [&](uint32_t x) { return !(utt[x].flags & UTT_NEEDS_NOISE); });
+    b->nQuiet = quietEnd - order.begin();
+    if (b->sortByLength) {
+        auto longer = [&](uint32_t x, uint32_t y) { return b->lens[x] > b->lens[y]; };
+        std::stable_sort(order.begin(), quietEnd, longer);
+        std::stable_sort(quietEnd, order.end(), longer);
+    }
     b->nSlots = nUtterances;
 
     if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>(nF, 1)) ||
@@ -576,15 +625,20 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     if (!b || !info || nInfo < 6) return -1;
     HIP_TRY(hipSetDevice(b->device));
     hipFuncAttributes fa;
-    HIP_TRY(hipFuncGetAttributes(&fa, reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false>)));
+    const bool noisy = b->nSlots - b->nQuiet >= b->nQuiet;   // report the larger group's kernel
+    const void* fn = b->mode == MODE_FAST
+        ? (noisy ? reinterpret_cast<const void*>(klatt_synthesize<MODE_FAST, false, true>) : reinterpret_cast<const void*>(klatt_synthesize<MODE_FAST, false, false>))
+        : (noisy ? reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false, true>) : reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false, false>));
+    HIP_TRY(hipFuncGetAttributes(&fa, fn));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, b->device));
     info[0] = fa.numRegs;
     info[1] = LdsLayout<false>::kBytes;
-    info[2] = (int)((b->nSlots + kLanes - 1) / kLanes);
+    info[2] = (int)((b->nQuiet + kLanes - 1) / kLanes + (b->nSlots - b->nQuiet + kLanes - 1) / kLanes);
     info[3] = prop.multiProcessorCount;
     info[4] = (int)(prop.sharedMemPerMultiprocessor / LdsLayout<false>::kBytes);
     info[5] = (int)fa.localSizeBytes;   // scratch; must be 0
+    if (nInfo >= 8) { info[6] = (int)((b->nQuiet + kLanes - 1) / kLanes); info[7] = noisy ? 1 : 0; }
     return 0;
 }
 

@@ -99,13 +99,15 @@ def make_batch(sel):
                 seeds=np.array(seeds, np.uint32))
 
 
-def test_batch_all_scenarios(all_scenarios):
+@pytest.mark.parametrize("mode", [0, 1])
+def test_batch_all_scenarios(all_scenarios, mode):
     """Every batchable scenario (vowels, all sampleIpa cases, vibrato, NaN hold, duration edges)
-    as ONE ragged batch through speechPlayer_batch_*; each utterance must equal a fresh oracle player."""
+    as ONE ragged batch through speechPlayer_batch_*; each utterance must equal a fresh oracle player.
+    mode 0 = MODE_EXACT, mode 1 = MODE_FAST (fused multiply-adds, straight-line exp/cos): same bar."""
     import nvspeechplayer_amd as eng
     sel = [s for s in all_scenarios if s.batchable and s.sr == 22050]
     batch = make_batch(sel)
-    bp = eng.BatchPlayer(22050)
+    bp = eng.BatchPlayer(22050, mode=mode)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
                      batch["isnull"], batch["seeds"])
     exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=4)
@@ -117,7 +119,7 @@ def test_batch_all_scenarios(all_scenarios):
     for i, s in enumerate(sel):
         flips += compare(got[got_start[i]:got_start[i + 1]], exp[exp_start[i]:exp_start[i + 1]], s.name)
         assert np.array_equal(bp.read(i), got[got_start[i]:got_start[i + 1]])
-    print("batch of %d utterances, %d samples: %d one-LSB differences" % (len(sel), total, flips))
+    print("mode %d: batch of %d utterances, %d samples: %d one-LSB differences" % (mode, len(sel), total, flips))
     # unsorted lane packing gives the same PCM
     bp.setOption("sort", 0)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],

@@ -21,6 +21,8 @@ __global__ void probe(unsigned long long* out, int iters, int activeLanes, doubl
     if (lane < activeLanes) {
         t0 = __builtin_amdgcn_s_memtime();
         for (int i = 0; i < iters; ++i) {
+#pragma unroll
+          for (int rep = 0; rep < 8; ++rep) {
             if (KIND == 0) {  // v_fma_f64
                 a0 = __builtin_fma(a0, m, c); a1 = __builtin_fma(a1, m, c); a2 = __builtin_fma(a2, m, c); a3 = __builtin_fma(a3, m, c);
                 a4 = __builtin_fma(a4, m, c); a5 = __builtin_fma(a5, m, c); a6 = __builtin_fma(a6, m, c); a7 = __builtin_fma(a7, m, c);
@@ -48,6 +50,7 @@ __global__ void probe(unsigned long long* out, int iters, int activeLanes, doubl
                 }
                 f0 = p0.x; f1 = p0.y; f2 = p1.x; f3 = p1.y; f4 = p2.x; f5 = p2.y; f6 = p3.x; f7 = p3.y;
             }
+          }
         }
         t1 = __builtin_amdgcn_s_memtime();
     }
@@ -59,19 +62,28 @@ __global__ void probe(unsigned long long* out, int iters, int activeLanes, doubl
 template <int KIND>
 int run(const char* name, int wavesPerSimd, int activeLanes, unsigned long long* dOut)
 {
-    const int iters = 20000;
+    const int iters = 4000;
     const int block = 64 * 4 * wavesPerSimd;  // one workgroup fills every SIMD of its CU with wavesPerSimd waves
     const int grid = 256;
-    probe<KIND><<<grid, block>>>(dOut, iters, activeLanes, 1.0);
+    probe<KIND><<<grid, block>>>(dOut, 10, activeLanes, 1.0);
     CHECK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    CHECK(hipEventRecord(e0));
+    probe<KIND><<<grid, block>>>(dOut, iters, activeLanes, 1.0);
+    CHECK(hipEventRecord(e1));
+    CHECK(hipDeviceSynchronize());
+    float msec = 0; CHECK(hipEventElapsedTime(&msec, e0, e1));
     std::vector<unsigned long long> h(grid * block / 64);
     CHECK(hipMemcpy(h.data(), dOut, h.size() * 8, hipMemcpyDeviceToHost));
     double mean = 0;
     for (auto v : h) mean += (double)v;
     mean /= h.size();
     // s_memtime ticks at 100 MHz on this part? report both raw ticks and per-instruction
-    printf("%-28s waves/SIMD=%d lanes=%2d : %.3f ticks per wave-instruction (x8 instr/iter)\n", name, wavesPerSimd, activeLanes,
-           mean / (iters * 8.0));
+    const double instr = (double)iters * 64.0;   // wave-instructions per wave
+    const double nsPerInstrPerSimd = msec * 1e6 / (instr * wavesPerSimd);
+    printf("%-22s waves/SIMD=%d lanes=%2d : %6.3f memtime ticks/instr/wave, %6.3f ns per instr per SIMD (=%5.2f cyc @2.4GHz), kernel %.3f ms\n",
+           name, wavesPerSimd, activeLanes, mean / instr, nsPerInstrPerSimd, nsPerInstrPerSimd * 2.4, msec);
     return 0;
 }
 

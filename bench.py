@@ -74,6 +74,7 @@ def main():
     import torch  # first: its HIP runtime is then the one the engine library binds to
     import numpy as np
     from nvspeechplayer_amd import BatchPlayer, workloads
+    from nvspeechplayer_amd.sharding import reduce_throughput
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
@@ -104,15 +105,7 @@ def main():
     kernel_ms = bp.time(args.steps)          # K launches, each between two HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        tot = torch.tensor([float(samples)], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
-        total_samples = float(tot.item())
-    else:
-        total_samples = float(samples)
+    elapsed, total_samples = reduce_throughput(elapsed, samples, dist, device="cuda")   # max / sum over ranks
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))

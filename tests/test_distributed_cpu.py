@@ -1,0 +1,56 @@
+"""The N > 1 path on CPU: two gloo ranks shard one batch by sample count, synthesise their shards
+(the oracle stands in for the GPU kernel here -- this test is about the host logic), and the
+reductions bench.py uses give the whole-job numbers.  No data-path collective exists to test."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from nvspeechplayer_amd import workloads
+    from nvspeechplayer_amd.sharding import reduce_throughput, shard_bounds
+    from tests import oracle
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    batch = workloads.make("cfg3", 24)
+    bounds = shard_bounds(batch.sample_counts(), world)
+    mine = batch.slice(int(bounds[rank]), int(bounds[rank + 1] - bounds[rank]))
+    pcm, out_start, total = oracle.batch_synthesize(batch["sr"], mine, threads=1)
+    elapsed, samples = reduce_throughput(1.0 + rank, total, dist)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), pcm=pcm, bounds=bounds, elapsed=elapsed, samples=samples,
+             total=total)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_sharding_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    from nvspeechplayer_amd import workloads
+    from tests import oracle
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    batch = workloads.make("cfg3", 24)
+    full, _, total = oracle.batch_synthesize(batch["sr"], batch, threads=2)
+    parts = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+    assert np.array_equal(np.concatenate([p["pcm"] for p in parts]), full)       # shards are disjoint and cover
+    for p in parts:
+        assert float(p["elapsed"]) == 2.0                                        # max over ranks
+        assert float(p["samples"]) == float(total)                               # sum over ranks
+    assert int(parts[0]["total"]) + int(parts[1]["total"]) == total

@@ -1,0 +1,102 @@
+"""CPU-side checks: the C-ABI library builds, loads and exports what the headers declare; the
+arithmetic helpers the kernel relies on are exact; workload recipes and sharding are consistent."""
+import json
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions(header):
+    text = open(os.path.join(ROOT, "include", header)).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(speechPlayer_[A-Za-z_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from nvspeechplayer_amd import _native
+    _native.build()
+    lib = _native.load()
+    names = declared_functions("speechPlayer.h") + declared_functions("speechPlayer_batch.h")
+    assert len(names) >= 21
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(names) <= set(_native.EXPORTS)
+
+
+def test_frame_struct_is_47_doubles():
+    import ctypes
+    from nvspeechplayer_amd import Frame
+    assert ctypes.sizeof(Frame) == 376
+    f = Frame.from_array(np.arange(47.0))
+    assert f.voicePitch == 0.0 and f.endVoicePitch == 46.0 and f.cfN0 == 13.0 and f.preFormantGain == 44.0
+    assert np.array_equal(f.as_array(), np.arange(47.0))
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """In this container there is no GPU: the product must refuse, not synthesise on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import nvspeechplayer_amd as eng
+    with pytest.raises(RuntimeError, match="no HIP device|failed"):
+        eng.SpeechPlayer(22050)
+    with pytest.raises(RuntimeError):
+        eng.BatchPlayer(22050)
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "nvspeechplayer_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "klatt_oracle" not in text.replace("restated by oracle/klatt_oracle.c", ""), f
+                assert "from tests" not in text and "import tests" not in text, f
+
+
+def test_kernel_arithmetic_helpers_on_host(tmp_path):
+    """Markstein division == '/', fast_exp / fast_cos within 1 ulp of libm (tests/native/check_math.cpp)."""
+    exe = str(tmp_path / "check_math")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", exe,
+                           os.path.join(ROOT, "tests", "native", "check_math.cpp")])
+    out = json.loads(subprocess.check_output([exe]).decode())
+    assert out["div_checked"] > 5e7 and out["div_bad"] == 0
+    assert out["exp_max_ulp"] <= 1 and out["cos_max_ulp"] <= 1
+    assert out["exp_wide_max_ulp"] <= 1 and out["cos_wide_max_ulp"] <= 2
+    assert out["exp0"] == 1.0 and out["cos0"] == 1.0
+
+
+def test_workload_recipes():
+    from nvspeechplayer_amd import workloads
+    b = workloads.make("cfg1", 64)
+    assert b.n_utt == 64 and len(b["min"]) == 128
+    assert np.all(b.sample_counts() == 22051 + 1104)          # (max(22050,1103)+1) + (max(1102,1103)+1)
+    assert b.algorithmic_bytes() == 2 * 64 * 23155 + 388 * 128
+    assert b["frames"][0][44] == 1.0 and b["frames"][0][45] == 1.0 and b["frames"][0][5] == 1.0
+    assert 79.9 < b["frames"][0][0] < 80.1 and b["frames"][0][0] == b["frames"][0][46]
+    c = workloads.make("cfg2", 16)
+    assert list(c.sample_counts()[:8]) == [8273, 29374, 29218, 20745, 12907, 41238, 13459, 29788]
+    assert np.array_equal(c.sample_counts()[:8], c.sample_counts()[8:16])      # pitch variants keep the timing
+    d = workloads.make("cfg3", 8)
+    assert np.all(d.sample_counts() <= 11025 + 2000)
+    s = c.slice(3, 5)
+    assert s.n_utt == 5 and np.array_equal(s.sample_counts(), c.sample_counts()[3:8])
+
+
+def test_shard_bounds():
+    from nvspeechplayer_amd.sharding import shard_bounds
+    rng = np.random.default_rng(0)
+    counts = rng.integers(1000, 40000, size=1000)
+    for world in (1, 2, 4, 8):
+        b = shard_bounds(counts, world)
+        assert b[0] == 0 and b[-1] == 1000 and np.all(np.diff(b) >= 0) and len(b) == world + 1
+        per = [counts[b[r]:b[r + 1]].sum() for r in range(world)]
+        assert max(per) - min(per) <= 2 * counts.max()
+    assert list(shard_bounds([], 4)) == [0, 0, 0, 0, 0]
+    assert list(shard_bounds([5], 2)) in ([0, 0, 1], [0, 1, 1])

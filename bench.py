@@ -37,6 +37,7 @@ def parse():
     ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg2", "cfg3"])
     ap.add_argument("--utterances", type=int, default=0, help="override the batch size per GPU")
     ap.add_argument("--mode", type=int, default=0, help="arithmetic mode (include/speechPlayer_batch.h)")
+    ap.add_argument("--layout", type=int, default=1, help="1: stage-parallel workgroups, 0: one wavefront per 64 utterances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
     return ap.parse_args()
@@ -86,7 +87,7 @@ def main():
 
     n_utt = args.utterances or {"cfg1": 4096, "cfg2": 65536, "cfg3": 131072}[args.workload]
     batch = workloads.make(args.workload, n_utt, first=rank * n_utt)
-    bp = BatchPlayer(batch["sr"], device=local_rank, mode=args.mode)
+    bp = BatchPlayer(batch["sr"], device=local_rank, mode=args.mode, layout=args.layout)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
                      batch["isnull"], batch["seeds"])
     samples = bp.totalSamples
@@ -126,7 +127,7 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": batch["name"], "utterances_per_gpu": n_utt, "samples_per_gpu": int(samples),
-                       "frames_per_gpu": int(bp.totalFrames), "sample_rate": batch["sr"], "mode": args.mode,
+                       "frames_per_gpu": int(bp.totalFrames), "sample_rate": batch["sr"], "mode": args.mode, "layout": args.layout,
                        "parallelism": "utterances sharded over %d GPU(s), no collective" % world},
             "realtime_factor": total_samples * args.steps / elapsed / batch["sr"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

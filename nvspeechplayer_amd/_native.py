@@ -14,7 +14,7 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libspeechPlayer.so")
 SOURCES = ["klatt_engine.hip"]
-HEADERS = ["klatt_device.h", os.path.join("..", "..", "include", "speechPlayer.h"),
+HEADERS = ["klatt_device.h", "klatt_systolic.h", "klatt_math.h", os.path.join("..", "..", "include", "speechPlayer.h"),
            os.path.join("..", "..", "include", "speechPlayer_batch.h")]
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
                "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib"]
@@ -68,10 +68,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("SPEECHPLAYER_LIB", LIB_PATH)     # A/B builds of the same ABI (tools/)
+    if not os.path.exists(path):
         raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
-                           "(the engine has no CPU fallback)" % LIB_PATH)
-    L = ctypes.CDLL(LIB_PATH)
+                           "(the engine has no CPU fallback)" % path)
+    L = ctypes.CDLL(path)
     vp, u32, i32, i64 = ctypes.c_void_p, ctypes.c_uint, ctypes.c_int, ctypes.c_longlong
     L.speechPlayer_initialize.restype = vp
     L.speechPlayer_initialize.argtypes = [i32]

@@ -63,7 +63,7 @@ struct UttDesc {             // 32 B per utterance
     uint32_t nFrames;
     uint32_t seed;
     uint32_t flags;          // UTT_NEEDS_NOISE: some frame has a non-zero (or non-finite) noise gain
-    uint32_t pad;
+    uint32_t length;         // samples this utterance produces (closed form, host-computed)
 };
 
 struct UttResult {           // written by the kernel
@@ -89,6 +89,7 @@ struct KernelArgs {
     double invSampleRate;        // RN(1/sr)
     double negPiOverSr;          // -pi/sr     (reference src/speechWaveGenerator.cpp:116)
     double twoPiOverSr;          // (2*pi)/sr  (reference src/speechWaveGenerator.cpp:118)
+    unsigned long long* debug;   // diagnostic builds only (KLATT_STAMPS): per-wave cycle sums; nullptr otherwise
 };
 
 // resonator r reads frequency parameter kResF[r] and bandwidth parameter kResB[r]
@@ -145,7 +146,7 @@ __device__ __forceinline__ double dot3(double a, double x, double b, double y, d
 // reference src/speechWaveGenerator.cpp:112-127
 struct Coef { double a, b, c; };
 template <int MODE>
-__device__ __attribute__((noinline)) Coef resonator_coefficients(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr)
+__device__ __forceinline__ Coef resonator_coefficients_inline(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr)
 {
     const double ex = negPiOverSr * bw;
     const double th = twoPiOverSr * -f;
@@ -168,6 +169,12 @@ __device__ __attribute__((noinline)) Coef resonator_coefficients(double f, doubl
     }
     Coef k; k.a = aa; k.b = bb; k.c = cc;
     return k;
+}
+// out-of-line copy for the lane kernel, whose 14 call sites would otherwise each inline exp and cos
+template <int MODE>
+__device__ __attribute__((noinline)) Coef resonator_coefficients(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr)
+{
+    return resonator_coefficients_inline<MODE>(f, bw, anti, negPiOverSr, twoPiOverSr);
 }
 
 // LDS per workgroup (one wavefront):
@@ -402,7 +409,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
     const bool live = (u != 0xFFFFFFFFu);
 
     UttDesc d;
-    d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.pad = 0;
+    d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
     const double* const myFrames = A.frames + d.frameStart * kNumParams;
     const FrameMeta* const myMeta = A.meta + d.frameStart;

@@ -8,6 +8,7 @@
 //   the additive batch entry points    (N independent streams per launch).
 // There is no CPU synthesis path in this library: without a HIP device every entry point fails.
 #include "klatt_device.h"
+#include "klatt_systolic.h"
 
 #include <algorithm>
 #include <cmath>
@@ -81,6 +82,21 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
+template <bool NOISE>
+int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
+{
+    if (nGroups <= 0) return 0;
+    if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
+    constexpr int ldsBytes = SysLds::kBytes;
+    switch (mode) {
+    case MODE_EXACT: hipLaunchKernelGGL((klatt_systolic<MODE_EXACT, NOISE>), dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a); break;
+    case MODE_FAST: hipLaunchKernelGGL((klatt_systolic<MODE_FAST, NOISE>), dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a); break;
+    default: set_error("unknown arithmetic mode %d", mode); return -1;
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 template <bool STREAM, bool NOISE>
 int launch(const KernelArgs& a, int mode, long long nWaves, hipStream_t stream)
 {
@@ -134,6 +150,7 @@ struct Batch {
     int device = 0;
     int mode = MODE_EXACT;
     int sortByLength = 1;
+    int layout = 1;                        // 1: stage-parallel workgroups (klatt_systolic.h); 0: one wave per 64 utterances
     hipStream_t stream = nullptr;
     hipStream_t sideStream = nullptr;      // the quiet group runs beside the noisy one
     hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
@@ -150,6 +167,7 @@ struct Batch {
     DeviceBuffer<uint32_t> dOrder;
     DeviceBuffer<int16_t> dPcm;
     DeviceBuffer<UttResult> dResult;
+    DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
 };
 
 int batch_launch(Batch* b)
@@ -158,6 +176,11 @@ int batch_launch(Batch* b)
     a.frames = b->dFrames.ptr; a.meta = b->dMeta.ptr; a.utt = b->dUtt.ptr;
     a.pcm = b->dPcm.ptr; a.result = b->dResult.ptr; a.state = nullptr; a.control = nullptr;
     b->resultsFresh = false;
+#ifdef KLATT_STAMPS
+    if (b->dDebug.reserve((size_t)(b->nSlots / kLanes + 2) * 32 * 2)) return -1;
+    HIP_TRY(hipMemsetAsync(b->dDebug.ptr, 0, b->dDebug.cap * 8, b->stream));
+    a.debug = b->dDebug.ptr;
+#endif
     const long long nNoisy = b->nSlots - b->nQuiet;
     const bool both = b->nQuiet > 0 && nNoisy > 0;
     if (b->nQuiet > 0) {
@@ -169,12 +192,14 @@ int batch_launch(Batch* b)
             st = b->sideStream;
         }
         a.order = b->dOrder.ptr; a.nSlots = b->nQuiet;
-        if (launch<false, false>(a, b->mode, (b->nQuiet + kLanes - 1) / kLanes, st)) return -1;
+        if (b->layout ? launch_systolic<false>(a, b->mode, (b->nQuiet + kLanes - 1) / kLanes, st)
+                      : launch<false, false>(a, b->mode, (b->nQuiet + kLanes - 1) / kLanes, st)) return -1;
         if (both) HIP_TRY(hipEventRecord(b->joinEvent, b->sideStream));
     }
     if (nNoisy > 0) {
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
-        if (launch<false, true>(a, b->mode, (nNoisy + kLanes - 1) / kLanes, b->stream)) return -1;
+        if (b->layout ? launch_systolic<true>(a, b->mode, (nNoisy + kLanes - 1) / kLanes, b->stream)
+                      : launch<false, true>(a, b->mode, (nNoisy + kLanes - 1) / kLanes, b->stream)) return -1;
         if (both) HIP_TRY(hipStreamWaitEvent(b->stream, b->joinEvent, 0));
     }
     return 0;
@@ -414,6 +439,7 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
         return 0;
     }
     if (!strcmp(name, "sort")) { b->sortByLength = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "layout")) { b->layout = value ? 1 : 0; return 0; }
     set_error("unknown option %s", name);
     return -1;
 }
@@ -460,6 +486,7 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         utt[u].outStart = pool;
         utt[u].nFrames = (uint32_t)(frameStart[u + 1] - frameStart[u]);
         utt[u].seed = noiseSeed ? noiseSeed[u] : (uint32_t)u;
+        utt[u].length = (uint32_t)len;
         // Noise sources and the parallel bank can be skipped for an utterance only if every frame has
         // all three noise gains exactly zero (voiceTurbulenceAmplitude, aspirationAmplitude,
         // fricationAmplitude) and no non-finite parameter that could turn 0*x into NaN.
@@ -619,6 +646,16 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
     return rc;
 }
 
+// diagnostic builds (-DKLATT_STAMPS): per workgroup and stage {work cycles, barrier-wait cycles} of the last launch
+int speechPlayer_batch_debugStamps(speechPlayer_batch_t batch, unsigned long long* out, int capacity)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || !out) return -1;
+    int n = (int)std::min<size_t>(b->dDebug.cap, (size_t)capacity);
+    if (n > 0) HIP_TRY(hipMemcpy(out, b->dDebug.ptr, (size_t)n * 8, hipMemcpyDeviceToHost));
+    return n;
+}
+
 int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo)
 {
     Batch* b = static_cast<Batch*>(batch);
@@ -626,17 +663,20 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     HIP_TRY(hipSetDevice(b->device));
     hipFuncAttributes fa;
     const bool noisy = b->nSlots - b->nQuiet >= b->nQuiet;   // report the larger group's kernel
-    const void* fn = b->mode == MODE_FAST
+    const void* fnSys = b->mode == MODE_FAST
+        ? (noisy ? reinterpret_cast<const void*>(klatt_systolic<MODE_FAST, true>) : reinterpret_cast<const void*>(klatt_systolic<MODE_FAST, false>))
+        : (noisy ? reinterpret_cast<const void*>(klatt_systolic<MODE_EXACT, true>) : reinterpret_cast<const void*>(klatt_systolic<MODE_EXACT, false>));
+    const void* fnLane = b->mode == MODE_FAST
         ? (noisy ? reinterpret_cast<const void*>(klatt_synthesize<MODE_FAST, false, true>) : reinterpret_cast<const void*>(klatt_synthesize<MODE_FAST, false, false>))
         : (noisy ? reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false, true>) : reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false, false>));
-    HIP_TRY(hipFuncGetAttributes(&fa, fn));
+    HIP_TRY(hipFuncGetAttributes(&fa, b->layout ? fnSys : fnLane));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, b->device));
     info[0] = fa.numRegs;
-    info[1] = LdsLayout<false>::kBytes;
-    info[2] = (int)((b->nQuiet + kLanes - 1) / kLanes + (b->nSlots - b->nQuiet + kLanes - 1) / kLanes);
+    info[1] = b->layout ? SysLds::kBytes : LdsLayout<false>::kBytes;
+    info[2] = (int)((b->nQuiet + kLanes - 1) / kLanes + (b->nSlots - b->nQuiet + kLanes - 1) / kLanes) * (b->layout ? kStages : 1);
     info[3] = prop.multiProcessorCount;
-    info[4] = (int)(prop.sharedMemPerMultiprocessor / LdsLayout<false>::kBytes);
+    info[4] = (int)(prop.sharedMemPerMultiprocessor / (b->layout ? SysLds::kBytes : LdsLayout<false>::kBytes));
     info[5] = (int)fa.localSizeBytes;   // scratch; must be 0
     if (nInfo >= 8) { info[6] = (int)((b->nQuiet + kLanes - 1) / kLanes); info[7] = noisy ? 1 : 0; }
     return 0;

@@ -103,13 +103,17 @@ class SpeechPlayer(object):
 class BatchPlayer(object):
     """N independent utterances per launch (include/speechPlayer_batch.h)."""
 
-    def __init__(self, sampleRate, device=-1, mode=0):
+    def __init__(self, sampleRate, device=-1, mode=0, layout=None):
+        """mode: SPEECHPLAYER_MODE_EXACT (0) or _FAST (1); layout: 1 = stage-parallel workgroups
+        (default), 0 = one wavefront per 64 utterances."""
         self.sampleRate = sampleRate
         self._dll = _native.load()
         self._h = self._dll.speechPlayer_batch_create(sampleRate, device)
         if not self._h:
             raise RuntimeError("speechPlayer_batch_create failed: %s" % _native.last_error())
         self._check(self._dll.speechPlayer_batch_setOption(self._h, b"mode", mode))
+        if layout is not None:
+            self._check(self._dll.speechPlayer_batch_setOption(self._h, b"layout", layout))
         self.nUtterances = 0
 
     def _check(self, rc):

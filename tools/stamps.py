@@ -1,0 +1,24 @@
+#!/usr/bin/env python3
+"""Diagnostic (KLATT_STAMPS build): where do the four stage waves spend their cycles?  Not a timing run."""
+import ctypes
+import os
+import sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from nvspeechplayer_amd import BatchPlayer, _native, workloads
+
+wl, n, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0
+batch = workloads.make(wl, n)
+bp = BatchPlayer(batch["sr"], mode=mode, layout=1)
+bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
+bp.synthesize(); bp.synthesize()
+L = _native.load()
+L.speechPlayer_batch_debugStamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+buf = np.zeros((n // 64 + 2) * 32, dtype=np.uint64)
+got = L.speechPlayer_batch_debugStamps(bp._h, buf.ctypes.data, len(buf))
+st = buf[:(n // 64) * 32].reshape(-1, 4, 8).astype(np.float64)
+print("%s n=%d mode=%d: per stage mean cycles  work / barrier-wait   (over %d workgroups)" % (wl, n, mode, st.shape[0]))
+for s in range(4):
+    m = st[:, s, :].mean(axis=0)
+    print("  stage %d: work %.3e wait %.3e | chunks steady/fade/general %5.0f %5.0f %5.0f | cycles per chunk %7.0f %7.0f %7.0f" % (
+        s, m[0], m[1], m[2], m[3], m[4], m[5] / max(m[2], 1), m[6] / max(m[3], 1), m[7] / max(m[4], 1)))

@@ -40,6 +40,14 @@ __global__ void probe(unsigned long long* out, int iters, int activeLanes, doubl
             } else if (KIND == 5) {  // dependent v_fma_f32 chain (latency)
                 f0 = __builtin_fmaf(f0, mf, cf); f0 = __builtin_fmaf(f0, mf, cf); f0 = __builtin_fmaf(f0, mf, cf); f0 = __builtin_fmaf(f0, mf, cf);
                 f0 = __builtin_fmaf(f0, mf, cf); f0 = __builtin_fmaf(f0, mf, cf); f0 = __builtin_fmaf(f0, mf, cf); f0 = __builtin_fmaf(f0, mf, cf);
+            } else if (KIND == 7) {   // ONE dependent chain of alternating v_mul_f64 / v_add_f64 (8 instructions)
+                a0 = a0 * m; a0 = a0 + c; a0 = a0 * m; a0 = a0 + c; a0 = a0 * m; a0 = a0 + c; a0 = a0 * m; a0 = a0 + c;
+            } else if (KIND == 8) {   // TWO such chains interleaved
+                a0 = a0 * m; a1 = a1 * m; a0 = a0 + c; a1 = a1 + c; a0 = a0 * m; a1 = a1 * m; a0 = a0 + c; a1 = a1 + c;
+            } else if (KIND == 9) {   // FOUR such chains interleaved
+                a0 = a0 * m; a1 = a1 * m; a2 = a2 * m; a3 = a3 * m; a0 = a0 + c; a1 = a1 + c; a2 = a2 + c; a3 = a3 + c;
+            } else if (KIND == 10) {  // dependent v_add_f64 chain
+                a0 = a0 + c; a0 = a0 + m; a0 = a0 + c; a0 = a0 + m; a0 = a0 + c; a0 = a0 + m; a0 = a0 + c; a0 = a0 + m;
             } else if (KIND == 6) {  // v_pk_fma_f32 (two floats per lane per instruction)
                 typedef float v2 __attribute__((ext_vector_type(2)));
                 v2 p0 = {f0, f1}, p1 = {f2, f3}, p2 = {f4, f5}, p3 = {f6, f7};
@@ -94,6 +102,13 @@ int main()
     hipDeviceProp_t p;
     CHECK(hipGetDeviceProperties(&p, 0));
     printf("%s, %d CUs, clock %d kHz\n", p.name, p.multiProcessorCount, p.clockRate);
+    for (int w : {1, 2}) {
+        run<7>("mul/add f64, 1 dep chain", w, 64, dOut);
+        run<8>("mul/add f64, 2 chains", w, 64, dOut);
+        run<9>("mul/add f64, 4 chains", w, 64, dOut);
+        run<10>("v_add_f64 dep chain", w, 64, dOut);
+        run<4>("v_fma_f64 dep chain", w, 64, dOut);
+    }
     for (int w : {1, 2, 4}) {
         run<0>("v_fma_f64", w, 64, dOut);
         run<0>("v_fma_f64", w, 16, dOut);

@@ -132,9 +132,9 @@ def main():
             "realtime_factor": total_samples * args.steps / elapsed / batch["sr"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "klatt_synthesize", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "klatt_systolic" if args.layout else "klatt_synthesize", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
-                         "note": "f64 VALU issue binds before HBM; see DESIGN.md"},
+                         "note": "f64 VALU issue binds before HBM, and a 4096-utterance batch fills only 64 of 256 CUs; see DESIGN.md"},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)

@@ -87,12 +87,23 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = SysLds::kBytes;
+    constexpr int ldsBytes = SysLds<NOISE>::kBytes;
+    auto go = [&](auto kernel, bool& attrSet) -> int {
+        if (!attrSet) {
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+            attrSet = true;
+        }
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a);
+        return 0;
+    };
+    static bool attrExact = false, attrFast = false;
+    int rc;
     switch (mode) {
-    case MODE_EXACT: hipLaunchKernelGGL((klatt_systolic<MODE_EXACT, NOISE>), dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a); break;
-    case MODE_FAST: hipLaunchKernelGGL((klatt_systolic<MODE_FAST, NOISE>), dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE>, attrExact); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE>, attrFast); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
+    if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -673,10 +684,11 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, b->device));
     info[0] = fa.numRegs;
-    info[1] = b->layout ? SysLds::kBytes : LdsLayout<false>::kBytes;
+    const int sysLds = noisy ? SysLds<true>::kBytes : SysLds<false>::kBytes;
+    info[1] = b->layout ? sysLds : LdsLayout<false>::kBytes;
     info[2] = (int)((b->nQuiet + kLanes - 1) / kLanes + (b->nSlots - b->nQuiet + kLanes - 1) / kLanes) * (b->layout ? kStages : 1);
     info[3] = prop.multiProcessorCount;
-    info[4] = (int)(prop.sharedMemPerMultiprocessor / (b->layout ? SysLds::kBytes : LdsLayout<false>::kBytes));
+    info[4] = (int)(prop.sharedMemPerMultiprocessor / (b->layout ? sysLds : LdsLayout<false>::kBytes));
     info[5] = (int)fa.localSizeBytes;   // scratch; must be 0
     if (nInfo >= 8) { info[6] = (int)((b->nQuiet + kLanes - 1) / kLanes); info[7] = noisy ? 1 : 0; }
     return 0;

@@ -37,10 +37,23 @@ def parse():
     ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg2", "cfg3"])
     ap.add_argument("--utterances", type=int, default=0, help="override the batch size per GPU")
     ap.add_argument("--mode", type=int, default=0, help="arithmetic mode (include/speechPlayer_batch.h)")
-    ap.add_argument("--layout", type=int, default=1, help="1: stage-parallel workgroups, 0: one wavefront per 64 utterances")
+    ap.add_argument("--layout", type=int, default=-1, help="-1: engine's choice, 1: stage-parallel workgroups, 0: one wavefront per 64 utterances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
     return ap.parse_args()
+
+
+def usable_cores():
+    """Host threads this process may really use: CPU affinity, capped by the cgroup CPU quota
+    (on the GPU box 256 hardware threads are visible but the container's quota is 16 CPUs)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period))))
+    except Exception:
+        pass
+    return n
 
 
 def cpu_baseline(batch, target_seconds):
@@ -48,7 +61,7 @@ def cpu_baseline(batch, target_seconds):
     same workload (no shared state: every utterance has its own player and noise stream).  The
     workload is repeated until about `target_seconds` of wall time have been spent."""
     from tests import oracle
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     probe = batch.slice(0, min(8, batch.n_utt))
     t0 = time.perf_counter()
     _, _, total = oracle.batch_synthesize(batch["sr"], probe, threads=1)
@@ -132,7 +145,7 @@ def main():
             "realtime_factor": total_samples * args.steps / elapsed / batch["sr"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "klatt_systolic" if args.layout else "klatt_synthesize", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": "klatt_systolic (stage-parallel, %d-sample hand-overs)" % info["stage_parallel_chunk"] if info["stage_parallel_chunk"] else "klatt_synthesize (lane kernel)", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
                          "note": "f64 VALU issue binds before HBM, and a 4096-utterance batch fills only 64 of 256 CUs; see DESIGN.md"},
         }

@@ -82,12 +82,12 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE>
+template <bool NOISE, int CH>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = SysLds<NOISE>::kBytes;
+    constexpr int ldsBytes = SysLds<NOISE, CH>::kBytes;
     auto go = [&](auto kernel, bool& attrSet) -> int {
         if (!attrSet) {
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
@@ -99,13 +99,29 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     static bool attrExact = false, attrFast = false;
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE>, attrExact); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE>, attrFast); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH>, attrExact); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH>, attrFast); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+// Which kernel runs a group of `nUtt` utterances (64 per wavefront)?
+//   stage-parallel workgroups (klatt_systolic.h) while the lane kernel could not fill the chip anyway
+//   (it keeps 3 wavefronts per CU resident): 4x the wavefronts per utterance, shorter critical path;
+//   the lane kernel beyond that, where every SIMD is busy either way and its lower per-sample overhead wins.
+// Quiet groups that fit one workgroup per CU use 32-sample hand-overs (fewer barriers), else 16.
+// The decision is taken on the whole batch (both groups run at the same time and share the CUs' LDS).
+struct GroupPlan { bool systolic; int chunk; };
+GroupPlan plan_group(int layout, bool noisy, long long nUttBatch, int cus)
+{
+    const long long groups = (nUttBatch + kLanes - 1) / kLanes + 1;
+    GroupPlan p;
+    p.systolic = layout == 1 || (layout < 0 && groups <= 3LL * cus);
+    p.chunk = (!noisy && groups <= cus) ? 32 : 16;
+    return p;
 }
 
 template <bool STREAM, bool NOISE>
@@ -161,7 +177,8 @@ struct Batch {
     int device = 0;
     int mode = MODE_EXACT;
     int sortByLength = 1;
-    int layout = 1;                        // 1: stage-parallel workgroups (klatt_systolic.h); 0: one wave per 64 utterances
+    int layout = -1;                       // -1: choose per group (plan_group); 1: stage-parallel workgroups; 0: one wave per 64 utterances
+    int cus = 256;
     hipStream_t stream = nullptr;
     hipStream_t sideStream = nullptr;      // the quiet group runs beside the noisy one
     hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
@@ -203,14 +220,17 @@ int batch_launch(Batch* b)
             st = b->sideStream;
         }
         a.order = b->dOrder.ptr; a.nSlots = b->nQuiet;
-        if (b->layout ? launch_systolic<false>(a, b->mode, (b->nQuiet + kLanes - 1) / kLanes, st)
-                      : launch<false, false>(a, b->mode, (b->nQuiet + kLanes - 1) / kLanes, st)) return -1;
+        const GroupPlan pl = plan_group(b->layout, false, b->nSlots, b->cus);
+        const long long g = (b->nQuiet + kLanes - 1) / kLanes;
+        if (pl.systolic ? (pl.chunk == 32 ? launch_systolic<false, 32>(a, b->mode, g, st) : launch_systolic<false, 16>(a, b->mode, g, st))
+                        : launch<false, false>(a, b->mode, g, st)) return -1;
         if (both) HIP_TRY(hipEventRecord(b->joinEvent, b->sideStream));
     }
     if (nNoisy > 0) {
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
-        if (b->layout ? launch_systolic<true>(a, b->mode, (nNoisy + kLanes - 1) / kLanes, b->stream)
-                      : launch<false, true>(a, b->mode, (nNoisy + kLanes - 1) / kLanes, b->stream)) return -1;
+        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, b->cus);
+        const long long g = (nNoisy + kLanes - 1) / kLanes;
+        if (pl.systolic ? launch_systolic<true, 16>(a, b->mode, g, b->stream) : launch<false, true>(a, b->mode, g, b->stream)) return -1;
         if (both) HIP_TRY(hipStreamWaitEvent(b->stream, b->joinEvent, 0));
     }
     return 0;
@@ -416,6 +436,7 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     Batch* b = new Batch;
     b->sampleRate = sampleRate;
     b->device = dev;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) b->cus = prop.multiProcessorCount; }
     if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&b->sideStream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) != hipSuccess ||
@@ -450,7 +471,7 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
         return 0;
     }
     if (!strcmp(name, "sort")) { b->sortByLength = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "layout")) { b->layout = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value ? 1 : 0); return 0; }
     set_error("unknown option %s", name);
     return -1;
 }
@@ -674,23 +695,28 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     HIP_TRY(hipSetDevice(b->device));
     hipFuncAttributes fa;
     const bool noisy = b->nSlots - b->nQuiet >= b->nQuiet;   // report the larger group's kernel
-    const void* fnSys = b->mode == MODE_FAST
-        ? (noisy ? reinterpret_cast<const void*>(klatt_systolic<MODE_FAST, true>) : reinterpret_cast<const void*>(klatt_systolic<MODE_FAST, false>))
-        : (noisy ? reinterpret_cast<const void*>(klatt_systolic<MODE_EXACT, true>) : reinterpret_cast<const void*>(klatt_systolic<MODE_EXACT, false>));
-    const void* fnLane = b->mode == MODE_FAST
-        ? (noisy ? reinterpret_cast<const void*>(klatt_synthesize<MODE_FAST, false, true>) : reinterpret_cast<const void*>(klatt_synthesize<MODE_FAST, false, false>))
-        : (noisy ? reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false, true>) : reinterpret_cast<const void*>(klatt_synthesize<MODE_EXACT, false, false>));
-    HIP_TRY(hipFuncGetAttributes(&fa, b->layout ? fnSys : fnLane));
+    const GroupPlan pl = plan_group(b->layout, noisy, b->nSlots, b->cus);
+    const bool fast = b->mode == MODE_FAST;
+    const void* fn;
+    int sysLds = 0;
+    if (pl.systolic) {
+        if (noisy) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16> : (const void*)klatt_systolic<MODE_EXACT, true, 16>; sysLds = SysLds<true, 16>::kBytes; }
+        else if (pl.chunk == 32) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 32> : (const void*)klatt_systolic<MODE_EXACT, false, 32>; sysLds = SysLds<false, 32>::kBytes; }
+        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 16> : (const void*)klatt_systolic<MODE_EXACT, false, 16>; sysLds = SysLds<false, 16>::kBytes; }
+    } else {
+        fn = fast ? (noisy ? (const void*)klatt_synthesize<MODE_FAST, false, true> : (const void*)klatt_synthesize<MODE_FAST, false, false>)
+                  : (noisy ? (const void*)klatt_synthesize<MODE_EXACT, false, true> : (const void*)klatt_synthesize<MODE_EXACT, false, false>);
+    }
+    HIP_TRY(hipFuncGetAttributes(&fa, fn));
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, b->device));
     info[0] = fa.numRegs;
-    const int sysLds = noisy ? SysLds<true>::kBytes : SysLds<false>::kBytes;
-    info[1] = b->layout ? sysLds : LdsLayout<false>::kBytes;
-    info[2] = (int)((b->nQuiet + kLanes - 1) / kLanes + (b->nSlots - b->nQuiet + kLanes - 1) / kLanes) * (b->layout ? kStages : 1);
+    info[1] = pl.systolic ? sysLds : LdsLayout<false>::kBytes;
+    info[2] = (int)((b->nQuiet + kLanes - 1) / kLanes + (b->nSlots - b->nQuiet + kLanes - 1) / kLanes) * (pl.systolic ? kStages : 1);
     info[3] = prop.multiProcessorCount;
-    info[4] = (int)(prop.sharedMemPerMultiprocessor / (b->layout ? sysLds : LdsLayout<false>::kBytes));
+    info[4] = (int)(prop.sharedMemPerMultiprocessor / (pl.systolic ? sysLds : LdsLayout<false>::kBytes));
     info[5] = (int)fa.localSizeBytes;   // scratch; must be 0
-    if (nInfo >= 8) { info[6] = (int)((b->nQuiet + kLanes - 1) / kLanes); info[7] = noisy ? 1 : 0; }
+    if (nInfo >= 8) { info[6] = pl.systolic ? pl.chunk : 0; info[7] = noisy ? 1 : 0; }
     return 0;
 }
 

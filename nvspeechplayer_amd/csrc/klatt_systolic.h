@@ -29,9 +29,6 @@
 
 namespace klatt {
 
-#ifndef KLATT_CHUNK
-#define KLATT_CHUNK 16
-#endif
 #ifndef KLATT_UNROLL
 #define KLATT_UNROLL 8
 #endif
@@ -41,14 +38,13 @@ namespace klatt {
 #define KLATT_STR2(x) #x
 #define KLATT_STR(x) KLATT_STR2(x)
 
-constexpr int kChunk = KLATT_CHUNK;           // samples per pipeline hand-over
 constexpr int kStages = 4;
 
-// LDS per workgroup: pipes [2 buffers][kChunk][64 lanes] f64 (4 noisy / 3 quiet), the PCM tile and row
-// info of the final stage, then each stage's old/new parameter region.
-template <bool NOISE>
+// LDS per workgroup: pipes [2 buffers][CH][64 lanes] f64 (4 noisy / 3 quiet), the PCM tile and row
+// info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
+template <bool NOISE, int CH>
 struct SysLds {
-    static constexpr int kPipeBytes = 2 * kChunk * kLanes * 8;
+    static constexpr int kPipeBytes = 2 * CH * kLanes * 8;
     static constexpr int kNumPipes = NOISE ? 4 : 3;
     static constexpr int kTileOff = kNumPipes * kPipeBytes;
     static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
@@ -247,12 +243,12 @@ __device__ __forceinline__ double resonate(double& z1, double& z2, double a, dou
     return y;
 }
 
-// all live lanes steady (0) / all fading beyond their first fade sample (1), with at least kChunk samples left; else -1
-template <class SF>
+// all live lanes steady (0) / all fading beyond their first fade sample (1), with at least CH samples left; else -1
+template <int CH, class SF>
 __device__ __forceinline__ int chunk_kind(const SF& f)
 {
     const uint32_t rem = f.hasNew ? (f.newFade - f.cnt) : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u);
-    const bool roomy = f.done || rem >= (uint32_t)kChunk;
+    const bool roomy = f.done || rem >= (uint32_t)CH;
     if (!__all(roomy)) return -1;
     if (!__any(!f.done && f.hasNew)) return 0;
     if (!__any(!f.done && (!f.hasNew || f.cnt == 0))) return 1;
@@ -276,10 +272,11 @@ struct Stamps {
 #endif
 
 // ---- the kernel ---------------------------------------------------------------------------
-template <int MODE, bool NOISE>
+template <int MODE, bool NOISE, int CH>
 __global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systolic(const KernelArgs A)
 {
-    using L = SysLds<NOISE>;
+    using L = SysLds<NOISE, CH>;
+    constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     double* const pipeX = reinterpret_cast<double*>(lds);                           // S0 -> S1
     double* const pipeO = reinterpret_cast<double*>(lds + L::kPipeBytes);           // S1 -> S2
@@ -326,7 +323,7 @@ __global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systol
         STAMP_BEGIN();                                                                                                             \
         const int c = iter - (DEPTH);                                                                                              \
         if (c >= 0 && c < nChunks) {                                                                                               \
-            const int kind = (VIBCHECK) ? -1 : chunk_kind(FRAMEVAR);                                                               \
+            const int kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                               \
             STAMP_KIND(kind);                                                                                                      \
             if (kind == 0) {                                                                                                       \
                 if (!FRAMEVAR.done) {                                                                                              \

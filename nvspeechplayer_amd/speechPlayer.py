@@ -104,8 +104,8 @@ class BatchPlayer(object):
     """N independent utterances per launch (include/speechPlayer_batch.h)."""
 
     def __init__(self, sampleRate, device=-1, mode=0, layout=None):
-        """mode: SPEECHPLAYER_MODE_EXACT (0) or _FAST (1); layout: 1 = stage-parallel workgroups
-        (default), 0 = one wavefront per 64 utterances."""
+        """mode: SPEECHPLAYER_MODE_EXACT (0) or _FAST (1); layout: None / -1 = chosen per batch (default),
+        1 = stage-parallel workgroups, 0 = one wavefront per 64 utterances."""
         self.sampleRate = sampleRate
         self._dll = _native.load()
         self._h = self._dll.speechPlayer_batch_create(sampleRate, device)
@@ -182,7 +182,8 @@ class BatchPlayer(object):
         info = np.zeros(8, dtype=np.int32)
         self._check(self._dll.speechPlayer_batch_kernelInfo(self._h, info.ctypes.data, len(info)))
         return dict(vgprs=int(info[0]), lds_bytes=int(info[1]), wavefronts=int(info[2]), cus=int(info[3]),
-                    workgroups_per_cu_by_lds=int(info[4]), scratch_bytes=int(info[5]))
+                    workgroups_per_cu_by_lds=int(info[4]), scratch_bytes=int(info[5]),
+                    stage_parallel_chunk=int(info[6]), noisy_group=bool(info[7]))
 
     def devicePcm(self):
         return self._dll.speechPlayer_batch_devicePcm(self._h)

@@ -99,7 +99,7 @@ def make_batch(sel):
                 seeds=np.array(seeds, np.uint32))
 
 
-@pytest.mark.parametrize("layout", [1, 0])
+@pytest.mark.parametrize("layout", [-1, 1, 0])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_batch_all_scenarios(all_scenarios, mode, layout):
     """Every batchable scenario (vowels, all sampleIpa cases, vibrato, NaN hold, duration edges)

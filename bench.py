@@ -92,15 +92,21 @@ def main():
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    torch.cuda.set_device(local_rank)
+    ndev = torch.cuda.device_count()
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
     dist = None
+    shared_device = world > ndev          # only in self-tests on a 1-GPU box: ranks share a device, RCCL cannot
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_device:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
     n_utt = args.utterances or {"cfg1": 4096, "cfg2": 65536, "cfg3": 131072}[args.workload]
     batch = workloads.make(args.workload, n_utt, first=rank * n_utt)
-    bp = BatchPlayer(batch["sr"], device=local_rank, mode=args.mode, layout=args.layout)
+    bp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
                      batch["isnull"], batch["seeds"])
     samples = bp.totalSamples
@@ -119,13 +125,20 @@ def main():
     kernel_ms = bp.time(args.steps)          # K launches, each between two HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, total_samples = reduce_throughput(elapsed, samples, dist, device="cuda")   # max / sum over ranks
+    elapsed, total_samples = reduce_throughput(elapsed, samples, dist, device="cpu" if shared_device else "cuda")   # max / sum over ranks
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         alg_bytes = batch.algorithmic_bytes()
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         info = bp.kernelInfo()
+        traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
+            if args.workload in tj and not args.utterances:
+                traffic = tj[args.workload]["hbm_bytes_per_launch"]
+        except Exception:
+            pass
         out = {
             "metric": "audio samples/sec (whole node) at 22.05 kHz Klatt synth, batch-N utterances",
             "value": total_samples * args.steps / elapsed,
@@ -144,7 +157,8 @@ def main():
                        "parallelism": "utterances sharded over %d GPU(s), no collective" % world},
             "realtime_factor": total_samples * args.steps / elapsed / batch["sr"],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
                          "kernel": "klatt_systolic (stage-parallel, %d-sample hand-overs)" % info["stage_parallel_chunk"] if info["stage_parallel_chunk"] else "klatt_synthesize (lane kernel)", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
                          "note": "f64 VALU issue binds before HBM, and a 4096-utterance batch fills only 64 of 256 CUs; see DESIGN.md"},

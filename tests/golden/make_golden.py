@@ -97,6 +97,15 @@ def main():
     for li, line in enumerate(lines):
         cases.append((li, 1.0, ".", 140.0, 0.5))
         cases.append((li, 1.0, ".", 70.0, 1.0))
+    # extra lines for the producer's tie-bar / length-mark / stress / unknown-symbol paths (appended, so the
+    # indices of the sampleIpa cases above do not move)
+    extra = ["ˈhɛləʊ ˌwɜːld", "t͡ʃɑːt͡ʃ d͡ʒʌd͡ʒɪz", "ɑj ɑw ɔj ˈbɑjk", "ðə kwɪk# brɑwn fɒks 7 d͡ʒʌmps", "ˈstɹɛŋθs ˌpliːz", "ʃiː sɛlz siːʃɛlz",
+             "lɛt mi θɪŋk əbɑwt ɪt", "p t k", "ˈɑ", "mmm nnn ŋŋŋ lll"]
+    for xi, xl in enumerate(extra):
+        lines.append(xl)
+        for speed, clause, pitch, infl in ((1.0, ".", 100.0, 0.5), (0.8, "?", 120.0, 0.7), (1.3, None, 90.0, 0.3)):
+            cases.append((8 + xi, speed, clause, pitch, infl))
+    out["ipa_lines"] = np.array([l.encode("utf8") for l in lines])
     fr_all, dur_all, fade_all, null_all, start = [], [], [], [], [0]
     meta = []
     for (li, speed, clause, pitch, infl) in cases:
@@ -116,6 +125,20 @@ def main():
     out["ipa_dur_ms"] = np.array(dur_all)
     out["ipa_fade_ms"] = np.array(fade_all)
     out["ipa_start"] = np.array(start, dtype=np.int64)
+
+    # --- the frame producer's data tables (numbers only), for nvspeechplayer_amd/ipa.py --------------
+    import json
+    data_dir = os.path.join(ROOT, "nvspeechplayer_amd", "data")
+    os.makedirs(data_dir, exist_ok=True)
+    table = {}
+    for i, name in enumerate(names):
+        entry = {"fields": {field_names[k]: float(ph[i, k]) for k in range(47) if mask[i, k]},
+                 "flags": {fl: bool(ipa.data[name].get(fl)) for fl in flag_names if ipa.data[name].get(fl)}}
+        table[name] = entry
+    with open(os.path.join(data_dir, "phonemes.json"), "w", encoding="utf8") as f:
+        json.dump(table, f, ensure_ascii=False, indent=0, sort_keys=True)
+    with open(os.path.join(data_dir, "intonation.json"), "w") as f:
+        json.dump(ipa.intonationParamTable, f, indent=1, sort_keys=True)
 
     np.savez_compressed(os.path.join(HERE, "ref_frames.npz"), **out)
     print("ref_frames.npz: %d phonemes, %d ipa cases, %d frames" % (len(names), len(cases), len(fr_all)))

@@ -138,6 +138,14 @@ class BatchPlayer(object):
         self._check(self._dll.speechPlayer_batch_setUtterances(self._h, n_utt, p(fs), p(fr), p(m), p(f), p(ix), p(nu), p(sd)))
         self.nUtterances = n_utt
 
+    def setIpa(self, texts, speed=1, basePitch=100, inflection=0.5, clauseType=None, noiseSeed=None):
+        """Text in, batch ready: every IPA string becomes one utterance through the frame producer
+        (nvspeechplayer_amd/ipa.py) followed by 150 ms of silence, as reference test_speakIpa.py:24-27 queues them."""
+        from . import ipa
+        pk = ipa.frames_for_batch(texts, sampleRate=self.sampleRate, speed=speed, basePitch=basePitch,
+                                  inflection=inflection, clauseType=clauseType)
+        self.setUtterances(pk["frame_start"], pk["frames"], pk["min"], pk["fade"], None, pk["isnull"], noiseSeed)
+
     @property
     def totalSamples(self):
         return self._dll.speechPlayer_batch_totalSamples(self._h)

@@ -84,35 +84,32 @@ def cfg1_steady_vowels(n_utt=4096, seconds=1.0, first=0, sr=SR):
 
 def cfg2_ipa_utterances(n_utt=65536, first=0, max_seconds=None, sr=SR):
     """BASELINE configs[2] (and configs[3] with max_seconds=0.5): utterance u = sampleIpa.txt line
-    (u mod 8) through the reference frame producer (speed 1, inflection 0.5, clause '.'), base pitch
-    100*2^(((u div 8) mod 64 - 32)/64) Hz applied by scaling the captured 100 Hz stream's voicePitch /
-    endVoicePitch, + NULL(150 ms, 0) (reference test_speakIpa.py:25-27); noise seed = u."""
+    (u mod 8) through the frame producer (nvspeechplayer_amd/ipa.py, identical to the reference's on the
+    captured cases) with speed 1, inflection 0.5, clause '.', base pitch 100*2^(((u div 8) mod 64 - 32)/64) Hz,
+    + NULL(150 ms, 0) (reference test_speakIpa.py:25-27); noise seed = u.  SURVEY.md section 8(d)."""
+    from . import ipa
     z = _load()
-    meta = z["ipa_case_meta"]
-    start = z["ipa_start"]
-    base = {}
-    for i, m in enumerate(meta):
-        if m[1] == 1.0 and int(m[2]) == 0 and m[3] == 100.0 and m[4] == 0.5:
-            a, b = start[i], start[i + 1]
-            fr = z["ipa_frames"][a:b].copy()
-            nu = z["ipa_isnull"][a:b].copy()
-            M = np.array([ms(d, sr) for d in z["ipa_dur_ms"][a:b]], np.uint32)
-            F = np.array([ms(d, sr) for d in z["ipa_fade_ms"][a:b]], np.uint32)
-            fr = np.concatenate([fr, np.zeros((1, 47))]); nu = np.concatenate([nu, [1]]).astype(np.uint8)
-            M = np.concatenate([M, [ms(150, sr)]]).astype(np.uint32); F = np.concatenate([F, [0]]).astype(np.uint32)
+    lines = [b.decode("utf8") for b in z["ipa_lines"]][:8]
+    cache = {}
+
+    def stream(line, variant):
+        key = (line, variant)
+        if key not in cache:
+            pk = ipa.frames_for_batch([lines[line]], sampleRate=sr, speed=1.0, basePitch=100.0 * 2.0 ** ((variant - 32) / 64.0),
+                                      inflection=0.5, clauseType=".", trailing_silence_ms=150.0)
+            fr, nu, M, F = pk["frames"], pk["isnull"], pk["min"], pk["fade"]
             if max_seconds is not None:
                 per = np.maximum(M.astype(np.int64), np.maximum(F.astype(np.int64), 1) + 1) + 1
                 keep = max(1, int(np.searchsorted(np.cumsum(per), max_seconds * sr, side="right")))
                 fr, nu, M, F = fr[:keep], nu[:keep], M[:keep], F[:keep]
-            base[int(m[0])] = (fr, nu, M, F)
+            cache[key] = (fr, nu, M, F)
+        return cache[key]
+
     frames, mins, fades, nul, fs = [], [], [], [], [0]
     for k in range(n_utt):
         u = first + k
-        fr, nu, M, F = base[u % 8]
-        scale = 2.0 ** ((((u // 8) % 64) - 32) / 64.0)
-        g = fr.copy()
-        g[:, VOICEPITCH] *= scale; g[:, ENDPITCH] *= scale
-        frames.append(g); mins.append(M); fades.append(F); nul.append(nu)
+        fr, nu, M, F = stream(u % 8, (u // 8) % 64)
+        frames.append(fr); mins.append(M); fades.append(F); nul.append(nu)
         fs.append(fs[-1] + len(M))
     nF = fs[-1]
     tag = "cfg2" if max_seconds is None else "cfg3-slice(<=%.2gs)" % max_seconds

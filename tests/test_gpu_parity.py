@@ -334,3 +334,20 @@ def test_zero_length_real_frame_division_by_zero(ref):
             assert np.array_equal(got, exp), (layout, u, int(np.count_nonzero(got != exp)))
             assert (exp == 32000).any()
         bp.close()
+
+
+def test_text_to_pcm_through_the_producer():
+    """IPA text -> nvspeechplayer_amd.ipa -> BatchPlayer equals the oracle fed with the same frames."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import ipa
+    texts = ["hælou", "ˈt͡ʃɑːt͡ʃ d͡ʒʌd͡ʒɪz", "ðɪs ɪz veɹj fɑn", "ʃiː sɛlz siːʃɛlz"]
+    bp = eng.BatchPlayer(22050)
+    bp.setIpa(texts, speed=1.0, basePitch=[100, 130, 85, 110], inflection=0.5, clauseType="?", noiseSeed=[9, 8, 7, 6])
+    bp.synthesize()
+    pk = ipa.frames_for_batch(texts, basePitch=[100, 130, 85, 110], clauseType="?")
+    for u in range(len(texts)):
+        o = oracle.OraclePlayer(22050, seed=9 - u)
+        for k in range(pk["frame_start"][u], pk["frame_start"][u + 1]):
+            o.queue(None if pk["isnull"][k] else pk["frames"][k], int(pk["min"][k]), int(pk["fade"][k]))
+        compare(bp.read(u), o.drain(), texts[u])
+    bp.close()

@@ -82,6 +82,7 @@ def test_workload_recipes():
     assert 79.9 < b["frames"][0][0] < 80.1 and b["frames"][0][0] == b["frames"][0][46]
     c = workloads.make("cfg2", 16)
     assert list(c.sample_counts()[:8]) == [8273, 29374, 29218, 20745, 12907, 41238, 13459, 29788]
+    assert abs(c["frames"][1][0] / c["frames"][1 + len(c["min"]) // 2][0] - 2.0 ** (-1 / 64.0)) < 1e-12   # pitch variants 0 and 1
     assert np.array_equal(c.sample_counts()[:8], c.sample_counts()[8:16])      # pitch variants keep the timing
     d = workloads.make("cfg3", 8)
     assert np.all(d.sample_counts() <= 11025 + 2000)

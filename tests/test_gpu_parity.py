@@ -351,3 +351,36 @@ def test_text_to_pcm_through_the_producer():
             o.queue(None if pk["isnull"][k] else pk["frames"][k], int(pk["min"][k]), int(pk["fade"][k]))
         compare(bp.read(u), o.drain(), texts[u])
     bp.close()
+
+
+def test_full_size_cfg2_properties():
+    """BASELINE configs[2] at full size (65 536 speech utterances, 1.5e9 samples): closed-form lengths,
+    idempotent relaunch, noise-free utterances are independent of their seed (line 8 is all vowels, so
+    u and u + 512 -- same line, same pitch variant, different noise stream -- must be bit-identical),
+    noisy ones differ, and a strided sample of utterances equals the oracle."""
+    import hashlib
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    batch = workloads.make("cfg2", 65536)
+    bp = eng.BatchPlayer(22050)
+    bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                     batch["isnull"], batch["seeds"])
+    counts = batch.sample_counts()
+    assert bp.totalSamples == int(counts.sum())
+    assert list(counts[:8]) == [8273, 29374, 29218, 20745, 12907, 41238, 13459, 29788]
+    bp.synthesize()
+    a, starts = bp.readAll()
+    assert np.array_equal(np.diff(starts), counts)
+    h1 = hashlib.sha1(a.tobytes()).hexdigest()
+    bp.synthesize()
+    b, _ = bp.readAll()
+    assert hashlib.sha1(b.tobytes()).hexdigest() == h1            # idempotent
+    del b
+    for u in (7, 15, 7 + 8 * 63):                                  # quiet line, three pitch variants
+        assert np.array_equal(a[starts[u]:starts[u + 1]], a[starts[u + 512]:starts[u + 513]])
+    for u in (2, 13):                                              # noisy lines: another seed, another PCM
+        assert not np.array_equal(a[starts[u]:starts[u + 1]], a[starts[u + 512]:starts[u + 513]])
+    for u in range(5, 65536, 1637):
+        exp, _, _ = oracle.batch_synthesize(22050, batch.slice(u, 1))
+        compare(a[starts[u]:starts[u + 1]], exp, "cfg2 utt %d" % u)
+    bp.close()

@@ -63,6 +63,9 @@ int speechPlayer_batch_wait(speechPlayer_batch_t batch);
 
 /* Copy utterance u's PCM to the host (after wait). Returns samples copied (<= capacity). */
 long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long utterance, sample* sampleBuf, long long capacity);
+/* The same as float samples in [-1, 1] (value / 32767, the scaling of the reference's audio sink,
+ * lavPlayer.py:17); the conversion runs on the device. Returns samples copied. */
+long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long utterance, float* sampleBuf, long long capacity);
 /* Copy every utterance's PCM, concatenated in utterance order; outStart[nUtterances+1] receives
  * the offsets. Returns total samples. */
 long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart);

@@ -28,7 +28,7 @@ EXPORTS = [
     "speechPlayer_batch_setUtterances", "speechPlayer_batch_utteranceSamples",
     "speechPlayer_batch_totalSamples", "speechPlayer_batch_totalFrames",
     "speechPlayer_batch_synthesize", "speechPlayer_batch_wait", "speechPlayer_batch_read",
-    "speechPlayer_batch_readAll", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
+    "speechPlayer_batch_readAll", "speechPlayer_batch_readFloat", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
     "speechPlayer_batch_deviceOffset", "speechPlayer_batch_time", "speechPlayer_batch_kernelInfo",
     "speechPlayer_lastError", "speechPlayer_setNoiseSeed",
 ]
@@ -108,6 +108,8 @@ def load():
     L.speechPlayer_batch_wait.argtypes = [vp]
     L.speechPlayer_batch_read.restype = i64
     L.speechPlayer_batch_read.argtypes = [vp, i64, vp, i64]
+    L.speechPlayer_batch_readFloat.restype = i64
+    L.speechPlayer_batch_readFloat.argtypes = [vp, i64, vp, i64]
     L.speechPlayer_batch_readAll.restype = i64
     L.speechPlayer_batch_readAll.argtypes = [vp, vp, i64, vp]
     L.speechPlayer_batch_getLastIndex.restype = i32

@@ -25,6 +25,27 @@
 
 using namespace klatt;
 
+// int16 PCM -> float in [-1, 1]: sample / 32767, the scaling of the reference's audio sink
+// (reference lavPlayer.py:17).  HBM-bound elementwise pass: 8 samples (16 B) in, 32 B out per lane.
+__global__ void __launch_bounds__(256) pcm_to_float(const int16_t* __restrict__ in, float* __restrict__ out, long long n8)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += stride) {
+        const uint4 v = reinterpret_cast<const uint4*>(in)[i];
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        float4 lo, hi;
+        float f[8];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            f[2 * k] = (float)(int16_t)(w[k] & 0xFFFFu) / 32767.0f;
+            f[2 * k + 1] = (float)(int16_t)(w[k] >> 16) / 32767.0f;
+        }
+        lo = make_float4(f[0], f[1], f[2], f[3]); hi = make_float4(f[4], f[5], f[6], f[7]);
+        reinterpret_cast<float4*>(out)[2 * i] = lo;
+        reinterpret_cast<float4*>(out)[2 * i + 1] = hi;
+    }
+}
+
 namespace {
 
 thread_local std::string g_lastError;
@@ -196,6 +217,8 @@ struct Batch {
     DeviceBuffer<int16_t> dPcm;
     DeviceBuffer<UttResult> dResult;
     DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
+    DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
+    bool floatFresh = false;
 };
 
 int batch_launch(Batch* b)
@@ -204,6 +227,7 @@ int batch_launch(Batch* b)
     a.frames = b->dFrames.ptr; a.meta = b->dMeta.ptr; a.utt = b->dUtt.ptr;
     a.pcm = b->dPcm.ptr; a.result = b->dResult.ptr; a.state = nullptr; a.control = nullptr;
     b->resultsFresh = false;
+    b->floatFresh = false;
 #ifdef KLATT_STAMPS
     if (b->dDebug.reserve((size_t)(b->nSlots / kLanes + 2) * 32 * 2)) return -1;
     HIP_TRY(hipMemsetAsync(b->dDebug.ptr, 0, b->dDebug.cap * 8, b->stream));
@@ -458,6 +482,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
     if (b->joinEvent) (void)hipEventDestroy(b->joinEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
+    b->dFloat.release(); b->dDebug.release();
     delete b;
 }
 
@@ -635,6 +660,28 @@ long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleB
     }
     if (outStart) outStart[b->nUtt] = pos;
     return pos;
+}
+
+long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long u, float* sampleBuf, long long capacity)
+{
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || u < 0 || u >= b->nUtt || !sampleBuf) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    if (!b->floatFresh) {
+        if (b->dFloat.reserve(std::max<size_t>(b->poolSamples, 8))) return -1;
+        const long long n8 = b->poolSamples / 8;     // the pool is a multiple of 32 samples
+        if (n8 > 0) {
+            const unsigned grid = (unsigned)std::min<long long>((n8 + 255) / 256, 2048);
+            hipLaunchKernelGGL(pcm_to_float, dim3(grid), dim3(256), 0, b->stream, b->dPcm.ptr, b->dFloat.ptr, n8);
+            HIP_TRY(hipGetLastError());
+        }
+        b->floatFresh = true;
+    }
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (fetch_results(b)) return -1;
+    long long n = std::min<long long>(b->results[u].produced, capacity);
+    if (n > 0) HIP_TRY(hipMemcpy(sampleBuf, b->dFloat.ptr + b->outStart[u], (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    return n;
 }
 
 int speechPlayer_batch_getLastIndex(speechPlayer_batch_t batch, long long u)

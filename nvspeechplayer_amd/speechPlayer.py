@@ -171,6 +171,21 @@ class BatchPlayer(object):
         got = self._check(self._dll.speechPlayer_batch_read(self._h, u, buf.ctypes.data, n))
         return buf[:got]
 
+    def readFloat(self, u):
+        """Utterance u as float32 in [-1, 1] (int16 / 32767, converted on the device)."""
+        n = self.utteranceSamples(u)
+        buf = np.zeros(max(n, 1), dtype=np.float32)
+        got = self._check(self._dll.speechPlayer_batch_readFloat(self._h, u, buf.ctypes.data, n))
+        return buf[:got]
+
+    def writeWav(self, u, path):
+        """Utterance u as a 16-bit mono WAV file at the batch's sample rate."""
+        import wave
+        pcm = self.read(u)
+        with wave.open(path, "wb") as w:
+            w.setnchannels(1); w.setsampwidth(2); w.setframerate(self.sampleRate)
+            w.writeframes(pcm.astype("<i2").tobytes())
+
     def readAll(self):
         total = self.totalSamples
         buf = np.zeros(max(total, 1), dtype=np.int16)

@@ -384,3 +384,24 @@ def test_full_size_cfg2_properties():
         exp, _, _ = oracle.batch_synthesize(22050, batch.slice(u, 1))
         compare(a[starts[u]:starts[u + 1]], exp, "cfg2 utt %d" % u)
     bp.close()
+
+
+def test_output_formats(ref, tmp_path):
+    """float samples scaled by 1/32767 (reference lavPlayer.py:17) and a WAV file,
+    at the NVDA driver's 16 kHz rate (reference nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:137)."""
+    import wave
+    import nvspeechplayer_amd as eng
+    bp = eng.BatchPlayer(16000)
+    bp.setIpa(["hælou", "ɑɑɑ"], clauseType=".")
+    bp.synthesize()
+    for u in range(2):
+        pcm = bp.read(u)
+        fl = bp.readFloat(u)
+        assert fl.dtype == np.float32 and len(fl) == len(pcm)
+        assert np.array_equal(fl, pcm.astype(np.float32) / np.float32(32767.0))
+    path = str(tmp_path / "u0.wav")
+    bp.writeWav(0, path)
+    with wave.open(path, "rb") as w:
+        assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 16000)
+        assert np.array_equal(np.frombuffer(w.readframes(w.getnframes()), dtype="<i2"), bp.read(0))
+    bp.close()

@@ -34,7 +34,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg2", "cfg3"])
+    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--utterances", type=int, default=0, help="override the batch size per GPU")
     ap.add_argument("--mode", type=int, default=0, help="arithmetic mode (include/speechPlayer_batch.h)")
     ap.add_argument("--layout", type=int, default=-1, help="-1: engine's choice, 1: stage-parallel workgroups, 0: one wavefront per 64 utterances")
@@ -104,7 +104,7 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
 
-    n_utt = args.utterances or {"cfg1": 4096, "cfg2": 65536, "cfg3": 131072}[args.workload]
+    n_utt = args.utterances or {"cfg1": 4096, "cfg2": 65536, "cfg3": 131072, "cfg4": 32768}[args.workload]
     batch = workloads.make(args.workload, n_utt, first=rank * n_utt)
     bp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],

@@ -119,6 +119,36 @@ def cfg2_ipa_utterances(n_utt=65536, first=0, max_seconds=None, sr=SR):
                  name="%s: %d sampleIpa utterances, 64 pitch variants" % (tag, n_utt), sr=sr)
 
 
+def cfg4_voice_variants(n_variants=256, utt_per_variant=16384, first_variant=0, sr=SR):
+    """BASELINE configs[4]: voice-parameter variants x utterances with per-frame pitch/formant glides.
+    Variant v draws multipliers from a generator seeded 1234+v, in the style of the NVDA driver's voice
+    presets (reference nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:86-125): cf1..cf3 x U[0.75, 1.05],
+    cb1 x U[1, 1.3], voicePitch and endVoicePitch x U[0.75, 1.5], fricationAmplitude x U[0.7, 1],
+    pa6 x U[1, 1.3]; its utterances are the cfg2 generator's."""
+    base = cfg2_ipa_utterances(utt_per_variant, first=0, sr=sr)
+    F = {n: i for i, n in enumerate(["voicePitch", "vibratoPitchOffset", "vibratoSpeed", "voiceTurbulenceAmplitude",
+                                     "glottalOpenQuotient", "voiceAmplitude", "aspirationAmplitude"])}
+    frames, seeds = [], []
+    for k in range(n_variants):
+        v = first_variant + k
+        rng = np.random.default_rng(1234 + v)
+        g = base["frames"].copy()
+        g[:, 7:10] *= rng.uniform(0.75, 1.05, size=3)          # cf1..cf3
+        g[:, 15] *= rng.uniform(1.0, 1.3)                      # cb1
+        pm = rng.uniform(0.75, 1.5)
+        g[:, 0] *= pm; g[:, 46] *= pm                          # voicePitch, endVoicePitch
+        g[:, 24] *= rng.uniform(0.7, 1.0)                      # fricationAmplitude
+        g[:, 42] *= rng.uniform(1.0, 1.3)                      # pa6
+        frames.append(g)
+        seeds.append(base["seeds"].astype(np.uint64) + np.uint64(v) * np.uint64(utt_per_variant))
+    nF = len(base["min"])
+    fs = np.concatenate([base["frame_start"][:-1] + k * nF for k in range(n_variants)] + [[n_variants * nF]])
+    return Batch(frames=np.concatenate(frames), min=np.tile(base["min"], n_variants), fade=np.tile(base["fade"], n_variants),
+                 index=np.full(nF * n_variants, -1, np.int32), isnull=np.tile(base["isnull"], n_variants),
+                 frame_start=fs.astype(np.int64), seeds=(np.concatenate(seeds) & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+                 name="cfg4: %d voice variants x %d utterances" % (n_variants, utt_per_variant), sr=sr)
+
+
 def make(workload, n_utt=None, first=0):
     if workload == "cfg1":
         return cfg1_steady_vowels(n_utt or 4096, first=first)
@@ -126,4 +156,7 @@ def make(workload, n_utt=None, first=0):
         return cfg2_ipa_utterances(n_utt or 65536, first=first)
     if workload == "cfg3":
         return cfg2_ipa_utterances(n_utt or 131072, first=first, max_seconds=0.5)
+    if workload == "cfg4":     # n_utt utterances per variant block of 1024; the full config is 32 variants x 16384 per GPU
+        per = 1024
+        return cfg4_voice_variants(max(1, (n_utt or 32768) // per), per, first_variant=first // per)
     raise ValueError(workload)

@@ -405,3 +405,20 @@ def test_output_formats(ref, tmp_path):
         assert (w.getnchannels(), w.getsampwidth(), w.getframerate()) == (1, 2, 16000)
         assert np.array_equal(np.frombuffer(w.readframes(w.getnframes()), dtype="<i2"), bp.read(0))
     bp.close()
+
+
+def test_cfg3_and_cfg4_recipes_small():
+    """BASELINE configs[3] (utterances cut to <= 0.5 s) and configs[4] (voice variants with pitch / formant
+    glides) at small size, utterance by utterance against the oracle."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    for batch in (workloads.make("cfg3", 200), workloads.cfg4_voice_variants(5, 40)):
+        exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
+        bp = eng.BatchPlayer(22050)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                         batch["isnull"], batch["seeds"])
+        bp.synthesize()
+        got, got_start = bp.readAll()
+        assert np.array_equal(got_start, exp_start)
+        compare(got, exp, batch["name"])
+        bp.close()

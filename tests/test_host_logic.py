@@ -86,6 +86,11 @@ def test_workload_recipes():
     assert np.array_equal(c.sample_counts()[:8], c.sample_counts()[8:16])      # pitch variants keep the timing
     d = workloads.make("cfg3", 8)
     assert np.all(d.sample_counts() <= 11025 + 2000)
+    e = workloads.cfg4_voice_variants(3, 16)
+    assert e.n_utt == 48 and np.array_equal(e.sample_counts()[:16], c.sample_counts()) and np.array_equal(e.sample_counts()[16:32], c.sample_counts())
+    assert not np.array_equal(e["frames"][0], e["frames"][len(c["min"])])      # another variant, other formants
+    e2 = workloads.cfg4_voice_variants(1, 16, first_variant=2)
+    assert np.array_equal(e2["frames"], e["frames"][2 * len(c["min"]):])         # variants are reproducible
     s = c.slice(3, 5)
     assert s.n_utt == 5 and np.array_equal(s.sample_counts(), c.sample_counts()[3:8])
 

@@ -422,3 +422,41 @@ def test_cfg3_and_cfg4_recipes_small():
         assert np.array_equal(got_start, exp_start)
         compare(got, exp, batch["name"])
         bp.close()
+
+
+def test_engine_against_committed_golden_fixtures(all_scenarios):
+    """The engine against tests/golden/expected.json + expected_pcm.npz directly (no oracle in the loop):
+    SHA-1 and length of every batchable scenario, full PCM where it is stored."""
+    import hashlib
+    import json
+    import os
+    import nvspeechplayer_amd as eng
+    table = json.load(open(os.path.join(scenarios.GOLDEN, "expected.json")))
+    stored = np.load(os.path.join(scenarios.GOLDEN, "expected_pcm.npz"))
+    for sr in (22050, 16000):
+        sel = [s for s in all_scenarios if s.batchable and s.sr == sr]
+        batch = make_batch(sel)
+        bp = eng.BatchPlayer(sr)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                         batch["isnull"], batch["seeds"])
+        bp.synthesize()
+        for i, s in enumerate(sel):
+            pcm = bp.read(i)
+            assert len(pcm) == table[s.name]["samples"], s.name
+            assert hashlib.sha1(pcm.tobytes()).hexdigest() == table[s.name]["sha1"], s.name
+            if s.name in stored.files:
+                assert np.array_equal(pcm, stored[s.name]), s.name
+        bp.close()
+
+
+def test_limits_are_reported_not_wrapped(ref):
+    """An utterance longer than 2^32 - 1 samples is refused with an error (lengths are 32-bit on the device)."""
+    import nvspeechplayer_amd as eng
+    fa = scenarios.vowel_frame(ref, "a", 120.0)
+    bp = eng.BatchPlayer(22050)
+    with pytest.raises(RuntimeError, match="too long"):
+        bp.setUtterances([0, 2], np.stack([fa, fa]), [4294967295, 4294967295], [1, 1])
+    bp.setUtterances([0, 1], fa[None, :], [100], [10])          # the object stays usable
+    bp.synthesize()
+    assert len(bp.read(0)) == 101
+    bp.close()

@@ -84,6 +84,19 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
 /* Kernel resource facts for reports: fills vgprs, ldsBytes, wavefronts launched, workgroups per CU. */
 int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo);
 
+/*
+ * Many LIVE streams on one GPU: advance nHandles handles created by
+ * speechPlayer_initialize by up to sampleCount samples each in ONE kernel launch, one handle per
+ * wavefront lane.  Exactly equivalent to calling speechPlayer_synthesize(handles[i], sampleCount,
+ * sampleBufs[i]) for every i (queued frames, purge requests, index marks and saved state are per handle);
+ * produced[i] receives each call's return value.  Handles must be distinct and share sample rate.
+ * The reference's consumer loop is one thread per stream pulling 8192 samples
+ * (nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:62-81); this is that loop for N streams.
+ */
+int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced);
+/* Choose a handle's noise stream (default 0); see DESIGN.md "Noise". */
+int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int seed);
+
 const char* speechPlayer_lastError(void);
 
 #ifdef __cplusplus

@@ -30,7 +30,7 @@ EXPORTS = [
     "speechPlayer_batch_synthesize", "speechPlayer_batch_wait", "speechPlayer_batch_read",
     "speechPlayer_batch_readAll", "speechPlayer_batch_readFloat", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
     "speechPlayer_batch_deviceOffset", "speechPlayer_batch_time", "speechPlayer_batch_kernelInfo",
-    "speechPlayer_lastError", "speechPlayer_setNoiseSeed",
+    "speechPlayer_lastError", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany",
 ]
 
 
@@ -86,6 +86,8 @@ def load():
     L.speechPlayer_terminate.argtypes = [vp]
     L.speechPlayer_setNoiseSeed.restype = i32
     L.speechPlayer_setNoiseSeed.argtypes = [vp, u32]
+    L.speechPlayer_synthesizeMany.restype = i32
+    L.speechPlayer_synthesizeMany.argtypes = [vp, i32, u32, vp, vp]
     L.speechPlayer_lastError.restype = ctypes.c_char_p
     L.speechPlayer_lastError.argtypes = []
     L.speechPlayer_batch_create.restype = vp

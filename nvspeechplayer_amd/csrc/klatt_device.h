@@ -81,6 +81,7 @@ struct KernelArgs {
     int16_t* pcm;
     UttResult* result;           // [nUtt]
     double* state;               // [nUtt][kStateDoubles] or nullptr (fresh streams, nothing saved)
+    double* const* statePtrs;    // streaming: per-utterance state blocks (one per live handle); overrides `state`
     const uint32_t* control;     // [nUtt] streaming only: bit0 = apply purge before synthesising
     long long nSlots;
     uint32_t maxSamples;         // per launch and utterance; 0xFFFFFFFF = until drained
@@ -435,9 +436,9 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
         for (int k = 0; k < 28; ++k) curFB[k * kLanes + lane] = 0.0;
     }
 
-    if (STREAM && live && A.state) {
+    if (STREAM && live && (A.state || A.statePtrs)) {
         // ---- resume a stream (layout: see the save block at the end) ----
-        const double* S = A.state + (size_t)u * kStateDoubles;
+        const double* S = A.statePtrs ? A.statePtrs[u] : A.state + (size_t)u * kStateDoubles;
         if (S[239] != 0.0) {
 #pragma unroll
             for (int k = 0; k < kSlots; ++k) { oldP[k * kLanes + lane] = S[k]; newP[k * kLanes + lane] = S[45 + k]; }
@@ -577,8 +578,8 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
         A.result[u] = res;
     }
 
-    if (STREAM && live && A.state) {
-        double* S = A.state + (size_t)u * kStateDoubles;
+    if (STREAM && live && (A.state || A.statePtrs)) {
+        double* S = A.statePtrs ? A.statePtrs[u] : A.state + (size_t)u * kStateDoubles;
 #pragma unroll
         for (int k = 0; k < kSlots; ++k) { S[k] = oldP[k * kLanes + lane]; S[45 + k] = newP[k * kLanes + lane]; }
 #pragma unroll

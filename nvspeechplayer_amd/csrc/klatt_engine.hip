@@ -273,21 +273,12 @@ struct Stream {
     int device = 0;
     int mode = MODE_EXACT;
     uint32_t seed = 0;
+    uintptr_t id = 0;
     std::mutex mu;                       // per call, not per sample (reference locks per sample: src/frame.cpp:122)
     std::vector<PendingFrame> pending;   // queued, not yet taken by the kernel
     bool purgePending = false;
     int lastIndex = -1;
-    hipStream_t stream = nullptr;
-    DeviceBuffer<double> dFrames;
-    DeviceBuffer<FrameMeta> dMeta;
-    DeviceBuffer<UttDesc> dUtt;
-    DeviceBuffer<uint32_t> dOrder;
-    DeviceBuffer<uint32_t> dControl;
-    DeviceBuffer<int16_t> dPcm;
-    DeviceBuffer<UttResult> dResult;
-    DeviceBuffer<double> dState;
-    std::vector<double> hFrames;
-    std::vector<FrameMeta> hMeta;
+    DeviceBuffer<double> dState;         // the stream's saved synthesiser state (kStateDoubles), lives on the GPU
 };
 
 std::mutex g_tableMutex;
@@ -303,63 +294,138 @@ Stream* lookup(speechPlayer_handle_t h)
     return g_streams[id - 1];
 }
 
+// Launch context shared by the live streams of one device: staging buffers for the frames the handles
+// have queued, the PCM of the call, results.  Calls on one device are serialised by `mu`.
+struct LiveContext {
+    std::mutex mu;
+    hipStream_t stream = nullptr;
+    DeviceBuffer<double> dFrames;
+    DeviceBuffer<FrameMeta> dMeta;
+    DeviceBuffer<UttDesc> dUtt;
+    DeviceBuffer<uint32_t> dOrder;
+    DeviceBuffer<uint32_t> dControl;
+    DeviceBuffer<int16_t> dPcm;
+    DeviceBuffer<UttResult> dResult;
+    DeviceBuffer<double*> dStatePtrs;
+    std::vector<double> hFrames;
+    std::vector<FrameMeta> hMeta;
+    std::vector<UttDesc> hUtt;
+    std::vector<uint32_t> hOrder, hControl;
+    std::vector<double*> hStatePtrs;
+    std::vector<UttResult> hResult;
+    std::vector<int16_t> hPcm;
+};
+std::mutex g_liveMutex;
+std::vector<LiveContext*> g_live;   // per device
+
+LiveContext* live_context(int device)
+{
+    std::lock_guard<std::mutex> g(g_liveMutex);
+    if ((int)g_live.size() <= device) g_live.resize(device + 1, nullptr);
+    if (!g_live[device]) {
+        LiveContext* c = new LiveContext;
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+            set_error("cannot create a stream on device %d", device);
+            delete c;
+            return nullptr;
+        }
+        g_live[device] = c;
+    }
+    return g_live[device];
+}
+
 int stream_init_device(Stream* s)
 {
     HIP_TRY(hipSetDevice(s->device));
-    HIP_TRY(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
-    if (s->dUtt.reserve(1) || s->dOrder.reserve(1) || s->dControl.reserve(1) || s->dResult.reserve(1) ||
-        s->dState.reserve(kStateDoubles))
-        return -1;
-    HIP_TRY(hipMemsetAsync(s->dState.ptr, 0, kStateDoubles * sizeof(double), s->stream));
-    const uint32_t zero = 0;
-    HIP_TRY(hipMemcpyAsync(s->dOrder.ptr, &zero, sizeof zero, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->dState.reserve(kStateDoubles)) return -1;
+    HIP_TRY(hipMemset(s->dState.ptr, 0, kStateDoubles * sizeof(double)));
     return 0;
 }
 
-int stream_synthesize(Stream* s, unsigned int count, sample* out)
+// Advance n live streams by up to `count` samples each in ONE launch (one stream per wavefront lane).
+// The callers hold every stream's mutex.  produced[i] receives speechPlayer_synthesize's return value.
+int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* const* outs, int* produced)
 {
-    if (count == 0) return 0;
-    HIP_TRY(hipSetDevice(s->device));
-    const size_t nf = s->pending.size();
-    if (nf) {
-        s->hFrames.resize(nf * kNumParams);
-        s->hMeta.resize(nf);
-        for (size_t k = 0; k < nf; ++k) {
-            memcpy(&s->hFrames[k * kNumParams], s->pending[k].p, sizeof(double) * kNumParams);
-            s->hMeta[k] = s->pending[k].meta;
+    for (int i = 0; i < n; ++i) produced[i] = 0;
+    if (count == 0 || n <= 0) return 0;
+    const int device = ss[0]->device, rate = ss[0]->sampleRate, mode = ss[0]->mode;
+    for (int i = 1; i < n; ++i)
+        if (ss[i]->device != device || ss[i]->sampleRate != rate || ss[i]->mode != mode) {
+            set_error("streams advanced together must share device, sample rate and mode");
+            return -1;
         }
-        if (s->dFrames.reserve(std::max<size_t>(nf, 64) * kNumParams) || s->dMeta.reserve(std::max<size_t>(nf, 64))) return -1;
-        HIP_TRY(hipMemcpyAsync(s->dFrames.ptr, s->hFrames.data(), nf * kNumParams * sizeof(double), hipMemcpyHostToDevice, s->stream));
-        HIP_TRY(hipMemcpyAsync(s->dMeta.ptr, s->hMeta.data(), nf * sizeof(FrameMeta), hipMemcpyHostToDevice, s->stream));
-    } else if (!s->dFrames.ptr) {
-        if (s->dFrames.reserve(64 * kNumParams) || s->dMeta.reserve(64)) return -1;
-    }
+    LiveContext* c = live_context(device);
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(device));
+    size_t nf = 0;
+    for (int i = 0; i < n; ++i) nf += ss[i]->pending.size();
     const size_t padded = ((size_t)count + kTile - 1) / kTile * kTile;
-    if (s->dPcm.reserve(padded)) return -1;
-    UttDesc d;
-    memset(&d, 0, sizeof d);
-    d.frameStart = 0; d.outStart = 0; d.nFrames = (uint32_t)nf; d.seed = s->seed;
-    const uint32_t control = s->purgePending ? 1u : 0u;
-    HIP_TRY(hipMemcpyAsync(s->dUtt.ptr, &d, sizeof d, hipMemcpyHostToDevice, s->stream));
-    HIP_TRY(hipMemcpyAsync(s->dControl.ptr, &control, sizeof control, hipMemcpyHostToDevice, s->stream));
+    c->hFrames.resize(std::max<size_t>(nf, 1) * kNumParams);
+    c->hMeta.resize(std::max<size_t>(nf, 1));
+    c->hUtt.resize(n); c->hOrder.resize(n); c->hControl.resize(n); c->hStatePtrs.resize(n); c->hResult.resize(n);
+    size_t k = 0;
+    for (int i = 0; i < n; ++i) {
+        UttDesc& d = c->hUtt[i];
+        memset(&d, 0, sizeof d);
+        d.frameStart = (long long)k; d.outStart = (long long)(i * padded); d.nFrames = (uint32_t)ss[i]->pending.size();
+        d.seed = ss[i]->seed; d.flags = UTT_NEEDS_NOISE;
+        for (const PendingFrame& f : ss[i]->pending) {
+            memcpy(&c->hFrames[k * kNumParams], f.p, sizeof(double) * kNumParams);
+            c->hMeta[k] = f.meta;
+            ++k;
+        }
+        c->hOrder[i] = (uint32_t)i;
+        c->hControl[i] = ss[i]->purgePending ? 1u : 0u;
+        c->hStatePtrs[i] = ss[i]->dState.ptr;
+    }
+    if (c->dFrames.reserve(std::max<size_t>(nf, 64) * kNumParams) || c->dMeta.reserve(std::max<size_t>(nf, 64)) ||
+        c->dUtt.reserve(n) || c->dOrder.reserve(n) || c->dControl.reserve(n) || c->dResult.reserve(n) ||
+        c->dStatePtrs.reserve(n) || c->dPcm.reserve(padded * n))
+        return -1;
+    if (nf) {
+        HIP_TRY(hipMemcpyAsync(c->dFrames.ptr, c->hFrames.data(), nf * kNumParams * sizeof(double), hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->dMeta.ptr, c->hMeta.data(), nf * sizeof(FrameMeta), hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(hipMemcpyAsync(c->dUtt.ptr, c->hUtt.data(), n * sizeof(UttDesc), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dOrder.ptr, c->hOrder.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dControl.ptr, c->hControl.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(hipMemcpyAsync(c->dStatePtrs.ptr, c->hStatePtrs.data(), n * sizeof(double*), hipMemcpyHostToDevice, c->stream));
 
-    KernelArgs a = base_args(s->sampleRate);
-    a.frames = s->dFrames.ptr; a.meta = s->dMeta.ptr; a.utt = s->dUtt.ptr; a.order = s->dOrder.ptr;
-    a.pcm = s->dPcm.ptr; a.result = s->dResult.ptr; a.state = s->dState.ptr; a.control = s->dControl.ptr;
-    a.nSlots = 1;
+    KernelArgs a = base_args(rate);
+    a.frames = c->dFrames.ptr; a.meta = c->dMeta.ptr; a.utt = c->dUtt.ptr; a.order = c->dOrder.ptr;
+    a.pcm = c->dPcm.ptr; a.result = c->dResult.ptr; a.state = nullptr; a.statePtrs = c->dStatePtrs.ptr; a.control = c->dControl.ptr;
+    a.nSlots = n;
     a.maxSamples = count;
-    if (launch<true, true>(a, s->mode, 1, s->stream)) return -1;
+    if (launch<true, true>(a, mode, (n + kLanes - 1) / kLanes, c->stream)) return -1;
 
-    UttResult r;
-    HIP_TRY(hipMemcpyAsync(&r, s->dResult.ptr, sizeof r, hipMemcpyDeviceToHost, s->stream));
-    HIP_TRY(hipStreamSynchronize(s->stream));
-    if (r.produced > count) { set_error("kernel produced %u > %u", r.produced, count); return -1; }
-    if (r.produced) HIP_TRY(hipMemcpy(out, s->dPcm.ptr, (size_t)r.produced * sizeof(int16_t), hipMemcpyDeviceToHost));
-    s->purgePending = false;
-    s->pending.erase(s->pending.begin(), s->pending.begin() + std::min<size_t>(r.framesTaken, nf));
-    s->lastIndex = r.lastIndex;
-    return (int)r.produced;
+    HIP_TRY(hipMemcpyAsync(c->hResult.data(), c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    size_t lastWithData = 0;
+    bool any = false;
+    for (int i = 0; i < n; ++i) {
+        if (c->hResult[i].produced > count) { set_error("kernel produced %u > %u", c->hResult[i].produced, count); return -1; }
+        if (c->hResult[i].produced) { lastWithData = i; any = true; }
+    }
+    if (any) {
+        if (n == 1) {
+            HIP_TRY(hipMemcpy(outs[0], c->dPcm.ptr, (size_t)c->hResult[0].produced * sizeof(int16_t), hipMemcpyDeviceToHost));
+        } else {
+            c->hPcm.resize((lastWithData + 1) * padded);
+            HIP_TRY(hipMemcpy(c->hPcm.data(), c->dPcm.ptr, c->hPcm.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
+            for (int i = 0; i < n; ++i)
+                if (c->hResult[i].produced) memcpy(outs[i], &c->hPcm[(size_t)i * padded], (size_t)c->hResult[i].produced * sizeof(int16_t));
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        Stream* s = ss[i];
+        const UttResult& r = c->hResult[i];
+        s->purgePending = false;
+        s->pending.erase(s->pending.begin(), s->pending.begin() + std::min<size_t>(r.framesTaken, s->pending.size()));
+        s->lastIndex = r.lastIndex;
+        produced[i] = (int)r.produced;
+    }
+    return 0;
 }
 
 }  // namespace
@@ -381,8 +447,9 @@ speechPlayer_handle_t speechPlayer_initialize(int sampleRate)
     if (stream_init_device(s)) { delete s; return nullptr; }
     std::lock_guard<std::mutex> g(g_tableMutex);
     for (size_t i = 0; i < g_streams.size(); ++i)
-        if (!g_streams[i]) { g_streams[i] = s; return reinterpret_cast<speechPlayer_handle_t>(i + 1); }
+        if (!g_streams[i]) { g_streams[i] = s; s->id = i + 1; return reinterpret_cast<speechPlayer_handle_t>(i + 1); }
     g_streams.push_back(s);
+    s->id = g_streams.size();
     return reinterpret_cast<speechPlayer_handle_t>(g_streams.size());
 }
 
@@ -411,8 +478,10 @@ int speechPlayer_synthesize(speechPlayer_handle_t playerHandle, unsigned int sam
     Stream* s = lookup(playerHandle);
     if (!s) { set_error("speechPlayer_synthesize: invalid handle"); return 0; }
     std::lock_guard<std::mutex> g(s->mu);
-    int n = stream_synthesize(s, sampleCount, sampleBuf);
-    return n < 0 ? 0 : n;
+    int produced = 0;
+    sample* out = sampleBuf;
+    if (streams_synthesize(&s, 1, sampleCount, &out, &produced)) return 0;
+    return produced;
 }
 
 int speechPlayer_getLastIndex(speechPlayer_handle_t playerHandle)
@@ -434,9 +503,8 @@ void speechPlayer_terminate(speechPlayer_handle_t playerHandle)
     }
     if (!s) return;
     (void)hipSetDevice(s->device);
-    if (s->stream) { (void)hipStreamSynchronize(s->stream); (void)hipStreamDestroy(s->stream); }
-    s->dFrames.release(); s->dMeta.release(); s->dUtt.release(); s->dOrder.release(); s->dControl.release();
-    s->dPcm.release(); s->dResult.release(); s->dState.release();
+    { std::lock_guard<std::mutex> g(s->mu); }   // let a call in flight finish
+    s->dState.release();
     delete s;
 }
 
@@ -448,6 +516,28 @@ int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int s
     std::lock_guard<std::mutex> g(s->mu);
     s->seed = seed;
     return 0;
+}
+
+// Additive: advance many live handles together -- one kernel launch, one handle per wavefront lane.
+// Equivalent to calling speechPlayer_synthesize(handles[i], sampleCount, sampleBufs[i]) for every i;
+// produced[i] receives each call's return value.  Handles must be distinct and share a sample rate.
+int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced)
+{
+    if (nHandles < 0 || (nHandles > 0 && (!handles || !sampleBufs || !produced))) { set_error("speechPlayer_synthesizeMany: bad arguments"); return -1; }
+    std::vector<Stream*> ss((size_t)nHandles);
+    for (int i = 0; i < nHandles; ++i) {
+        ss[i] = lookup(handles[i]);
+        if (!ss[i]) { set_error("speechPlayer_synthesizeMany: invalid handle at %d", i); return -1; }
+    }
+    // lock in handle order (no deadlock between concurrent calls); duplicates are an error
+    std::vector<Stream*> order(ss);
+    std::sort(order.begin(), order.end(), [](Stream* x, Stream* y) { return x->id < y->id; });
+    for (size_t i = 1; i < order.size(); ++i)
+        if (order[i] == order[i - 1]) { set_error("speechPlayer_synthesizeMany: handle listed twice"); return -1; }
+    for (Stream* s : order) s->mu.lock();
+    const int rc = streams_synthesize(ss.data(), nHandles, sampleCount, sampleBufs, produced);
+    for (Stream* s : order) s->mu.unlock();
+    return rc;
 }
 
 // ==========================================================================================

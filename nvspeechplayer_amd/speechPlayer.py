@@ -8,7 +8,7 @@ interface (include/speechPlayer_batch.h): many frame streams, one kernel launch.
 
 Everything here calls the HIP library through its C-ABI; there is no CPU path.
 """
-from ctypes import Structure, byref, c_double, c_short
+from ctypes import POINTER, Structure, byref, c_double, c_int, c_short, c_void_p, cast
 
 import numpy as np
 
@@ -87,6 +87,30 @@ class SpeechPlayer(object):
 
     def getLastIndex(self):
         return self._dll.speechPlayer_getLastIndex(self._speechHandle)
+
+    @staticmethod
+    def synthesizeMany(players, numSamples):
+        """Advance many live players together in one kernel launch (speechPlayer_synthesizeMany).
+        Returns a list with what each player's synthesize(numSamples) would have returned."""
+        n = len(players)
+        if n == 0:
+            return []
+        dll = players[0]._dll
+        handles = (c_void_p * n)(*[p._speechHandle for p in players])
+        bufs = [(c_short * numSamples)() for _ in range(n)]
+        ptrs = (c_void_p * n)(*[cast(b, c_void_p) for b in bufs])
+        produced = (c_int * n)()
+        rc = dll.speechPlayer_synthesizeMany(handles, n, numSamples, ptrs, produced)
+        if rc != 0:
+            raise RuntimeError("speechPlayer_synthesizeMany failed: %s" % _native.last_error())
+        out = []
+        for b, got in zip(bufs, produced):
+            if got > 0:
+                b.length = min(got, len(b))
+                out.append(b)
+            else:
+                out.append(None)
+        return out
 
     def close(self):
         if getattr(self, "_speechHandle", None):

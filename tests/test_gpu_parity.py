@@ -460,3 +460,44 @@ def test_limits_are_reported_not_wrapped(ref):
     bp.synthesize()
     assert len(bp.read(0)) == 101
     bp.close()
+
+
+def test_many_live_streams_one_launch(ref, all_scenarios):
+    """speechPlayer_synthesizeMany: 130 live handles (3 wavefronts) at unrelated points of unrelated streams,
+    pulled together in uneven chunks, one of them purged on the way, frames queued between pulls --
+    each handle's PCM, call lengths and index marks equal its own oracle player's."""
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(5)
+    cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=130)]
+    players = [eng.SpeechPlayer(22050, noiseSeed=300 + k) for k in range(len(cases))]
+    oracles = [oracle.OraclePlayer(22050, seed=300 + k) for k in range(len(cases))]
+    fz = scenarios.vowel_frame(ref, "z", 130.0, 90.0)
+    for k, case in enumerate(cases):
+        half = len(case) // 2 if k % 3 == 0 else len(case)        # every third stream gets the rest later
+        for j, (fr, m, f) in enumerate(case[:half]):
+            players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, j)
+            oracles[k].queue(fr, m, f, j)
+    got = [[] for _ in cases]
+    exp = [[] for _ in cases]
+    for step, n in enumerate((3000, 1, 777, 8192, 4096, 8192, 8192, 8192, 8192, 8192, 8192)):
+        if step == 2:
+            players[7].queueFrameSamples(eng.Frame.from_array(fz), 900, 300, 99, True)     # purge one live stream
+            oracles[7].queue(fz, 900, 300, 99, True)
+        if step == 3:
+            for k, case in enumerate(cases):
+                if k % 3 == 0:
+                    for j, (fr, m, f) in enumerate(case[len(case) // 2:]):
+                        players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, 1000 + j)
+                        oracles[k].queue(fr, m, f, 1000 + j)
+        bufs = eng.SpeechPlayer.synthesizeMany(players, n)
+        for k, b in enumerate(bufs):
+            e = oracles[k].synthesize(n)
+            g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
+            assert len(g) == len(e), (step, k, len(g), len(e))
+            assert players[k].getLastIndex() == oracles[k].last_index(), (step, k)
+            got[k].append(g); exp[k].append(e)
+    total = 0
+    for k in range(len(cases)):
+        total += compare(np.concatenate(got[k]), np.concatenate(exp[k]), "live stream %d" % k)
+        players[k].close()
+    assert total == 0

@@ -129,18 +129,20 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     return 0;
 }
 
-// Which kernel runs a group of `nUtt` utterances (64 per wavefront)?
-//   stage-parallel workgroups (klatt_systolic.h) while the lane kernel could not fill the chip anyway
-//   (it keeps 3 wavefronts per CU resident): 4x the wavefronts per utterance, shorter critical path;
-//   the lane kernel beyond that, where every SIMD is busy either way and its lower per-sample overhead wins.
-// Quiet groups that fit one workgroup per CU use 32-sample hand-overs (fewer barriers), else 16.
+// Which kernel runs the batch's groups (64 utterances per group)?  Measured on MI355X:
+//   * stage-parallel workgroups (klatt_systolic.h) win at every size for quiet (noise-free) batches --
+//     4 wavefronts per group, two workgroups per CU when the batch is large: 2.8e11 samples/s at 65 536
+//     steady vowels against 1.3e11 for the lane kernel;
+//   * with noisy utterances they win while the lane kernel could not fill the chip (<= 3 groups per CU) and
+//     tie or lose by ~10 % beyond, so large noisy batches use the lane kernel.
 // The decision is taken on the whole batch (both groups run at the same time and share the CUs' LDS).
+// Quiet groups that fit one workgroup per CU use 32-sample hand-overs (fewer barriers), else 16.
 struct GroupPlan { bool systolic; int chunk; };
-GroupPlan plan_group(int layout, bool noisy, long long nUttBatch, int cus)
+GroupPlan plan_group(int layout, bool noisy, long long nUttBatch, long long nNoisyBatch, int cus)
 {
     const long long groups = (nUttBatch + kLanes - 1) / kLanes + 1;
     GroupPlan p;
-    p.systolic = layout == 1 || (layout < 0 && groups <= 3LL * cus);
+    p.systolic = layout == 1 || (layout < 0 && (nNoisyBatch == 0 || groups <= 3LL * cus));
     p.chunk = (!noisy && groups <= cus) ? 32 : 16;
     return p;
 }
@@ -244,7 +246,7 @@ int batch_launch(Batch* b)
             st = b->sideStream;
         }
         a.order = b->dOrder.ptr; a.nSlots = b->nQuiet;
-        const GroupPlan pl = plan_group(b->layout, false, b->nSlots, b->cus);
+        const GroupPlan pl = plan_group(b->layout, false, b->nSlots, b->nSlots - b->nQuiet, b->cus);
         const long long g = (b->nQuiet + kLanes - 1) / kLanes;
         if (pl.systolic ? (pl.chunk == 32 ? launch_systolic<false, 32>(a, b->mode, g, st) : launch_systolic<false, 16>(a, b->mode, g, st))
                         : launch<false, false>(a, b->mode, g, st)) return -1;
@@ -252,7 +254,7 @@ int batch_launch(Batch* b)
     }
     if (nNoisy > 0) {
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
-        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, b->cus);
+        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, b->nSlots - b->nQuiet, b->cus);
         const long long g = (nNoisy + kLanes - 1) / kLanes;
         if (pl.systolic ? launch_systolic<true, 16>(a, b->mode, g, b->stream) : launch<false, true>(a, b->mode, g, b->stream)) return -1;
         if (both) HIP_TRY(hipStreamWaitEvent(b->stream, b->joinEvent, 0));
@@ -832,7 +834,7 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     HIP_TRY(hipSetDevice(b->device));
     hipFuncAttributes fa;
     const bool noisy = b->nSlots - b->nQuiet >= b->nQuiet;   // report the larger group's kernel
-    const GroupPlan pl = plan_group(b->layout, noisy, b->nSlots, b->cus);
+    const GroupPlan pl = plan_group(b->layout, noisy, b->nSlots, b->nSlots - b->nQuiet, b->cus);
     const bool fast = b->mode == MODE_FAST;
     const void* fn;
     int sysLds = 0;

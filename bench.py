@@ -39,6 +39,7 @@ def parse():
     ap.add_argument("--mode", type=int, default=0, help="arithmetic mode (include/speechPlayer_batch.h)")
     ap.add_argument("--layout", type=int, default=-1, help="-1: engine's choice, 1: stage-parallel workgroups, 0: one wavefront per 64 utterances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-large-batch", action="store_true", help="skip the extra measurement of the same recipe at 65536 utterances")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
     return ap.parse_args()
 
@@ -163,6 +164,19 @@ def main():
                          "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
                          "note": "f64 VALU issue binds before HBM, and a 4096-utterance batch fills only 64 of 256 CUs; see DESIGN.md"},
         }
+        if world == 1 and args.workload == "cfg1" and not args.utterances and not args.no_large_batch:
+            # The metric is "batch-N utterances": the same recipe at N = 65 536 fills the chip (2 workgroups per CU).
+            bp.close()
+            big = workloads.make("cfg1", 65536)
+            bp = BatchPlayer(big["sr"], device=device, mode=args.mode, layout=args.layout)
+            bp.setUtterances(big["frame_start"], big["frames"], big["min"], big["fade"], big["index"], big["isnull"], big["seeds"])
+            bp.time(1)
+            big_ms = float(np.mean(bp.time(3)))
+            big_bytes = big.algorithmic_bytes()
+            out["same_recipe_at_batch_65536"] = {
+                "value": bp.totalSamples / (big_ms * 1e-3), "unit": "samples/s", "kernel_ms": big_ms,
+                "roofline_frac": big_bytes / (big_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                "note": "not the headline config; shows the occupancy limit of a 4096-utterance batch"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -62,17 +62,19 @@ def cfg1_steady_vowels(n_utt=4096, seconds=1.0, first=0, sr=SR):
     z = _load()
     names = [b.decode("utf8") for b in z["phoneme_names"]]
     vowels = [i for i in range(len(names)) if z["phoneme_isVowel"][i]]
-    frames = np.zeros((n_utt * 2, 47))
-    for k in range(n_utt):
-        u = first + k
-        i = vowels[u % len(vowels)]
+    protos = np.zeros((len(vowels), 47))
+    for j, i in enumerate(vowels):
         f = np.zeros(47)
         f[PREGAIN] = 1.0; f[VOICEAMP] = 1.0; f[OUTGAIN] = 1.0
         mask = z["phoneme_mask"][i].astype(bool)
         f[mask] = z["phoneme_frames"][i][mask]
-        pitch = 80.0 * 2.0 ** (((u // len(vowels)) % 205) / 205.0 * 2.0)
-        f[VOICEPITCH] = pitch; f[ENDPITCH] = pitch
-        frames[2 * k] = f
+        protos[j] = f
+    u = first + np.arange(n_utt)
+    frames = np.zeros((n_utt * 2, 47))
+    frames[0::2] = protos[u % len(vowels)]
+    pitch = 80.0 * 2.0 ** (((u // len(vowels)) % 205) / 205.0 * 2.0)
+    frames[0::2, VOICEPITCH] = pitch
+    frames[0::2, ENDPITCH] = pitch
     M, F = ms(1000 * seconds, sr), ms(50, sr)
     return Batch(frames=frames, min=np.tile(np.array([M, F], np.uint32), n_utt),
                  fade=np.tile(np.array([F, F], np.uint32), n_utt), index=np.full(n_utt * 2, -1, np.int32),

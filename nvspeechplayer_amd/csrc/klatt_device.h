@@ -23,8 +23,8 @@
 //     lane, whole 64-byte row segments per utterance.
 //
 // Arithmetic is IEEE double.  This translation unit is compiled with -ffp-contract=off.
-// MODE_EXACT rounds every multiply and add separately, as the reference binary does, and
-// uses the device library's exp/cos.  MODE_FAST fuses multiply-adds and uses klatt_math.h.
+// MODE_EXACT rounds every multiply and add of the signal path separately, as the reference binary does;
+// MODE_FAST fuses the resonators' multiply-adds.  Both evaluate exp/cos with klatt_math.h (<= 1 ulp).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -152,14 +152,10 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
     const double ex = negPiOverSr * bw;
     const double th = twoPiOverSr * -f;
     double rad, cs;
-    if (MODE == MODE_FAST) {
-        // straight-line versions; arguments outside their range take the library path
-        if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
-        else { rad = exp(ex); cs = cos(th); }
-    } else {
-        rad = exp(ex);
-        cs = cos(th);
-    }
+    // exp and cos: the straight-line versions of klatt_math.h (<= 1 ulp, like a libm); arguments outside their
+    // validated range take the device library.  Same code in both arithmetic modes.
+    if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
+    else { rad = exp(ex); cs = cos(th); }
     double cc = -(rad * rad);
     double bb = rad * cs * 2.0;
     double aa = 1.0 - bb - cc;

@@ -130,19 +130,17 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
 }
 
 // Which kernel runs the batch's groups (64 utterances per group)?  Measured on MI355X:
-//   * stage-parallel workgroups (klatt_systolic.h) win at every size for quiet (noise-free) batches --
-//     4 wavefronts per group, two workgroups per CU when the batch is large: 2.8e11 samples/s at 65 536
-//     steady vowels against 1.3e11 for the lane kernel;
-//   * with noisy utterances they win while the lane kernel could not fill the chip (<= 3 groups per CU) and
-//     tie or lose by ~10 % beyond, so large noisy batches use the lane kernel.
-// The decision is taken on the whole batch (both groups run at the same time and share the CUs' LDS).
-// Quiet groups that fit one workgroup per CU use 32-sample hand-overs (fewer barriers), else 16.
+// stage-parallel workgroups (klatt_systolic.h) win at every batch size and for both groups -- 2.8e11 samples/s
+// at 65 536 steady vowels against 1.3e11 for the lane kernel, 28.8 ms against 37.1 ms on cfg2 -- so "auto"
+// always takes them; the lane kernel stays selectable (layout 0) and runs the streaming handles.
+// Quiet batches that fit one workgroup per CU use 32-sample hand-overs (fewer barriers), else 16.
 struct GroupPlan { bool systolic; int chunk; };
 GroupPlan plan_group(int layout, bool noisy, long long nUttBatch, long long nNoisyBatch, int cus)
 {
     const long long groups = (nUttBatch + kLanes - 1) / kLanes + 1;
     GroupPlan p;
-    p.systolic = layout == 1 || (layout < 0 && (nNoisyBatch == 0 || groups <= 3LL * cus));
+    p.systolic = layout != 0;
+    (void)nNoisyBatch;
     p.chunk = (!noisy && groups <= cus) ? 32 : 16;
     return p;
 }

@@ -94,10 +94,10 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES>& f, bo
 
 // Stage descriptor.  GAIN = index into P of parameter 44 (or -1): NULL frames force it to 0
 // (reference src/frame.cpp:61,66).  ANTI0: resonator 0 is the anti-resonator N0.
-template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_>
+template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false>
 struct StageDesc {
     static constexpr int NPARAM = NPARAM_, NRES = NRES_, GAIN = GAIN_;
-    static constexpr bool PITCH = PITCH_, ANTI0 = ANTI0_;
+    static constexpr bool PITCH = PITCH_, ANTI0 = ANTI0_, INLINE_COEF = INLINE_COEF_;
 };
 
 struct StageCtx {          // what every stage needs from the launch
@@ -203,7 +203,11 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
 #pragma unroll
     for (int r = 0; r < D::NRES; ++r) {
         if (wRes & (1u << r)) {
-            const Coef k = resonator_coefficients<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr);
+            // inlined where fades dominate (speech); the quiet kernels keep one out-of-line copy, which keeps
+            // their loops small (measured: cfg1 1.72 ms vs 1.86 ms inlined; cfg2 29.2 ms inlined vs 36.6 ms called)
+            const Coef k = D::INLINE_COEF
+                ? resonator_coefficients_inline<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr)
+                : resonator_coefficients<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr);
             f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
         }
     }
@@ -419,7 +423,7 @@ __global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systol
     } else if (stage == 1) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
         constexpr int NR = NOISE ? 5 : 3;
-        using D = StageDesc<2 * NR + 1, NR, -1, false, true>;
+        using D = StageDesc<2 * NR + 1, NR, -1, false, true, NOISE>;
         // parameter list: (f, bw) of N0, NP, r6 [, r5, r4], then caNP
         constexpr int P[11] = {13, 21, 14, 22, 12, 20, NOISE ? 11 : 23, 19, 10, 18, 23};
         constexpr int RF[5] = {0, 2, 4, 6, 8};
@@ -444,7 +448,7 @@ __global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systol
     } else if (NOISE && stage == 3) {
         // ================= noisy S3: frication noise, parallel r1..r4 partial sum =================
         // tracked: (pf, pb) of parallel 1..4, then 24 fricationAmplitude, 44 preFormantGain, pa1..4 (37..40)
-        using D = StageDesc<14, 4, 9, false, false>;
+        using D = StageDesc<14, 4, 9, false, false, true>;
         constexpr int P[14] = {25, 31, 26, 32, 27, 33, 28, 34, 24, 44, 37, 38, 39, 40};
         constexpr int RF[4] = {0, 2, 4, 6}, RB[4] = {1, 3, 5, 7};
         StageFrame<14, 4> f;
@@ -494,7 +498,7 @@ __global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systol
         constexpr int NC = NOISE ? 3 : 2;                 // cascade resonators here
         constexpr int NR = NOISE ? 5 : 2;
         constexpr int NPAR = NOISE ? 14 : 5;
-        using D = StageDesc<NPAR, NR, -1, false, false>;
+        using D = StageDesc<NPAR, NR, -1, false, false, NOISE>;
         constexpr int P[14] = {NOISE ? 9 : 8, NOISE ? 17 : 16, NOISE ? 8 : 7, NOISE ? 16 : 15, NOISE ? 7 : 45, 15,
                                29, 35, 30, 36, 41, 42, 43, 45};
         constexpr int RF[5] = {0, 2, NOISE ? 4 : 0, 6, 8};

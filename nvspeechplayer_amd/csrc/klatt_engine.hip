@@ -103,7 +103,7 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE, int CH>
+template <bool NOISE, int CH, int WPS = 1>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
@@ -120,8 +120,8 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     static bool attrExact = false, attrFast = false;
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH>, attrExact); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH>, attrFast); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS>, attrExact); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS>, attrFast); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -141,7 +141,8 @@ GroupPlan plan_group(int layout, bool noisy, long long nUttBatch, long long nNoi
     GroupPlan p;
     p.systolic = layout != 0;
     (void)nNoisyBatch;
-    p.chunk = (!noisy && groups <= cus) ? 32 : 16;
+    p.chunk = noisy ? (groups <= cus ? 16 : 8)      // noisy: 8-sample hand-overs fit two workgroups per CU (LDS 80 KB each)
+                    : (groups <= cus ? 32 : 16);
     return p;
 }
 
@@ -254,7 +255,8 @@ int batch_launch(Batch* b)
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, b->nSlots - b->nQuiet, b->cus);
         const long long g = (nNoisy + kLanes - 1) / kLanes;
-        if (pl.systolic ? launch_systolic<true, 16>(a, b->mode, g, b->stream) : launch<false, true>(a, b->mode, g, b->stream)) return -1;
+        if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, 8, 2>(a, b->mode, g, b->stream) : launch_systolic<true, 16>(a, b->mode, g, b->stream))
+                        : launch<false, true>(a, b->mode, g, b->stream)) return -1;
         if (both) HIP_TRY(hipStreamWaitEvent(b->stream, b->joinEvent, 0));
     }
     return 0;
@@ -837,7 +839,8 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     const void* fn;
     int sysLds = 0;
     if (pl.systolic) {
-        if (noisy) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16> : (const void*)klatt_systolic<MODE_EXACT, true, 16>; sysLds = SysLds<true, 16>::kBytes; }
+        if (noisy && pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 8, 2> : (const void*)klatt_systolic<MODE_EXACT, true, 8, 2>; sysLds = SysLds<true, 8>::kBytes; }
+        else if (noisy) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16> : (const void*)klatt_systolic<MODE_EXACT, true, 16>; sysLds = SysLds<true, 16>::kBytes; }
         else if (pl.chunk == 32) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 32> : (const void*)klatt_systolic<MODE_EXACT, false, 32>; sysLds = SysLds<false, 32>::kBytes; }
         else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 16> : (const void*)klatt_systolic<MODE_EXACT, false, 16>; sysLds = SysLds<false, 16>::kBytes; }
     } else {

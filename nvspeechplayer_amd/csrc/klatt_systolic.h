@@ -53,7 +53,7 @@ struct SysLds {
     static constexpr int kFrames = kMaxLen + 16;
     // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
     static constexpr int kParams0 = 7, kParams1 = NOISE ? 11 : 7, kParams2 = NOISE ? 14 : 6, kParams3 = NOISE ? 14 : 5;
-    static constexpr int kFrames1 = kFrames + 2 * kParams0 * kLanes * 8;
+    static constexpr int kFrames1 = kFrames + 1 * kParams0 * kLanes * 8;    // S0 keeps its target values in registers
     static constexpr int kFrames2 = kFrames1 + 2 * kParams1 * kLanes * 8;
     static constexpr int kFrames3 = kFrames2 + 2 * kParams2 * kLanes * 8;
     static constexpr int kBytes = kFrames3 + 2 * kParams3 * kLanes * 8;
@@ -61,10 +61,13 @@ struct SysLds {
 
 // ---- the frame state machine, restricted to a stage's parameter subset ----------------------
 // NPARAM tracked parameters P[0..NPARAM); resonator r uses (P[RF[r]], P[RB[r]]).
-template <int NPARAM, int NRES>
+template <int NPARAM, int NRES, bool NWREG = false>
 struct StageFrame {
     double* oldL;     // LDS [NPARAM][64]: this lane's slot k at oldL[k * 64]
-    double* nwL;
+    double* nwL;      // the fade's target values: LDS like oldL, or (NWREG, small stages) registers
+    double nwR[NWREG && NPARAM > 0 ? NPARAM : 1];
+    __device__ __forceinline__ double getNew(int k) const { return NWREG ? nwR[k] : nwL[k * kLanes]; }
+    __device__ __forceinline__ void setNew(int k, double v) { if (NWREG) nwR[k] = v; else nwL[k * kLanes] = v; }
     double cur[NPARAM > 0 ? NPARAM : 1];
     double ra[NRES > 0 ? NRES : 1], rb[NRES > 0 ? NRES : 1], rc[NRES > 0 ? NRES : 1];
     double z1[NRES > 0 ? NRES : 1], z2[NRES > 0 ? NRES : 1];
@@ -78,13 +81,13 @@ struct PitchState {
     double cur0, old0, new0, oldInc, newInc;
 };
 
-template <int NPARAM, int NRES>
-__device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES>& f, bool live, unsigned char* region, int lane)
+template <int NPARAM, int NRES, bool NWREG>
+__device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>& f, bool live, unsigned char* region, int lane)
 {
     f.oldL = reinterpret_cast<double*>(region) + lane;
     f.nwL = f.oldL + NPARAM * kLanes;
 #pragma unroll
-    for (int k = 0; k < NPARAM; ++k) { f.oldL[k * kLanes] = 0.0; f.nwL[k * kLanes] = 0.0; f.cur[k] = 0.0; }
+    for (int k = 0; k < NPARAM; ++k) { f.oldL[k * kLanes] = 0.0; f.setNew(k, 0.0); f.cur[k] = 0.0; }
 #pragma unroll
     for (int r = 0; r < NRES; ++r) { f.ra[r] = 0.0; f.rb[r] = 2.0; f.rc[r] = -1.0; f.z1[r] = 0.0; f.z2[r] = 0.0; }
     f.invFade = 1.0;
@@ -125,7 +128,7 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
 {
     if (f.hasNew) {   // fade finished (reference src/frame.cpp:44-47)
 #pragma unroll
-        for (int k = 0; k < D::NPARAM; ++k) f.oldL[k * kLanes] = f.nwL[k * kLanes];
+        for (int k = 0; k < D::NPARAM; ++k) f.oldL[k * kLanes] = f.getNew(k);
         f.oldMin = f.newMin; f.oldNull = f.newNull;
         if (D::PITCH) { ps->old0 = ps->new0; ps->oldInc = ps->newInc; }
         f.hasNew = false;
@@ -139,24 +142,24 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
     constexpr int GI = D::GAIN >= 0 ? D::GAIN : 0;
     if (f.newNull) {   // silence keeps the old shape, gain gated off (:59-63)
 #pragma unroll
-        for (int k = 0; k < D::NPARAM; ++k) f.nwL[k * kLanes] = f.oldL[k * kLanes];
+        for (int k = 0; k < D::NPARAM; ++k) f.setNew(k, f.oldL[k * kLanes]);
         uint32_t pm = 0;
-        if (D::GAIN >= 0) { pm = (f.oldL[GI * kLanes] != 0.0) ? (1u << GI) : 0u; f.nwL[GI * kLanes] = 0.0; }
+        if (D::GAIN >= 0) { pm = (f.oldL[GI * kLanes] != 0.0) ? (1u << GI) : 0u; f.setNew(GI, 0.0); }
         if (D::PITCH) { ps->new0 = ps->cur0; ps->newInc = 0.0; }
         f.resMask = 0; f.parMask = pm;
     } else {
         uint32_t pm = 0, mk = 0;
         if (f.oldNull) {   // coming out of silence: start from the new shape, gain 0 (:64-67)
 #pragma unroll
-            for (int k = 0; k < D::NPARAM; ++k) { const double v = g[P[k]]; f.nwL[k * kLanes] = v; f.oldL[k * kLanes] = v; }
-            if (D::GAIN >= 0) { pm = (f.nwL[GI * kLanes] != 0.0) ? (1u << GI) : 0u; f.oldL[GI * kLanes] = 0.0; }
+            for (int k = 0; k < D::NPARAM; ++k) { const double v = g[P[k]]; f.setNew(k, v); f.oldL[k * kLanes] = v; }
+            if (D::GAIN >= 0) { pm = (f.getNew(GI) != 0.0) ? (1u << GI) : 0u; f.oldL[GI * kLanes] = 0.0; }
         } else {
             bool moved[D::NPARAM > 0 ? D::NPARAM : 1];
 #pragma unroll
             for (int k = 0; k < D::NPARAM; ++k) {
                 const double v = g[P[k]];
                 moved[k] = !(v == f.oldL[k * kLanes]);      // NaN ("hold") counts as moving: harmless
-                f.nwL[k * kLanes] = v;
+                f.setNew(k, v);
                 pm |= moved[k] ? (1u << k) : 0u;
             }
 #pragma unroll
@@ -196,7 +199,7 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
     if (lerp) {
         double o[D::NPARAM > 0 ? D::NPARAM : 1], n[D::NPARAM > 0 ? D::NPARAM : 1];
 #pragma unroll
-        for (int k = 0; k < D::NPARAM; ++k) { o[k] = f.oldL[k * kLanes]; n[k] = f.nwL[k * kLanes]; }
+        for (int k = 0; k < D::NPARAM; ++k) { o[k] = f.oldL[k * kLanes]; n[k] = f.getNew(k); }
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = fade_value(o[k], n[k], ratio);
     }
@@ -276,8 +279,8 @@ struct Stamps {
 #endif
 
 // ---- the kernel ---------------------------------------------------------------------------
-template <int MODE, bool NOISE, int CH>
-__global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systolic(const KernelArgs A)
+template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES>
+__global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const KernelArgs A)
 {
     using L = SysLds<NOISE, CH>;
     constexpr int kChunk = CH;
@@ -366,7 +369,7 @@ __global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systol
         using D = StageDesc<7, 0, 6, true, false>;
         constexpr int P[7] = {1, 2, 3, 4, 5, 6, 44};
         constexpr int RF[1] = {0}, RB[1] = {0};
-        StageFrame<7, 0> f;
+        StageFrame<7, 0, true> f;         // 7 target values in registers: S0 has the room, the workgroup's LDS does not
         PitchState ps;
         stage_frame_init(f, live, lds + L::kFrames, lane);
         ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
@@ -407,7 +410,7 @@ __global__ void __launch_bounds__(kLanes * kStages, KLATT_MINWAVES) klatt_systol
 #define S0_BODY(c, i, steady) do { if (steady) ps.cur0 += ps.oldInc; PIPE(pipeX, c, i) = source(false); } while (0)
 #define S0_EMIT do {                                                                                             \
             if (emit && f.hasNew && f.cnt == 0)                                                                  \
-                vibFrames = f.oldL[0] != 0.0 || f.oldL[kLanes] != 0.0 || f.nwL[0] != 0.0 || f.nwL[kLanes] != 0.0; \
+                vibFrames = f.oldL[0] != 0.0 || f.oldL[kLanes] != 0.0 || f.getNew(0) != 0.0 || f.getNew(1) != 0.0; \
             const bool waveVib = __any(emit && vib_live_now());                                                  \
             if (emit) { PIPE(pipeX, c, i) = source(waveVib); f.produced++; }                                     \
         } while (0)

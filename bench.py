@@ -164,6 +164,14 @@ def main():
                          "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
                          "note": "f64 VALU issue binds before HBM, and a 4096-utterance batch fills only 64 of 256 CUs; see DESIGN.md"},
         }
+        if world == 1 and args.mode == 0 and not args.no_large_batch:
+            # same batch in MODE_FAST (fused multiply-adds; identical PCM on every test so far, not guaranteed bit-exact)
+            bp.setOption("mode", 1)
+            bp.time(1)
+            fast_ms = float(np.mean(bp.time(max(3, args.steps // 2))))
+            bp.setOption("mode", 0)
+            out["mode_fast"] = {"value": samples / (fast_ms * 1e-3), "unit": "samples/s", "kernel_ms": fast_ms,
+                                "roofline_frac": alg_bytes / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
         if world == 1 and args.workload == "cfg1" and not args.utterances and not args.no_large_batch:
             # The metric is "batch-N utterances": the same recipe at N = 65 536 fills the chip (2 workgroups per CU).
             bp.close()

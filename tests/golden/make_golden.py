@@ -130,13 +130,11 @@ def main():
     import json
     data_dir = os.path.join(ROOT, "nvspeechplayer_amd", "data")
     os.makedirs(data_dir, exist_ok=True)
-    table = {}
-    for i, name in enumerate(names):
-        entry = {"fields": {field_names[k]: float(ph[i, k]) for k in range(47) if mask[i, k]},
-                 "flags": {fl: bool(ipa.data[name].get(fl)) for fl in flag_names if ipa.data[name].get(fl)}}
-        table[name] = entry
-    with open(os.path.join(data_dir, "phonemes.json"), "w", encoding="utf8") as f:
-        json.dump(table, f, ensure_ascii=False, indent=0, sort_keys=True)
+    # the phoneme table as matrices: values[49, 47], which fields an entry sets, its class flags
+    np.savez_compressed(os.path.join(data_dir, "phonemes.npz"),
+                        names=np.array([n.encode("utf8") for n in names]), values=ph, mask=mask,
+                        flag_names=np.array([f.encode() for f in flag_names]),
+                        flags=np.array([[bool(ipa.data[n].get(fl)) for fl in flag_names] for n in names], dtype=np.uint8))
     with open(os.path.join(data_dir, "intonation.json"), "w") as f:
         json.dump(ipa.intonationParamTable, f, indent=1, sort_keys=True)
 

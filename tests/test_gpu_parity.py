@@ -501,3 +501,22 @@ def test_many_live_streams_one_launch(ref, all_scenarios):
         total += compare(np.concatenate(got[k]), np.concatenate(exp[k]), "live stream %d" % k)
         players[k].close()
     assert total == 0
+
+
+def test_random_ragged_batch_large():
+    """One big random batch (20 000 utterances, ~8e7 samples, both launch groups, two workgroups per CU):
+    bit-for-bit against the oracle.  Bounds the rate of differing samples well below 1e-7."""
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(11)
+    batch = random_batch(rng, 20000, wild=True)
+    exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=16)
+    bp = eng.BatchPlayer(22050)
+    bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                     batch["isnull"], batch["seeds"])
+    bp.synthesize()
+    got, got_start = bp.readAll()
+    assert np.array_equal(got_start, exp_start)
+    nbad = int(np.count_nonzero(got != exp))
+    print("large random batch: %d samples, %d differ" % (total, nbad))
+    assert nbad == 0
+    bp.close()

@@ -90,6 +90,22 @@ struct DeviceBuffer {
     }
 };
 
+// Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, and a process may
+// drive several devices (one BatchPlayer each).
+int ensure_lds_limit(const void* kernel, int ldsBytes)
+{
+    static std::mutex mu;
+    static std::vector<std::pair<const void*, int>> done;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    for (const auto& e : done)
+        if (e.first == kernel && e.second == dev) return 0;
+    HIP_TRY(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+    done.emplace_back(kernel, dev);
+    return 0;
+}
+
 KernelArgs base_args(int sampleRate)
 {
     KernelArgs a;
@@ -109,19 +125,15 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
     constexpr int ldsBytes = SysLds<NOISE, CH>::kBytes;
-    auto go = [&](auto kernel, bool& attrSet) -> int {
-        if (!attrSet) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
-            attrSet = true;
-        }
+    auto go = [&](auto kernel) -> int {
+        if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a);
         return 0;
     };
-    static bool attrExact = false, attrFast = false;
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS>, attrExact); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS>, attrFast); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS>); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -152,19 +164,15 @@ int launch(const KernelArgs& a, int mode, long long nWaves, hipStream_t stream)
     if (nWaves <= 0) return 0;
     if (nWaves > 0x7FFFFFFF) { set_error("too many wavefronts: %lld", nWaves); return -1; }
     constexpr int ldsBytes = LdsLayout<STREAM>::kBytes;
-    auto go = [&](auto kernel, bool& attrSet) -> int {
-        if (!attrSet) {
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
-            attrSet = true;
-        }
+    auto go = [&](auto kernel) -> int {
+        if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nWaves), dim3(kLanes), ldsBytes, stream, a);
         return 0;
     };
-    static bool attrExact = false, attrFast = false;
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_synthesize<MODE_EXACT, STREAM, NOISE>, attrExact); break;
-    case MODE_FAST: rc = go(klatt_synthesize<MODE_FAST, STREAM, NOISE>, attrFast); break;
+    case MODE_EXACT: rc = go(klatt_synthesize<MODE_EXACT, STREAM, NOISE>); break;
+    case MODE_FAST: rc = go(klatt_synthesize<MODE_FAST, STREAM, NOISE>); break;
     default:
         set_error("unknown arithmetic mode %d", mode);
         return -1;
@@ -803,7 +811,12 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
     Batch* b = static_cast<Batch*>(batch);
     if (!b || launches <= 0 || !msPerLaunch) return -1;
     HIP_TRY(hipSetDevice(b->device));
-    std::vector<hipEvent_t> ev((size_t)launches * 2);
+    struct Events {
+        std::vector<hipEvent_t> v;
+        ~Events() { for (auto e : v) if (e) (void)hipEventDestroy(e); }
+    } events;
+    events.v.assign((size_t)launches * 2, nullptr);
+    std::vector<hipEvent_t>& ev = events.v;
     for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
     int rc = 0;
     for (int i = 0; i < launches && !rc; ++i) {
@@ -813,7 +826,6 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
     }
     HIP_TRY(hipStreamSynchronize(b->stream));
     for (int i = 0; i < launches && !rc; ++i) HIP_TRY(hipEventElapsedTime(&msPerLaunch[i], ev[2 * i], ev[2 * i + 1]));
-    for (auto& e : ev) (void)hipEventDestroy(e);
     return rc;
 }
 

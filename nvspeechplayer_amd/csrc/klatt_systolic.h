@@ -23,6 +23,13 @@
 // current values, coefficients and filter memories in registers.  No operation, operand or
 // rounding differs from the lane kernel / the reference: the stages compute the same values in the
 // same order, only on different SIMDs.  A 4096-utterance batch becomes 256 wavefronts instead of 64.
+//
+// Barrier discipline: the four waves take four different branches (stage = wave index), and every branch
+// runs the same loop `for iter < nIter` with exactly one __syncthreads() per iteration; nIter comes from the
+// longest utterance of the group (LDS atomicMax before the loops), so every wave reaches every barrier
+// whether or not it has a chunk to process.  A stage of depth d works on chunk iter - d: it reads what its
+// producer wrote in the previous iteration into buffer (chunk & 1) while the producer fills the other one.
+// The PCM tile belongs to the final stage's wave alone (wave-level ordering, no barrier).
 #pragma once
 
 #include "klatt_device.h"

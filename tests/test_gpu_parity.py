@@ -520,3 +520,61 @@ def test_random_ragged_batch_large():
     print("large random batch: %d samples, %d differ" % (total, nbad))
     assert nbad == 0
     bp.close()
+
+
+def test_threads_and_lifetime(ref):
+    """Producer/consumer threading as in the NVDA driver (queueFrame from one thread, synthesize from another,
+    reference nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:62-81,231-235), several handles at once from
+    several threads, and repeated create/destroy of handles and batches."""
+    import threading
+    import nvspeechplayer_amd as eng
+    cases = [ref.ipa_case(ref.find_ipa(k)) for k in (1, 2, 3, 5)]
+    results = [None] * len(cases)
+
+    def worker(k):
+        p = eng.SpeechPlayer(22050, noiseSeed=70 + k)
+        done_queueing = threading.Event()
+
+        def producer():
+            for fr, m, f in cases[k]:
+                p.queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f)
+            done_queueing.set()
+        t = threading.Thread(target=producer)
+        t.start()
+        done_queueing.wait()          # the PCM depends on when frames arrive relative to pulls; keep it deterministic
+        parts = []
+        while True:
+            buf = p.synthesize(2048)
+            if buf is None:
+                break
+            parts.append(np.frombuffer(buf, dtype=np.int16)[:buf.length].copy())
+            if buf.length < 2048:
+                break
+        t.join()
+        results[k] = np.concatenate(parts)
+        p.close()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    for k, case in enumerate(cases):
+        o = oracle.OraclePlayer(22050, seed=70 + k)
+        for fr, m, f in case:
+            o.queue(fr, m, f)
+        compare(results[k], o.drain(), "thread %d" % k)
+    fa = scenarios.vowel_frame(ref, "a", 120.0)
+    first = None
+    for rep in range(30):                                   # handles and batches come and go
+        p = eng.SpeechPlayer(22050)
+        p.queueFrameSamples(eng.Frame.from_array(fa), 200, 20)
+        b = p.synthesize(512)
+        bp = eng.BatchPlayer(22050)
+        bp.setUtterances([0, 1], fa[None, :], [200], [20])
+        bp.synthesize()
+        x = bp.read(0)
+        if first is None:
+            first = x.copy()
+        assert np.array_equal(x, first) and np.array_equal(np.frombuffer(b, dtype=np.int16)[:b.length], first)
+        bp.close(); p.close()

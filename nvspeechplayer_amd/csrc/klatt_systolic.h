@@ -198,12 +198,16 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
 // every lane exactly what the reference computes.
 template <class D, int MODE, class SF>
 __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelArgs& A, const int* RF, const int* RB,
-                                           bool lerp, uint32_t wRes)
+                                           bool lerp, uint32_t wRes, bool gainOnly = false)
 {
     if (!D::PITCH && !lerp) return;
     const double ratio = div_by((double)f.cnt, (double)f.newFade, f.invFade);
     if (D::PITCH) ps->cur0 = fade_value(ps->old0, ps->new0, ratio);
-    if (lerp) {
+    constexpr int GI = D::GAIN >= 0 ? D::GAIN : 0;
+    if (D::GAIN >= 0 && lerp && gainOnly) {
+        // fades into and out of silence move nothing but the gain (reference src/frame.cpp:59-67); `gainOnly` is wave-uniform
+        f.cur[GI] = fade_value(f.oldL[GI * kLanes], f.getNew(GI), ratio);
+    } else if (lerp) {
         double o[D::NPARAM > 0 ? D::NPARAM : 1], n[D::NPARAM > 0 ? D::NPARAM : 1];
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) { o[k] = f.oldL[k * kLanes]; n[k] = f.getNew(k); }
@@ -313,6 +317,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart};
     const uint32_t nkey = noise_key(d.seed);
     constexpr int FINAL = NOISE ? 2 : 3;
+    // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out
+    // together instead of one LDS latency per unrolled group); the noisy kernels have no registers to spare
+#ifndef KLATT_PRELOAD
+#define KLATT_PRELOAD 1
+#endif
+    constexpr bool kPre = !NOISE && KLATT_PRELOAD;
 
     if (threadIdx.x == 0) *maxLenP = 0;
     __syncthreads();
@@ -332,26 +342,39 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // Generic chunk loop of a stage.  BODY(c, i, steady) computes sample i of chunk c from the stage's pipe
     // inputs and writes its outputs; ON_EMIT is the general-step tail (uses `emit`).  One barrier per
     // iteration, the same number of iterations in every wave.
-#define RUN_STAGE(DEPTH, FRAMEVAR, PSPTR, IDXPTR, DESC, VIBCHECK, BODY, ON_STEADY_DONE, ON_FADE_DONE, ON_EMIT, PER_CHUNK)            \
+#define RUN_STAGE(DEPTH, FRAMEVAR, PSPTR, IDXPTR, DESC, VIBCHECK, BODY, ON_STEADY_DONE, ON_FADE_DONE, ON_EMIT, PER_CHUNK, PRELOAD, PRE_IN)     \
     for (int iter = 0; iter < nIter; ++iter) {                                                                                     \
         STAMP_BEGIN();                                                                                                             \
         const int c = iter - (DEPTH);                                                                                              \
         if (c >= 0 && c < nChunks) {                                                                                               \
-            const int kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                               \
+            int kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                                 \
+            bool lerp = false, gainOnly = false;                                                                                   \
+            uint32_t wRes = 0;                                                                                                     \
+            if (kind == 1) {                                                                                                       \
+                lerp = __any(!FRAMEVAR.done && FRAMEVAR.parMask != 0u);                                                            \
+                gainOnly = !NOISE && DESC::GAIN >= 0 && !__any(!FRAMEVAR.done && (FRAMEVAR.parMask & ~(1u << (DESC::GAIN >= 0 ? DESC::GAIN : 0))) != 0u); \
+                wRes = wave_or_bits<DESC::NRES>(FRAMEVAR.done ? 0u : FRAMEVAR.resMask);                                            \
+                /* a fade in which nothing of THIS stage moves is a steady chunk for it (only the counter advances) */             \
+                if (!DESC::PITCH && !lerp && wRes == 0u) kind = 0;                                                                 \
+            }                                                                                                                      \
             STAMP_KIND(kind);                                                                                                      \
+            double pre[PRELOAD ? kChunk : 1];                                                                                      \
             if (kind == 0) {                                                                                                       \
                 if (!FRAMEVAR.done) {                                                                                              \
-                    _Pragma(KLATT_STR(unroll KLATT_UNROLL)) for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }                 \
+                    if (PRELOAD) {                                                                                                 \
+                        _Pragma("unroll") for (int i = 0; i < kChunk; ++i) pre[i] = (PRE_IN);                                      \
+                        _Pragma("unroll") for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }                                   \
+                    } else {                                                                                                       \
+                        _Pragma(KLATT_STR(unroll KLATT_UNROLL)) for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }             \
+                    }                                                                                                              \
                     FRAMEVAR.cnt += kChunk;                                                                                        \
                     ON_STEADY_DONE;                                                                                                \
                 }                                                                                                                  \
             } else if (kind == 1) {                                                                                                \
-                const bool lerp = __any(!FRAMEVAR.done && FRAMEVAR.parMask != 0u);                                                 \
-                const uint32_t wRes = wave_or_bits<DESC::NRES>(FRAMEVAR.done ? 0u : FRAMEVAR.resMask);                             \
                 if (!FRAMEVAR.done) {                                                                                              \
                     _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                         \
                         FRAMEVAR.cnt++;                                                                                            \
-                        stage_fade<DESC, MODE>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes);                                            \
+                        stage_fade<DESC, MODE>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                                  \
                         BODY(c, i, false);                                                                                         \
                     }                                                                                                              \
                     ON_FADE_DONE;                                                                                                  \
@@ -422,7 +445,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             if (emit) { PIPE(pipeX, c, i) = source(waveVib); f.produced++; }                                     \
         } while (0)
         RUN_STAGE(0, f, &ps, &lastIndex, D, __any(!f.done && vib_live_now()), S0_BODY,
-                  (ps.old0 = ps.cur0, f.produced += kChunk), (f.produced += kChunk), S0_EMIT, (void)0)
+                  (ps.old0 = ps.cur0, f.produced += kChunk), (f.produced += kChunk), S0_EMIT, (void)0, false, 0.0)
 #undef S0_BODY
 #undef S0_EMIT
         if (live) {
@@ -450,9 +473,9 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 2; r < NR; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define S1_BODY(c, i, steady) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i))
+#define S1_BODY(c, i, steady) PIPE(pipeO, c, i) = dsp((kPre && steady) ? pre[i] : PIPE(pipeX, c, i))
 #define S1_EMIT do { if (emit) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i)); } while (0)
-        RUN_STAGE(1, f, nullptr, nullptr, D, false, S1_BODY, (void)0, (void)0, S1_EMIT, (void)0)
+        RUN_STAGE(1, f, nullptr, nullptr, D, false, S1_BODY, (void)0, (void)0, S1_EMIT, (void)0, kPre, PIPE(pipeX, c, i))
 #undef S1_BODY
 #undef S1_EMIT
     } else if (NOISE && stage == 3) {
@@ -481,7 +504,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         };
 #define S3_BODY(c, i, steady) do { double y_; const double p_ = dsp(y_); PIPE(pipeA, c, i) = y_; PIPE(pipeB, c, i) = p_; } while (0)
 #define S3_EMIT do { if (emit) { double y_; const double p_ = dsp(y_); PIPE(pipeA, c, i) = y_; PIPE(pipeB, c, i) = p_; } } while (0)
-        RUN_STAGE(1, f, nullptr, nullptr, D, false, S3_BODY, (void)0, (void)0, S3_EMIT, (void)0)
+        RUN_STAGE(1, f, nullptr, nullptr, D, false, S3_BODY, (void)0, (void)0, S3_EMIT, (void)0, false, 0.0)
 #undef S3_BODY
 #undef S3_EMIT
     } else if (!NOISE && stage == 2) {
@@ -496,9 +519,9 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define S2_BODY(c, i, steady) PIPE(pipeA, c, i) = dsp(PIPE(pipeO, c, i))
+#define S2_BODY(c, i, steady) PIPE(pipeA, c, i) = dsp((kPre && steady) ? pre[i] : PIPE(pipeO, c, i))
 #define S2_EMIT do { if (emit) PIPE(pipeA, c, i) = dsp(PIPE(pipeO, c, i)); } while (0)
-        RUN_STAGE(2, f, nullptr, nullptr, D, false, S2_BODY, (void)0, (void)0, S2_EMIT, (void)0)
+        RUN_STAGE(2, f, nullptr, nullptr, D, false, S2_BODY, (void)0, (void)0, S2_EMIT, (void)0, kPre, PIPE(pipeO, c, i))
 #undef S2_BODY
 #undef S2_EMIT
     } else {
@@ -558,13 +581,17 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         };
 
         uint32_t it = 0;   // samples stepped so far (wave-uniform); the chunk being processed starts at `it`
-#define FIN_IN(c, i) (NOISE ? PIPE(pipeO, c, i) : PIPE(pipeA, c, i)), (NOISE ? PIPE(pipeA, c, i) : 0.0), (NOISE ? PIPE(pipeB, c, i) : 0.0)
-#define FIN_BODY(c, i, steady) myRow[(it % kTile) + i] = (int16_t)finish(FIN_IN(c, i))
+#define FIN_IN0(c, i) (NOISE ? PIPE(pipeO, c, i) : PIPE(pipeA, c, i))
+#define FIN_IN12(c, i) (NOISE ? PIPE(pipeA, c, i) : 0.0), (NOISE ? PIPE(pipeB, c, i) : 0.0)
+#define FIN_IN(c, i) FIN_IN0(c, i), FIN_IN12(c, i)
+#define FIN_BODY(c, i, steady) myRow[(it % kTile) + i] = (int16_t)finish((kPre && steady) ? pre[i] : FIN_IN0(c, i), FIN_IN12(c, i))
 #define FIN_EMIT do { if (emit) { myRow[(it % kTile) + i] = (int16_t)finish(FIN_IN(c, i)); f.produced++; } } while (0)
 #define FIN_CHUNK do { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); } while (0)
-        RUN_STAGE((NOISE ? 2 : 3), f, nullptr, nullptr, D, false, FIN_BODY, (f.produced += kChunk), (f.produced += kChunk), FIN_EMIT, FIN_CHUNK)
+        RUN_STAGE((NOISE ? 2 : 3), f, nullptr, nullptr, D, false, FIN_BODY, (f.produced += kChunk), (f.produced += kChunk), FIN_EMIT, FIN_CHUNK, kPre, FIN_IN0(c, i))
         if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
 #undef FIN_IN
+#undef FIN_IN0
+#undef FIN_IN12
 #undef FIN_BODY
 #undef FIN_EMIT
 #undef FIN_CHUNK

@@ -146,6 +146,9 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
 // at 65 536 steady vowels against 1.3e11 for the lane kernel, 28.8 ms against 37.1 ms on cfg2 -- so "auto"
 // always takes them; the lane kernel stays selectable (layout 0) and runs the streaming handles.
 // Quiet batches that fit one workgroup per CU use 32-sample hand-overs (fewer barriers), else 16.
+#ifndef KLATT_NOISY_CH
+#define KLATT_NOISY_CH 8
+#endif
 struct GroupPlan { bool systolic; int chunk; };
 GroupPlan plan_group(int layout, bool noisy, long long nUttBatch, long long nNoisyBatch, int cus)
 {
@@ -263,7 +266,7 @@ int batch_launch(Batch* b)
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, b->nSlots - b->nQuiet, b->cus);
         const long long g = (nNoisy + kLanes - 1) / kLanes;
-        if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, 8, 2>(a, b->mode, g, b->stream) : launch_systolic<true, 16>(a, b->mode, g, b->stream))
+        if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, 2>(a, b->mode, g, b->stream) : launch_systolic<true, 16>(a, b->mode, g, b->stream))
                         : launch<false, true>(a, b->mode, g, b->stream)) return -1;
         if (both) HIP_TRY(hipStreamWaitEvent(b->stream, b->joinEvent, 0));
     }

@@ -582,16 +582,26 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave alone owns the tile: wave-level ordering is enough
             constexpr int kChunksPerRow = kTile / 8;
             constexpr int kRowsPerPass = kLanes / kChunksPerRow;
+            constexpr int kPasses = kLanes / kRowsPerPass;
+            const int chunk = lane % kChunksPerRow;
+            const uint32_t first = tileStart + (uint32_t)chunk * 8u;
+            // every LDS read of all passes first (one wait), then the stores
+            uint2 lo[kPasses], hi[kPasses];
+            uint32_t cnt[kPasses];
+            long long base[kPasses];
 #pragma unroll
-            for (int p = 0; p < kLanes / kRowsPerPass; ++p) {
+            for (int p = 0; p < kPasses; ++p) {
                 const int row = p * kRowsPerPass + lane / kChunksPerRow;
-                const int chunk = lane % kChunksPerRow;
                 const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
-                const uint2 lo = src[0], hi = src[1];
-                const uint32_t first = tileStart + (uint32_t)chunk * 8u;
-                if (rowCount[row] > first && first < validTo) {
-                    uint4* dst = reinterpret_cast<uint4*>(A.pcm + rowBase[row] + first);
-                    *dst = make_uint4(lo.x, lo.y, hi.x, hi.y);
+                lo[p] = src[0]; hi[p] = src[1];
+                cnt[p] = rowCount[row];
+                base[p] = rowBase[row];
+            }
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                if (cnt[p] > first && first < validTo) {
+                    uint4* dst = reinterpret_cast<uint4*>(A.pcm + base[p] + first);
+                    *dst = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

@@ -578,3 +578,37 @@ def test_threads_and_lifetime(ref):
             first = x.copy()
         assert np.array_equal(x, first) and np.array_equal(np.frombuffer(b, dtype=np.int16)[:b.length], first)
         bp.close(); p.close()
+
+
+@pytest.mark.parametrize("workload,n_utt", [("cfg3", 131072), ("cfg4", 32768)])
+def test_full_size_cfg3_cfg4_properties(workload, n_utt):
+    """BASELINE configs[3] and configs[4] at bench.py's per-GPU size (131 072 cut utterances = 10^6 / 8; 32 voice
+    variants x 1024 utterances): closed-form lengths, the two independent kernel layouts (stage-parallel workgroups and one
+    wavefront per 64 utterances) produce the same bytes, both arithmetic modes stay within the tolerance, and
+    a strided sample of utterances equals the oracle."""
+    import hashlib
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    batch = workloads.make(workload, n_utt)
+    counts = batch.sample_counts()
+    digests = {}
+    keep = None
+    for layout, mode in ((1, 0), (0, 0), (1, 1)):
+        bp = eng.BatchPlayer(22050, mode=mode, layout=layout)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                         batch["isnull"], batch["seeds"])
+        assert bp.totalSamples == int(counts.sum())
+        bp.synthesize()
+        a, starts = bp.readAll()
+        assert np.array_equal(np.diff(starts), counts)
+        digests[(layout, mode)] = hashlib.sha1(a.tobytes()).hexdigest()
+        if keep is None:
+            keep = a
+            for u in range(3, n_utt, max(1, n_utt // 40)):
+                exp, _, _ = oracle.batch_synthesize(22050, batch.slice(u, 1))
+                compare(a[starts[u]:starts[u + 1]], exp, "%s utt %d" % (workload, u))
+        elif mode == 1 and digests[(layout, mode)] != digests[(1, 0)]:
+            compare(a, keep, "%s MODE_FAST against MODE_EXACT" % workload)     # tolerance, not identity
+        del a
+        bp.close()
+    assert digests[(1, 0)] == digests[(0, 0)], "the two kernel layouts disagree on %s" % workload

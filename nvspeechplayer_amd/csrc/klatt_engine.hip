@@ -90,6 +90,33 @@ struct DeviceBuffer {
     }
 };
 
+// two pinned host buffers + events for pipelined device-to-host copies
+struct PinnedPair {
+    void* buf[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        release();
+        for (int i = 0; i < 2; ++i) {
+            HIP_TRY(hipHostMalloc(&buf[i], bytes, hipHostMallocDefault));
+            HIP_TRY(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+        }
+        cap = bytes;
+        return 0;
+    }
+    void release()
+    {
+        for (int i = 0; i < 2; ++i) {
+            if (buf[i]) (void)hipHostFree(buf[i]);
+            if (ev[i]) (void)hipEventDestroy(ev[i]);
+            buf[i] = nullptr; ev[i] = nullptr;
+        }
+        cap = 0;
+    }
+};
+
 // Raise a kernel's dynamic-LDS limit once per (kernel, device): the attribute is per device, and a process may
 // drive several devices (one BatchPlayer each).
 int ensure_lds_limit(const void* kernel, int ldsBytes)
@@ -230,6 +257,7 @@ struct Batch {
     DeviceBuffer<UttResult> dResult;
     DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
+    PinnedPair bounce;                         // speechPlayer_batch_readAll
     bool floatFresh = false;
 };
 
@@ -585,7 +613,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
     if (b->joinEvent) (void)hipEventDestroy(b->joinEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
-    b->dFloat.release(); b->dDebug.release();
+    b->dFloat.release(); b->dDebug.release(); b->bounce.release();
     delete b;
 }
 
@@ -751,17 +779,41 @@ long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleB
     HIP_TRY(hipSetDevice(b->device));
     HIP_TRY(hipStreamSynchronize(b->stream));
     if (fetch_results(b)) return -1;
-    std::vector<int16_t> pool((size_t)b->poolSamples);
-    if (b->poolSamples) HIP_TRY(hipMemcpy(pool.data(), b->dPcm.ptr, (size_t)b->poolSamples * sizeof(int16_t), hipMemcpyDeviceToHost));
+    // compact positions first (the device pool pads every utterance to a multiple of 32 samples)
+    std::vector<long long> dstStart((size_t)b->nUtt + 1);
     long long pos = 0;
-    for (long long u = 0; u < b->nUtt; ++u) {
-        if (outStart) outStart[u] = pos;
-        long long n = b->results[u].produced;
-        if (pos + n > capacity) { set_error("readAll: capacity %lld too small", capacity); return -1; }
-        memcpy(reinterpret_cast<int16_t*>(sampleBuf) + pos, pool.data() + b->outStart[u], (size_t)n * sizeof(int16_t));
-        pos += n;
+    for (long long u = 0; u < b->nUtt; ++u) { dstStart[u] = pos; pos += b->results[u].produced; }
+    dstStart[b->nUtt] = pos;
+    if (pos > capacity) { set_error("readAll: capacity %lld too small for %lld samples", capacity, pos); return -1; }
+    if (outStart) memcpy(outStart, dstStart.data(), sizeof(long long) * ((size_t)b->nUtt + 1));
+    // The pool comes over in 16 MB pieces through two pinned buffers: piece k + 1 is in flight while piece k is
+    // compacted into the caller's buffer (pageable memory would cap the copy at a few GB/s).
+    constexpr long long kPiece = 8ll << 20;   // samples
+    if (b->bounce.ensure((size_t)kPiece * sizeof(int16_t))) return -1;
+    const long long nPieces = (b->poolSamples + kPiece - 1) / kPiece;
+    auto issue = [&](long long k) -> int {
+        const long long off = k * kPiece, n = std::min(kPiece, b->poolSamples - off);
+        HIP_TRY(hipMemcpyAsync(b->bounce.buf[k & 1], b->dPcm.ptr + off, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipEventRecord(b->bounce.ev[k & 1], b->stream));
+        return 0;
+    };
+    if (nPieces > 0 && issue(0)) return -1;
+    int16_t* const dst = reinterpret_cast<int16_t*>(sampleBuf);
+    long long u = 0;
+    for (long long k = 0; k < nPieces; ++k) {
+        if (k + 1 < nPieces && issue(k + 1)) return -1;
+        HIP_TRY(hipEventSynchronize(b->bounce.ev[k & 1]));
+        const long long c0 = k * kPiece, c1 = std::min(c0 + kPiece, b->poolSamples);
+        const int16_t* const src = static_cast<const int16_t*>(b->bounce.buf[k & 1]);
+        while (u < b->nUtt) {
+            const long long s0 = b->outStart[u], e0 = s0 + b->results[u].produced;
+            if (s0 >= c1) break;
+            const long long lo = std::max(s0, c0), hi = std::min(e0, c1);
+            if (hi > lo) memcpy(dst + dstStart[u] + (lo - s0), src + (lo - c0), (size_t)(hi - lo) * sizeof(int16_t));
+            if (e0 > c1) break;       // continues in the next piece
+            ++u;
+        }
     }
-    if (outStart) outStart[b->nUtt] = pos;
     return pos;
 }
 

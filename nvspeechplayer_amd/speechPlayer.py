@@ -210,9 +210,16 @@ class BatchPlayer(object):
             w.setnchannels(1); w.setsampwidth(2); w.setframerate(self.sampleRate)
             w.writeframes(pcm.astype("<i2").tobytes())
 
-    def readAll(self):
+    def readAll(self, out=None):
+        """All utterances' PCM, concatenated, and the nUtterances + 1 start offsets.  `out`: an int16 array of at
+        least totalSamples to fill instead of a new one (a reused buffer avoids the page faults of a fresh one)."""
         total = self.totalSamples
-        buf = np.zeros(max(total, 1), dtype=np.int16)
+        if out is not None:
+            if out.dtype != np.int16 or not out.flags["C_CONTIGUOUS"] or out.size < total:
+                raise ValueError("readAll: out must be a contiguous int16 array of at least %d samples" % total)
+            buf = out
+        else:
+            buf = np.empty(max(total, 1), dtype=np.int16)
         starts = np.zeros(self.nUtterances + 1, dtype=np.int64)
         got = self._check(self._dll.speechPlayer_batch_readAll(self._h, buf.ctypes.data, total, starts.ctypes.data))
         return buf[:got], starts

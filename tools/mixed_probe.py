@@ -3,8 +3,10 @@
 sentences, so after the sort by length every wavefront holds 64 copies of one sentence: all lanes fade together.)
   sorted     : cfg2 as benchmarked
   unsorted   : the same batch with the sort by length off (ragged lengths + de-aligned fades)
-  staggered  : sorted, but every utterance starts with 0..200 ms of silence of its own (lengths within 10 %,
-               fades de-aligned) -- isolates the cost of the general (mixed) chunk path
+  staggered  : sorted, but every utterance starts with 0..200 ms of silence of its own (the sort by length puts
+               similar delays side by side again: lanes end up skewed by ~100 samples only)
+  rotated    : sorted, every utterance's frame list rotated by a random amount (same lengths, fully de-aligned
+               fades) -- the stand-in for 64 different sentences per wave
 """
 import os
 import sys
@@ -33,6 +35,22 @@ def stagger(b, seed=1):
     return workloads.Batch(frame_start=new_fs, seeds=b["seeds"], name=b["name"] + " staggered", sr=b["sr"], **out)
 
 
+def rotate(b, seed=1):
+    """Every utterance keeps its frames (and so its length) but starts at a random one of them: waves still hold
+    64 utterances of equal length after the sort, yet no two lanes fade at the same time -- the closest cheap
+    stand-in for a batch of 64 different sentences of similar length."""
+    rng = np.random.default_rng(seed)
+    fs = b["frame_start"]
+    perm = np.arange(len(b["min"]))
+    for u in range(b.n_utt):
+        a, e = int(fs[u]), int(fs[u + 1]) - 1          # the last frame (the closing NULL frame) stays last
+        if e - a > 1:
+            k = int(rng.integers(0, e - a))
+            perm[a:e] = np.roll(np.arange(a, e), -k)
+    out = {k: b[k][perm] for k in ("frames", "min", "fade", "index", "isnull")}
+    return workloads.Batch(frame_start=fs, seeds=b["seeds"], name=b["name"] + " rotated", sr=b["sr"], **out)
+
+
 def run(name, b, sort, mode=0):
     bp = BatchPlayer(b["sr"], mode=mode)
     bp.setOption("sort", sort)
@@ -49,3 +67,4 @@ if __name__ == "__main__":
     run("sorted", b, 1)
     run("unsorted", b, 0)
     run("staggered", stagger(b), 1)
+    run("rotated", rotate(b), 1)

@@ -8,7 +8,14 @@ import numpy as np
 from nvspeechplayer_amd import BatchPlayer, _native, workloads
 
 wl, n, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0
-batch = workloads.make(wl, n)
+if wl == "staggered":          # cfg2 with per-utterance leading silence: lanes of a wave do not fade together
+    from mixed_probe import stagger
+    batch = stagger(workloads.make("cfg2", n))
+elif wl == "rotated":
+    from mixed_probe import rotate
+    batch = rotate(workloads.make("cfg2", n))
+else:
+    batch = workloads.make(wl, n)
 bp = BatchPlayer(batch["sr"], mode=mode, layout=1)
 bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
 bp.synthesize(); bp.synthesize()

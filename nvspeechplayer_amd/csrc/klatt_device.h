@@ -154,7 +154,11 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
     double rad, cs;
     // exp and cos: the straight-line versions of klatt_math.h (<= 1 ulp, like a libm); arguments outside their
     // validated range take the device library.  Same code in both arithmetic modes.
-    if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
+    // Wave-uniform short cut (klatt_math.h): when no active lane's argument needs a range reduction the kernels
+    // alone return the same bits as fast_exp / fast_cos.  (Separate decisions for exp and cos, and a third
+    // variant for the quadrant of f > 2756 Hz, were measured slower: more branches and spills than they save.)
+    if (__all(exp_is_unreduced(ex) && cos_is_unreduced(th))) { rad = exp_unreduced(ex); cs = cos_unreduced(th); }
+    else if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
     else { rad = exp(ex); cs = cos(th); }
     double cc = -(rad * rad);
     double bb = rad * cs * 2.0;

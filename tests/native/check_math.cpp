@@ -84,7 +84,17 @@ int main()
         if (e > expWide) expWide = e;
         if (c > cosWide) cosWide = c;
     }
-    printf("{\"div_checked\": %lld, \"div_bad\": %lld, \"exp_max_ulp\": %.0f, \"cos_max_ulp\": %.0f, "
+    // the unreduced short path must return the same bits as the full functions wherever it is allowed
+    long long unredN = 0, unredBad = 0;
+    std::uniform_real_distribution<double> sx(-0.36, 0.36), st(-0.80, 0.80);
+    for (int i = 0; i < 4000000; ++i) {
+        double x = sx(rng), t = st(rng);
+        if (i < 64) { x = (i & 1 ? -1 : 1) * 0.34657359027997264 * (1.0 - (i >> 1) * 1e-16); t = (i & 1 ? -1 : 1) * 0.78539816339744828 * (1.0 - (i >> 1) * 1e-16); }
+        if (klatt::exp_is_unreduced(x)) { unredN++; double a = klatt::exp_unreduced(x), b = klatt::fast_exp(x); if (memcmp(&a, &b, 8)) unredBad++; }
+        if (klatt::cos_is_unreduced(t)) { unredN++; double a = klatt::cos_unreduced(t), b = klatt::fast_cos(t); if (memcmp(&a, &b, 8)) unredBad++; }
+    }
+    printf("{\"unreduced_checked\": %lld, \"unreduced_bad\": %lld, ", unredN, unredBad);
+    printf("\"div_checked\": %lld, \"div_bad\": %lld, \"exp_max_ulp\": %.0f, \"cos_max_ulp\": %.0f, "
            "\"exp_mean_ulp\": %.4f, \"cos_mean_ulp\": %.4f, \"exp_wide_max_ulp\": %.0f, \"cos_wide_max_ulp\": %.0f, "
            "\"exp0\": %.17g, \"cos0\": %.17g}\n",
            divN, divBad, expMax, cosMax, expSum / n, cosSum / n, expWide, cosWide, klatt::fast_exp(0.0), klatt::fast_cos(0.0));

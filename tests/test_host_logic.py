@@ -70,6 +70,7 @@ def test_kernel_arithmetic_helpers_on_host(tmp_path):
     assert out["exp_max_ulp"] <= 1 and out["cos_max_ulp"] <= 1
     assert out["exp_wide_max_ulp"] <= 1 and out["cos_wide_max_ulp"] <= 2
     assert out["exp0"] == 1.0 and out["cos0"] == 1.0
+    assert out["unreduced_checked"] > 7e6 and out["unreduced_bad"] == 0     # the short path returns the same bits
 
 
 def test_workload_recipes():

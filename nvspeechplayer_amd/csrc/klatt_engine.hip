@@ -354,7 +354,8 @@ struct LiveContext {
     std::vector<uint32_t> hOrder, hControl;
     std::vector<double*> hStatePtrs;
     std::vector<UttResult> hResult;
-    std::vector<int16_t> hPcm;
+    std::vector<size_t> hTake;
+    PinnedPair bounce;
 };
 std::mutex g_liveMutex;
 std::vector<LiveContext*> g_live;   // per device
@@ -399,8 +400,23 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     if (!c) return -1;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(device));
+    // Only the frames this pull can reach travel: the shortest prefix of the queue whose spans (the closed form
+    // of speechPlayer_batch_setUtterances) cover `count` samples, plus one.  The rest stays queued on the host.
+    std::vector<size_t>& take = c->hTake;
+    take.resize(n);
     size_t nf = 0;
-    for (int i = 0; i < n; ++i) nf += ss[i]->pending.size();
+    for (int i = 0; i < n; ++i) {
+        unsigned long long span = 0;
+        size_t k = 0;
+        const size_t have = ss[i]->pending.size();
+        while (k < have && span < count) {
+            const unsigned long long m = ss[i]->pending[k].meta.minSamples, f = ss[i]->pending[k].meta.fadeSamples;
+            span += std::max(m, f + 1) + 1;
+            ++k;
+        }
+        take[i] = std::min(have, k + 1);
+        nf += take[i];
+    }
     const size_t padded = ((size_t)count + kTile - 1) / kTile * kTile;
     c->hFrames.resize(std::max<size_t>(nf, 1) * kNumParams);
     c->hMeta.resize(std::max<size_t>(nf, 1));
@@ -409,9 +425,10 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     for (int i = 0; i < n; ++i) {
         UttDesc& d = c->hUtt[i];
         memset(&d, 0, sizeof d);
-        d.frameStart = (long long)k; d.outStart = (long long)(i * padded); d.nFrames = (uint32_t)ss[i]->pending.size();
+        d.frameStart = (long long)k; d.outStart = (long long)(i * padded); d.nFrames = (uint32_t)take[i];
         d.seed = ss[i]->seed; d.flags = UTT_NEEDS_NOISE;
-        for (const PendingFrame& f : ss[i]->pending) {
+        for (size_t j = 0; j < take[i]; ++j) {
+            const PendingFrame& f = ss[i]->pending[j];
             memcpy(&c->hFrames[k * kNumParams], f.p, sizeof(double) * kNumParams);
             c->hMeta[k] = f.meta;
             ++k;
@@ -452,10 +469,26 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         if (n == 1) {
             HIP_TRY(hipMemcpy(outs[0], c->dPcm.ptr, (size_t)c->hResult[0].produced * sizeof(int16_t), hipMemcpyDeviceToHost));
         } else {
-            c->hPcm.resize((lastWithData + 1) * padded);
-            HIP_TRY(hipMemcpy(c->hPcm.data(), c->dPcm.ptr, c->hPcm.size() * sizeof(int16_t), hipMemcpyDeviceToHost));
-            for (int i = 0; i < n; ++i)
-                if (c->hResult[i].produced) memcpy(outs[i], &c->hPcm[(size_t)i * padded], (size_t)c->hResult[i].produced * sizeof(int16_t));
+            // whole rows in pieces of about 16 MB through two pinned buffers; piece k + 1 is in flight while the
+            // rows of piece k are handed to their callers
+            const size_t rowsPerPiece = std::max<size_t>(1, (8u << 20) / padded);
+            if (c->bounce.ensure(rowsPerPiece * padded * sizeof(int16_t))) return -1;
+            const size_t rows = lastWithData + 1, nPieces = (rows + rowsPerPiece - 1) / rowsPerPiece;
+            auto issue = [&](size_t k) -> int {
+                const size_t r0 = k * rowsPerPiece, r1 = std::min(rows, r0 + rowsPerPiece);
+                HIP_TRY(hipMemcpyAsync(c->bounce.buf[k & 1], c->dPcm.ptr + r0 * padded, (r1 - r0) * padded * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipEventRecord(c->bounce.ev[k & 1], c->stream));
+                return 0;
+            };
+            if (issue(0)) return -1;
+            for (size_t k = 0; k < nPieces; ++k) {
+                if (k + 1 < nPieces && issue(k + 1)) return -1;
+                HIP_TRY(hipEventSynchronize(c->bounce.ev[k & 1]));
+                const size_t r0 = k * rowsPerPiece, r1 = std::min(rows, r0 + rowsPerPiece);
+                const int16_t* src = static_cast<const int16_t*>(c->bounce.buf[k & 1]);
+                for (size_t i = r0; i < r1; ++i)
+                    if (c->hResult[i].produced) memcpy(outs[i], src + (i - r0) * padded, (size_t)c->hResult[i].produced * sizeof(int16_t));
+            }
         }
     }
     for (int i = 0; i < n; ++i) {

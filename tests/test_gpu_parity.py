@@ -8,6 +8,7 @@ glibc's, which can move a sample by one LSB when a value sits on a truncation bo
 the tests therefore allow at most MAX_FLIPS one-LSB differences per million samples
 and print what they saw.
 """
+import os
 import numpy as np
 import pytest
 
@@ -612,3 +613,28 @@ def test_full_size_cfg3_cfg4_properties(workload, n_utt):
         del a
         bp.close()
     assert digests[(1, 0)] == digests[(0, 0)], "the two kernel layouts disagree on %s" % workload
+
+
+def test_native_c_client(ref, tmp_path):
+    """A C program built with gcc against include/speechPlayer.h and the engine library (no Python, no
+    prototypes beyond the header) gets the oracle's PCM, in one pull and in ragged pulls."""
+    import subprocess
+    from nvspeechplayer_amd import _native
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib = os.environ.get("SPEECHPLAYER_LIB") or _native.LIB_PATH
+    exe = str(tmp_path / "c_client")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(root, "include"), "-o", exe,
+                           os.path.join(root, "tests", "native", "c_client.c"), lib, "-Wl,-rpath," + os.path.dirname(lib)])
+    for name, pitch, pull in (("a", 120.0, 22050), ("s", 0.0, 777), ("m", 95.0, 4096)):
+        fr = scenarios.vowel_frame(ref, name, pitch)
+        fbin = tmp_path / ("frame_%s.bin" % name)
+        fbin.write_bytes(np.asarray(fr, dtype=np.float64).tobytes())
+        out = tmp_path / ("out_%s.pcm" % name)
+        line = subprocess.check_output([exe, str(fbin), str(out), "22050", "3000", "400", str(pull)]).decode().split()
+        pcm = np.frombuffer(out.read_bytes(), dtype=np.int16)
+        o = oracle.OraclePlayer(22050, seed=0)
+        o.queue(fr, 3000, 400, 7)
+        o.queue(None, 400, 400, -1)
+        exp = o.drain()
+        assert int(line[0]) == len(exp) == len(pcm) and int(line[1]) == 7
+        compare(pcm, exp, "c client %s" % name)

@@ -107,3 +107,17 @@ def test_shard_bounds():
         assert max(per) - min(per) <= 2 * counts.max()
     assert list(shard_bounds([], 4)) == [0, 0, 0, 0, 0]
     assert list(shard_bounds([5], 2)) in ([0, 0, 1], [0, 1, 1])
+
+
+def test_headers_are_plain_c_and_cpp(tmp_path):
+    """include/*.h must be consumable by a C host (C99) and a C++ host, and the frame must keep the reference's
+    376-byte layout (reference src/frame.h:20-45); the C client of the GPU suite compiles against them too."""
+    src = tmp_path / "hdr.c"
+    src.write_text('#include "speechPlayer.h"\n#include "speechPlayer_batch.h"\n'
+                   'typedef char frame_is_376_bytes[sizeof(speechPlayer_frame_t) == 376 ? 1 : -1];\n'
+                   'typedef char sample_is_2_bytes[sizeof(sample) == 2 ? 1 : -1];\nint main(void) { return 0; }\n')
+    inc = os.path.join(ROOT, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)])
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc,
+                           os.path.join(ROOT, "tests", "native", "c_client.c")])

@@ -9,6 +9,7 @@
 // There is no CPU synthesis path in this library: without a HIP device every entry point fails.
 #include "klatt_device.h"
 #include "klatt_systolic.h"
+#include "klatt_lanepipe.h"
 
 #include <algorithm>
 #include <cmath>
@@ -146,7 +147,7 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE, int CH, int WPS = 1>
+template <bool NOISE, int CH, int WPS = 1, bool NASAL = true>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
@@ -159,8 +160,30 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS>); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS>); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL>); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL>); break;
+    default: set_error("unknown arithmetic mode %d", mode); return -1;
+    }
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int CH, int WPS>
+int launch_lanepipe(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
+{
+    if (nGroups <= 0) return 0;
+    if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
+    constexpr int ldsBytes = LpLds<CH>::kBytes;
+    auto go = [&](auto kernel) -> int {
+        if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a);
+        return 0;
+    };
+    int rc;
+    switch (mode) {
+    case MODE_EXACT: rc = go(klatt_lanepipe<MODE_EXACT, CH, WPS>); break;
+    case MODE_FAST: rc = go(klatt_lanepipe<MODE_FAST, CH, WPS>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -237,13 +260,14 @@ struct Batch {
     int device = 0;
     int mode = MODE_EXACT;
     int sortByLength = 1;
-    int layout = -1;                       // -1: choose per group (plan_group); 1: stage-parallel workgroups; 0: one wave per 64 utterances
+    int layout = -1;                       // -1: choose per group (plan_group); 2: lane-pipelined where eligible; 1: stage-parallel workgroups; 0: one wave per 64 utterances
     int cus = 256;
     hipStream_t stream = nullptr;
-    hipStream_t sideStream = nullptr;      // the quiet group runs beside the noisy one
-    hipEvent_t forkEvent = nullptr, joinEvent = nullptr;
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the quiet groups run beside the noisy one (batch_launch)
+    hipEvent_t forkEvent = nullptr, join[3] = {nullptr, nullptr, nullptr};
     long long nUtt = 0, nFrames = 0, nSlots = 0;
     long long nQuiet = 0;                  // order[0..nQuiet) = utterances without noise, the rest with
+    long long nNoNasal = 0;                // order[0..nNoNasal) = quiet utterances that never couple the nasal pair (UTT_NO_NASAL)
     long long totalSamples = 0, poolSamples = 0;
     std::vector<uint32_t> lens;
     std::vector<long long> outStart;   // padded offsets in the device pool
@@ -261,6 +285,14 @@ struct Batch {
     bool floatFresh = false;
 };
 
+// How many of the quiet, nasal-free utterances (the head of `order`) the lane-pipelined kernel takes.
+// layout 2 forces it; "auto" takes it where it measured faster than the stage-parallel kernel.
+long long lanepipe_count(const Batch* b)
+{
+    if (b->layout == 2) return b->nNoNasal;
+    return 0;
+}
+
 int batch_launch(Batch* b)
 {
     KernelArgs a = base_args(b->sampleRate);
@@ -269,34 +301,61 @@ int batch_launch(Batch* b)
     b->resultsFresh = false;
     b->floatFresh = false;
 #ifdef KLATT_STAMPS
-    if (b->dDebug.reserve((size_t)(b->nSlots / kLanes + 2) * 32 * 2)) return -1;
+    if (b->dDebug.reserve((size_t)(b->nSlots / kLpUPG + 2) * 32 * 2)) return -1;
     HIP_TRY(hipMemsetAsync(b->dDebug.ptr, 0, b->dDebug.cap * 8, b->stream));
     a.debug = b->dDebug.ptr;
 #endif
+    // up to four groups, each with its own kernel, side by side on their own streams:
+    //   order[0, nLp)              quiet, nasal-free -> lane-pipelined kernel (klatt_lanepipe.h), when the plan takes it
+    //   order[nLp, nNoNasal)       quiet, nasal-free -> stage-parallel kernel without the nasal pair (NASAL = false)
+    //   order[nNoNasal, nQuiet)    quiet             -> stage-parallel (or lane) kernel, NOISE = false
+    //   order[nQuiet, nSlots)      noisy             -> stage-parallel (or lane) kernel, NOISE = true
     const long long nNoisy = b->nSlots - b->nQuiet;
-    const bool both = b->nQuiet > 0 && nNoisy > 0;
-    if (b->nQuiet > 0) {
-        // quiet group: no noise sources, no parallel bank.  Beside a noisy group it runs on the side stream.
-        hipStream_t st = b->stream;
-        if (both) {
-            HIP_TRY(hipEventRecord(b->forkEvent, b->stream));
-            HIP_TRY(hipStreamWaitEvent(b->sideStream, b->forkEvent, 0));
-            st = b->sideStream;
-        }
-        a.order = b->dOrder.ptr; a.nSlots = b->nQuiet;
-        const GroupPlan pl = plan_group(b->layout, false, b->nSlots, b->nSlots - b->nQuiet, b->cus);
-        const long long g = (b->nQuiet + kLanes - 1) / kLanes;
-        if (pl.systolic ? (pl.chunk == 32 ? launch_systolic<false, 32>(a, b->mode, g, st) : launch_systolic<false, 16>(a, b->mode, g, st))
-                        : launch<false, false>(a, b->mode, g, st)) return -1;
-        if (both) HIP_TRY(hipEventRecord(b->joinEvent, b->sideStream));
+    const long long nLp = lanepipe_count(b);
+    const bool laneKernel = b->layout == 0;
+    const long long nNn = laneKernel ? 0 : b->nNoNasal - nLp;
+    const long long nQ = b->nQuiet - nLp - nNn;
+    const int parts = (nLp > 0) + (nNn > 0) + (nQ > 0) + (nNoisy > 0);
+    const bool fork = parts > 1;
+    if (fork) HIP_TRY(hipEventRecord(b->forkEvent, b->stream));
+    int sideUsed = 0, seen = 0;
+    // the last non-empty group runs on the main stream, the others beside it
+    auto next_stream = [&]() -> hipStream_t {
+        if (!fork || ++seen == parts) return b->stream;
+        hipStream_t st = b->side[sideUsed++];
+        (void)hipStreamWaitEvent(st, b->forkEvent, 0);
+        return st;
+    };
+    const GroupPlan plq = plan_group(b->layout, false, b->nSlots, nNoisy, b->cus);
+    if (nLp > 0) {
+        hipStream_t st = next_stream();
+        a.order = b->dOrder.ptr; a.nSlots = nLp;
+        const long long g = (nLp + kLpUPG - 1) / kLpUPG;
+        if (g <= b->cus ? launch_lanepipe<32, 1>(a, b->mode, g, st) : launch_lanepipe<16, 2>(a, b->mode, g, st)) return -1;
+    }
+    if (nNn > 0) {
+        hipStream_t st = next_stream();
+        a.order = b->dOrder.ptr + nLp; a.nSlots = nNn;
+        const long long g = (nNn + kLanes - 1) / kLanes;
+        if (plq.chunk == 32 ? launch_systolic<false, 32, 1, false>(a, b->mode, g, st) : launch_systolic<false, 16, 1, false>(a, b->mode, g, st)) return -1;
+    }
+    if (nQ > 0) {
+        hipStream_t st = next_stream();
+        a.order = b->dOrder.ptr + nLp + nNn; a.nSlots = nQ;
+        const long long g = (nQ + kLanes - 1) / kLanes;
+        if (plq.systolic ? (plq.chunk == 32 ? launch_systolic<false, 32>(a, b->mode, g, st) : launch_systolic<false, 16>(a, b->mode, g, st))
+                         : launch<false, false>(a, b->mode, g, st)) return -1;
     }
     if (nNoisy > 0) {
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
-        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, b->nSlots - b->nQuiet, b->cus);
+        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nNoisy, b->cus);
         const long long g = (nNoisy + kLanes - 1) / kLanes;
         if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, 2>(a, b->mode, g, b->stream) : launch_systolic<true, 16>(a, b->mode, g, b->stream))
                         : launch<false, true>(a, b->mode, g, b->stream)) return -1;
-        if (both) HIP_TRY(hipStreamWaitEvent(b->stream, b->joinEvent, 0));
+    }
+    for (int i = 0; i < sideUsed; ++i) {
+        HIP_TRY(hipEventRecord(b->join[i], b->side[i]));
+        HIP_TRY(hipStreamWaitEvent(b->stream, b->join[i], 0));
     }
     return 0;
 }
@@ -625,12 +684,14 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     b->sampleRate = sampleRate;
     b->device = dev;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) b->cus = prop.multiProcessorCount; }
-    if (hipSetDevice(dev) != hipSuccess || hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&b->sideStream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->joinEvent, hipEventDisableTiming) != hipSuccess) {
+    bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 3 && ok; ++i)
+        ok = hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) == hipSuccess &&
+             hipEventCreateWithFlags(&b->join[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) {
         set_error("cannot create a stream on device %d", dev);
-        delete b;
+        speechPlayer_batch_destroy(b);
         return nullptr;
     }
     return b;
@@ -642,9 +703,11 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    if (b->sideStream) { (void)hipStreamSynchronize(b->sideStream); (void)hipStreamDestroy(b->sideStream); }
+    for (int i = 0; i < 3; ++i) {
+        if (b->side[i]) { (void)hipStreamSynchronize(b->side[i]); (void)hipStreamDestroy(b->side[i]); }
+        if (b->join[i]) (void)hipEventDestroy(b->join[i]);
+    }
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
-    if (b->joinEvent) (void)hipEventDestroy(b->joinEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->bounce.release();
     delete b;
@@ -660,7 +723,7 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
         return 0;
     }
     if (!strcmp(name, "sort")) { b->sortByLength = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value ? 1 : 0); return 0; }
+    if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value > 2 ? 1 : value); return 0; }
     set_error("unknown option %s", name);
     return -1;
 }
@@ -720,6 +783,24 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
                 if (!std::isfinite(p[i])) needsNoise = true;
         }
         utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : 0u;
+        // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152).
+        // With caNP == 0 in every frame that is x + (np - x) * 0 == x as long as np stays finite, and nothing else
+        // reads N0's or NP's memories: such an utterance may skip the pair.  np stays finite when the source is
+        // bounded (gains <= 1e30), N0's zero pair is not degenerate (bandwidth >= 1 Hz keeps 1 - b - c away from 0,
+        // reference :122) and NP does not grow (bandwidth >= 0).  Frequencies and bandwidths are bounded so that
+        // the coefficients stay finite.
+        if (!needsNoise) {
+            bool noNasal = true;
+            for (long long k = frameStart[u]; k < frameStart[u + 1] && noNasal; ++k) {
+                if (meta[k].flags & FRAME_NULL) continue;
+                const double* p = reinterpret_cast<const double*>(frames + k);
+                if (p[23] != 0.0 || !(p[21] >= 1.0) || !(p[22] >= 0.0) || !(p[21] <= 1e6) || !(p[22] <= 1e6) ||
+                    !(std::fabs(p[13]) <= 1e6) || !(std::fabs(p[14]) <= 1e6) || !(std::fabs(p[5]) <= 1e30) || !(std::fabs(p[44]) <= 1e30) ||
+                    !(std::fabs(p[0]) <= 1e30) || !(std::fabs(p[46]) <= 1e30))
+                    noNasal = false;
+            }
+            if (noNasal) utt[u].flags |= UTT_NO_NASAL;
+        }
         total += (long long)len;
         pool += ((long long)len + kTile - 1) / kTile * kTile;
     }
@@ -732,9 +813,12 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     std::iota(order.begin(), order.end(), 0u);
     auto quietEnd = std::stable_partition(order.begin(), order.end(), [&](uint32_t x) { return !(utt[x].flags & UTT_NEEDS_NOISE); });
     b->nQuiet = quietEnd - order.begin();
+    auto noNasalEnd = std::stable_partition(order.begin(), quietEnd, [&](uint32_t x) { return (utt[x].flags & UTT_NO_NASAL) != 0; });
+    b->nNoNasal = noNasalEnd - order.begin();
     if (b->sortByLength) {
         auto longer = [&](uint32_t x, uint32_t y) { return b->lens[x] > b->lens[y]; };
-        std::stable_sort(order.begin(), quietEnd, longer);
+        std::stable_sort(order.begin(), noNasalEnd, longer);
+        std::stable_sort(noNasalEnd, quietEnd, longer);
         std::stable_sort(quietEnd, order.end(), longer);
     }
     b->nSlots = nUtterances;
@@ -933,16 +1017,35 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     if (!b || !info || nInfo < 6) return -1;
     HIP_TRY(hipSetDevice(b->device));
     hipFuncAttributes fa;
-    const bool noisy = b->nSlots - b->nQuiet >= b->nQuiet;   // report the larger group's kernel
-    const GroupPlan pl = plan_group(b->layout, noisy, b->nSlots, b->nSlots - b->nQuiet, b->cus);
+    // report the kernel of the largest of the three groups (batch_launch)
+    const long long nNoisy = b->nSlots - b->nQuiet, nLp = lanepipe_count(b);
+    const long long nNn = b->layout == 0 ? 0 : b->nNoNasal - nLp, nQ = b->nQuiet - nLp - nNn;
+    const bool lanepipe = nLp > 0 && nLp >= nQ && nLp >= nNoisy && nLp >= nNn;
+    const bool nasalFree = !lanepipe && nNn > 0 && nNn >= nQ && nNn >= nNoisy;
+    const bool noisy = !lanepipe && !nasalFree && nNoisy >= nQ;
+    const GroupPlan pl = plan_group(b->layout, noisy, b->nSlots, nNoisy, b->cus);
     const bool fast = b->mode == MODE_FAST;
     const void* fn;
-    int sysLds = 0;
-    if (pl.systolic) {
-        if (noisy && pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 8, 2> : (const void*)klatt_systolic<MODE_EXACT, true, 8, 2>; sysLds = SysLds<true, 8>::kBytes; }
-        else if (noisy) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16> : (const void*)klatt_systolic<MODE_EXACT, true, 16>; sysLds = SysLds<true, 16>::kBytes; }
-        else if (pl.chunk == 32) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 32> : (const void*)klatt_systolic<MODE_EXACT, false, 32>; sysLds = SysLds<false, 32>::kBytes; }
-        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 16> : (const void*)klatt_systolic<MODE_EXACT, false, 16>; sysLds = SysLds<false, 16>::kBytes; }
+    int ldsBytes = LdsLayout<false>::kBytes, chunk = 0, wavesPerGroup = 1;
+    long long groups = (nNn + kLanes - 1) / kLanes + (nQ + kLanes - 1) / kLanes + (nNoisy + kLanes - 1) / kLanes;
+    if (nasalFree) {
+        if (pl.chunk == 32) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 32, 1, false> : (const void*)klatt_systolic<MODE_EXACT, false, 32, 1, false>; ldsBytes = SysLds<false, 32>::kBytes; }
+        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 16, 1, false> : (const void*)klatt_systolic<MODE_EXACT, false, 16, 1, false>; ldsBytes = SysLds<false, 16>::kBytes; }
+        chunk = pl.chunk;
+        wavesPerGroup = kStages;
+    } else if (lanepipe) {
+        const long long g = (nLp + kLpUPG - 1) / kLpUPG;
+        if (g <= b->cus) { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 32, 1> : (const void*)klatt_lanepipe<MODE_EXACT, 32, 1>; ldsBytes = LpLds<32>::kBytes; chunk = 32; }
+        else { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 16, 2> : (const void*)klatt_lanepipe<MODE_EXACT, 16, 2>; ldsBytes = LpLds<16>::kBytes; chunk = 16; }
+        wavesPerGroup = kStages;
+        groups = g;
+    } else if (pl.systolic) {
+        if (noisy && pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 8, 2> : (const void*)klatt_systolic<MODE_EXACT, true, 8, 2>; ldsBytes = SysLds<true, 8>::kBytes; }
+        else if (noisy) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16> : (const void*)klatt_systolic<MODE_EXACT, true, 16>; ldsBytes = SysLds<true, 16>::kBytes; }
+        else if (pl.chunk == 32) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 32> : (const void*)klatt_systolic<MODE_EXACT, false, 32>; ldsBytes = SysLds<false, 32>::kBytes; }
+        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 16> : (const void*)klatt_systolic<MODE_EXACT, false, 16>; ldsBytes = SysLds<false, 16>::kBytes; }
+        chunk = pl.chunk;
+        wavesPerGroup = kStages;
     } else {
         fn = fast ? (noisy ? (const void*)klatt_synthesize<MODE_FAST, false, true> : (const void*)klatt_synthesize<MODE_FAST, false, false>)
                   : (noisy ? (const void*)klatt_synthesize<MODE_EXACT, false, true> : (const void*)klatt_synthesize<MODE_EXACT, false, false>);
@@ -951,12 +1054,14 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, b->device));
     info[0] = fa.numRegs;
-    info[1] = pl.systolic ? sysLds : LdsLayout<false>::kBytes;
-    info[2] = (int)((b->nQuiet + kLanes - 1) / kLanes + (b->nSlots - b->nQuiet + kLanes - 1) / kLanes) * (pl.systolic ? kStages : 1);
+    info[1] = ldsBytes;
+    info[2] = (int)(groups * wavesPerGroup);
     info[3] = prop.multiProcessorCount;
-    info[4] = (int)(prop.sharedMemPerMultiprocessor / (pl.systolic ? sysLds : LdsLayout<false>::kBytes));
-    info[5] = (int)fa.localSizeBytes;   // scratch; must be 0
-    if (nInfo >= 8) { info[6] = pl.systolic ? pl.chunk : 0; info[7] = noisy ? 1 : 0; }
+    info[4] = (int)(prop.sharedMemPerMultiprocessor / ldsBytes);
+    info[5] = (int)fa.localSizeBytes;   // scratch
+    if (nInfo >= 8) { info[6] = chunk; info[7] = noisy ? 1 : 0; }
+    if (nInfo >= 10) { info[8] = lanepipe ? 1 : 0; info[9] = (int)std::min<long long>(nLp, 0x7FFFFFFF); }
+    if (nInfo >= 12) { info[10] = nasalFree ? 1 : 0; info[11] = (int)std::min<long long>(nNn, 0x7FFFFFFF); }
     return 0;
 }
 

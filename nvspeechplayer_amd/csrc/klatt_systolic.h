@@ -293,9 +293,15 @@ struct Stamps {
 #endif
 
 // ---- the kernel ---------------------------------------------------------------------------
-template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES>
+// NASAL = false (quiet launches only): every utterance of the launch is nasal-free (UTT_NO_NASAL, classified on the
+// host): caNP == 0 in every frame with bounded, stable N0/NP parameters.  The cascade input then passes the nasal pair
+// untouched (reference :151-152: x + (np - x) * 0 == x for finite np) and nothing else reads N0's or NP's memories,
+// so both are skipped and the six formant resonators are spread evenly:
+//   quiet, nasal-free   S0 frame + glottal source | S1 r6, r5, r4 | S2 r3, r2, r1 | S3 gain, clip, int16 -> PCM
+template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true>
 __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const KernelArgs A)
 {
+    static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
     using L = SysLds<NOISE, CH>;
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -356,6 +362,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // pipe slot of sample i of chunk c
 #define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
 
+    // A stage may offer straight-line versions of a whole steady / fading chunk (they return true when they took it);
+    // only S0 of a quiet launch does, see below.
+#define KL_STEADY_ALT(c) false
+#define KL_FADE_ALT(c, lerp, gainOnly) false
     // Generic chunk loop of a stage.  BODY(c, i, steady) computes sample i of chunk c from the stage's pipe
     // inputs and writes its outputs; ON_EMIT is the general-step tail (uses `emit`).  One barrier per
     // iteration, the same number of iterations in every wave.
@@ -378,7 +388,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             double pre[PRELOAD ? kChunk : 1];                                                                                      \
             if (kind == 0) {                                                                                                       \
                 if (!FRAMEVAR.done) {                                                                                              \
-                    if (PRELOAD) {                                                                                                 \
+                    if (KL_STEADY_ALT(c)) {                                                                                        \
+                    } else if (PRELOAD) {                                                                                          \
                         _Pragma("unroll") for (int i = 0; i < kChunk; ++i) pre[i] = (PRE_IN);                                      \
                         _Pragma("unroll") for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }                                   \
                     } else {                                                                                                       \
@@ -389,10 +400,13 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 }                                                                                                                  \
             } else if (kind == 1) {                                                                                                \
                 if (!FRAMEVAR.done) {                                                                                              \
-                    _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                         \
-                        FRAMEVAR.cnt++;                                                                                            \
-                        stage_fade<DESC, MODE>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                                  \
-                        BODY(c, i, false);                                                                                         \
+                    if (KL_FADE_ALT(c, lerp, gainOnly)) {                                                                          \
+                    } else {                                                                                                       \
+                        _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                     \
+                            FRAMEVAR.cnt++;                                                                                        \
+                            stage_fade<DESC, MODE>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                              \
+                            BODY(c, i, false);                                                                                     \
+                        }                                                                                                          \
                     }                                                                                                              \
                     ON_FADE_DONE;                                                                                                  \
                 }                                                                                                                  \
@@ -454,6 +468,61 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         auto vib_live_now = [&]() __attribute__((always_inline)) -> bool {
             return vibFrames || f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase;
         };
+        // Straight-line chunks of the quiet source (vibrato off, checked by VIBCHECK; called with the live lanes active).
+        // Steady chunk without a pitch glide in any lane: cur0 + 0 repeated is cur0 + 0 once, and the phase increment
+        // (cur0 * 1) / sr is one value for the whole chunk.
+        auto s0_steady_alt = [&](int c) __attribute__((always_inline)) -> bool {
+            if (NOISE || __any(ps.oldInc != 0.0)) return false;
+            ps.cur0 += ps.oldInc;
+            const double inc = div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate);
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) {
+                pitchPhase = frac_toward_zero(inc + pitchPhase);
+                PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * f.cur[6]) * 0.5;
+            }
+            return true;
+        };
+        // Fading chunk in which only the gain (and the pitch) move -- fades into and out of silence, reference
+        // src/frame.cpp:59-67 -- and no target is NaN ("hold", src/utils.h:21): from + ((to - from) * ratio) with the
+        // differences taken once, the old/new values read from LDS once.  Same operations on the same operands as
+        // stage_fade + source, sample by sample.
+        auto s0_fade_alt = [&](int c, bool lerp, bool gainOnly) __attribute__((always_inline)) -> bool {
+            if (NOISE || !gainOnly) return false;
+            constexpr int GI = 6;
+            const double g0 = lerp ? f.oldL[GI * kLanes] : f.cur[GI], g1 = lerp ? f.getNew(GI) : f.cur[GI];
+            if (__any(g1 != g1 || ps.new0 != ps.new0)) return false;
+            const double gd = g1 - g0, p0 = ps.old0, pd = ps.new0 - p0, nf = (double)f.newFade;
+            if (!__any(pd != 0.0 || p0 != p0)) {
+                // the pitch does not move either: p0 + ((p0 - p0) * ratio) == p0 + 0
+                ps.cur0 = p0 + 0.0;
+                const double inc = div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate);
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    f.cnt++;
+                    const double ratio = div_by((double)f.cnt, nf, f.invFade);
+                    const double gain = g0 + (gd * ratio);
+                    pitchPhase = frac_toward_zero(inc + pitchPhase);
+                    PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * gain) * 0.5;
+                    if (i == kChunk - 1) f.cur[GI] = gain;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kChunk; ++i) {
+                    f.cnt++;
+                    const double ratio = div_by((double)f.cnt, nf, f.invFade);
+                    ps.cur0 = p0 + (pd * ratio);
+                    const double gain = g0 + (gd * ratio);
+                    pitchPhase = frac_toward_zero(div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate) + pitchPhase);
+                    PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * gain) * 0.5;
+                    if (i == kChunk - 1) f.cur[GI] = gain;
+                }
+            }
+            return true;
+        };
+#undef KL_STEADY_ALT
+#undef KL_FADE_ALT
+#define KL_STEADY_ALT(c) s0_steady_alt(c)
+#define KL_FADE_ALT(c, lerp, gainOnly) s0_fade_alt(c, lerp, gainOnly)
 #define S0_BODY(c, i, steady) do { if (steady) ps.cur0 += ps.oldInc; PIPE(pipeX, c, i) = source(false); } while (0)
 #define S0_EMIT do {                                                                                             \
             if (emit && f.hasNew && f.cnt == 0)                                                                  \
@@ -465,11 +534,36 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                   (ps.old0 = ps.cur0, f.produced += kChunk), (f.produced += kChunk), S0_EMIT, (void)0, false, 0.0)
 #undef S0_BODY
 #undef S0_EMIT
+#undef KL_STEADY_ALT
+#undef KL_FADE_ALT
+#define KL_STEADY_ALT(c) false
+#define KL_FADE_ALT(c, lerp, gainOnly) false
         if (live) {
             UttResult res;
             res.produced = f.produced; res.framesTaken = f.nextFrame; res.lastIndex = lastIndex; res.drained = 1u;
             A.result[u] = res;
         }
+    } else if (!NOISE && !NASAL && (stage == 1 || stage == 2)) {
+        // ================= quiet, nasal-free S1: r6, r5, r4 and S2: r3, r2, r1 =================
+        using D = StageDesc<6, 3, -1, false, false>;
+        const bool s1 = (stage == 1);
+        const int P[6] = {s1 ? 12 : 9, s1 ? 20 : 17, s1 ? 11 : 8, s1 ? 19 : 16, s1 ? 10 : 7, s1 ? 18 : 15};
+        constexpr int RF[3] = {0, 2, 4}, RB[3] = {1, 3, 5};
+        StageFrame<6, 3> f;
+        stage_frame_init(f, live, lds + (s1 ? L::kFrames1 : L::kFrames2), lane);
+        double* const pin = s1 ? pipeX : pipeO;
+        double* const pout = s1 ? pipeO : pipeA;
+        auto dsp = [&](double o) __attribute__((always_inline)) -> double {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
+            return o;
+        };
+#define SN_BODY(c, i, steady) PIPE(pout, c, i) = dsp((kPre && steady) ? pre[i] : PIPE(pin, c, i))
+#define SN_EMIT do { if (emit) PIPE(pout, c, i) = dsp(PIPE(pin, c, i)); } while (0)
+        if (s1) { RUN_STAGE(1, f, nullptr, nullptr, D, false, SN_BODY, (void)0, (void)0, SN_EMIT, (void)0, kPre, PIPE(pin, c, i)) }
+        else { RUN_STAGE(2, f, nullptr, nullptr, D, false, SN_BODY, (void)0, (void)0, SN_EMIT, (void)0, kPre, PIPE(pin, c, i)) }
+#undef SN_BODY
+#undef SN_EMIT
     } else if (stage == 1) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
         constexpr int NR = NOISE ? 5 : 3;
@@ -544,16 +638,16 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else {
         // ================= final stage: rest of the cascade, (parallel r5, r6 + bypass), gain, clip, PCM ===
         // noisy (stage 2): r3, r2, r1 | parallel 5, 6 | pa5, pa6, parallelBypass, outputGain
-        // quiet (stage 3): r2, r1 | outputGain
-        constexpr int NC = NOISE ? 3 : 2;                 // cascade resonators here
-        constexpr int NR = NOISE ? 5 : 2;
-        constexpr int NPAR = NOISE ? 14 : 5;
+        // quiet (stage 3): r2, r1 | outputGain          quiet, nasal-free (stage 3): outputGain only
+        constexpr int NC = NOISE ? 3 : (NASAL ? 2 : 0);   // cascade resonators here
+        constexpr int NR = NOISE ? 5 : NC;
+        constexpr int NPAR = NOISE ? 14 : (NASAL ? 5 : 1);
         using D = StageDesc<NPAR, NR, -1, false, false, NOISE>;
-        constexpr int P[14] = {NOISE ? 9 : 8, NOISE ? 17 : 16, NOISE ? 8 : 7, NOISE ? 16 : 15, NOISE ? 7 : 45, 15,
+        constexpr int P[14] = {NOISE ? 9 : (NASAL ? 8 : 45), NOISE ? 17 : 16, NOISE ? 8 : 7, NOISE ? 16 : 15, NOISE ? 7 : 45, 15,
                                29, 35, 30, 36, 41, 42, 43, 45};
         constexpr int RF[5] = {0, 2, NOISE ? 4 : 0, 6, 8};
         constexpr int RB[5] = {1, 3, NOISE ? 5 : 0, 7, 9};
-        constexpr int OUTGAIN = NOISE ? 13 : 4;
+        constexpr int OUTGAIN = NOISE ? 13 : (NASAL ? 4 : 0);
         StageFrame<NPAR, NR> f;
         stage_frame_init(f, live, lds + (NOISE ? L::kFrames2 : L::kFrames3), lane);
         int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
@@ -630,6 +724,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     }
 #endif
 #undef RUN_STAGE
+#undef KL_STEADY_ALT
+#undef KL_FADE_ALT
 #undef PIPE
 }
 

@@ -100,13 +100,14 @@ def make_batch(sel):
                 seeds=np.array(seeds, np.uint32))
 
 
-@pytest.mark.parametrize("layout", [-1, 1, 0])
+@pytest.mark.parametrize("layout", [-1, 2, 1, 0])
 @pytest.mark.parametrize("mode", [0, 1])
 def test_batch_all_scenarios(all_scenarios, mode, layout):
     """Every batchable scenario (vowels, all sampleIpa cases, vibrato, NaN hold, duration edges)
     as ONE ragged batch through speechPlayer_batch_*; each utterance must equal a fresh oracle player.
     mode 0 = MODE_EXACT, mode 1 = MODE_FAST (fused multiply-adds, straight-line exp/cos): same bar.
-    layout 1 = stage-parallel workgroups (klatt_systolic.h), 0 = one wavefront per 64 utterances."""
+    layout 1 = stage-parallel workgroups (klatt_systolic.h), 0 = one wavefront per 64 utterances,
+    2 = lane-pipelined workgroups (klatt_lanepipe.h) for the quiet, nasal-free utterances."""
     import nvspeechplayer_amd as eng
     sel = [s for s in all_scenarios if s.batchable and s.sr == 22050]
     batch = make_batch(sel)
@@ -133,7 +134,7 @@ def test_batch_all_scenarios(all_scenarios, mode, layout):
     bp.close()
 
 
-@pytest.mark.parametrize("layout", [1, 0])
+@pytest.mark.parametrize("layout", [2, 1, 0])
 def test_batch_edge_shapes(ref, layout):
     """Empty batch, empty utterances, a single utterance, 65 utterances (one lane in the 2nd wavefront)."""
     import nvspeechplayer_amd as eng
@@ -243,7 +244,7 @@ def test_full_size_cfg1_properties():
     bp.close()
 
 
-def random_batch(rng, n_utt, quiet_fraction=0.3, wild=False):
+def random_batch(rng, n_utt, quiet_fraction=0.3, wild=False, nasal_fraction=0.4):
     """Ragged random utterances: random formants / bandwidths / gains / pitches, random durations
     (including fade > frame, fade 0, 1-sample frames), NULL frames anywhere, optional NaN holds."""
     frames, mins, fades, nul, start, seeds = [], [], [], [], [0], []
@@ -261,7 +262,7 @@ def random_batch(rng, n_utt, quiet_fraction=0.3, wild=False):
                 f[3] = rng.uniform(0, 0.5) * (rng.random() < 0.5); f[4] = rng.uniform(0, 1)
                 f[6] = rng.uniform(0, 1) * (rng.random() < 0.5); f[24] = rng.uniform(0, 1) * (rng.random() < 0.6)
             f[7:13] = np.sort(rng.uniform(150, 5500, 6)); f[13] = rng.uniform(0, 600) * (rng.random() < 0.5); f[14] = rng.uniform(200, 500)
-            f[15:23] = rng.uniform(30, 1000, 8); f[23] = rng.uniform(0, 1) * (rng.random() < 0.4)
+            f[15:23] = rng.uniform(30, 1000, 8); f[23] = rng.uniform(0, 1) * (rng.random() < nasal_fraction)
             f[25:31] = np.sort(rng.uniform(150, 5500, 6)); f[31:37] = rng.uniform(30, 1000, 6); f[37:43] = rng.uniform(0, 1, 6)
             f[43] = rng.uniform(0, 1); f[44] = rng.uniform(0, 1.5); f[45] = rng.uniform(0.2, 2.5)
             is_null = rng.random() < 0.2
@@ -307,6 +308,54 @@ def test_random_ragged_batches(seed, wild, layout):
         assert nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
         assert float(np.sqrt(np.mean((d / 32768.0) ** 2))) < RMS_TOL
         bp.close()
+
+
+def test_lane_pipelined_kernel():
+    """klatt_lanepipe.h (cascade resonators across lanes) on what it is for -- quiet, nasal-free utterances:
+    ragged random ones (events, fades, NULL frames, vibrato in every wavefront) and a slice of BASELINE
+    configs[1]; every utterance must take that kernel and equal the oracle, in both arithmetic modes,
+    for one workgroup per CU (32-sample hand-overs) and beyond (16-sample hand-overs, two per CU)."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    rng = np.random.default_rng(7)
+    ragged = random_batch(rng, 700, quiet_fraction=1.0, nasal_fraction=0.0)
+    vowels = workloads.make("cfg1", 230)
+    for name, batch in (("ragged", ragged), ("cfg1 slice", vowels)):
+        n = len(batch["frame_start"]) - 1
+        exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
+        for mode in (0, 1):
+            bp = eng.BatchPlayer(22050, mode=mode, layout=2)
+            bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                             batch["isnull"], batch["seeds"])
+            info = bp.kernelInfo()
+            assert info["lane_pipelined"] and info["lane_pipelined_utterances"] == n, info
+            bp.synthesize()
+            got, got_start = bp.readAll()
+            assert np.array_equal(got_start, exp_start)
+            nbad = int(np.count_nonzero(got != exp))
+            print("%s mode %d: %d utterances, %d samples, %d differ; %s" % (name, mode, n, total, nbad, info))
+            if mode == 0:
+                assert nbad == 0
+            else:
+                compare(got, exp, name)
+            bp.close()
+    # 6000 vowels: more workgroups than CUs (the two-per-CU instantiation), against the stage-parallel kernel and the oracle
+    big = workloads.make("cfg1", 6000)
+    bp = eng.BatchPlayer(22050, layout=2)
+    bp.setUtterances(big["frame_start"], big["frames"], big["min"], big["fade"], big["index"], big["isnull"], big["seeds"])
+    assert bp.kernelInfo()["stage_parallel_chunk"] == 16
+    bp.synthesize()
+    got, got_start = bp.readAll()
+    bp1 = eng.BatchPlayer(22050, layout=1)
+    bp1.setUtterances(big["frame_start"], big["frames"], big["min"], big["fade"], big["index"], big["isnull"], big["seeds"])
+    bp1.synthesize()
+    ref1, _ = bp1.readAll()
+    assert np.array_equal(got, ref1)
+    for u in range(0, 6000, 997):
+        sub = big.slice(u, 1)
+        e, _, _ = oracle.batch_synthesize(22050, sub)
+        assert np.array_equal(got[got_start[u]:got_start[u + 1]], e), u
+    bp.close(); bp1.close()
 
 
 def test_zero_length_real_frame_division_by_zero(ref):

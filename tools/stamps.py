@@ -8,6 +8,8 @@ import numpy as np
 from nvspeechplayer_amd import BatchPlayer, _native, workloads
 
 wl, n, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0
+layout = int(sys.argv[4]) if len(sys.argv) > 4 else 1     # 2: lane-pipelined workgroups (20 utterances each)
+per = 20 if layout == 2 else 64
 if wl == "staggered":          # cfg2 with per-utterance leading silence: lanes of a wave do not fade together
     from mixed_probe import stagger
     batch = stagger(workloads.make("cfg2", n))
@@ -16,14 +18,14 @@ elif wl == "rotated":
     batch = rotate(workloads.make("cfg2", n))
 else:
     batch = workloads.make(wl, n)
-bp = BatchPlayer(batch["sr"], mode=mode, layout=1)
+bp = BatchPlayer(batch["sr"], mode=mode, layout=layout)
 bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
 bp.synthesize(); bp.synthesize()
 L = _native.load()
 L.speechPlayer_batch_debugStamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
-buf = np.zeros((n // 64 + 2) * 32, dtype=np.uint64)
+buf = np.zeros((n // per + 2) * 32, dtype=np.uint64)
 got = L.speechPlayer_batch_debugStamps(bp._h, buf.ctypes.data, len(buf))
-st = buf[:(n // 64) * 32].reshape(-1, 4, 8).astype(np.float64)
+st = buf[:(n // per) * 32].reshape(-1, 4, 8).astype(np.float64)
 print("%s n=%d mode=%d: per stage mean cycles  work / barrier-wait   (over %d workgroups)" % (wl, n, mode, st.shape[0]))
 for s in range(4):
     m = st[:, s, :].mean(axis=0)

@@ -1,0 +1,260 @@
+// ubench_lanepipe.hip -- what does one step of the lane-pipelined resonator cost a lone wave?
+// Variants of the hand-over: none, wave_ror:1, row_shr:1, ds_bpermute, with/without the select of the
+// first lane's LDS input, with/without the LDS store.  hipcc -O3 --offload-arch=gfx950 -ffp-contract=off
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+
+template <int CTRL>
+__device__ __forceinline__ double dpp_move(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double bperm_move(double v, int src)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_ds_bpermute(src * 4, lo);
+    hi = __builtin_amdgcn_ds_bpermute(src * 4, hi);
+    return __hiloint2double(hi, lo);
+}
+
+// VARIANT: 0 no hand-over (in = out); 1 wave_ror:1; 2 row_shr:1; 3 ds_bpermute; 4 wave_ror + select; 5 wave_ror + select + LDS store
+//          6: two independent pipelines interleaved (variant 5 twice); 7: FMA form y = fma(a, in, s), s = fma(b, z1, c * z2) + select + store
+template <int VARIANT>
+__global__ void __launch_bounds__(64) k(double* out, const double* coef, int steps, int probe)
+{
+    __shared__ double xs[64 * 32];
+    __shared__ double ys[64 * 33];
+    const int lane = threadIdx.x;
+    const double a = coef[lane], b = coef[64 + lane], c = coef[128 + lane];
+    double z1 = 0.0, z2 = 0.0, y = 1e-3 * lane;
+    double z1b = 0.0, z2b = 0.0, yb = 2e-3 * lane;
+    const bool first = (lane % 6) == 0;
+    for (int i = 0; i < 32; ++i) xs[i * 64 + lane] = 1e-3 * (i + lane);
+    __syncthreads();
+    const int src = (lane + 63) & 63;
+    for (int t = 0; t < steps; t += 32) {
+        double pre[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) pre[i] = xs[i * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            double in;
+            if (VARIANT == 0) in = y;
+            else if (VARIANT == 2 || VARIANT == 8) in = dpp_move<0x111>(y);
+            else if (VARIANT == 3) in = bperm_move(y, src);
+            else in = dpp_move<0x13C>(y);
+            if (VARIANT >= 4) in = first ? pre[i] : in;
+            if (VARIANT == 7) {
+                const double s = __builtin_fma(b, z1, c * z2);
+                const double w = __builtin_fma(a, in, s);
+                z2 = z1; z1 = w; y = w;
+            } else {
+                const double w = a * in + b * z1 + c * z2;
+                z2 = z1; z1 = w; y = w;
+            }
+            if (VARIANT >= 5) ys[i * 66 + lane] = y;
+            if (VARIANT == 6) {
+                double inb = dpp_move<0x13C>(yb);
+                inb = first ? pre[31 - i] : inb;
+                const double w = a * inb + b * z1b + c * z2b;
+                z2b = z1b; z1b = w; yb = w;
+                ys[i * 66 + 2 + lane] = yb;
+            }
+        }
+    }
+    out[blockIdx.x * 64 + lane] = y + yb + ys[(probe & 31) * 66 + lane];
+}
+
+// The whole workgroup of klatt_lanepipe.h in miniature: wave 0 source-like (phase chain + 5 elementwise operations
+// + LDS store), waves 1-2 the filter step of variant 5 fed from LDS, wave 3 final-like (two multiplies, clamp,
+// convert, ds_write_b16), one barrier per 32-sample chunk, double-buffered pipes.  ROLES: bit w set = wave w works.
+template <int ROLES, bool SYNC = true>
+__global__ void __launch_bounds__(256) wg(double* out, const double* coef, int steps)
+{
+    __shared__ double px[2 * 32 * 20];
+    __shared__ double py[4 * 32 * 20 + 64 + 32 * 20];
+    __shared__ short tile[64 * 36];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const double a = coef[lane], b = coef[64 + lane], c = coef[128 + lane];
+    double z1 = 0.0, z2 = 0.0, y = 1e-3 * lane, pp = 0.0, acc = 0.0;
+    const bool first = (lane % 6) == 0, last = (lane % 6) == 5;
+    const int uw = (wave == 1 || wave == 2) ? ((wave - 1) * 10 + lane / 6) % 20 : lane % 20;
+    for (int i = threadIdx.x; i < 2 * 32 * 20; i += 256) px[i] = 1e-3 * i;
+    for (int i = threadIdx.x; i < 4 * 32 * 20; i += 256) py[i] = 1e-3 * i;
+    __syncthreads();
+    const int nChunks = steps / 32;
+    for (int it = 0; it < nChunks + 3; ++it) {
+        if (wave == 0 && (ROLES & 1)) {
+            double* row = px + ((it & 1) * 32) * 20 + uw;
+            if (lane < 20) {
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const double t = b + pp;
+                    pp = t - __builtin_trunc(t);
+                    row[i * 20] = ((((pp * 2.0) - 1.0) * a) * c) * 0.5;
+                }
+            }
+        } else if ((wave == 1 || wave == 2) && (ROLES & (1 << wave))) {
+            const double* xin = px + (((it + 1) & 1) * 32) * 20 + uw;
+            double* yrow = last ? (py + (((it + 3) & 3) * 32) * 20 + uw) : (py + 4 * 32 * 20 + lane);
+            double pre[32];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) pre[i] = xin[i * 20];
+#pragma unroll
+            for (int i = 0; i < 32; ++i) {
+                double in = dpp_move<0x13C>(y);
+                in = first ? pre[i] : in;
+                const double w = a * in + b * z1 + c * z2;
+                z2 = z1; z1 = w; y = w;
+                yrow[i * 20] = y;
+            }
+        } else if (wave == 3 && (ROLES & 8)) {
+            const double* yin = py + uw;
+            short* myRow = tile + lane * 36;
+            if (lane < 20) {
+                double pre[32];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) pre[i] = yin[((((it + 1) & 3) * 32 + i + 5) & 127) * 20];
+#pragma unroll
+                for (int i = 0; i < 32; ++i) {
+                    const double v = (pre[i] * a) * 4000.0;
+                    const double lo = (v < 32000.0) ? v : 32000.0;
+                    const double cl = (lo > -32000.0) ? lo : -32000.0;
+                    myRow[i] = (short)(int)cl;
+                }
+                acc += myRow[5];
+            }
+        }
+        if (SYNC) __syncthreads();
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = y + pp + acc;
+}
+
+template <int ROLES, bool SYNC = true>
+void run_wg(const char* name, double* dOut, double* dCoef, int blocks)
+{
+    const int steps = 32 * 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((wg<ROLES, SYNC>), dim3(blocks), dim3(256), 0, 0, dOut, dCoef, steps);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((wg<ROLES, SYNC>), dim3(blocks), dim3(256), 0, 0, dOut, dCoef, steps);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-58s blocks=%5d : %7.2f ns per step\n", name, blocks, ms * 1e6 / steps);
+}
+
+// What does an LDS store cost the issuing wave?  A resonator chain (5 f64 operations per step) plus, per step:
+// KIND 0 nothing, 1 ds_write_b64, 2 ds_write_b32, 3 ds_write_b16, 4 one ds_write_b64 every 4th step,
+// 5 ds_write_b64 from 16 lanes only, 6 one ds_write_b128 every 2nd step, 7 ds_read_b64 (result used 8 steps later)
+template <int KIND>
+__global__ void __launch_bounds__(64) ldscost(double* out, const double* coef, int steps, int probe)
+{
+    __shared__ double buf[64 * 40];
+    const int lane = threadIdx.x;
+    const double a = coef[lane], b = coef[64 + lane], c = coef[128 + lane];
+    double z1 = 0.0, z2 = 0.0, y = 1e-3 * lane, acc = 0.0;
+    for (int i = 0; i < 40; ++i) buf[i * 64 + lane] = 1e-3 * i;
+    __syncthreads();
+    double hold = 0.0;
+    for (int t = 0; t < steps; t += 32) {
+        double rd[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            double in = y + acc;
+            const double w = a * in + b * z1 + c * z2;
+            z2 = z1; z1 = w; y = w;
+            if (KIND == 1) buf[i * 64 + lane] = y;
+            if (KIND == 2) reinterpret_cast<float*>(buf)[i * 64 + lane] = (float)y;
+            if (KIND == 3) reinterpret_cast<short*>(buf)[i * 66 + lane * 36] = (short)(int)y;
+            if (KIND == 4 && (i & 3) == 3) buf[i * 64 + lane] = y;
+            if (KIND == 5 && lane < 16) buf[i * 64 + lane] = y;
+            if (KIND == 6) { if (i & 1) *reinterpret_cast<double2*>(&buf[(i >> 1) * 128 + lane * 2]) = make_double2(hold, y); else hold = y; }
+            if (KIND == 7) { rd[i] = buf[i * 64 + lane]; if (i >= 8) acc = rd[i - 8] * 1e-30; }
+        }
+    }
+    out[blockIdx.x * 64 + lane] = y + buf[(probe & 31) * 64 + lane];
+}
+
+template <int KIND>
+void run_lds(const char* name, double* dOut, double* dCoef, int blocks)
+{
+    const int steps = 32 * 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(ldscost<KIND>, dim3(blocks), dim3(64), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(ldscost<KIND>, dim3(blocks), dim3(64), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-58s blocks=%5d : %7.2f ns per step\n", name, blocks, ms * 1e6 / steps);
+}
+
+template <int V>
+void run(const char* name, double* dOut, double* dCoef, int blocks)
+{
+    const int steps = 32 * 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(64), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(k<V>, dim3(blocks), dim3(64), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-58s blocks=%5d : %7.2f ns per step\n", name, blocks, ms * 1e6 / steps);
+}
+
+int main()
+{
+    double *dOut, *dCoef;
+    hipMalloc(&dOut, 4096 * 256 * 8);
+    hipMalloc(&dCoef, 192 * 8);
+    std::vector<double> h(192);
+    for (int i = 0; i < 64; ++i) { h[i] = 0.01; h[64 + i] = 1.2; h[128 + i] = -0.5; }
+    hipMemcpy(dCoef, h.data(), 192 * 8, hipMemcpyHostToDevice);
+    for (int blocks : {256, 1024}) {
+        run_lds<0>("chain only", dOut, dCoef, blocks);
+        run_lds<1>("chain + ds_write_b64 per step", dOut, dCoef, blocks);
+        run_lds<2>("chain + cvt + ds_write_b32 per step", dOut, dCoef, blocks);
+        run_lds<3>("chain + cvt + ds_write_b16 per step", dOut, dCoef, blocks);
+        run_lds<4>("chain + ds_write_b64 every 4th step", dOut, dCoef, blocks);
+        run_lds<5>("chain + ds_write_b64 per step from 16 lanes", dOut, dCoef, blocks);
+        run_lds<6>("chain + ds_write_b128 every 2nd step", dOut, dCoef, blocks);
+        run_lds<7>("chain + ds_read_b64 per step", dOut, dCoef, blocks);
+    }
+    for (int blocks : {64}) {
+        run_wg<0>("workgroup: nobody works (loop + barrier)", dOut, dCoef, blocks);
+        run_wg<0, false>("workgroup: nobody works, no barrier", dOut, dCoef, blocks);
+    }
+    for (int blocks : {205}) {
+        run_wg<1>("workgroup: source wave only", dOut, dCoef, blocks);
+        run_wg<2>("workgroup: one filter wave only", dOut, dCoef, blocks);
+        run_wg<6>("workgroup: both filter waves", dOut, dCoef, blocks);
+        run_wg<8>("workgroup: final wave only", dOut, dCoef, blocks);
+        run_wg<15>("workgroup: all four waves", dOut, dCoef, blocks);
+        run_wg<2, false>("workgroup: one filter wave only, NO barrier (timing only)", dOut, dCoef, blocks);
+        run_wg<15, false>("workgroup: all four waves, NO barrier (timing only)", dOut, dCoef, blocks);
+    }
+    for (int blocks : {256, 2048}) {
+        run<0>("resonator only (in = own output)", dOut, dCoef, blocks);
+        run<1>("wave_ror:1 hand-over", dOut, dCoef, blocks);
+        run<2>("row_shr:1 hand-over", dOut, dCoef, blocks);
+        run<3>("ds_bpermute hand-over", dOut, dCoef, blocks);
+        run<4>("wave_ror:1 + first-lane select", dOut, dCoef, blocks);
+        run<5>("wave_ror:1 + select + LDS store", dOut, dCoef, blocks);
+        run<6>("two interleaved pipelines (per step of both)", dOut, dCoef, blocks);
+        run<7>("wave_ror:1 + select + store, FMA form (1 op on the chain)", dOut, dCoef, blocks);
+        run<8>("row_shr:1 + select + LDS store", dOut, dCoef, blocks);
+    }
+    return 0;
+}

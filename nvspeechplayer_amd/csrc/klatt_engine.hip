@@ -290,7 +290,12 @@ struct Batch {
 long long lanepipe_count(const Batch* b)
 {
     if (b->layout == 2) return b->nNoNasal;
-    return 0;
+    if (b->layout != -1 || b->nNoNasal == 0) return 0;
+    // Its workgroups hold 20 utterances against 64, at 37 ns per sample against 46 for the stage-parallel kernel's
+    // slowest stage (MI355X, tools/len_probe.py): it wins while every workgroup of the launch has a CU of its own --
+    // 1.03 against 1.22 ms at 4096 vowels -- and loses beyond (8192 vowels: 1.73 against 1.30 ms).
+    const long long groups = (b->nNoNasal + kLpUPG - 1) / kLpUPG + (b->nSlots - b->nNoNasal + kLanes - 1) / kLanes;
+    return groups <= b->cus ? b->nNoNasal : 0;
 }
 
 int batch_launch(Batch* b)

@@ -80,11 +80,17 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
 #ifdef KLATT_STAMPS
     Stamps st;
 #endif
+    uint32_t steadyLeft = 0;   // further chunks already known to be steady for every live lane (steady_run)
     for (int iter = 0; iter < nIter; ++iter) {
         STAMP_BEGIN();
         const int c = iter - depth;
         if (c >= 0 && c < nChunks) {
-            int kind = forceGeneral() ? -1 : chunk_kind<CH>(f);
+            int kind = 0;
+            if (steadyLeft > 0u) steadyLeft--;
+            else {
+                kind = forceGeneral() ? -1 : chunk_kind<CH>(f);
+                if (kind == 0) steadyLeft = steady_run<CH>(f) - 1u;
+            }
             bool lerp = false, gainOnly = false;
             uint32_t wRes = 0;
             if (kind == 1) {

@@ -264,16 +264,34 @@ __device__ __forceinline__ double resonate(double& z1, double& z2, double a, dou
     return y;
 }
 
-// all live lanes steady (0) / all fading beyond their first fade sample (1), with at least CH samples left; else -1
-template <int CH, class SF>
-__device__ __forceinline__ int chunk_kind(const SF& f)
+// all live lanes steady (0) / all fading beyond their first fade sample (1), with at least n samples left; else -1
+template <class SF>
+__device__ __forceinline__ int run_kind(const SF& f, uint32_t n)
 {
     const uint32_t rem = f.hasNew ? (f.newFade - f.cnt) : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u);
-    const bool roomy = f.done || rem >= (uint32_t)CH;
+    const bool roomy = f.done || rem >= n;
     if (!__all(roomy)) return -1;
     if (!__any(!f.done && f.hasNew)) return 0;
     if (!__any(!f.done && (!f.hasNew || f.cnt == 0))) return 1;
     return -1;
+}
+template <int CH, class SF>
+__device__ __forceinline__ int chunk_kind(const SF& f) { return run_kind(f, (uint32_t)CH); }
+
+// After chunk_kind() == 0: how many chunks (this one included) every live lane stays steady for, i.e. the minimum
+// over the live lanes of (samples left in the steady stretch) / CH.  The chunks after the first need no new decision:
+// nothing but the sample counter changes in a steady chunk (vibrato, which forces the sample-by-sample path, can only
+// come alive at an event).  Wave-uniform result.
+template <int CH, class SF>
+__device__ __forceinline__ uint32_t steady_run(const SF& f)
+{
+    uint32_t n = f.done ? 0xFFFFFFFFu : (f.oldMin - f.cnt) / (uint32_t)CH;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)n, m, kLanes);
+        n = o < n ? o : n;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
 }
 
 #ifdef KLATT_STAMPS
@@ -370,11 +388,16 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // inputs and writes its outputs; ON_EMIT is the general-step tail (uses `emit`).  One barrier per
     // iteration, the same number of iterations in every wave.
 #define RUN_STAGE(DEPTH, FRAMEVAR, PSPTR, IDXPTR, DESC, VIBCHECK, BODY, ON_STEADY_DONE, ON_FADE_DONE, ON_EMIT, PER_CHUNK, PRELOAD, PRE_IN)     \
-    for (int iter = 0; iter < nIter; ++iter) {                                                                                     \
+    for (uint32_t steadyLeft = 0, iter = 0; (int)iter < nIter; ++iter) {                                                           \
         STAMP_BEGIN();                                                                                                             \
-        const int c = iter - (DEPTH);                                                                                              \
+        const int c = (int)iter - (DEPTH);                                                                                         \
         if (c >= 0 && c < nChunks) {                                                                                               \
-            int kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                                 \
+            int kind = 0;                                                                                                          \
+            if (!NOISE && steadyLeft > 0u) steadyLeft--;   /* noisy kernels: no register to spare for the run length */           \
+            else {                                                                                                                 \
+                kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                                 \
+                if (!NOISE && kind == 0) steadyLeft = steady_run<CH>(FRAMEVAR) - 1u;                                               \
+            }                                                                                                                      \
             bool lerp = false, gainOnly = false;                                                                                   \
             uint32_t wRes = 0;                                                                                                     \
             if (kind == 1) {                                                                                                       \
@@ -388,6 +411,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             double pre[PRELOAD ? kChunk : 1];                                                                                      \
             if (kind == 0) {                                                                                                       \
                 if (!FRAMEVAR.done) {                                                                                              \
+                    constexpr bool usePre = true; constexpr int runLen = kChunk;                                                   \
                     if (KL_STEADY_ALT(c)) {                                                                                        \
                     } else if (PRELOAD) {                                                                                          \
                         _Pragma("unroll") for (int i = 0; i < kChunk; ++i) pre[i] = (PRE_IN);                                      \
@@ -395,11 +419,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     } else {                                                                                                       \
                         _Pragma(KLATT_STR(unroll KLATT_UNROLL)) for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }             \
                     }                                                                                                              \
-                    FRAMEVAR.cnt += kChunk;                                                                                        \
+                    FRAMEVAR.cnt += runLen;                                                                                        \
                     ON_STEADY_DONE;                                                                                                \
                 }                                                                                                                  \
             } else if (kind == 1) {                                                                                                \
                 if (!FRAMEVAR.done) {                                                                                              \
+                    constexpr bool usePre = false; constexpr int runLen = kChunk;                                                  \
                     if (KL_FADE_ALT(c, lerp, gainOnly)) {                                                                          \
                     } else {                                                                                                       \
                         _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                     \
@@ -475,11 +500,13 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             if (NOISE || __any(ps.oldInc != 0.0)) return false;
             ps.cur0 += ps.oldInc;
             const double inc = div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate);
+            // the phase recurrence (three dependent operations per sample) first, then the element-wise rest, whose
+            // operations are independent across samples and fill the recurrence's issue gaps
+            double ph[kChunk];
 #pragma unroll
-            for (int i = 0; i < kChunk; ++i) {
-                pitchPhase = frac_toward_zero(inc + pitchPhase);
-                PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * f.cur[6]) * 0.5;
-            }
+            for (int i = 0; i < kChunk; ++i) { pitchPhase = frac_toward_zero(inc + pitchPhase); ph[i] = pitchPhase; }
+#pragma unroll
+            for (int i = 0; i < kChunk; ++i) PIPE(pipeX, c, i) = ((((ph[i] * 2.0) - 1.0) * f.cur[4]) * f.cur[6]) * 0.5;
             return true;
         };
         // Fading chunk in which only the gain (and the pitch) move -- fades into and out of silence, reference
@@ -531,7 +558,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             if (emit) { PIPE(pipeX, c, i) = source(waveVib); f.produced++; }                                     \
         } while (0)
         RUN_STAGE(0, f, &ps, &lastIndex, D, __any(!f.done && vib_live_now()), S0_BODY,
-                  (ps.old0 = ps.cur0, f.produced += kChunk), (f.produced += kChunk), S0_EMIT, (void)0, false, 0.0)
+                  (ps.old0 = ps.cur0, f.produced += runLen), (f.produced += runLen), S0_EMIT, (void)0, false, 0.0)
 #undef S0_BODY
 #undef S0_EMIT
 #undef KL_STEADY_ALT
@@ -558,7 +585,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define SN_BODY(c, i, steady) PIPE(pout, c, i) = dsp((kPre && steady) ? pre[i] : PIPE(pin, c, i))
+#define SN_BODY(c, i, steady) PIPE(pout, c, i) = dsp((kPre && steady && usePre) ? pre[i] : PIPE(pin, c, i))
 #define SN_EMIT do { if (emit) PIPE(pout, c, i) = dsp(PIPE(pin, c, i)); } while (0)
         if (s1) { RUN_STAGE(1, f, nullptr, nullptr, D, false, SN_BODY, (void)0, (void)0, SN_EMIT, (void)0, kPre, PIPE(pin, c, i)) }
         else { RUN_STAGE(2, f, nullptr, nullptr, D, false, SN_BODY, (void)0, (void)0, SN_EMIT, (void)0, kPre, PIPE(pin, c, i)) }
@@ -584,7 +611,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 2; r < NR; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define S1_BODY(c, i, steady) PIPE(pipeO, c, i) = dsp((kPre && steady) ? pre[i] : PIPE(pipeX, c, i))
+#define S1_BODY(c, i, steady) PIPE(pipeO, c, i) = dsp((kPre && steady && usePre) ? pre[i] : PIPE(pipeX, c, i))
 #define S1_EMIT do { if (emit) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i)); } while (0)
         RUN_STAGE(1, f, nullptr, nullptr, D, false, S1_BODY, (void)0, (void)0, S1_EMIT, (void)0, kPre, PIPE(pipeX, c, i))
 #undef S1_BODY
@@ -630,7 +657,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define S2_BODY(c, i, steady) PIPE(pipeA, c, i) = dsp((kPre && steady) ? pre[i] : PIPE(pipeO, c, i))
+#define S2_BODY(c, i, steady) PIPE(pipeA, c, i) = dsp((kPre && steady && usePre) ? pre[i] : PIPE(pipeO, c, i))
 #define S2_EMIT do { if (emit) PIPE(pipeA, c, i) = dsp(PIPE(pipeO, c, i)); } while (0)
         RUN_STAGE(2, f, nullptr, nullptr, D, false, S2_BODY, (void)0, (void)0, S2_EMIT, (void)0, kPre, PIPE(pipeO, c, i))
 #undef S2_BODY
@@ -705,10 +732,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
 #define FIN_IN0(c, i) (NOISE ? PIPE(pipeO, c, i) : PIPE(pipeA, c, i))
 #define FIN_IN12(c, i) (NOISE ? PIPE(pipeA, c, i) : 0.0), (NOISE ? PIPE(pipeB, c, i) : 0.0)
 #define FIN_IN(c, i) FIN_IN0(c, i), FIN_IN12(c, i)
-#define FIN_BODY(c, i, steady) myRow[(it % kTile) + i] = (int16_t)finish((kPre && steady) ? pre[i] : FIN_IN0(c, i), FIN_IN12(c, i))
+#define FIN_BODY(c, i, steady) myRow[(it % kTile) + i] = (int16_t)finish((kPre && steady && usePre) ? pre[i] : FIN_IN0(c, i), FIN_IN12(c, i))
 #define FIN_EMIT do { if (emit) { myRow[(it % kTile) + i] = (int16_t)finish(FIN_IN(c, i)); f.produced++; } } while (0)
 #define FIN_CHUNK do { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); } while (0)
-        RUN_STAGE((NOISE ? 2 : 3), f, nullptr, nullptr, D, false, FIN_BODY, (f.produced += kChunk), (f.produced += kChunk), FIN_EMIT, FIN_CHUNK, kPre, FIN_IN0(c, i))
+        RUN_STAGE((NOISE ? 2 : 3), f, nullptr, nullptr, D, false, FIN_BODY, (f.produced += runLen), (f.produced += runLen), FIN_EMIT, FIN_CHUNK, kPre, FIN_IN0(c, i))
         if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
 #undef FIN_IN
 #undef FIN_IN0

@@ -198,6 +198,64 @@ void run_lds(const char* name, double* dOut, double* dCoef, int blocks)
     printf("%-58s blocks=%5d : %7.2f ns per step\n", name, blocks, ms * 1e6 / steps);
 }
 
+// One stage of the stage-parallel kernel: three resonators in series per sample, input preloaded from LDS, output to LDS.
+// SKEW 0: sample by sample (r_a, r_b, r_c of sample i back to back, as klatt_systolic.h's steady loop is written);
+// SKEW 1: software-pipelined -- iteration i runs r_a on sample i, r_b on sample i - 1, r_c on sample i - 2, so the three
+//         chains of an iteration are independent (same operations on the same operands, only issued in another order)
+template <int SKEW>
+__global__ void __launch_bounds__(64) chain3(double* out, const double* coef, int steps, int probe)
+{
+    __shared__ double xs[64 * 32];
+    __shared__ double ys[64 * 32];
+    const int lane = threadIdx.x;
+    const double a0 = coef[lane], b0 = coef[64 + lane], c0 = coef[128 + lane];
+    const double a1 = a0 * 1.01, b1 = b0 * 0.99, c1 = c0 * 1.02, a2 = a0 * 0.98, b2 = b0 * 1.01, c2 = c0 * 0.97;
+    double p0 = 0, q0 = 0, p1 = 0, q1 = 0, p2 = 0, q2 = 0, oa = 0, ob = 0;
+    for (int i = 0; i < 32; ++i) xs[i * 64 + lane] = 1e-3 * (i + lane);
+    __syncthreads();
+    for (int t = 0; t < steps; t += 32) {
+        double pre[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) pre[i] = xs[i * 64 + lane];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            if (SKEW == 0) {
+                double o = a0 * pre[i] + b0 * p0 + c0 * q0; q0 = p0; p0 = o;
+                o = a1 * o + b1 * p1 + c1 * q1; q1 = p1; p1 = o;
+                o = a2 * o + b2 * p2 + c2 * q2; q2 = p2; p2 = o;
+                ys[i * 64 + lane] = o;
+            } else {
+                // interleaved by hand: the products first, then the sums level by level
+                const double ta = a0 * pre[i], tb = a1 * oa, tc = a2 * ob;
+                const double ua = b0 * p0, ub = b1 * p1, uc = b2 * p2;
+                const double va = c0 * q0, vb = c1 * q1, vc = c2 * q2;
+                const double sa = ta + ua, sb = tb + ub, sc = tc + uc;
+                const double na = sa + va, nb = sb + vb, nc = sc + vc;
+                q0 = p0; p0 = na; q1 = p1; p1 = nb; q2 = p2; p2 = nc;
+                oa = na; ob = nb;
+                ys[i * 64 + lane] = nc;
+            }
+        }
+    }
+    out[blockIdx.x * 64 + lane] = p2 + ys[(probe & 31) * 64 + lane];
+}
+
+template <int SKEW>
+void run_chain3(const char* name, double* dOut, double* dCoef, int blocks)
+{
+    const int steps = 32 * 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(chain3<SKEW>, dim3(blocks), dim3(64), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL(chain3<SKEW>, dim3(blocks), dim3(64), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-58s blocks=%5d : %7.2f ns per step\n", name, blocks, ms * 1e6 / steps);
+}
+
 template <int V>
 void run(const char* name, double* dOut, double* dCoef, int blocks)
 {
@@ -222,7 +280,11 @@ int main()
     std::vector<double> h(192);
     for (int i = 0; i < 64; ++i) { h[i] = 0.01; h[64 + i] = 1.2; h[128 + i] = -0.5; }
     hipMemcpy(dCoef, h.data(), 192 * 8, hipMemcpyHostToDevice);
-    for (int blocks : {256, 1024}) {
+    for (int blocks : {256, 1024, 2048}) {
+        run_chain3<0>("three resonators in series, sample by sample", dOut, dCoef, blocks);
+        run_chain3<1>("three resonators, software-pipelined (skewed)", dOut, dCoef, blocks);
+    }
+    for (int blocks : {256}) {
         run_lds<0>("chain only", dOut, dCoef, blocks);
         run_lds<1>("chain + ds_write_b64 per step", dOut, dCoef, blocks);
         run_lds<2>("chain + cvt + ds_write_b32 per step", dOut, dCoef, blocks);

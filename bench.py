@@ -44,6 +44,15 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_name(info):
+    """The kernel of the batch's largest group (speechPlayer_batch_kernelInfo)."""
+    if info.get("lane_pipelined"):
+        return "klatt_lanepipe (cascade across lanes, %d-sample hand-overs)" % info["stage_parallel_chunk"]
+    if info["stage_parallel_chunk"]:
+        return "klatt_systolic (stage-parallel%s, %d-sample hand-overs)" % (", nasal-free" if info.get("nasal_free") else "", info["stage_parallel_chunk"])
+    return "klatt_synthesize (lane kernel)"
+
+
 def usable_cores():
     """Host threads this process may really use: CPU affinity, capped by the cgroup CPU quota
     (on the GPU box 256 hardware threads are visible but the container's quota is 16 CPUs)."""
@@ -160,9 +169,10 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": "profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
-                         "kernel": "klatt_systolic (stage-parallel, %d-sample hand-overs)" % info["stage_parallel_chunk"] if info["stage_parallel_chunk"] else "klatt_synthesize (lane kernel)", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                         "kernel": kernel_name(info), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                          "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
-                         "note": "f64 VALU issue binds before HBM, and a 4096-utterance batch fills only 64 of 256 CUs; see DESIGN.md"},
+                         "note": "f64 VALU issue binds before HBM (a sample is a strict recurrence: its time per sample, not its bytes, "
+                                 "bounds a launch); see DESIGN.md section 4"},
         }
         if world == 1 and args.mode == 0 and not args.no_large_batch:
             # same batch in MODE_FAST (fused multiply-adds; identical PCM on every test so far, not guaranteed bit-exact)

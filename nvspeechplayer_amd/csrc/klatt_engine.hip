@@ -169,6 +169,9 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     return 0;
 }
 
+#ifndef KLATT_LP_CH
+#define KLATT_LP_CH 32     // hand-over size of the lane-pipelined kernel with one workgroup per CU
+#endif
 template <int CH, int WPS>
 int launch_lanepipe(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
@@ -336,7 +339,7 @@ int batch_launch(Batch* b)
         hipStream_t st = next_stream();
         a.order = b->dOrder.ptr; a.nSlots = nLp;
         const long long g = (nLp + kLpUPG - 1) / kLpUPG;
-        if (g <= b->cus ? launch_lanepipe<32, 1>(a, b->mode, g, st) : launch_lanepipe<16, 2>(a, b->mode, g, st)) return -1;
+        if (g <= b->cus ? launch_lanepipe<KLATT_LP_CH, 1>(a, b->mode, g, st) : launch_lanepipe<16, 2>(a, b->mode, g, st)) return -1;
     }
     if (nNn > 0) {
         hipStream_t st = next_stream();
@@ -1040,7 +1043,7 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         wavesPerGroup = kStages;
     } else if (lanepipe) {
         const long long g = (nLp + kLpUPG - 1) / kLpUPG;
-        if (g <= b->cus) { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 32, 1> : (const void*)klatt_lanepipe<MODE_EXACT, 32, 1>; ldsBytes = LpLds<32>::kBytes; chunk = 32; }
+        if (g <= b->cus) { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, KLATT_LP_CH, 1> : (const void*)klatt_lanepipe<MODE_EXACT, KLATT_LP_CH, 1>; ldsBytes = LpLds<KLATT_LP_CH>::kBytes; chunk = KLATT_LP_CH; }
         else { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 16, 2> : (const void*)klatt_lanepipe<MODE_EXACT, 16, 2>; ldsBytes = LpLds<16>::kBytes; chunk = 16; }
         wavesPerGroup = kStages;
         groups = g;

@@ -40,7 +40,9 @@ struct LpLds {
     static constexpr int kPipeY = kPipeX + 2 * CH * kLpUPG * 8;        // F -> FIN: ring [4][CH][kLpUPG] f64
     static constexpr int kDummy = kPipeY + 4 * CH * kLpUPG * 8;       // where the lanes that are not last in their group "store"
     static constexpr int kTileOff = kDummy + (CH * kLpUPG + kLanes) * 8;
-    static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
+    static constexpr int kT = CH > kTile ? CH : kTile;                // samples per tile row: a whole chunk leaves at once
+    static constexpr int kTStride = kT * 2 + 8;                        // bytes per row; the pad keeps ds_write_b16 conflict-free
+    static constexpr int kRowBase = kTileOff + kLanes * kTStride;
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
     static constexpr int kFrames0 = kMaxLen + 16;                      // S0: old values of 7 parameters (targets in registers)
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
         StageFrame<1, 0> f;
         stage_frame_init(f, live, lds + L::kFramesFin, lane);
         rowBase[lane] = d.outStart; rowCount[lane] = 0;     // read by this wave only
-        int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
+        int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * L::kTStride);
         uint32_t delay = 0;
         uint32_t it = 0;             // samples stepped so far (wave-uniform)
 
@@ -372,7 +374,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
         auto flush_tile = [&](uint32_t tileStart, uint32_t validTo) __attribute__((always_inline)) {
             rowCount[lane] = f.produced;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave alone owns the tile
-            constexpr int kChunksPerRow = kTile / 8;
+            constexpr int kChunksPerRow = L::kT / 8;
             constexpr int kRowsPerPass = kLanes / kChunksPerRow;
             constexpr int kPasses = (kLpUPG + kRowsPerPass - 1) / kRowsPerPass;   // only the first kLpUPG rows are in use
             const int chunk = lane % kChunksPerRow;
@@ -383,7 +385,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
 #pragma unroll
             for (int p = 0; p < kPasses; ++p) {
                 const int row = p * kRowsPerPass + lane / kChunksPerRow;
-                const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
+                const uint2* src = reinterpret_cast<const uint2*>(tile + row * L::kTStride + chunk * 16);
                 lo[p] = src[0]; hi[p] = src[1];
                 cnt[p] = rowCount[row];
                 base[p] = rowBase[row];
@@ -401,16 +403,16 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
             [&]() { return false; },
             [&](int) -> bool { return true; },
             [&](int c, int i) { return LP_Y(c * CH + i + kLpSkew); },
-            [&](int c, int i, bool, double) { myRow[(it % kTile) + i] = (int16_t)finish(LP_Y(c * CH + i + kLpSkew)); },
-            [&](int, int i, double pre) { myRow[(it % kTile) + i] = (int16_t)finish(pre); },
+            [&](int c, int i, bool, double) { myRow[(it % L::kT) + i] = (int16_t)finish(LP_Y(c * CH + i + kLpSkew)); },
+            [&](int, int i, double pre) { myRow[(it % L::kT) + i] = (int16_t)finish(pre); },
             [&](int, bool, bool) -> bool { return false; },
             [&](int c, int i, bool emit) {
-                if (emit) { myRow[(it % kTile) + i] = (int16_t)finish(LP_Y(c * CH + i + kLpSkew)); f.produced++; }
+                if (emit) { myRow[(it % L::kT) + i] = (int16_t)finish(LP_Y(c * CH + i + kLpSkew)); f.produced++; }
             },
             [&]() { f.produced += CH; },
             [&]() { f.produced += CH; },
-            [&]() { it += CH; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
-        if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
+            [&]() { it += CH; if ((it % L::kT) == 0) flush_tile(it - L::kT, it); });
+        if ((it % L::kT) != 0) flush_tile(it - (it % L::kT), it);
     }
 #undef LP_X
 #undef LP_Y

@@ -32,8 +32,9 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device);
 void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
 
 /* Options: "mode" (see above); "sort" (1: pack wavefronts by utterance length, default 1);
- * "layout" (-1: chosen per batch, default; 1: stage-parallel workgroups, four wavefronts per 64
- * utterances; 0: one wavefront per 64 utterances).  No option changes the PCM. */
+ * "layout" (-1: chosen per batch, default; 2: lane-pipelined workgroups for the quiet, nasal-free utterances
+ * whatever the batch size; 1: stage-parallel workgroups, four wavefronts per 64 utterances; 0: one wavefront
+ * per 64 utterances).  No option changes the PCM. */
 int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value);
 
 /*

@@ -25,7 +25,7 @@ typedef void* speechPlayer_batch_t;
 
 /* Arithmetic modes (speechPlayer_batch_setOption(b, "mode", ...)). */
 #define SPEECHPLAYER_MODE_EXACT 0 /* f64, separate rounding of every operation, libm-grade coefficients */
-#define SPEECHPLAYER_MODE_FAST 1  /* f64 state, fused multiply-add, coefficient recurrences inside fades */
+#define SPEECHPLAYER_MODE_FAST 1  /* f64 state, the resonators' multiply-adds fused (within the tolerance, not bit-exact by construction) */
 
 /* Bind a batch engine to HIP device `device` (-1: the current device). NULL on failure. */
 speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device);

@@ -124,7 +124,7 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
                         for (int i = 0; i < CH; ++i) body(c, i, true, PRE ? pre[i] : 0.0);
                     }
                     f.cnt += CH;
-                    steadyDone();
+                    steadyDone(CH);
                 }
             } else if (kind == 1) {
                 if (!f.done) {
@@ -136,11 +136,57 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
                             body(c, i, false, 0.0);
                         }
                     }
-                    fadeDone();
+                    fadeDone(CH);
                 }
             } else {
+                // A chunk with an event in it: [uniform run][event steps][uniform run].  Only the event steps need
+                // the state machine sample by sample; whenever every live lane is inside a steady stretch (or every one
+                // inside a fade, past its first sample) the next n = min over the lanes of samples left in the stretch
+                // run as a rolled loop of the steady / fading body.  n comes from a bisection with ballots.
+                int i = 0;
 #pragma nounroll
-                for (int i = 0; i < CH; ++i) {
+                while (i < CH) {
+                    int n = 0, kr = 0;
+                    if (!forceGeneral()) {
+                        const bool fad = f.hasNew;
+                        const uint32_t rem = f.done ? 0xFFFFFFFFu : (fad ? f.newFade - f.cnt : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
+                        const bool anyFad = __any(!f.done && fad), anySteady = __any(!f.done && !fad);
+                        if (!(anyFad && anySteady) && !__any(!f.done && fad && f.cnt == 0u)) {
+                            const int cap = CH - i;
+#pragma unroll
+                            for (int st = CH; st >= 1; st >>= 1)
+                                if (n + st <= cap && __all(rem >= (uint32_t)(n + st))) n += st;
+                            kr = anyFad ? 1 : 0;
+                        }
+                    }
+                    if (n >= 2) {
+                        bool lerpR = false, gainOnlyR = false;
+                        uint32_t wResR = 0;
+                        if (kr == 1) {
+                            lerpR = __any(!f.done && f.parMask != 0u);
+                            gainOnlyR = D::GAIN >= 0 && !__any(!f.done && (f.parMask & ~(1u << (D::GAIN >= 0 ? D::GAIN : 0))) != 0u);
+                            wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(f.done ? 0u : f.resMask);
+                            if (!D::PITCH && !lerpR && wResR == 0u) kr = 0;
+                        }
+                        if (!f.done) {
+                            if (kr == 0) {
+#pragma nounroll
+                                for (int j = i; j < i + n; ++j) body(c, j, true, 0.0);
+                                f.cnt += (uint32_t)n;
+                                steadyDone(n);
+                            } else {
+#pragma nounroll
+                                for (int j = i; j < i + n; ++j) {
+                                    f.cnt++;
+                                    stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerpR, wResR, gainOnlyR);
+                                    body(c, j, false, 0.0);
+                                }
+                                fadeDone(n);
+                            }
+                        }
+                        i += n;
+                        continue;
+                    }
                     // a lane that has not started yet (pipeline skew) sits this step out
                     const bool hold = delay > 0u;
                     const bool wasDone = f.done;
@@ -148,6 +194,7 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
                     const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
                     if (hold) f.done = wasDone;
                     gen(c, i, emit);
+                    ++i;
                 }
             }
             perChunk();
@@ -305,8 +352,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
                 const bool waveVib = __any(emit && vib_live_now());
                 if (emit) { LP_X(c, i) = source(waveVib); f.produced++; }
             },
-            [&]() { ps.old0 = ps.cur0; f.produced += CH; },
-            [&]() { f.produced += CH; },
+            [&](int n) { ps.old0 = ps.cur0; f.produced += n; },
+            [&](int n) { f.produced += n; },
             [&]() {});
         if (live) {
             UttResult res;
@@ -352,7 +399,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
                     if (last) LP_Y(c * CH + i) = out;
                 }
             },
-            [&]() {}, [&]() {}, [&]() {});
+            [&](int) {}, [&](int) {}, [&]() {});
     } else {
         // ================= FIN: outputGain, x 4000, clip, int16, PCM tile (reference :207-208) =================
         using D = StageDesc<1, 0, -1, false, false>;
@@ -409,8 +456,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
             [&](int c, int i, bool emit) {
                 if (emit) { myRow[(it % L::kT) + i] = (int16_t)finish(LP_Y(c * CH + i + kLpSkew)); f.produced++; }
             },
-            [&]() { f.produced += CH; },
-            [&]() { f.produced += CH; },
+            [&](int n) { f.produced += n; },
+            [&](int n) { f.produced += n; },
             [&]() { it += CH; if ((it % L::kT) == 0) flush_tile(it - L::kT, it); });
         if ((it % L::kT) != 0) flush_tile(it - (it % L::kT), it);
     }

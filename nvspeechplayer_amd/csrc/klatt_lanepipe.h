@@ -91,6 +91,7 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
             if (steadyLeft > 0u) steadyLeft--;
             else {
                 kind = forceGeneral() ? -1 : chunk_kind<CH>(f);
+                if (kind == 1 && nan_target_live(f)) kind = -1;   // "hold" targets: sample by sample, with the NaN test
                 if (kind == 0) steadyLeft = steady_run<CH>(f) - 1u;
             }
             bool lerp = false, gainOnly = false;
@@ -151,7 +152,7 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
                         const bool fad = f.hasNew;
                         const uint32_t rem = f.done ? 0xFFFFFFFFu : (fad ? f.newFade - f.cnt : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
                         const bool anyFad = __any(!f.done && fad), anySteady = __any(!f.done && !fad);
-                        if (!(anyFad && anySteady) && !__any(!f.done && fad && f.cnt == 0u)) {
+                        if (!(anyFad && anySteady) && !__any(!f.done && fad && f.cnt == 0u) && !(anyFad && nan_target_live(f))) {
                             const int cap = CH - i;
 #pragma unroll
                             for (int st = CH; st >= 1; st >>= 1)
@@ -178,7 +179,7 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
 #pragma nounroll
                                 for (int j = i; j < i + n; ++j) {
                                     f.cnt++;
-                                    stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerpR, wResR, gainOnlyR);
+                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR, gainOnlyR);
                                     body(c, j, false, 0.0);
                                 }
                                 fadeDone(n);

@@ -131,6 +131,14 @@ __device__ __forceinline__ uint32_t wave_or_bits(uint32_t m)
     return w;
 }
 
+// parMask bit 31: some target of the running fade is NaN ("hold", reference src/utils.h:21).  When no live lane of
+// the wave has the bit, the whole-chunk fade paths interpolate without the NaN test (three instructions per parameter and sample);
+// with it the chunk goes sample by sample.
+constexpr uint32_t kNanTarget = 0x80000000u;
+// wave-uniform: some live lane fades toward a NaN target
+template <class SF>
+__device__ __forceinline__ bool nan_target_live(const SF& f) { return __any(!f.done && (f.parMask & kNanTarget) != 0u); }
+
 // one event sample (fade end / dequeue / end of queue) for a stage; mirrors event_step() of klatt_device.h
 template <class D, class SF>
 __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* lastIndex, const int* P, const int* RF, const int* RB,
@@ -161,7 +169,7 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
         uint32_t pm = 0, mk = 0;
         if (f.oldNull) {   // coming out of silence: start from the new shape, gain 0 (:64-67)
 #pragma unroll
-            for (int k = 0; k < D::NPARAM; ++k) { const double v = g[P[k]]; f.setNew(k, v); f.oldL[k * kLanes] = v; }
+            for (int k = 0; k < D::NPARAM; ++k) { const double v = g[P[k]]; f.setNew(k, v); f.oldL[k * kLanes] = v; pm |= (v != v) ? kNanTarget : 0u; }
             if (D::GAIN >= 0) { pm = (f.getNew(GI) != 0.0) ? (1u << GI) : 0u; f.oldL[GI * kLanes] = 0.0; }
         } else {
             bool moved[D::NPARAM > 0 ? D::NPARAM : 1];
@@ -171,6 +179,7 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
                 moved[k] = !(v == f.oldL[k * kLanes]);      // NaN ("hold") counts as moving: harmless
                 f.setNew(k, v);
                 pm |= moved[k] ? (1u << k) : 0u;
+                pm |= (v != v) ? kNanTarget : 0u;
             }
 #pragma unroll
             for (int r = 0; r < D::NRES; ++r) mk |= (moved[RF[r]] || moved[RB[r]]) ? (1u << r) : 0u;
@@ -185,7 +194,10 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
     }
     if (lastIndex && m.userIndex != -1) *lastIndex = m.userIndex;   // (:69)
     f.cnt = 0;                                                       // (:70)
-    if (D::PITCH) ps->new0 += ps->newInc * (double)f.newFade;        // (:71)
+    if (D::PITCH) {
+        ps->new0 += ps->newInc * (double)f.newFade;                  // (:71)
+        f.parMask |= (ps->new0 != ps->new0) ? kNanTarget : 0u;
+    }
     f.invFade = 1.0 / (double)f.newFade;
     f.hasNew = true;
     return true;
@@ -199,7 +211,7 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
 // For a lane whose own old == new the update recomputes the value it already holds (old + 0*ratio;
 // coefficients are a pure function of (f, bw), reference :112-127), so wave-level decisions give
 // every lane exactly what the reference computes.
-template <class D, int MODE, class SF>
+template <class D, int MODE, bool PLAIN = false, class SF>
 __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelArgs& A, const int* RF, const int* RB,
                                            bool lerp, uint32_t wRes, bool gainOnly = false)
 {
@@ -215,7 +227,7 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) { o[k] = f.oldL[k * kLanes]; n[k] = f.getNew(k); }
 #pragma unroll
-        for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = fade_value(o[k], n[k], ratio);
+        for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = PLAIN ? o[k] + ((n[k] - o[k]) * ratio) : fade_value(o[k], n[k], ratio);   // PLAIN: no NaN target in any live lane
     }
 #pragma unroll
     for (int r = 0; r < D::NRES; ++r) {
@@ -396,6 +408,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             if (!NOISE && steadyLeft > 0u) steadyLeft--;   /* noisy kernels: no register to spare for the run length */           \
             else {                                                                                                                 \
                 kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                                 \
+                if (kind == 1 && nan_target_live(FRAMEVAR)) kind = -1;   /* "hold" targets: sample by sample, with the NaN test */ \
                 if (!NOISE && kind == 0) steadyLeft = steady_run<CH>(FRAMEVAR) - 1u;                                               \
             }                                                                                                                      \
             bool lerp = false, gainOnly = false;                                                                                   \
@@ -429,7 +442,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     } else {                                                                                                       \
                         _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                     \
                             FRAMEVAR.cnt++;                                                                                        \
-                            stage_fade<DESC, MODE>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                              \
+                            stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                        \
                             BODY(c, i, false);                                                                                     \
                         }                                                                                                          \
                     }                                                                                                              \

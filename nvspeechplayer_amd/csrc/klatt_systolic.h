@@ -449,9 +449,55 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     ON_FADE_DONE;                                                                                                  \
                 }                                                                                                                  \
             } else {                                                                                                               \
-                _Pragma("nounroll") for (int i = 0; i < kChunk; ++i) {                                                             \
+                /* Quiet launches: a chunk with an event in it runs [uniform run][event steps][uniform run]; only the   */         \
+                /* event steps need the state machine sample by sample.  Whenever every live lane is inside a steady    */         \
+                /* stretch (or every one inside a fade, past its first sample, no NaN target) the next n = min over the */         \
+                /* lanes of samples left in the stretch run as a rolled loop of the steady / fading body; n by ballot   */         \
+                /* bisection.  The noisy kernels have no registers to spare for it (measured: cfg2 19.9 -> 30.8 ms).    */         \
+                int i = 0;                                                                                                         \
+                _Pragma("nounroll") while (i < kChunk) {                                                                           \
+                    if (!NOISE && !(VIBCHECK)) {                                                                                   \
+                        const bool fad = FRAMEVAR.hasNew;                                                                          \
+                        const uint32_t rem = FRAMEVAR.done ? 0xFFFFFFFFu : (fad ? FRAMEVAR.newFade - FRAMEVAR.cnt : (FRAMEVAR.oldMin > FRAMEVAR.cnt ? FRAMEVAR.oldMin - FRAMEVAR.cnt : 0u)); \
+                        const bool anyFad = __any(!FRAMEVAR.done && fad), anySteady = __any(!FRAMEVAR.done && !fad);              \
+                        int runLen = 0;                                                                                            \
+                        if (!(anyFad && anySteady) && !__any(!FRAMEVAR.done && fad && FRAMEVAR.cnt == 0u) && !(anyFad && nan_target_live(FRAMEVAR))) { \
+                            const int cap = kChunk - i;                                                                            \
+                            _Pragma("unroll") for (int st = kChunk; st >= 1; st >>= 1)                                             \
+                                if (runLen + st <= cap && __all(rem >= (uint32_t)(runLen + st))) runLen += st;                     \
+                        }                                                                                                          \
+                        if (runLen >= 2) {                                                                                         \
+                            int kr = anyFad ? 1 : 0;                                                                               \
+                            bool lerpR = false, gainOnlyR = false;                                                                 \
+                            uint32_t wResR = 0;                                                                                    \
+                            if (kr == 1) {                                                                                         \
+                                lerpR = __any(!FRAMEVAR.done && FRAMEVAR.parMask != 0u);                                           \
+                                gainOnlyR = DESC::GAIN >= 0 && !__any(!FRAMEVAR.done && (FRAMEVAR.parMask & ~(1u << (DESC::GAIN >= 0 ? DESC::GAIN : 0))) != 0u); \
+                                wResR = wave_or_bits<DESC::NRES>(FRAMEVAR.done ? 0u : FRAMEVAR.resMask);                           \
+                                if (!DESC::PITCH && !lerpR && wResR == 0u) kr = 0;                                                 \
+                            }                                                                                                      \
+                            if (!FRAMEVAR.done) {                                                                                  \
+                                constexpr bool usePre = false;                                                                     \
+                                if (kr == 0) {                                                                                     \
+                                    _Pragma("nounroll") for (int j = i; j < i + runLen; ++j) { BODY(c, j, true); }                 \
+                                    FRAMEVAR.cnt += (uint32_t)runLen;                                                              \
+                                    ON_STEADY_DONE;                                                                                \
+                                } else {                                                                                           \
+                                    _Pragma("nounroll") for (int j = i; j < i + runLen; ++j) {                                     \
+                                        FRAMEVAR.cnt++;                                                                            \
+                                        stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerpR, wResR, gainOnlyR);         \
+                                        BODY(c, j, false);                                                                         \
+                                    }                                                                                              \
+                                    ON_FADE_DONE;                                                                                  \
+                                }                                                                                                  \
+                            }                                                                                                      \
+                            i += runLen;                                                                                           \
+                            continue;                                                                                              \
+                        }                                                                                                          \
+                    }                                                                                                              \
                     const bool emit = stage_advance<DESC, MODE>(FRAMEVAR, PSPTR, IDXPTR, P, RF, RB, X);                            \
                     ON_EMIT;                                                                                                       \
+                    ++i;                                                                                                           \
                 }                                                                                                                  \
             }                                                                                                                      \
             PER_CHUNK;                                                                                                             \

@@ -345,7 +345,7 @@ int batch_launch(Batch* b)
         hipStream_t st = next_stream();
         a.order = b->dOrder.ptr + nLp; a.nSlots = nNn;
         const long long g = (nNn + kLanes - 1) / kLanes;
-        if (plq.chunk == 32 ? launch_systolic<false, 32, 1, false>(a, b->mode, g, st) : launch_systolic<false, 16, 1, false>(a, b->mode, g, st)) return -1;
+        if (plq.chunk == 32 ? launch_systolic<false, 32, 1, false>(a, b->mode, g, st) : launch_systolic<false, 16, 2, false>(a, b->mode, g, st)) return -1;
     }
     if (nQ > 0) {
         hipStream_t st = next_stream();
@@ -1038,7 +1038,7 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     long long groups = (nNn + kLanes - 1) / kLanes + (nQ + kLanes - 1) / kLanes + (nNoisy + kLanes - 1) / kLanes;
     if (nasalFree) {
         if (pl.chunk == 32) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 32, 1, false> : (const void*)klatt_systolic<MODE_EXACT, false, 32, 1, false>; ldsBytes = SysLds<false, 32>::kBytes; }
-        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 16, 1, false> : (const void*)klatt_systolic<MODE_EXACT, false, 16, 1, false>; ldsBytes = SysLds<false, 16>::kBytes; }
+        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, false, 16, 2, false> : (const void*)klatt_systolic<MODE_EXACT, false, 16, 2, false>; ldsBytes = SysLds<false, 16>::kBytes; }
         chunk = pl.chunk;
         wavesPerGroup = kStages;
     } else if (lanepipe) {

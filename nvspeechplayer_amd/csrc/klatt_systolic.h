@@ -366,14 +366,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // Which wave runs which stage.  With two workgroups per CU every SIMD hosts one wave of each, and the
     // hardware places wave w of the newer workgroup beside wave w + 1 of the older one (tools/hwid2.hip), which
     // puts the two heaviest noisy stages on one SIMD.  Choosing the stage from the SIMD the wave sits on and the
-    // parity of its wave slot pairs S0 with S2 and S1 with S3 instead.  The choice is only taken when it gives the
+    // parity of its wave slot pairs S0 with S2 and S1 with S3 instead (noisy: 34 + 16 work units per SIMD pair become
+    // 25 + 25; quiet nasal-free, in f64 operations per sample: 27 + 30 + 24 + 21 become 27 + 24).  The choice is only taken when it gives the
     // four waves four different stages (checked through LDS); otherwise stage = wave index.  Any bijection is
     // correct -- the waves are interchangeable until they pick a stage.
     uint32_t* const stageMaskP = maxLenP + 1;
     if (threadIdx.x == 0) { *maxLenP = 0; *stageMaskP = 0; }
     __syncthreads();
     int cand = wave;
-    if (KLATT_PAIR && NOISE && WPS == 2) {
+    if (KLATT_PAIR && WPS == 2 && (NOISE || !NASAL)) {
         const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
         cand = (int)((((hw >> 4) & 3u) + ((hw & 1u) ? 2u : 0u)) & 3u);
     }

@@ -358,6 +358,44 @@ def test_lane_pipelined_kernel():
     bp.close(); bp1.close()
 
 
+def test_nasal_free_classification_boundaries():
+    """Which utterances may skip the nasal pair (UTT_NO_NASAL, klatt_engine.hip): a slice of BASELINE configs[1] with,
+    per utterance, one property pushed over a boundary of the classification -- caNP != 0 in one frame, a degenerate
+    N0 bandwidth, a negative NP bandwidth, an enormous gain, a noise gain.  The engine must count exactly the untouched
+    utterances as nasal-free, and every utterance (skipped pair or not) must equal the oracle."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    batch = workloads.make("cfg1", 60)
+    fr = batch["frames"].copy()
+    real = np.arange(0, 120, 2)                       # frame 0 of each utterance (frame 1 is the NULL frame)
+    def touch(u, idx, value):
+        fr[real[u], idx] = value
+    touched = set()
+    for u, (idx, value) in enumerate([(23, 0.25), (23, -0.0), (21, 0.5), (21, 0.0), (22, -1.0), (22, 0.0), (44, 1e31),
+                                      (5, -3.0), (24, 0.1), (6, 0.05), (3, 0.2), (13, 2.0e6), (14, 300.0), (13, 0.0)]):
+        touch(u, idx, value)
+        if not ((idx == 23 and value == 0.0) or (idx == 22 and value == 0.0) or (idx == 5) or (idx == 14) or (idx == 13 and value == 0.0)):
+            touched.add(u)                            # -0.0 caNP, NP bandwidth 0, a negative amplitude, another NP/N0 frequency stay eligible
+    batch["frames"] = fr
+    exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=4)
+    for layout in (-1, 2, 1):
+        bp = eng.BatchPlayer(22050, layout=layout)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                         batch["isnull"], batch["seeds"])
+        info = bp.kernelInfo()
+        assert info["lane_pipelined_utterances"] + info["nasal_free_utterances"] == 60 - len(touched), (layout, info, sorted(touched))
+        bp.synthesize()
+        got, got_start = bp.readAll()
+        assert np.array_equal(got_start, exp_start)
+        for u in range(60):
+            a, b = got[got_start[u]:got_start[u + 1]], exp[exp_start[u]:exp_start[u + 1]]
+            if u == 6:
+                compare(a, b, "utterance 6 (gain 1e31: every sample clips)")
+            else:
+                assert np.array_equal(a, b), (layout, u, int(np.count_nonzero(a != b)))
+        bp.close()
+
+
 def test_zero_length_real_frame_division_by_zero(ref):
     """minFrameDuration = 0 on a real frame makes voicePitchInc = (end - start) / 0 (reference src/frame.cpp:98):
     +-inf or NaN pitch, NaN phase, and the reference's min/max macros turn the NaN sample into 32000.

@@ -82,18 +82,31 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
 #ifdef KLATT_STAMPS
     Stamps st;
 #endif
-    uint32_t steadyLeft = 0;   // further chunks already known to be steady for every live lane (steady_run)
+    // one whole steady chunk (the live lanes): inputs preloaded, CH samples straight-line
+    auto steadyChunk = [&](int c, bool useAlt) __attribute__((always_inline)) {
+        if (!f.done) {
+            double pre[PRE ? CH : 1];
+            if (PRE) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) pre[i] = preIn(c, i);
+            }
+            if (useAlt) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) alt(c, i, PRE ? pre[i] : 0.0);
+            } else {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) body(c, i, true, PRE ? pre[i] : 0.0);
+            }
+            f.cnt += CH;
+            steadyDone(CH);
+        }
+    };
     for (int iter = 0; iter < nIter; ++iter) {
         STAMP_BEGIN();
-        const int c = iter - depth;
+        int c = iter - depth;
         if (c >= 0 && c < nChunks) {
-            int kind = 0;
-            if (steadyLeft > 0u) steadyLeft--;
-            else {
-                kind = forceGeneral() ? -1 : chunk_kind<CH>(f);
-                if (kind == 1 && nan_target_live(f)) kind = -1;   // "hold" targets: sample by sample, with the NaN test
-                if (kind == 0) steadyLeft = steady_run<CH>(f) - 1u;
-            }
+            int kind = forceGeneral() ? -1 : chunk_kind<CH>(f);
+            if (kind == 1 && nan_target_live(f)) kind = -1;   // "hold" targets: sample by sample, with the NaN test
             bool lerp = false, gainOnly = false;
             uint32_t wRes = 0;
             if (kind == 1) {
@@ -105,28 +118,23 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
             STAMP_KIND(kind);
             const bool useAlt = begin(kind);
             if (kind == 0) {
-                if (!f.done) {
-                    double pre[PRE ? CH : 1];
-                    if (PRE) {
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) pre[i] = preIn(c, i);
-                    }
-#ifdef KLATT_STAMPS
-                    const unsigned long long tb0 = __builtin_amdgcn_s_memtime();
-#endif
-                    if (useAlt) {
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) alt(c, i, PRE ? pre[i] : 0.0);
-#ifdef KLATT_STAMPS
-                        st.c[1] += __builtin_amdgcn_s_memtime() - tb0;   // diagnostic: the straight-line block alone (reported in the fade column)
-#endif
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) body(c, i, true, PRE ? pre[i] : 0.0);
-                    }
-                    f.cnt += CH;
-                    steadyDone(CH);
+                // A steady stretch is decided once (steady_run: the minimum over the live lanes of chunks left in it):
+                // its chunks run in a tight loop of their own -- preload, straight-line block, barrier -- with the
+                // same count of barriers as the outer loop would execute.  (Nothing but the sample counter changes in
+                // a steady chunk, and begin()'s verdict holds for the stretch: a lane's glide increment is constant.)
+                uint32_t run = __any(!f.done && f.hasNew) ? 1u : steady_run<CH>(f);     // a fade that moves nothing here: chunk by chunk
+                const uint32_t room = (uint32_t)(nChunks - c);
+                run = run < room ? run : room;
+                for (uint32_t q = 1; q < run; ++q) {
+                    steadyChunk(c, useAlt);
+                    perChunk();
+                    STAMP_WORKED();
+                    __syncthreads();
+                    STAMP_SYNCED();
+                    STAMP_BEGIN();
+                    ++iter; ++c;
                 }
+                steadyChunk(c, useAlt);
             } else if (kind == 1) {
                 if (!f.done) {
                     if (!fadeAlt(c, lerp, gainOnly)) {

@@ -401,17 +401,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // inputs and writes its outputs; ON_EMIT is the general-step tail (uses `emit`).  One barrier per
     // iteration, the same number of iterations in every wave.
 #define RUN_STAGE(DEPTH, FRAMEVAR, PSPTR, IDXPTR, DESC, VIBCHECK, BODY, ON_STEADY_DONE, ON_FADE_DONE, ON_EMIT, PER_CHUNK, PRELOAD, PRE_IN)     \
-    for (uint32_t steadyLeft = 0, iter = 0; (int)iter < nIter; ++iter) {                                                           \
+    for (int iter = 0; iter < nIter; ++iter) {                                                                                     \
         STAMP_BEGIN();                                                                                                             \
-        const int c = (int)iter - (DEPTH);                                                                                         \
+        int c = iter - (DEPTH);                                                                                                    \
         if (c >= 0 && c < nChunks) {                                                                                               \
-            int kind = 0;                                                                                                          \
-            if (!NOISE && steadyLeft > 0u) steadyLeft--;   /* noisy kernels: no register to spare for the run length */           \
-            else {                                                                                                                 \
-                kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                                 \
-                if (kind == 1 && nan_target_live(FRAMEVAR)) kind = -1;   /* "hold" targets: sample by sample, with the NaN test */ \
-                if (!NOISE && kind == 0) steadyLeft = steady_run<CH>(FRAMEVAR) - 1u;                                               \
-            }                                                                                                                      \
+            int kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                                 \
+            if (kind == 1 && nan_target_live(FRAMEVAR)) kind = -1;   /* "hold" targets: sample by sample, with the NaN test */     \
             bool lerp = false, gainOnly = false;                                                                                   \
             uint32_t wRes = 0;                                                                                                     \
             if (kind == 1) {                                                                                                       \
@@ -424,18 +419,39 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             STAMP_KIND(kind);                                                                                                      \
             double pre[PRELOAD ? kChunk : 1];                                                                                      \
             if (kind == 0) {                                                                                                       \
-                if (!FRAMEVAR.done) {                                                                                              \
-                    constexpr bool usePre = true; constexpr int runLen = kChunk;                                                   \
-                    if (KL_STEADY_ALT(c)) {                                                                                        \
-                    } else if (PRELOAD) {                                                                                          \
-                        _Pragma("unroll") for (int i = 0; i < kChunk; ++i) pre[i] = (PRE_IN);                                      \
-                        _Pragma("unroll") for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }                                   \
-                    } else {                                                                                                       \
-                        _Pragma(KLATT_STR(unroll KLATT_UNROLL)) for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }             \
+                /* one whole steady chunk for the live lanes */                                                                    \
+                auto steadyChunk = [&](int c) __attribute__((always_inline)) {                                                     \
+                    if (!FRAMEVAR.done) {                                                                                          \
+                        constexpr bool usePre = true; constexpr int runLen = kChunk;                                               \
+                        if (KL_STEADY_ALT(c)) {                                                                                    \
+                        } else if (PRELOAD) {                                                                                      \
+                            _Pragma("unroll") for (int i = 0; i < kChunk; ++i) pre[i] = (PRE_IN);                                  \
+                            _Pragma("unroll") for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }                               \
+                        } else {                                                                                                   \
+                            _Pragma(KLATT_STR(unroll KLATT_UNROLL)) for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }         \
+                        }                                                                                                          \
+                        FRAMEVAR.cnt += runLen;                                                                                    \
+                        ON_STEADY_DONE;                                                                                            \
                     }                                                                                                              \
-                    FRAMEVAR.cnt += runLen;                                                                                        \
-                    ON_STEADY_DONE;                                                                                                \
+                };                                                                                                                 \
+                if (!NOISE) {                                                                                                      \
+                    /* Quiet launches decide a steady stretch once (steady_run) and run its chunks in a tight loop of their */     \
+                    /* own -- preload, straight-line block, barrier -- with the barrier count of the outer loop; the noisy  */     \
+                    /* kernels have no register to spare for the run length.                                                */     \
+                    uint32_t run = __any(!FRAMEVAR.done && FRAMEVAR.hasNew) ? 1u : steady_run<CH>(FRAMEVAR);                       \
+                    const uint32_t room = (uint32_t)(nChunks - c);                                                                 \
+                    run = run < room ? run : room;                                                                                 \
+                    for (uint32_t q = 1; q < run; ++q) {                                                                           \
+                        steadyChunk(c);                                                                                            \
+                        PER_CHUNK;                                                                                                 \
+                        STAMP_WORKED();                                                                                            \
+                        __syncthreads();                                                                                           \
+                        STAMP_SYNCED();                                                                                            \
+                        STAMP_BEGIN();                                                                                             \
+                        ++iter; ++c;                                                                                               \
+                    }                                                                                                              \
                 }                                                                                                                  \
+                steadyChunk(c);                                                                                                    \
             } else if (kind == 1) {                                                                                                \
                 if (!FRAMEVAR.done) {                                                                                              \
                     constexpr bool usePre = false; constexpr int runLen = kChunk;                                                  \

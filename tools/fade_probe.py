@@ -19,8 +19,8 @@ for fade_ms in (50, 200, 400, 800):
     bp.synthesize(); bp.wait()
     ms = float(np.mean(bp.time(8)))
     samples = bp.totalSamples // n
-    xs.append(2 * F); ys.append(ms - 36.4e-6 * (samples - 2 * F))
+    xs.append(2 * F); ys.append(ms - 31.3e-6 * (samples - 2 * F))
     print("layout %d, fades of %d ms (%d fade samples of %d): %.4f ms" % (layout, fade_ms, 2 * F, samples, ms))
     bp.close()
 b, a = np.polyfit(xs, ys, 1)
-print("fit (steady samples charged at 36.4 ns): %.1f us fixed + %.2f ns per fade sample" % (a * 1e3, b * 1e6))
+print("fit (steady samples charged at 31.3 ns): %.1f us fixed + %.2f ns per fade sample" % (a * 1e3, b * 1e6))

@@ -422,7 +422,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 /* one whole steady chunk for the live lanes */                                                                    \
                 auto steadyChunk = [&](int c) __attribute__((always_inline)) {                                                     \
                     if (!FRAMEVAR.done) {                                                                                          \
-                        constexpr bool usePre = true; constexpr int runLen = kChunk;                                               \
+                        [[maybe_unused]] constexpr bool usePre = true; [[maybe_unused]] constexpr int runLen = kChunk;             \
                         if (KL_STEADY_ALT(c)) {                                                                                    \
                         } else if (PRELOAD) {                                                                                      \
                             _Pragma("unroll") for (int i = 0; i < kChunk; ++i) pre[i] = (PRE_IN);                                  \
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 steadyChunk(c);                                                                                                    \
             } else if (kind == 1) {                                                                                                \
                 if (!FRAMEVAR.done) {                                                                                              \
-                    constexpr bool usePre = false; constexpr int runLen = kChunk;                                                  \
+                    [[maybe_unused]] constexpr bool usePre = false; [[maybe_unused]] constexpr int runLen = kChunk;                \
                     if (KL_FADE_ALT(c, lerp, gainOnly)) {                                                                          \
                     } else {                                                                                                       \
                         _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                     \
@@ -494,7 +494,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                                 if (!DESC::PITCH && !lerpR && wResR == 0u) kr = 0;                                                 \
                             }                                                                                                      \
                             if (!FRAMEVAR.done) {                                                                                  \
-                                constexpr bool usePre = false;                                                                     \
+                                [[maybe_unused]] constexpr bool usePre = false;                                                    \
                                 if (kr == 0) {                                                                                     \
                                     _Pragma("nounroll") for (int j = i; j < i + runLen; ++j) { BODY(c, j, true); }                 \
                                     FRAMEVAR.cnt += (uint32_t)runLen;                                                              \

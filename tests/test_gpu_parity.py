@@ -598,16 +598,20 @@ def test_random_ragged_batch_large():
     rng = np.random.default_rng(11)
     batch = random_batch(rng, 20000, wild=True)
     exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=16)
-    bp = eng.BatchPlayer(22050)
-    bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
-                     batch["isnull"], batch["seeds"])
-    bp.synthesize()
-    got, got_start = bp.readAll()
-    assert np.array_equal(got_start, exp_start)
-    nbad = int(np.count_nonzero(got != exp))
-    print("large random batch: %d samples, %d differ" % (total, nbad))
-    assert nbad == 0
-    bp.close()
+    for layout in (-1, 2):     # 2: the quiet, nasal-free utterances (about 1000 of them, ragged) through the lane-pipelined kernel
+        bp = eng.BatchPlayer(22050, layout=layout)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                         batch["isnull"], batch["seeds"])
+        info = bp.kernelInfo()
+        bp.synthesize()
+        got, got_start = bp.readAll()
+        assert np.array_equal(got_start, exp_start)
+        nbad = int(np.count_nonzero(got != exp))
+        print("large random batch, layout %d: %d samples, %d differ (lane-pipelined %d, nasal-free stage-parallel %d utterances)" % (
+            layout, total, nbad, info["lane_pipelined_utterances"], info["nasal_free_utterances"]))
+        assert nbad == 0
+        assert info["lane_pipelined_utterances"] + info["nasal_free_utterances"] > 300
+        bp.close()
 
 
 def test_threads_and_lifetime(ref):

@@ -130,10 +130,14 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 // the engine's noise definition (restated by oracle/klatt_oracle.c klatt_noise31)
 __device__ __forceinline__ uint32_t noise_key(uint32_t seed) { return mix32(seed ^ 0x9E3779B9u); }
 __device__ __forceinline__ uint32_t noise31(uint32_t key, uint32_t k) { return mix32((k * 0x9E3779B1u) ^ key) >> 1; }
-// (double)rand()/RAND_MAX with RAND_MAX = 2^31-1 (reference src/speechWaveGenerator.cpp:40)
+// (double)rand()/RAND_MAX with RAND_MAX = 2^31-1 (reference src/speechWaveGenerator.cpp:40).  For the integers
+// r < 2^31 the correctly rounded quotient is fma(r, yh, r * yl) with 1/(2^31-1) = yh + yl to double-double
+// (yh = 0x1.00000002p-31, yl = 2^-93; r * yl is exact): two operations instead of div_by's three.
+// tests/native/check_math.cpp compares it with '/' for ALL 2^31 values.
 __device__ __forceinline__ double noise_uniform(uint32_t key, uint32_t k)
 {
-    return div_by((double)noise31(key, k), 2147483647.0, 0x1.00000002p-31);
+    const double r = (double)noise31(key, k);
+    return __builtin_fma(r, 0x1.00000002p-31, r * 0x1p-93);
 }
 
 // a*x + b*y + c*z in the reference's order: ((a*x) + (b*y)) + (c*z)

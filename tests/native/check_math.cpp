@@ -1,5 +1,6 @@
 // Host check of the kernel's arithmetic helpers (compiled and run by tests/test_host_logic.py):
 //  * div_by(): correctly rounded division from a rounded reciprocal, against the '/' operator;
+//  * noise_uniform()'s two-operation division by 2^31-1, against '/' for every 31-bit integer;
 //  * fast_exp()/fast_cos(): ulp error against libm over the ranges a frame can produce.
 #include <cmath>
 #include <cstdint>
@@ -60,6 +61,15 @@ int main()
         divN++;
         if (div_by((double)c, (double)F, 1.0 / (double)F) != (double)c / (double)F) divBad++;
     }
+
+    // noise_uniform(): r / (2^31 - 1) as fma(r, yh, r * yl), exhaustively over every value noise31() can return
+    long long noiseBad = 0;
+    for (uint64_t r = 0; r < 2147483648ull; ++r) {
+        const double x = (double)r;
+        if (std::fma(x, 0x1.00000002p-31, x * 0x1p-93) != x / 2147483647.0) noiseBad++;
+    }
+    divN += 2147483648ll;
+    divBad += noiseBad;
 
     double expMax = 0, cosMax = 0, expSum = 0, cosSum = 0;
     long long n = 0;

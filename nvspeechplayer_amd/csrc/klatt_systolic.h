@@ -45,6 +45,9 @@ namespace klatt {
 #ifndef KLATT_PAIR
 #define KLATT_PAIR 1
 #endif
+#ifndef KLATT_NOISY_TIGHT
+#define KLATT_NOISY_TIGHT 1     // the noisy kernels run steady stretches in a tight loop too (cfg2 20.4 -> 16.2 ms); 0 decides chunk by chunk
+#endif
 #define KLATT_STR2(x) #x
 #define KLATT_STR(x) KLATT_STR2(x)
 
@@ -434,7 +437,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                         ON_STEADY_DONE;                                                                                            \
                     }                                                                                                              \
                 };                                                                                                                 \
-                if (!NOISE) {                                                                                                      \
+                if (!NOISE || KLATT_NOISY_TIGHT) {                                                                                 \
                     /* Quiet launches decide a steady stretch once (steady_run) and run its chunks in a tight loop of their */     \
                     /* own -- preload, straight-line block, barrier -- with the barrier count of the outer loop; the noisy  */     \
                     /* kernels have no register to spare for the run length.                                                */     \

@@ -45,6 +45,9 @@ namespace klatt {
 #ifndef KLATT_PAIR
 #define KLATT_PAIR 1
 #endif
+#ifndef KLATT_FADE_TIGHT
+#define KLATT_FADE_TIGHT 1      // a fade's chunks run in a tight loop (what moves is fixed for the fade): cfg2 16.4 -> 15.7 ms; 0 decides chunk by chunk
+#endif
 #ifndef KLATT_NOISY_TIGHT
 #define KLATT_NOISY_TIGHT 1     // the noisy kernels run steady stretches in a tight loop too (cfg2 20.4 -> 16.2 ms); 0 decides chunk by chunk
 #endif
@@ -309,6 +312,19 @@ __device__ __forceinline__ uint32_t steady_run(const SF& f)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
 }
 
+// After chunk_kind() == 1: how many chunks (this one included) every live lane keeps fading for.
+template <int CH, class SF>
+__device__ __forceinline__ uint32_t fade_run(const SF& f)
+{
+    uint32_t n = f.done ? 0xFFFFFFFFu : (f.newFade - f.cnt) / (uint32_t)CH;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = (uint32_t)__shfl_xor((int)n, m, kLanes);
+        n = o < n ? o : n;
+    }
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+}
+
 #ifdef KLATT_STAMPS
 struct Stamps {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0, n[3] = {0, 0, 0}, c[3] = {0, 0, 0};
@@ -456,18 +472,37 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 }                                                                                                                  \
                 steadyChunk(c);                                                                                                    \
             } else if (kind == 1) {                                                                                                \
-                if (!FRAMEVAR.done) {                                                                                              \
-                    [[maybe_unused]] constexpr bool usePre = false; [[maybe_unused]] constexpr int runLen = kChunk;                \
-                    if (KL_FADE_ALT(c, lerp, gainOnly)) {                                                                          \
-                    } else {                                                                                                       \
-                        _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                     \
-                            FRAMEVAR.cnt++;                                                                                        \
-                            stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                        \
-                            BODY(c, i, false);                                                                                     \
+                /* one whole fading chunk for the live lanes */                                                                    \
+                auto fadeChunk = [&](int c) __attribute__((always_inline)) {                                                       \
+                    if (!FRAMEVAR.done) {                                                                                          \
+                        [[maybe_unused]] constexpr bool usePre = false; [[maybe_unused]] constexpr int runLen = kChunk;            \
+                        if (KL_FADE_ALT(c, lerp, gainOnly)) {                                                                      \
+                        } else {                                                                                                   \
+                            _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                 \
+                                FRAMEVAR.cnt++;                                                                                    \
+                                stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                    \
+                                BODY(c, i, false);                                                                                 \
+                            }                                                                                                      \
                         }                                                                                                          \
+                        ON_FADE_DONE;                                                                                              \
                     }                                                                                                              \
-                    ON_FADE_DONE;                                                                                                  \
+                };                                                                                                                 \
+                if (KLATT_FADE_TIGHT) {                                                                                            \
+                    /* what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too */    \
+                    uint32_t run = fade_run<CH>(FRAMEVAR);                                                                         \
+                    const uint32_t room = (uint32_t)(nChunks - c);                                                                 \
+                    run = run < room ? run : room;                                                                                 \
+                    for (uint32_t q = 1; q < run; ++q) {                                                                           \
+                        fadeChunk(c);                                                                                              \
+                        PER_CHUNK;                                                                                                 \
+                        STAMP_WORKED();                                                                                            \
+                        __syncthreads();                                                                                           \
+                        STAMP_SYNCED();                                                                                            \
+                        STAMP_BEGIN();                                                                                             \
+                        ++iter; ++c;                                                                                               \
+                    }                                                                                                              \
                 }                                                                                                                  \
+                fadeChunk(c);                                                                                                      \
             } else {                                                                                                               \
                 /* Quiet launches: a chunk with an event in it runs [uniform run][event steps][uniform run]; only the   */         \
                 /* event steps need the state machine sample by sample.  Whenever every live lane is inside a steady    */         \

@@ -136,17 +136,33 @@ __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f,
                 }
                 steadyChunk(c, useAlt);
             } else if (kind == 1) {
-                if (!f.done) {
-                    if (!fadeAlt(c, lerp, gainOnly)) {
+                // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
+                auto fadeChunk = [&](int c) __attribute__((always_inline)) {
+                    if (!f.done) {
+                        if (!fadeAlt(c, lerp, gainOnly)) {
 #pragma unroll 2
-                        for (int i = 0; i < CH; ++i) {
-                            f.cnt++;
-                            stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly);
-                            body(c, i, false, 0.0);
+                            for (int i = 0; i < CH; ++i) {
+                                f.cnt++;
+                                stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly);
+                                body(c, i, false, 0.0);
+                            }
                         }
+                        fadeDone(CH);
                     }
-                    fadeDone(CH);
+                };
+                uint32_t run = fade_run<CH>(f);
+                const uint32_t room = (uint32_t)(nChunks - c);
+                run = run < room ? run : room;
+                for (uint32_t q = 1; q < run; ++q) {
+                    fadeChunk(c);
+                    perChunk();
+                    STAMP_WORKED();
+                    __syncthreads();
+                    STAMP_SYNCED();
+                    STAMP_BEGIN();
+                    ++iter; ++c;
                 }
+                fadeChunk(c);
             } else {
                 // A chunk with an event in it: [uniform run][event steps][uniform run].  Only the event steps need
                 // the state machine sample by sample; whenever every live lane is inside a steady stretch (or every one

@@ -45,6 +45,9 @@ namespace klatt {
 #ifndef KLATT_PAIR
 #define KLATT_PAIR 1
 #endif
+#ifndef KLATT_NOISY_RUNS
+#define KLATT_NOISY_RUNS 0      // 1: uniform runs inside event chunks for the noisy kernels too (measured slower: cfg2 15.8 -> 16.8 ms)
+#endif
 #ifndef KLATT_FADE_TIGHT
 #define KLATT_FADE_TIGHT 1      // a fade's chunks run in a tight loop (what moves is fixed for the fade): cfg2 16.4 -> 15.7 ms; 0 decides chunk by chunk
 #endif
@@ -508,10 +511,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 /* event steps need the state machine sample by sample.  Whenever every live lane is inside a steady    */         \
                 /* stretch (or every one inside a fade, past its first sample, no NaN target) the next n = min over the */         \
                 /* lanes of samples left in the stretch run as a rolled loop of the steady / fading body; n by ballot   */         \
-                /* bisection.  The noisy kernels have no registers to spare for it (measured: cfg2 19.9 -> 30.8 ms).    */         \
+                /* bisection.  Not for the noisy kernels (KLATT_NOISY_RUNS): the extra code costs them more than it saves */         \
                 int i = 0;                                                                                                         \
                 _Pragma("nounroll") while (i < kChunk) {                                                                           \
-                    if (!NOISE && !(VIBCHECK)) {                                                                                   \
+                    if ((!NOISE || KLATT_NOISY_RUNS) && !(VIBCHECK)) {                                                             \
                         const bool fad = FRAMEVAR.hasNew;                                                                          \
                         const uint32_t rem = FRAMEVAR.done ? 0xFFFFFFFFu : (fad ? FRAMEVAR.newFade - FRAMEVAR.cnt : (FRAMEVAR.oldMin > FRAMEVAR.cnt ? FRAMEVAR.oldMin - FRAMEVAR.cnt : 0u)); \
                         const bool anyFad = __any(!FRAMEVAR.done && fad), anySteady = __any(!FRAMEVAR.done && !fad);              \

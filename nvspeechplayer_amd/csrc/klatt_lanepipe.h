@@ -70,8 +70,10 @@ __device__ __forceinline__ double wave_ror1(double v)
 //   alt(c, i, pre)           one sample of a steady chunk, alternative straight-line version
 //   fadeAlt(c, lerp, gainOnly)  a whole fading chunk, straight-line; returns false to decline
 //   gen(c, i, emit)          one sample on the general path
-// The steady paths are branch-free so that a whole chunk is one basic block: a lone wave pays ~8 cycles per
-// DEPENDENT instruction against 4 per independent one, and only the scheduler can interleave the samples' chains.
+// The steady paths are branch-free so that a whole chunk is one basic block (no EXEC changes: a masked store costs a
+// lone wave ~11 ns), and steady and fading stretches are decided once and then run in tight loops of their own (chunk,
+// barrier, chunk, ...): the structurised three-way chunk loop costs ~6 ns per sample in register shuffles and
+// VALU -> SALU -> branch round trips (tools/ubench_lanepipe.hip, tools/len_probe.py).
 template <class D, int MODE, int CH, bool PRE, class SF, class FForce, class FBegin, class FPre, class FBody, class FAlt, class FFadeAlt, class FGen,
           class FSteadyDone, class FFadeDone, class FChunk>
 __device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f, PitchState* ps, int32_t* lastIndex, uint32_t& delay,

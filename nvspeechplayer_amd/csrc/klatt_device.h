@@ -150,8 +150,15 @@ __device__ __forceinline__ double dot3(double a, double x, double b, double y, d
 
 // reference src/speechWaveGenerator.cpp:112-127
 struct Coef { double a, b, c; };
+// `cls` (wave-uniform): what the caller already knows about the arguments of every active lane -- COEF_UNREDUCED: no
+// range reduction needed (exp k = 0, cos n = 0); COEF_QUADRANT_M1: exp k = 0, cos n = -1 (F3 and up);
+// COEF_UNKNOWN: decide here, per evaluation, with ballots.  A whole-fade caller classifies once from the fade's end
+// points (fade_classes in klatt_systolic.h): the ballots and the VALU -> SALU -> branch round trips per evaluation are
+// what the short paths cost most.
+enum { COEF_UNREDUCED = 0, COEF_QUADRANT_M1 = 1, COEF_UNKNOWN = 2 };
 template <int MODE>
-__device__ __forceinline__ Coef resonator_coefficients_inline(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr)
+__device__ __forceinline__ Coef resonator_coefficients_inline(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr,
+                                                              int cls = COEF_UNKNOWN)
 {
     const double ex = negPiOverSr * bw;
     const double th = twoPiOverSr * -f;
@@ -161,7 +168,11 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
     // Wave-uniform short cut (klatt_math.h): when no active lane's argument needs a range reduction the kernels
     // alone return the same bits as fast_exp / fast_cos.  (Separate decisions for exp and cos, and a third
     // variant for the quadrant of f > 2756 Hz, were measured slower: more branches and spills than they save.)
-    if (__all(exp_is_unreduced(ex) && cos_is_unreduced(th))) { rad = exp_unreduced(ex); cs = cos_unreduced(th); }
+    const bool eu = exp_is_unreduced(ex);
+    if (cls == COEF_UNREDUCED) { rad = exp_unreduced(ex); cs = cos_unreduced(th); }
+    else if (cls == COEF_QUADRANT_M1) { rad = exp_unreduced(ex); cs = cos_quadrant_m1(th); }
+    else if (__all(eu && cos_is_unreduced(th))) { rad = exp_unreduced(ex); cs = cos_unreduced(th); }
+    else if (__all(eu && cos_is_quadrant_m1(th))) { rad = exp_unreduced(ex); cs = cos_quadrant_m1(th); }   // F3 and up
     else if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
     else { rad = exp(ex); cs = cos(th); }
     double cc = -(rad * rad);

@@ -93,6 +93,17 @@ KLATT_HD double fast_cos(double t)
 // (r = x - 0, ldexp(e, 0) = e, quadrant 0 = the cosine kernel), so these two return bit for bit what fast_exp
 // and fast_cos return; a caller that knows k = n = 0 for all its lanes skips the reductions, the sine kernel
 // and the quadrant selects (about 35 of 60 instructions).
+// Third formant and up: cos(2 pi (-f) / sr) has n = -1 for f between 2756 and 8268 Hz at 22.05 kHz.  With n = -1 the
+// reduction is r = (t + pi/2_hi) + pi/2_lo (fma(-n, c, t) with -n = 1 is one rounded addition), the quadrant is 3 and
+// the result is +sin_kernel(r): cos_quadrant_m1 returns bit for bit what fast_cos returns there, without the cosine
+// kernel and the selects.
+KLATT_HD bool cos_is_quadrant_m1(double t) { return __builtin_rint(t * kTwoOverPi) == -1.0; }
+KLATT_HD double cos_quadrant_m1(double t)
+{
+    double r = __builtin_fma(1.0, 1.5707963267948965580e+00, t);
+    r = __builtin_fma(1.0, 6.1232339957367660359e-17, r);
+    return sin_kernel(r, r * r);
+}
 KLATT_HD bool exp_is_unreduced(double x) { return __builtin_rint(x * kLog2e) == 0.0; }
 KLATT_HD bool cos_is_unreduced(double t) { return __builtin_rint(t * kTwoOverPi) == 0.0; }
 KLATT_HD double exp_unreduced(double x) { return exp_kernel(x); }

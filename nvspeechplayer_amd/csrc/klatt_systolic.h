@@ -220,9 +220,32 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
 // For a lane whose own old == new the update recomputes the value it already holds (old + 0*ratio;
 // coefficients are a pure function of (f, bw), reference :112-127), so wave-level decisions give
 // every lane exactly what the reference computes.
+// Classes of the stage's resonators for one whole fade, two bits each (COEF_*), from the fade's end points: the
+// interpolated (f, bw) stay between them, so if both ends of every live lane need no reduction (or sit in quadrant -1),
+// with a margin against the one-ulp overshoot of `from + (to - from) * ratio`, every sample of the fade does.  Wave-uniform.
+constexpr uint32_t kCoefAllUnknown = 0xAAAAAAAAu;
+template <class D, class SF>
+__device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& A, const int* RF, const int* RB, uint32_t wRes)
+{
+    uint32_t bits = kCoefAllUnknown;
+    if (!D::INLINE_COEF) return bits;
+#pragma unroll
+    for (int r = 0; r < D::NRES; ++r) {
+        if (!(wRes & (1u << r))) continue;
+        const double xo = A.negPiOverSr * f.oldL[RB[r] * kLanes] * kLog2e, xn = A.negPiOverSr * f.getNew(RB[r]) * kLog2e;
+        const double to = A.twoPiOverSr * -f.oldL[RF[r] * kLanes] * kTwoOverPi, tn = A.twoPiOverSr * -f.getNew(RF[r]) * kTwoOverPi;
+        const bool eu = __builtin_fabs(xo) <= 0.499 && __builtin_fabs(xn) <= 0.499;
+        const bool c0 = __builtin_fabs(to) <= 0.499 && __builtin_fabs(tn) <= 0.499;
+        const bool c1 = to <= -0.501 && to >= -1.499 && tn <= -0.501 && tn >= -1.499;
+        const uint32_t cls = __all(f.done || (eu && c0)) ? COEF_UNREDUCED : (__all(f.done || (eu && c1)) ? COEF_QUADRANT_M1 : COEF_UNKNOWN);
+        bits = (bits & ~(3u << (2 * r))) | (cls << (2 * r));
+    }
+    return bits;
+}
+
 template <class D, int MODE, bool PLAIN = false, class SF>
 __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelArgs& A, const int* RF, const int* RB,
-                                           bool lerp, uint32_t wRes, bool gainOnly = false)
+                                           bool lerp, uint32_t wRes, bool gainOnly = false, uint32_t coefCls = kCoefAllUnknown)
 {
     if (!D::PITCH && !lerp) return;
     const double ratio = div_by((double)f.cnt, (double)f.newFade, f.invFade);
@@ -244,7 +267,8 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
             // inlined where fades dominate (speech); the quiet kernels keep one out-of-line copy, which keeps
             // their loops small (measured: cfg1 1.72 ms vs 1.86 ms inlined; cfg2 29.2 ms inlined vs 36.6 ms called)
             const Coef k = D::INLINE_COEF
-                ? resonator_coefficients_inline<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr)
+                ? resonator_coefficients_inline<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr,
+                                                      (int)((coefCls >> (2 * r)) & 3u))
                 : resonator_coefficients<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr);
             f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
         }
@@ -475,6 +499,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 }                                                                                                                  \
                 steadyChunk(c);                                                                                                    \
             } else if (kind == 1) {                                                                                                \
+                const uint32_t coefCls = fade_classes<DESC>(FRAMEVAR, A, RF, RB, wRes);   /* once per fade stretch */              \
                 /* one whole fading chunk for the live lanes */                                                                    \
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {                                                       \
                     if (!FRAMEVAR.done) {                                                                                          \
@@ -483,7 +508,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                         } else {                                                                                                   \
                             _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                 \
                                 FRAMEVAR.cnt++;                                                                                    \
-                                stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly);                    \
+                                stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly, coefCls);           \
                                 BODY(c, i, false);                                                                                 \
                             }                                                                                                      \
                         }                                                                                                          \

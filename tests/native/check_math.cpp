@@ -103,6 +103,13 @@ int main()
         if (klatt::exp_is_unreduced(x)) { unredN++; double a = klatt::exp_unreduced(x), b = klatt::fast_exp(x); if (memcmp(&a, &b, 8)) unredBad++; }
         if (klatt::cos_is_unreduced(t)) { unredN++; double a = klatt::cos_unreduced(t), b = klatt::fast_cos(t); if (memcmp(&a, &b, 8)) unredBad++; }
     }
+    // ... and so must the n = -1 quadrant path of cos (F3 and up)
+    std::uniform_real_distribution<double> qt(-2.40, -0.75);
+    for (int i = 0; i < 4000000; ++i) {
+        double t = qt(rng);
+        if (i < 64) t = -((i & 1) ? 0.78539816339744839 : 2.3561944901923448) * (1.0 + ((i & 2) ? 1 : -1) * (i >> 2) * 1e-16);
+        if (klatt::cos_is_quadrant_m1(t)) { unredN++; double a = klatt::cos_quadrant_m1(t), b = klatt::fast_cos(t); if (memcmp(&a, &b, 8)) unredBad++; }
+    }
     printf("{\"unreduced_checked\": %lld, \"unreduced_bad\": %lld, ", unredN, unredBad);
     printf("\"div_checked\": %lld, \"div_bad\": %lld, \"exp_max_ulp\": %.0f, \"cos_max_ulp\": %.0f, "
            "\"exp_mean_ulp\": %.4f, \"cos_mean_ulp\": %.4f, \"exp_wide_max_ulp\": %.0f, \"cos_wide_max_ulp\": %.0f, "

@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the Klatt hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--workload cfg1|cfg2|cfg3] [--mode 0]
+    python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg1|cfg3|cfg4] [--mode 0]
 
-A step is one pass of the synthesis kernel over one batch of synthetic frame streams
-that is already resident in HBM (frames in, int16 PCM out, both in HBM).  At N = 1 the
-workload is BASELINE.json configs[1] (4096 steady vowels x 1 s); with N > 1 every rank
-(one process per GPU, launched by torch.distributed.run) synthesises its own batch of
-the same shape with different utterance numbers (weak scaling, no collective on the
-data path -- utterances are independent).  Rank 0 prints ONE JSON line.
+A step is one pass of the synthesis kernel over one batch of synthetic frame streams that is already resident in
+HBM (frames in, int16 PCM out, both in HBM).  The headline workload is BASELINE.json configs[2], the largest
+single-GPU configuration: 65 536 IPA utterances from sampleIpa.txt through the frame producer (1.5e9 samples per
+step); the other configurations are selectable and cfg1 (configs[1]) is measured as an extra key.
 
-The K timed launches are individually bracketed by HIP events on the engine's stream
-(speechPlayer_batch_time); their mean is the kernel duration the roofline uses, the
-wall clock around all K (barrier + device synchronize on both sides, max over ranks)
-gives `value`.  The CPU baseline is the oracle (oracle/klatt_oracle.c, "port") timed
-on this box's host cores on the same workload, rank 0 at N = 1 only.
+N > 1: one process per GPU.  Under `torch.distributed.run` the ranks come from the environment; a plain
+`python bench.py --gpus N` starts its own N rank processes (the parent never touches the GPU, relays rank 0's JSON
+line and returns the ranks' worst exit code).  The node's batch is N times the per-GPU configuration (weak scaling);
+its utterance list is cut into N contiguous shards of near-equal total SAMPLE count (closed-form lengths,
+nvspeechplayer_amd.sharding.shard_bounds) and every rank builds and synthesises its own shard.  Utterances are
+independent: there is no collective on the data path; the process group only carries the timing barrier, the max of
+the elapsed times and the sum of the sample counts.
+
+The K timed launches are individually bracketed by HIP events on the engine's stream (speechPlayer_batch_time); their
+mean is the kernel duration the roofline uses, the wall clock around all K (barrier + device synchronize on both
+sides, max over ranks) gives `value`.  The CPU baseline is the oracle (oracle/klatt_oracle.c, "port") timed on this
+box's host cores on a bounded sample of the same workload, rank 0 at N = 1 only.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,21 +35,38 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# f64 VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz; a wave64 f64 instruction occupies a SIMD for 4 cycles by the datasheet
+# (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz) and for 4.8 measured (profiles/r1_ubench_issue_rates.txt)
+SIMDS, CLOCK_HZ, F64_CYCLES_SPEC, F64_CYCLES_MEASURED = 1024, 2.4e9, 4.0, 4.8
+PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
+    ap.add_argument("--steps", type=int, default=100, help="timed launches (cfg2: ~12 ms each, so the default times > 1 s)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"])
     ap.add_argument("--utterances", type=int, default=0, help="override the batch size per GPU")
     ap.add_argument("--mode", type=int, default=0, help="arithmetic mode (include/speechPlayer_batch.h)")
     ap.add_argument("--layout", type=int, default=-1, help="-1: engine's choice, 1: stage-parallel workgroups, 0: one wavefront per 64 utterances")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-large-batch", action="store_true", help="skip the extra measurement of the same recipe at 65536 utterances")
+    ap.add_argument("--no-extras", "--no-large-batch", dest="no_extras", action="store_true",
+                    help="skip the extra measurements (MODE_FAST, cfg1, cfg1 recipe at 65536 utterances)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall time to spend on the CPU baseline")
-    return ap.parse_args()
+    ap.add_argument("--dry-run", action="store_true",
+                    help="everything but the GPU: ranks, rendezvous (gloo), shard dealing, workload build, reductions; value is null")
+    return ap.parse_args(argv)
+
+
+def engine_source_digest():
+    """Identifies the kernels a PMC file was collected from: sha1 over csrc/*.h, *.hip, *.inc, *.cpp."""
+    csrc = os.path.join(ROOT, "nvspeechplayer_amd", "csrc")
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(csrc)):
+        if f.endswith((".h", ".hip", ".cpp", ".inc")):
+            h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def kernel_name(info):
@@ -49,7 +74,8 @@ def kernel_name(info):
     if info.get("lane_pipelined"):
         return "klatt_lanepipe (cascade across lanes, %d-sample hand-overs)" % info["stage_parallel_chunk"]
     if info["stage_parallel_chunk"]:
-        return "klatt_systolic (stage-parallel%s, %d-sample hand-overs)" % (", nasal-free" if info.get("nasal_free") else "", info["stage_parallel_chunk"])
+        return "klatt_systolic (stage-parallel%s%s, %d-sample hand-overs)" % (", noisy" if info.get("noisy_group") else "",
+                                                                             ", nasal-free" if info.get("nasal_free") else "", info["stage_parallel_chunk"])
     return "klatt_synthesize (lane kernel)"
 
 
@@ -67,31 +93,85 @@ def usable_cores():
 
 
 def cpu_baseline(batch, target_seconds):
-    """Oracle on the host cores: one OpenMP thread per core, each synthesising whole utterances of the
-    same workload (no shared state: every utterance has its own player and noise stream).  The
-    workload is repeated until about `target_seconds` of wall time have been spent."""
+    """Oracle on the host cores: one OpenMP thread per core, each synthesising whole utterances of the same workload (no
+    shared state: every utterance has its own player and noise stream).  Bounded sample: a leading slice of the workload
+    sized from a one-thread probe so that one pass takes about `target_seconds` (the headline workload is 1.5e9 samples
+    -- minutes of CPU work -- so the whole of it is not run)."""
     from tests import oracle
     cores = usable_cores()
     probe = batch.slice(0, min(8, batch.n_utt))
     t0 = time.perf_counter()
     _, _, total = oracle.batch_synthesize(batch["sr"], probe, threads=1)
     one_core = total / (time.perf_counter() - t0)
+    budget = one_core * cores * target_seconds * 0.8                 # samples the cores should manage in the time
+    mean = max(1.0, float(batch.sample_counts().mean()))
+    n = int(min(batch.n_utt, max(cores * 8, budget / mean)))
+    n -= n % 8 if n >= 16 else 0                                      # whole periods of the eight sampleIpa lines
+    sample = batch.slice(0, n)
     oracle.batch_synthesize(batch["sr"], batch.slice(0, min(batch.n_utt, cores)), threads=cores)   # start the thread pool
     done, reps, t0 = 0, 0, time.perf_counter()
     while True:
-        _, _, total = oracle.batch_synthesize(batch["sr"], batch, threads=cores)
+        _, _, total = oracle.batch_synthesize(batch["sr"], sample, threads=cores)
         done += total
         reps += 1
         dt = time.perf_counter() - t0
-        if dt >= target_seconds or reps >= 200:
+        if dt >= target_seconds * 0.75 or reps >= 200:
             break
     return {"value": done / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "the whole workload (%d utterances) x %d passes = %d samples on %d OpenMP threads in %.1f s; "
-                      "1 thread: %.3g samples/s" % (batch.n_utt, reps, done, cores, dt, one_core)}
+            "sample": "the first %d of %d utterances x %d pass(es) = %d samples on %d OpenMP threads in %.1f s; "
+                      "1 thread: %.3g samples/s" % (n, batch.n_utt, reps, done, cores, dt, one_core)}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# N > 1 without a launcher: the parent starts the ranks itself
+# ------------------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """Start n rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment), relay rank 0's
+    output, return the worst exit code.  Nothing here touches HIP or torch: the children are fresh interpreters."""
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    sys.stdout.write(out.decode("utf8", "replace"))
+    sys.stdout.flush()
+    rc = 0
+    for p in procs:
+        p.wait()
+        rc = max(rc, abs(p.returncode))
+    return rc
+
+
+def build_shard(args, rank, world):
+    """This rank's piece of the node's batch: contiguous utterances with a near-equal share of the node's samples."""
+    from nvspeechplayer_amd import workloads
+    from nvspeechplayer_amd.sharding import shard_bounds
+    per_gpu = args.utterances or workloads.PER_GPU[args.workload]
+    node_utt = per_gpu * world
+    counts = workloads.sample_counts(args.workload, node_utt)
+    bounds = shard_bounds(counts, world)
+    first, n = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+    batch = workloads.make(args.workload, n, first=first)
+    assert batch.n_utt == n and int(batch.sample_counts().sum()) == int(counts[first:first + n].sum())
+    return batch, {"node_utterances": node_utt, "node_samples": int(counts.sum()), "first_utterance": first, "utterances": n,
+                   "bounds": [int(b) for b in bounds]}
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -100,39 +180,45 @@ def main():
     from nvspeechplayer_amd import BatchPlayer, workloads
     from nvspeechplayer_amd.sharding import reduce_throughput
 
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU (the engine has no CPU path)")
-    ndev = torch.cuda.device_count()
-    device = local_rank % ndev
-    torch.cuda.set_device(device)
+    dry = args.dry_run
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the engine has no CPU path); --dry-run exercises the host side only")
+    ndev = 0 if dry else torch.cuda.device_count()
+    device = 0 if dry else local_rank % ndev
+    if not dry:
+        torch.cuda.set_device(device)
     dist = None
-    shared_device = world > ndev          # only in self-tests on a 1-GPU box: ranks share a device, RCCL cannot
+    shared_device = dry or world > ndev   # self-tests on a 1-GPU box: ranks share a device, RCCL cannot
     if world > 1:
         import torch.distributed as dist
         if shared_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+        assert dist.get_world_size() == world and dist.get_rank() == rank
 
-    n_utt = args.utterances or {"cfg1": 4096, "cfg2": 65536, "cfg3": 131072, "cfg4": 32768}[args.workload]
-    batch = workloads.make(args.workload, n_utt, first=rank * n_utt)
-    bp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
-    bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
-                     batch["isnull"], batch["seeds"])
-    samples = bp.totalSamples
-    assert samples == int(batch.sample_counts().sum())
+    batch, shard = build_shard(args, rank, world)
+    samples = int(batch.sample_counts().sum())
+    bp = None
+    if not dry:
+        bp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
+                         batch["isnull"], batch["seeds"])
+        assert bp.totalSamples == samples
 
     def barrier():
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+        if not dry:
+            torch.cuda.synchronize()
 
-    if args.warmup > 0:
+    if args.warmup > 0 and not dry:
         bp.time(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    kernel_ms = bp.time(args.steps)          # K launches, each between two HIP events on the launch stream
+    kernel_ms = bp.time(args.steps) if not dry else np.zeros(args.steps)      # K launches, each between two HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed, total_samples = reduce_throughput(elapsed, samples, dist, device="cpu" if shared_device else "cuda")   # max / sum over ranks
@@ -140,18 +226,10 @@ def main():
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         alg_bytes = batch.algorithmic_bytes()
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        info = bp.kernelInfo()
-        traffic = None   # HBM bytes per launch from the PMC passes committed under profiles/ (bench.py cannot run rocprofv3 on itself)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))
-            if args.workload in tj and not args.utterances:
-                traffic = tj[args.workload]["hbm_bytes_per_launch"]
-        except Exception:
-            pass
+        info = bp.kernelInfo() if not dry else {}
         out = {
             "metric": "audio samples/sec (whole node) at 22.05 kHz Klatt synth, batch-N utterances",
-            "value": total_samples * args.steps / elapsed,
+            "value": None if dry else total_samples * args.steps / elapsed,
             "unit": "samples/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -162,43 +240,75 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": batch["name"], "utterances_per_gpu": n_utt, "samples_per_gpu": int(samples),
-                       "frames_per_gpu": int(bp.totalFrames), "sample_rate": batch["sr"], "mode": args.mode, "layout": args.layout,
-                       "parallelism": "utterances sharded over %d GPU(s), no collective" % world},
-            "realtime_factor": total_samples * args.steps / elapsed / batch["sr"],
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "traffic_source": "profiles/r1_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
-                         "kernel": kernel_name(info), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
-                         "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"],
-                         "note": "f64 VALU issue binds before HBM (a sample is a strict recurrence: its time per sample, not its bytes, "
-                                 "bounds a launch); see DESIGN.md section 4"},
+            "config": {"workload": batch["name"], "utterances_per_gpu": shard["utterances"], "samples_per_gpu": samples,
+                       "frames_per_gpu": int(len(batch["min"])), "sample_rate": batch["sr"], "mode": args.mode, "layout": args.layout,
+                       "node_utterances": shard["node_utterances"], "node_samples": shard["node_samples"],
+                       "shard_bounds": shard["bounds"], "process_group": None if dist is None else dist.get_backend(),
+                       "world_size": 1 if dist is None else dist.get_world_size(),
+                       "parallelism": "node batch cut into %d contiguous shards of near-equal sample count, one process per GPU, no collective on the data path" % world},
         }
-        if world == 1 and args.mode == 0 and not args.no_large_batch:
-            # same batch in MODE_FAST (fused multiply-adds; identical PCM on every test so far, not guaranteed bit-exact)
-            bp.setOption("mode", 1)
-            bp.time(1)
-            fast_ms = float(np.mean(bp.time(max(3, args.steps // 2))))
-            bp.setOption("mode", 0)
-            out["mode_fast"] = {"value": samples / (fast_ms * 1e-3), "unit": "samples/s", "kernel_ms": fast_ms,
-                                "roofline_frac": alg_bytes / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
-        if world == 1 and args.workload == "cfg1" and not args.utterances and not args.no_large_batch:
-            # The metric is "batch-N utterances": the same recipe at N = 65 536 fills the chip (2 workgroups per CU).
-            bp.close()
-            big = workloads.make("cfg1", 65536)
-            bp = BatchPlayer(big["sr"], device=device, mode=args.mode, layout=args.layout)
-            bp.setUtterances(big["frame_start"], big["frames"], big["min"], big["fade"], big["index"], big["isnull"], big["seeds"])
-            bp.time(1)
-            big_ms = float(np.mean(bp.time(3)))
-            big_bytes = big.algorithmic_bytes()
-            out["same_recipe_at_batch_65536"] = {
-                "value": bp.totalSamples / (big_ms * 1e-3), "unit": "samples/s", "kernel_ms": big_ms,
-                "roofline_frac": big_bytes / (big_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "note": "not the headline config; shows the occupancy limit of a 4096-utterance batch"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)
+        if dry:
+            out["dry_run"] = True
+            out["total_samples_all_ranks"] = total_samples
+        else:
+            out["realtime_factor"] = total_samples * args.steps / elapsed / batch["sr"]
+            achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "kernel": kernel_name(info), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
+                    "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "scratch_bytes": info["scratch_bytes"],
+                    "note": "declared bound: HBM (2 B per sample + 388 B per frame). What binds is f64 VALU issue -- a sample is a strict "
+                            "recurrence of ~190 dependent-ish f64 operations -- see `valu` and DESIGN.md section 4"}
+            # HBM bytes and VALU instructions per launch come from the PMC passes of tools/profile.sh (bench.py cannot run rocprofv3 on
+            # itself); the file names the engine sources it was collected from, and is ignored when they have changed since
+            try:
+                pj = json.load(open(PMC_FILE))
+                ent = pj.get(args.workload)
+                if ent and not args.utterances and world == 1 and args.mode == 0 and args.layout == -1:
+                    if pj.get("engine_sources_sha") == engine_source_digest():
+                        roof["traffic"] = ent["hbm_bytes_per_launch"]
+                        roof["traffic_source"] = "profiles/r2_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
+                        insts = ent["valu_insts_per_launch"]
+                        peak = SIMDS * CLOCK_HZ / F64_CYCLES_MEASURED
+                        roof["valu"] = {"insts_per_launch": insts, "achieved": insts / (k_ms * 1e-3), "peak": peak,
+                                        "unit": "wave64 VALU instructions/s", "frac": insts / (k_ms * 1e-3) / peak,
+                                        "peak_spec": SIMDS * CLOCK_HZ / F64_CYCLES_SPEC,
+                                        "insts_per_64_samples": insts * 64.0 / samples,
+                                        "source": "profiles/r2_pmc.json SQ_INSTS_VALU; peak = 1024 SIMDs x 2.4 GHz / 4.8 cycles per f64 wave instruction "
+                                                  "(measured; 4 by the datasheet = peak_spec); instructions that are not f64 issue faster, so frac is a lower bound on issue-slot use"}
+                    else:
+                        roof["traffic_source"] = "profiles/r2_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
+            except Exception:
+                pass
+            out["roofline"] = roof
+            if world == 1 and args.mode == 0 and not args.no_extras:
+                # same batch in MODE_FAST (fused multiply-adds; identical PCM on every test so far, not guaranteed bit-exact)
+                bp.setOption("mode", 1)
+                bp.time(1)
+                fast_ms = float(np.mean(bp.time(max(3, args.steps // 4))))
+                bp.setOption("mode", 0)
+                out["mode_fast"] = {"value": samples / (fast_ms * 1e-3), "unit": "samples/s", "kernel_ms": fast_ms,
+                                    "roofline_frac": alg_bytes / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if world == 1 and not args.utterances and not args.no_extras:
+                # the other single-GPU configuration (BASELINE configs[1], 4096 steady vowels) and its recipe at 65 536 utterances
+                bp.close()
+                for key, wl, n, reps in (("cfg1", "cfg1", 4096, 50), ("cfg1_recipe_at_batch_65536", "cfg1", 65536, 10)):
+                    if key == "cfg1" and args.workload == "cfg1":
+                        continue
+                    xb = workloads.make(wl, n)
+                    bp = BatchPlayer(xb["sr"], device=device, mode=args.mode, layout=args.layout)
+                    bp.setUtterances(xb["frame_start"], xb["frames"], xb["min"], xb["fade"], xb["index"], xb["isnull"], xb["seeds"])
+                    bp.time(2)
+                    x_ms = float(np.mean(bp.time(reps)))
+                    xi = bp.kernelInfo()
+                    out[key] = {"workload": xb["name"], "value": bp.totalSamples / (x_ms * 1e-3), "unit": "samples/s", "kernel_ms": x_ms,
+                                "roofline_frac": xb.algorithmic_bytes() / (x_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "kernel": kernel_name(xi)}
+                    bp.close()
+                bp = None
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)
         print(json.dumps(out), flush=True)
-    bp.close()
+    if bp is not None:
+        bp.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

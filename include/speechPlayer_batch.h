@@ -57,6 +57,7 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
 long long speechPlayer_batch_utteranceSamples(speechPlayer_batch_t batch, long long utterance);
 long long speechPlayer_batch_totalSamples(speechPlayer_batch_t batch);
 long long speechPlayer_batch_totalFrames(speechPlayer_batch_t batch);
+int speechPlayer_batch_sampleRate(speechPlayer_batch_t batch);
 
 /* Launch the synthesis kernel on the batch's stream (asynchronous), and wait for it. */
 int speechPlayer_batch_synthesize(speechPlayer_batch_t batch);
@@ -70,6 +71,10 @@ long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long utt
 /* Copy every utterance's PCM, concatenated in utterance order; outStart[nUtterances+1] receives
  * the offsets. Returns total samples. */
 long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart);
+/* Digest of the PCM, computed on the device (for checks of batches whose PCM is too large to copy): perUtterance[u]
+ * (may be NULL) = sum over utterance u's samples of mix64(position, value), *whole (may be NULL) = a digest of those in
+ * utterance order.  Equal PCM <=> equal digests (up to 2^-64); the kernel is an HBM-bound read of the pool. */
+int speechPlayer_batch_digest(speechPlayer_batch_t batch, unsigned long long* perUtterance, unsigned long long* whole);
 /* speechPlayer_getLastIndex for utterance u after the run. */
 int speechPlayer_batch_getLastIndex(speechPlayer_batch_t batch, long long utterance);
 
@@ -98,7 +103,48 @@ int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, un
 /* Choose a handle's noise stream (default 0); see DESIGN.md "Noise". */
 int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int seed);
 
+/*
+ * The frame producer: IPA text -> the frame stream a caller would queue.  Host code, no GPU needed.
+ * Native counterpart of the reference's ipa.generateFramesAndTiming (ipa.py:336-353, with :39-334 behind it) and of the
+ * NVDA driver's voice presets (nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:86-125); same values for the same input.
+ *   clauseType   '.', ',', '?', '!' or 0 (none: the statement contour), as the reference's clauseType argument
+ *   voiceName    NULL / "" for none, else one of speechPlayer_voiceName(0 .. speechPlayer_voiceCount()-1); the preset is
+ *                applied to every non-silence frame: absolute values first, then multipliers (applyVoiceToFrame)
+ */
+/* One utterance.  Returns its number of frames n; fills the arrays (each may be NULL) when n <= capacity.  isNull[k] != 0
+ * marks silence (the reference yields None); durations are in MILLISECONDS as the reference yields them.  -1: unknown voice. */
+long long speechPlayer_ipa_frames(const char* ipaUtf8, double speed, double basePitch, double inflection, int clauseType,
+	const char* voiceName, speechPlayer_frame_t* frames, unsigned char* isNull, double* durationMs, double* fadeMs, long long capacity);
+/* Many utterances, packed as speechPlayer_batch_setUtterances takes them: durations converted to samples the way the
+ * reference wrapper does (speechPlayer.py:53), each utterance followed by silence of trailingSilenceMs (fade 0) as
+ * test_speakIpa.py:27 queues it (negative: none).  basePitch[nTexts] may be NULL (100 Hz), clauseTypes[nTexts] may be NULL
+ * (none).  Returns the total number of frames; writes frameStart[nTexts+1] when given, and the frame arrays when all four
+ * are given and frameCapacity suffices (call once with NULL arrays to size them).  Distinct (text, clause, pitch)
+ * combinations are built once per call and instanced. */
+long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed, const double* basePitch,
+	double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
+	long long* frameStart, speechPlayer_frame_t* frames, unsigned int* minFrameDuration, unsigned int* fadeDuration,
+	unsigned char* isNull, long long frameCapacity);
+/* Text in, batch resident in HBM: speechPlayer_ipa_pack at the batch's sample rate + speechPlayer_batch_setUtterances. */
+int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
+	const double* basePitch, double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
+	const unsigned int* noiseSeed);
+/* The voice presets of the NVDA driver (reference __init__.py:86-116), by index and by name. */
+int speechPlayer_voiceCount(void);
+const char* speechPlayer_voiceName(int index);
+/* reference __init__.py:118-125.  0, or -1 for an unknown voice. */
+int speechPlayer_applyVoiceToFrame(speechPlayer_frame_t* frame, const char* voiceName);
+
 const char* speechPlayer_lastError(void);
+/* The reference has no error convention (src/speechPlayer.cpp:25-53 return nothing but counts): its
+ * speechPlayer_synthesize returns 0 both when the queue has drained and -- here -- when the GPU call failed.
+ * This tells the two apart: 0 after a call that succeeded, one of the codes below after one that failed
+ * (per calling thread, describes the most recent speechPlayer_* call that can fail). */
+#define SPEECHPLAYER_OK 0
+#define SPEECHPLAYER_ERR_ARGUMENT 1   /* invalid handle, NULL pointer, inconsistent arrays, limit exceeded */
+#define SPEECHPLAYER_ERR_NO_DEVICE 2  /* no HIP device: the engine has no CPU path */
+#define SPEECHPLAYER_ERR_HIP 3        /* a HIP runtime call failed (allocation, copy, launch) */
+int speechPlayer_lastErrorCode(void);
 
 #ifdef __cplusplus
 }

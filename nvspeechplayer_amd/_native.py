@@ -13,11 +13,15 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_DIR = os.path.join(PKG_DIR, "lib")
 LIB_PATH = os.path.join(LIB_DIR, "libspeechPlayer.so")
-SOURCES = ["klatt_engine.hip"]
-HEADERS = ["klatt_device.h", "klatt_systolic.h", "klatt_math.h", os.path.join("..", "..", "include", "speechPlayer.h"),
-           os.path.join("..", "..", "include", "speechPlayer_batch.h")]
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17",
-               "-Wall", "-Wno-unused-function", "-Wl,-rpath,/opt/rocm/lib"]
+# translation units: (source, compiler, what it depends on besides itself)
+#   klatt_engine.hip    kernels + the C-ABI's GPU half       hipcc for gfx950
+#   frame_producer.cpp  IPA text -> frame streams (host)     g++
+SOURCES = ["klatt_engine.hip", "frame_producer.cpp"]
+INCLUDE_DIR = os.path.join(os.path.dirname(PKG_DIR), "include")
+OBJ_DIR = os.path.join(PKG_DIR, "build_tmp")
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+CXX_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wextra"]
+LINK_FLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,-rpath,/opt/rocm/lib"]
 
 EXPORTS = [
     # include/speechPlayer.h
@@ -26,38 +30,72 @@ EXPORTS = [
     # include/speechPlayer_batch.h
     "speechPlayer_batch_create", "speechPlayer_batch_destroy", "speechPlayer_batch_setOption",
     "speechPlayer_batch_setUtterances", "speechPlayer_batch_utteranceSamples",
-    "speechPlayer_batch_totalSamples", "speechPlayer_batch_totalFrames",
+    "speechPlayer_batch_totalSamples", "speechPlayer_batch_totalFrames", "speechPlayer_batch_sampleRate",
     "speechPlayer_batch_synthesize", "speechPlayer_batch_wait", "speechPlayer_batch_read",
-    "speechPlayer_batch_readAll", "speechPlayer_batch_readFloat", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
+    "speechPlayer_batch_readAll", "speechPlayer_batch_readFloat", "speechPlayer_batch_digest", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
     "speechPlayer_batch_deviceOffset", "speechPlayer_batch_time", "speechPlayer_batch_kernelInfo",
-    "speechPlayer_lastError", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany",
+    "speechPlayer_lastError", "speechPlayer_lastErrorCode", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany",
+    "speechPlayer_ipa_frames", "speechPlayer_ipa_pack", "speechPlayer_batch_setIpa",
+    "speechPlayer_voiceCount", "speechPlayer_voiceName", "speechPlayer_applyVoiceToFrame",
 ]
+
+
+def _deps(source):
+    """Files a translation unit is built from: itself, every header / generated table beside it, the public headers."""
+    own = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))]
+    pub = [os.path.join(INCLUDE_DIR, f) for f in os.listdir(INCLUDE_DIR) if f.endswith(".h")]
+    return [os.path.join(CSRC, source)] + own + pub
+
+
+def _obj(source):
+    return os.path.join(OBJ_DIR, os.path.splitext(source)[0] + ".o")
+
+
+def _obj_stale(source):
+    o = _obj(source)
+    if not os.path.exists(o):
+        return True
+    t = os.path.getmtime(o)
+    return any(os.path.getmtime(p) > t for p in _deps(source))
 
 
 def _stale():
     if not os.path.exists(LIB_PATH):
         return True
     t = os.path.getmtime(LIB_PATH)
-    for f in SOURCES + HEADERS:
-        p = os.path.join(CSRC, f)
-        if os.path.exists(p) and os.path.getmtime(p) > t:
-            return True
-    return False
+    return any(os.path.getmtime(p) > t for src in SOURCES for p in _deps(src))
 
 
-def build(force=False, verbose=False):
-    """Compile the HIP engine in-tree (cross-compiles without a GPU)."""
-    if not force and not _stale():
-        return LIB_PATH
+def build(force=False, verbose=False, extra_hipcc_flags=(), lib_path=None):
+    """Compile the engine in-tree: hipcc for the HIP translation unit (cross-compiles for gfx950 without a GPU),
+    g++ for the host-only one, objects under build_tmp/ (rebuilt when a source, header or generated table changed),
+    linked into lib/libspeechPlayer.so.  `extra_hipcc_flags` / `lib_path`: A/B builds of the same ABI (tools/)."""
+    out = lib_path or LIB_PATH
+    variant = bool(extra_hipcc_flags) or lib_path is not None
+    if not force and not variant and not _stale():
+        return out
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
     if not os.path.exists(hipcc):
-        raise RuntimeError("hipcc not found; cannot build %s" % LIB_PATH)
-    os.makedirs(LIB_DIR, exist_ok=True)
-    cmd = [hipcc] + HIPCC_FLAGS + ["-o", LIB_PATH] + [os.path.join(CSRC, s) for s in SOURCES]
+        raise RuntimeError("hipcc not found; cannot build %s" % out)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    os.makedirs(OBJ_DIR, exist_ok=True)
+    objs = []
+    for src in SOURCES:
+        is_hip = src.endswith(".hip")
+        # a variant build recompiles the HIP translation unit into an object of its own; host objects are shared
+        own = variant and is_hip
+        o = os.path.join(OBJ_DIR, os.path.basename(out) + "." + os.path.splitext(src)[0] + ".o") if own else _obj(src)
+        if force or own or _obj_stale(src):
+            cmd = ([hipcc] + HIPCC_FLAGS + list(extra_hipcc_flags) if is_hip else ["g++"] + CXX_FLAGS) + ["-c", os.path.join(CSRC, src), "-o", o]
+            if verbose:
+                print(" ".join(cmd))
+            subprocess.check_call(cmd)
+        objs.append(o)
+    cmd = [hipcc] + LINK_FLAGS + ["-o", out] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB_PATH
+    return out
 
 
 _lib = None
@@ -90,6 +128,8 @@ def load():
     L.speechPlayer_synthesizeMany.argtypes = [vp, i32, u32, vp, vp]
     L.speechPlayer_lastError.restype = ctypes.c_char_p
     L.speechPlayer_lastError.argtypes = []
+    L.speechPlayer_lastErrorCode.restype = i32
+    L.speechPlayer_lastErrorCode.argtypes = []
     L.speechPlayer_batch_create.restype = vp
     L.speechPlayer_batch_create.argtypes = [i32, i32]
     L.speechPlayer_batch_destroy.restype = None
@@ -114,6 +154,8 @@ def load():
     L.speechPlayer_batch_readFloat.argtypes = [vp, i64, vp, i64]
     L.speechPlayer_batch_readAll.restype = i64
     L.speechPlayer_batch_readAll.argtypes = [vp, vp, i64, vp]
+    L.speechPlayer_batch_digest.restype = i32
+    L.speechPlayer_batch_digest.argtypes = [vp, vp, vp]
     L.speechPlayer_batch_getLastIndex.restype = i32
     L.speechPlayer_batch_getLastIndex.argtypes = [vp, i64]
     L.speechPlayer_batch_devicePcm.restype = vp
@@ -124,9 +166,29 @@ def load():
     L.speechPlayer_batch_time.argtypes = [vp, i32, vp]
     L.speechPlayer_batch_kernelInfo.restype = i32
     L.speechPlayer_batch_kernelInfo.argtypes = [vp, vp, i32]
+    L.speechPlayer_batch_sampleRate.restype = i32
+    L.speechPlayer_batch_sampleRate.argtypes = [vp]
+    f64 = ctypes.c_double
+    L.speechPlayer_ipa_frames.restype = i64
+    L.speechPlayer_ipa_frames.argtypes = [ctypes.c_char_p, f64, f64, f64, i32, ctypes.c_char_p, vp, vp, vp, vp, i64]
+    L.speechPlayer_ipa_pack.restype = i64
+    L.speechPlayer_ipa_pack.argtypes = [i32, i64, vp, f64, vp, f64, ctypes.c_char_p, ctypes.c_char_p, f64, vp, vp, vp, vp, vp, i64]
+    L.speechPlayer_batch_setIpa.restype = i32
+    L.speechPlayer_batch_setIpa.argtypes = [vp, i64, vp, f64, vp, f64, ctypes.c_char_p, ctypes.c_char_p, f64, vp]
+    L.speechPlayer_voiceCount.restype = i32
+    L.speechPlayer_voiceCount.argtypes = []
+    L.speechPlayer_voiceName.restype = ctypes.c_char_p
+    L.speechPlayer_voiceName.argtypes = [i32]
+    L.speechPlayer_applyVoiceToFrame.restype = i32
+    L.speechPlayer_applyVoiceToFrame.argtypes = [vp, ctypes.c_char_p]
     _lib = L
     return L
 
 
 def last_error():
     return (load().speechPlayer_lastError() or b"").decode("utf8", "replace")
+
+
+def last_error_code():
+    """0 after a call that succeeded, a SPEECHPLAYER_ERR_* code after one that failed (include/speechPlayer_batch.h)."""
+    return int(load().speechPlayer_lastErrorCode())

@@ -47,9 +47,46 @@ __global__ void __launch_bounds__(256) pcm_to_float(const int16_t* __restrict__ 
     }
 }
 
+// 64-bit digest of every utterance's PCM, computed where the PCM lives: sum over the utterance's samples of
+// mix64(position, value).  A sum, so lanes and wavefronts may add their shares in any order; one wavefront per utterance,
+// 16 B (8 samples) per lane and step.  HBM-bound read of the pool.  (Checks of full-size configurations compare digests
+// instead of copying tens of GB of PCM to the host; tests/test_gpu_parity.py restates the formula in numpy.)
+__host__ __device__ inline unsigned long long digest_mix(unsigned long long pos, unsigned int value16)
+{
+    unsigned long long x = (pos + 1ull) * 0x9E3779B97F4A7C15ull ^ ((unsigned long long)value16 + 1ull) * 0xC2B2AE3D27D4EB4Full;
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return x;
+}
+__global__ void __launch_bounds__(256) pcm_digest(const int16_t* __restrict__ pcm, const UttDesc* __restrict__ utt,
+                                                  const UttResult* __restrict__ result, unsigned long long* __restrict__ out, long long nUtt)
+{
+    const int lane = threadIdx.x & 63;
+    const long long wavesPerGrid = (long long)gridDim.x * (blockDim.x >> 6);
+    for (long long u = (long long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6); u < nUtt; u += wavesPerGrid) {
+        const long long base = utt[u].outStart;          // multiple of 32 samples: 16-B aligned
+        const unsigned int n = result[u].produced;
+        unsigned long long acc = 0;
+        for (unsigned int i = (unsigned int)lane * 8u; i < n; i += 64u * 8u) {
+            const uint4 v = *reinterpret_cast<const uint4*>(pcm + base + i);
+            const unsigned int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (i + (unsigned int)k < n) acc += digest_mix(i + (unsigned int)k, (w[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu);
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const unsigned int lo = (unsigned int)__shfl_xor((int)(unsigned int)acc, m, 64);
+            const unsigned int hi = (unsigned int)__shfl_xor((int)(unsigned int)(acc >> 32), m, 64);
+            acc += ((unsigned long long)hi << 32) | lo;
+        }
+        if (lane == 0) out[u] = acc;
+    }
+}
+
 namespace {
 
 thread_local std::string g_lastError;
+thread_local int g_lastErrorCode = 0;      // speechPlayer_lastErrorCode(): 0 after a call that succeeded
 
 void set_error(const char* fmt, ...)
 {
@@ -59,13 +96,18 @@ void set_error(const char* fmt, ...)
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
     g_lastError = buf;
+    if (g_lastErrorCode == 0) g_lastErrorCode = SPEECHPLAYER_ERR_ARGUMENT;
     fprintf(stderr, "[speechPlayer/hip] %s\n", buf);
 }
+void set_error_code(int code) { g_lastErrorCode = code; }
+// every entry point that can fail starts with this: the code then describes THIS call
+void begin_call() { g_lastErrorCode = 0; }
 
 #define HIP_TRY(expr)                                                                       \
     do {                                                                                    \
         hipError_t e_ = (expr);                                                             \
         if (e_ != hipSuccess) {                                                             \
+            set_error_code(SPEECHPLAYER_ERR_HIP);                                           \
             set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
             return -1;                                                                      \
         }                                                                                   \
@@ -243,6 +285,7 @@ int pick_device(int device)
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0) {
+        set_error_code(SPEECHPLAYER_ERR_NO_DEVICE);
         set_error("no HIP device available (%s); this engine has no CPU path", e == hipSuccess ? "count 0" : hipGetErrorString(e));
         return -1;
     }
@@ -284,6 +327,7 @@ struct Batch {
     DeviceBuffer<UttResult> dResult;
     DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
+    DeviceBuffer<unsigned long long> dDigest;  // per-utterance digests (speechPlayer_batch_digest)
     PinnedPair bounce;                         // speechPlayer_batch_readAll
     bool floatFresh = false;
 };
@@ -577,9 +621,11 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
 extern "C" {
 
 const char* speechPlayer_lastError(void) { return g_lastError.c_str(); }
+int speechPlayer_lastErrorCode(void) { return g_lastErrorCode; }
 
 speechPlayer_handle_t speechPlayer_initialize(int sampleRate)
 {
+    begin_call();
     int dev = pick_device(-1);
     if (dev < 0) return nullptr;
     Stream* s = new Stream;
@@ -597,6 +643,7 @@ speechPlayer_handle_t speechPlayer_initialize(int sampleRate)
 void speechPlayer_queueFrame(speechPlayer_handle_t playerHandle, speechPlayer_frame_t* framePtr, unsigned int minFrameDuration,
                              unsigned int fadeDuration, int userIndex, bool purgeQueue)
 {
+    begin_call();
     Stream* s = lookup(playerHandle);
     if (!s) { set_error("speechPlayer_queueFrame: invalid handle"); return; }
     PendingFrame f;
@@ -616,6 +663,7 @@ void speechPlayer_queueFrame(speechPlayer_handle_t playerHandle, speechPlayer_fr
 
 int speechPlayer_synthesize(speechPlayer_handle_t playerHandle, unsigned int sampleCount, sample* sampleBuf)
 {
+    begin_call();
     Stream* s = lookup(playerHandle);
     if (!s) { set_error("speechPlayer_synthesize: invalid handle"); return 0; }
     std::lock_guard<std::mutex> g(s->mu);
@@ -634,6 +682,7 @@ int speechPlayer_getLastIndex(speechPlayer_handle_t playerHandle)
 
 void speechPlayer_terminate(speechPlayer_handle_t playerHandle)
 {
+    begin_call();
     Stream* s = nullptr;
     {
         uintptr_t id = reinterpret_cast<uintptr_t>(playerHandle) & 0xFFFFFFFFu;
@@ -652,6 +701,7 @@ void speechPlayer_terminate(speechPlayer_handle_t playerHandle)
 // Additive: choose the handle's noise stream (default 0) and arithmetic mode.
 int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int seed)
 {
+    begin_call();
     Stream* s = lookup(playerHandle);
     if (!s) return -1;
     std::lock_guard<std::mutex> g(s->mu);
@@ -664,6 +714,7 @@ int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int s
 // produced[i] receives each call's return value.  Handles must be distinct and share a sample rate.
 int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced)
 {
+    begin_call();
     if (nHandles < 0 || (nHandles > 0 && (!handles || !sampleBufs || !produced))) { set_error("speechPlayer_synthesizeMany: bad arguments"); return -1; }
     std::vector<Stream*> ss((size_t)nHandles);
     for (int i = 0; i < nHandles; ++i) {
@@ -686,6 +737,7 @@ int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, un
 // ==========================================================================================
 speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
 {
+    begin_call();
     int dev = pick_device(device);
     if (dev < 0) return nullptr;
     Batch* b = new Batch;
@@ -717,12 +769,13 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     }
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
-    b->dFloat.release(); b->dDebug.release(); b->bounce.release();
+    b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
     delete b;
 }
 
 int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || !name) return -1;
     if (!strcmp(name, "mode")) {
@@ -741,19 +794,24 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
                                      const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
                                      const unsigned int* noiseSeed)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || nUtterances < 0 || !frameStart) { set_error("setUtterances: bad arguments"); return -1; }
     if (nUtterances >= 0xFFFFFFFFll) { set_error("setUtterances: too many utterances"); return -1; }
     HIP_TRY(hipSetDevice(b->device));
+    // validate the index array before anything reads through it
+    if (frameStart[0] != 0) { set_error("setUtterances: frameStart[0] must be 0"); return -1; }
+    for (long long u = 0; u < nUtterances; ++u)
+        if (frameStart[u + 1] < frameStart[u]) { set_error("setUtterances: frameStart not monotone at %lld", u); return -1; }
     const long long nF = frameStart[nUtterances];
-    if (frameStart[0] != 0 || nF < 0 || (nF > 0 && (!frames || !minFrameDuration || !fadeDuration))) {
+    if (nF > 0 && (!frames || !minFrameDuration || !fadeDuration)) {
         set_error("setUtterances: bad frame arrays");
         return -1;
     }
-    b->nUtt = nUtterances;
-    b->nFrames = nF;
-    b->lens.assign((size_t)nUtterances, 0);
-    b->outStart.assign((size_t)nUtterances + 1, 0);
+    // everything below is built in locals and committed to the Batch only after the uploads succeeded: a call that fails
+    // validation leaves the previous batch in place, one that fails while uploading leaves an empty batch
+    std::vector<uint32_t> lens((size_t)nUtterances, 0);
+    std::vector<long long> outStart((size_t)nUtterances + 1, 0);
     std::vector<FrameMeta> meta((size_t)nF);
     for (long long k = 0; k < nF; ++k) {
         meta[k].minSamples = minFrameDuration[k];
@@ -764,15 +822,14 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     std::vector<UttDesc> utt((size_t)nUtterances);
     long long total = 0, pool = 0;
     for (long long u = 0; u < nUtterances; ++u) {
-        if (frameStart[u + 1] < frameStart[u]) { set_error("setUtterances: frameStart not monotone at %lld", u); return -1; }
         unsigned long long len = 0;
         for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
             const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
             len += std::max(m, f + 1) + 1;   // samples one request spans (follows from reference src/frame.cpp:41-80)
         }
         if (len >= 0xFFFFFFFFull) { set_error("utterance %lld too long (%llu samples)", u, len); return -1; }
-        b->lens[u] = (uint32_t)len;
-        b->outStart[u] = pool;
+        lens[u] = (uint32_t)len;
+        outStart[u] = pool;
         memset(&utt[u], 0, sizeof(UttDesc));
         utt[u].frameStart = frameStart[u];
         utt[u].outStart = pool;
@@ -789,6 +846,11 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
             if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) needsNoise = true;
             for (int i = 0; i < kNumParams && !needsNoise; ++i)
                 if (!std::isfinite(p[i])) needsNoise = true;
+            // The skipped parallel bank contributes exactly 0 only while its coefficients are finite (a * 0 with a = inf
+            // is NaN, which the reference clips to 32000): a negative bandwidth makes exp(-pi bw / sr) grow without
+            // bound, so the bandwidths must be in [0, 1e6] and the frequencies bounded (reference :112-127).
+            for (int i = 25; i <= 30 && !needsNoise; ++i)
+                if (!(std::fabs(p[i]) <= 1e6) || !(p[i + 6] >= 0.0) || !(p[i + 6] <= 1e6)) needsNoise = true;
         }
         utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : 0u;
         // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152).
@@ -812,41 +874,52 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         total += (long long)len;
         pool += ((long long)len + kTile - 1) / kTile * kTile;
     }
-    b->outStart[nUtterances] = pool;
-    b->totalSamples = total;
-    b->poolSamples = pool;
+    outStart[nUtterances] = pool;
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
     // (within the quiet group and within the noisy group, which are launched as separate kernels)
     std::vector<uint32_t> order((size_t)nUtterances);
     std::iota(order.begin(), order.end(), 0u);
     auto quietEnd = std::stable_partition(order.begin(), order.end(), [&](uint32_t x) { return !(utt[x].flags & UTT_NEEDS_NOISE); });
-    b->nQuiet = quietEnd - order.begin();
+    const long long nQuiet = quietEnd - order.begin();
     auto noNasalEnd = std::stable_partition(order.begin(), quietEnd, [&](uint32_t x) { return (utt[x].flags & UTT_NO_NASAL) != 0; });
-    b->nNoNasal = noNasalEnd - order.begin();
+    const long long nNoNasal = noNasalEnd - order.begin();
     if (b->sortByLength) {
-        auto longer = [&](uint32_t x, uint32_t y) { return b->lens[x] > b->lens[y]; };
+        auto longer = [&](uint32_t x, uint32_t y) { return lens[x] > lens[y]; };
         std::stable_sort(order.begin(), noNasalEnd, longer);
         std::stable_sort(noNasalEnd, quietEnd, longer);
         std::stable_sort(quietEnd, order.end(), longer);
     }
-    b->nSlots = nUtterances;
 
-    if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>(nF, 1)) ||
-        b->dUtt.reserve(std::max<size_t>(nUtterances, 1)) || b->dOrder.reserve(std::max<size_t>(nUtterances, 1)) ||
-        b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
+    auto upload = [&]() -> int {
+        if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>(nF, 1)) ||
+            b->dUtt.reserve(std::max<size_t>(nUtterances, 1)) || b->dOrder.reserve(std::max<size_t>(nUtterances, 1)) ||
+            b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
+            return -1;
+        if (nF) {
+            HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dMeta.ptr, meta.data(), (size_t)nF * sizeof(FrameMeta), hipMemcpyHostToDevice, b->stream));
+        }
+        if (nUtterances) {
+            HIP_TRY(hipMemcpyAsync(b->dUtt.ptr, utt.data(), (size_t)nUtterances * sizeof(UttDesc), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dOrder.ptr, order.data(), (size_t)nUtterances * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nUtterances * sizeof(UttResult), b->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(b->stream));
+        return 0;
+    };
+    if (upload()) {
+        // the device buffers may hold a mix of the old and the new batch now: the object becomes an empty batch
+        b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
+        b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
         return -1;
-    if (nF) {
-        HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->dMeta.ptr, meta.data(), (size_t)nF * sizeof(FrameMeta), hipMemcpyHostToDevice, b->stream));
     }
-    if (nUtterances) {
-        HIP_TRY(hipMemcpyAsync(b->dUtt.ptr, utt.data(), (size_t)nUtterances * sizeof(UttDesc), hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipMemcpyAsync(b->dOrder.ptr, order.data(), (size_t)nUtterances * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
-        HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nUtterances * sizeof(UttResult), b->stream));
-    }
-    HIP_TRY(hipStreamSynchronize(b->stream));
+    b->nUtt = nUtterances; b->nFrames = nF; b->nSlots = nUtterances;
+    b->nQuiet = nQuiet; b->nNoNasal = nNoNasal;
+    b->totalSamples = total; b->poolSamples = pool;
+    b->lens.swap(lens); b->outStart.swap(outStart);
     b->results.clear();
     b->resultsFresh = false;
+    b->floatFresh = false;
     return 0;
 }
 
@@ -858,9 +931,11 @@ long long speechPlayer_batch_utteranceSamples(speechPlayer_batch_t batch, long l
 }
 long long speechPlayer_batch_totalSamples(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->totalSamples : -1; }
 long long speechPlayer_batch_totalFrames(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->nFrames : -1; }
+int speechPlayer_batch_sampleRate(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->sampleRate : -1; }
 
 int speechPlayer_batch_synthesize(speechPlayer_batch_t batch)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -869,6 +944,7 @@ int speechPlayer_batch_synthesize(speechPlayer_batch_t batch)
 
 int speechPlayer_batch_wait(speechPlayer_batch_t batch)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -887,6 +963,7 @@ static int fetch_results(Batch* b)
 
 long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long u, sample* sampleBuf, long long capacity)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || u < 0 || u >= b->nUtt || !sampleBuf) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -899,6 +976,7 @@ long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long u, sampl
 
 long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || !sampleBuf) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -944,6 +1022,7 @@ long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleB
 
 long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long u, float* sampleBuf, long long capacity)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || u < 0 || u >= b->nUtt || !sampleBuf) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -964,8 +1043,33 @@ long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long u, 
     return n;
 }
 
+int speechPlayer_batch_digest(speechPlayer_batch_t batch, unsigned long long* perUtterance, unsigned long long* whole)
+{
+    begin_call();
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b) { set_error("digest: no batch"); return -1; }
+    HIP_TRY(hipSetDevice(b->device));
+    std::vector<unsigned long long> host((size_t)b->nUtt);
+    if (b->nUtt) {
+        if (b->dDigest.reserve((size_t)b->nUtt)) return -1;
+        const unsigned grid = (unsigned)std::min<long long>((b->nUtt + 3) / 4, 16384);
+        hipLaunchKernelGGL(pcm_digest, dim3(grid), dim3(256), 0, b->stream, b->dPcm.ptr, b->dUtt.ptr, b->dResult.ptr, b->dDigest.ptr, b->nUtt);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host.data(), b->dDigest.ptr, (size_t)b->nUtt * sizeof(unsigned long long), hipMemcpyDeviceToHost, b->stream));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    if (perUtterance && b->nUtt) memcpy(perUtterance, host.data(), (size_t)b->nUtt * sizeof(unsigned long long));
+    if (whole) {
+        unsigned long long acc = 0;
+        for (long long u = 0; u < b->nUtt; ++u) acc += digest_mix((unsigned long long)u, 0u) ^ host[u] * 0x9E3779B97F4A7C15ull;
+        *whole = acc;
+    }
+    return 0;
+}
+
 int speechPlayer_batch_getLastIndex(speechPlayer_batch_t batch, long long u)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || u < 0 || u >= b->nUtt) return -1;
     if (hipSetDevice(b->device) != hipSuccess || hipStreamSynchronize(b->stream) != hipSuccess) return -1;
@@ -988,6 +1092,7 @@ long long speechPlayer_batch_deviceOffset(speechPlayer_batch_t batch, long long 
 
 int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msPerLaunch)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || launches <= 0 || !msPerLaunch) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -1021,6 +1126,7 @@ int speechPlayer_batch_debugStamps(speechPlayer_batch_t batch, unsigned long lon
 
 int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo)
 {
+    begin_call();
     Batch* b = static_cast<Batch*>(batch);
     if (!b || !info || nInfo < 6) return -1;
     HIP_TRY(hipSetDevice(b->device));

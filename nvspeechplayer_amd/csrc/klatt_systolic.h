@@ -179,7 +179,9 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
         if (f.oldNull) {   // coming out of silence: start from the new shape, gain 0 (:64-67)
 #pragma unroll
             for (int k = 0; k < D::NPARAM; ++k) { const double v = g[P[k]]; f.setNew(k, v); f.oldL[k * kLanes] = v; pm |= (v != v) ? kNanTarget : 0u; }
-            if (D::GAIN >= 0) { pm = (f.getNew(GI) != 0.0) ? (1u << GI) : 0u; f.oldL[GI * kLanes] = 0.0; }
+            // nothing but the gain moves (old == new elsewhere); a NaN target ("hold", src/utils.h:21) keeps its flag so that
+            // the whole-chunk fade paths, which interpolate without the NaN test, stay away from this fade
+            if (D::GAIN >= 0) { pm = (pm & kNanTarget) | ((f.getNew(GI) != 0.0) ? (1u << GI) : 0u); f.oldL[GI * kLanes] = 0.0; }
         } else {
             bool moved[D::NPARAM > 0 ? D::NPARAM : 1];
 #pragma unroll

@@ -124,6 +124,16 @@ class SpeechPlayer(object):
             pass
 
 
+def pcm_digest(pcm):
+    """speechPlayer_batch_digest's per-utterance value for a host int16 array (uint64 arithmetic wraps)."""
+    v = np.asarray(pcm, dtype=np.int16).view(np.uint16).astype(np.uint64)
+    pos = np.arange(len(v), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        x = (pos + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15) ^ (v + np.uint64(1)) * np.uint64(0xC2B2AE3D27D4EB4F)
+        x ^= x >> np.uint64(29); x *= np.uint64(0xBF58476D1CE4E5B9); x ^= x >> np.uint64(32)
+        return int(x.sum(dtype=np.uint64))
+
+
 class BatchPlayer(object):
     """N independent utterances per launch (include/speechPlayer_batch.h)."""
 
@@ -162,13 +172,24 @@ class BatchPlayer(object):
         self._check(self._dll.speechPlayer_batch_setUtterances(self._h, n_utt, p(fs), p(fr), p(m), p(f), p(ix), p(nu), p(sd)))
         self.nUtterances = n_utt
 
-    def setIpa(self, texts, speed=1, basePitch=100, inflection=0.5, clauseType=None, noiseSeed=None):
-        """Text in, batch ready: every IPA string becomes one utterance through the frame producer
-        (nvspeechplayer_amd/ipa.py) followed by 150 ms of silence, as reference test_speakIpa.py:24-27 queues them."""
-        from . import ipa
-        pk = ipa.frames_for_batch(texts, sampleRate=self.sampleRate, speed=speed, basePitch=basePitch,
-                                  inflection=inflection, clauseType=clauseType)
-        self.setUtterances(pk["frame_start"], pk["frames"], pk["min"], pk["fade"], None, pk["isnull"], noiseSeed)
+    def setIpa(self, texts, speed=1, basePitch=100, inflection=0.5, clauseType=None, noiseSeed=None, voice=None,
+               trailing_silence_ms=150.0):
+        """Text in, batch ready (speechPlayer_batch_setIpa): every IPA string becomes one utterance through the native
+        frame producer followed by 150 ms of silence, as reference test_speakIpa.py:24-27 queues them.  basePitch and
+        clauseType may be sequences (one per text); voice: one of nvspeechplayer_amd.ipa.voices()."""
+        import ctypes
+        n = len(texts)
+        enc = [t.encode("utf8") for t in texts]
+        ptrs = (ctypes.c_char_p * max(n, 1))(*enc)
+        pitch = np.ascontiguousarray(np.broadcast_to(np.asarray(basePitch, dtype=np.float64), (n,)))
+        code = lambda c: 0 if not c else ord(c[0])
+        clauses = bytes([code(clauseType)]) * n if (clauseType is None or isinstance(clauseType, str)) else bytes(code(c) for c in clauseType)
+        sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
+        self._check(self._dll.speechPlayer_batch_setIpa(self._h, n, ptrs, float(speed), pitch.ctypes.data, float(inflection), clauses + b"\0",
+                                                        None if not voice else voice.encode("utf8"),
+                                                        -1.0 if trailing_silence_ms is None else float(trailing_silence_ms),
+                                                        None if sd is None else sd.ctypes.data))
+        self.nUtterances = n
 
     @property
     def totalSamples(self):
@@ -223,6 +244,15 @@ class BatchPlayer(object):
         starts = np.zeros(self.nUtterances + 1, dtype=np.int64)
         got = self._check(self._dll.speechPlayer_batch_readAll(self._h, buf.ctypes.data, total, starts.ctypes.data))
         return buf[:got], starts
+
+    def digest(self, per_utterance=False):
+        """Digest of the whole PCM pool, computed on the device (speechPlayer_batch_digest); with per_utterance also the
+        array of per-utterance digests.  `pcm_digest` below is the same formula on a host array."""
+        import ctypes
+        whole = ctypes.c_ulonglong(0)
+        per = np.zeros(max(self.nUtterances, 1), dtype=np.uint64) if per_utterance else None
+        self._check(self._dll.speechPlayer_batch_digest(self._h, None if per is None else per.ctypes.data, ctypes.byref(whole)))
+        return (int(whole.value), per[:self.nUtterances]) if per_utterance else int(whole.value)
 
     def getLastIndex(self, u):
         return self._dll.speechPlayer_batch_getLastIndex(self._h, u)

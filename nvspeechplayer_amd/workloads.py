@@ -1,16 +1,15 @@
 """Synthetic frame-stream batches for BASELINE.json's configurations.
 
-The phoneme parameter vectors and the sampleIpa.txt frame streams are the ones the
-reference's own frame producer emits (captured as data in tests/golden/ref_frames.npz
-by tests/golden/make_golden.py); this module only instances them into batches, following
-the recipes of SURVEY.md section 8(d).
+Inputs are data shipped with the package (nvspeechplayer_amd/data/workload_inputs.npz: the sampleIpa.txt lines
+and the phoneme parameter vectors, dumped by tests/golden/make_golden.py); the speech streams come out of the
+native frame producer (csrc/frame_producer.cpp through ipa.frames_for_batch -- one C call per batch, no Python
+loop per utterance).  Recipes: SURVEY.md section 8(d).
 """
 import os
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_FRAMES = os.path.join(ROOT, "tests", "golden", "ref_frames.npz")
+INPUTS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "workload_inputs.npz")
 SR = 22050
 
 VOICEPITCH, VOICEAMP, PREGAIN, OUTGAIN, ENDPITCH = 0, 5, 44, 45, 46
@@ -51,7 +50,7 @@ class Batch(dict):
 
 
 def _load():
-    return np.load(REF_FRAMES)
+    return np.load(INPUTS)
 
 
 def cfg1_steady_vowels(n_utt=4096, seconds=1.0, first=0, sr=SR):
@@ -92,49 +91,50 @@ def cfg2_ipa_utterances(n_utt=65536, first=0, max_seconds=None, sr=SR):
     from . import ipa
     z = _load()
     lines = [b.decode("utf8") for b in z["ipa_lines"]][:8]
-    cache = {}
-
-    def stream(line, variant):
-        key = (line, variant)
-        if key not in cache:
-            pk = ipa.frames_for_batch([lines[line]], sampleRate=sr, speed=1.0, basePitch=100.0 * 2.0 ** ((variant - 32) / 64.0),
-                                      inflection=0.5, clauseType=".", trailing_silence_ms=150.0)
-            fr, nu, M, F = pk["frames"], pk["isnull"], pk["min"], pk["fade"]
-            if max_seconds is not None:
-                per = np.maximum(M.astype(np.int64), np.maximum(F.astype(np.int64), 1) + 1) + 1
-                keep = max(1, int(np.searchsorted(np.cumsum(per), max_seconds * sr, side="right")))
-                fr, nu, M, F = fr[:keep], nu[:keep], M[:keep], F[:keep]
-            cache[key] = (fr, nu, M, F)
-        return cache[key]
-
-    frames, mins, fades, nul, fs = [], [], [], [], [0]
-    for k in range(n_utt):
-        u = first + k
-        fr, nu, M, F = stream(u % 8, (u // 8) % 64)
-        frames.append(fr); mins.append(M); fades.append(F); nul.append(nu)
-        fs.append(fs[-1] + len(M))
-    nF = fs[-1]
+    u = first + np.arange(n_utt, dtype=np.int64)
+    variant = (u // 8) % 64
+    pitch_of = np.array([100.0 * 2.0 ** ((v - 32) / 64.0) for v in range(64)])      # libm pow per variant (numpy's differs in the last place)
+    pk = ipa.frames_for_batch([lines[i] for i in (u % 8)], sampleRate=sr, speed=1.0, basePitch=pitch_of[variant],
+                              inflection=0.5, clauseType=".", trailing_silence_ms=150.0)
+    fs, frames, M, F, nul = pk["frame_start"], pk["frames"], pk["min"], pk["fade"], pk["isnull"]
+    if max_seconds is not None:
+        # keep the leading frames of every utterance whose spans end within max_seconds (at least one frame)
+        per = np.maximum(M.astype(np.int64), np.maximum(F.astype(np.int64), 1) + 1) + 1
+        c = np.cumsum(per)
+        before = np.concatenate([[0], c])[fs[:-1]]                    # samples before each utterance
+        owner = np.repeat(np.arange(n_utt), np.diff(fs))
+        within = (c - before[owner]) <= max_seconds * sr
+        within[fs[:-1]] = True
+        frames, M, F, nul = frames[within], M[within], F[within], nul[within]
+        fs = np.concatenate([[0], np.cumsum(np.bincount(owner[within], minlength=n_utt))]).astype(np.int64)
+    nF = int(fs[-1])
     tag = "cfg2" if max_seconds is None else "cfg3-slice(<=%.2gs)" % max_seconds
-    return Batch(frames=np.concatenate(frames), min=np.concatenate(mins), fade=np.concatenate(fades),
-                 index=np.full(nF, -1, np.int32), isnull=np.concatenate(nul), frame_start=np.array(fs, np.int64),
+    return Batch(frames=frames, min=M, fade=F, index=np.full(nF, -1, np.int32), isnull=nul, frame_start=fs,
                  seeds=(np.arange(n_utt) + first).astype(np.uint32),
                  name="%s: %d sampleIpa utterances, 64 pitch variants" % (tag, n_utt), sr=sr)
 
 
-def cfg4_voice_variants(n_variants=256, utt_per_variant=16384, first_variant=0, sr=SR):
+def cfg4_voice_variants(n_variants=256, utt_per_variant=16384, first_variant=0, sr=SR, first_utt=0, n_utt=None):
     """BASELINE configs[4]: voice-parameter variants x utterances with per-frame pitch/formant glides.
     Variant v draws multipliers from a generator seeded 1234+v, in the style of the NVDA driver's voice
     presets (reference nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:86-125): cf1..cf3 x U[0.75, 1.05],
     cb1 x U[1, 1.3], voicePitch and endVoicePitch x U[0.75, 1.5], fricationAmplitude x U[0.7, 1],
-    pa6 x U[1, 1.3]; its utterances are the cfg2 generator's."""
+    pa6 x U[1, 1.3]; its utterances are the cfg2 generator's.
+    The config is the flat list (variant, utterance); `first_utt` / `n_utt` cut a contiguous piece out of the
+    n_variants x utt_per_variant list that starts at variant `first_variant` (for the shards of a node)."""
     base = cfg2_ipa_utterances(utt_per_variant, first=0, sr=sr)
-    F = {n: i for i, n in enumerate(["voicePitch", "vibratoPitchOffset", "vibratoSpeed", "voiceTurbulenceAmplitude",
-                                     "glottalOpenQuotient", "voiceAmplitude", "aspirationAmplitude"])}
-    frames, seeds = [], []
-    for k in range(n_variants):
+    total = n_variants * utt_per_variant
+    lo = first_utt
+    hi = total if n_utt is None else min(total, first_utt + n_utt)
+    frames, mins, fades, nul, counts, seeds = [], [], [], [], [], []
+    bfs = base["frame_start"]
+    for k in range(lo // utt_per_variant, (max(hi, lo + 1) - 1) // utt_per_variant + 1):
         v = first_variant + k
+        a, b = max(lo, k * utt_per_variant) - k * utt_per_variant, min(hi, (k + 1) * utt_per_variant) - k * utt_per_variant
+        if b <= a:
+            continue
         rng = np.random.default_rng(1234 + v)
-        g = base["frames"].copy()
+        g = base["frames"][bfs[a]:bfs[b]].copy()
         g[:, 7:10] *= rng.uniform(0.75, 1.05, size=3)          # cf1..cf3
         g[:, 15] *= rng.uniform(1.0, 1.3)                      # cb1
         pm = rng.uniform(0.75, 1.5)
@@ -142,23 +142,48 @@ def cfg4_voice_variants(n_variants=256, utt_per_variant=16384, first_variant=0, 
         g[:, 24] *= rng.uniform(0.7, 1.0)                      # fricationAmplitude
         g[:, 42] *= rng.uniform(1.0, 1.3)                      # pa6
         frames.append(g)
-        seeds.append(base["seeds"].astype(np.uint64) + np.uint64(v) * np.uint64(utt_per_variant))
-    nF = len(base["min"])
-    fs = np.concatenate([base["frame_start"][:-1] + k * nF for k in range(n_variants)] + [[n_variants * nF]])
-    return Batch(frames=np.concatenate(frames), min=np.tile(base["min"], n_variants), fade=np.tile(base["fade"], n_variants),
-                 index=np.full(nF * n_variants, -1, np.int32), isnull=np.tile(base["isnull"], n_variants),
-                 frame_start=fs.astype(np.int64), seeds=(np.concatenate(seeds) & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+        mins.append(base["min"][bfs[a]:bfs[b]]); fades.append(base["fade"][bfs[a]:bfs[b]]); nul.append(base["isnull"][bfs[a]:bfs[b]])
+        counts.append(np.diff(bfs[a:b + 1]))
+        seeds.append(base["seeds"][a:b].astype(np.uint64) + np.uint64(v) * np.uint64(utt_per_variant))
+    if not frames:
+        frames, mins, fades, nul, counts, seeds = ([np.zeros((0, 47))], [np.zeros(0, np.uint32)], [np.zeros(0, np.uint32)],
+                                                   [np.zeros(0, np.uint8)], [np.zeros(0, np.int64)], [np.zeros(0, np.uint64)])
+    fs = np.concatenate([[0], np.cumsum(np.concatenate(counts))]).astype(np.int64)
+    nF = int(fs[-1])
+    return Batch(frames=np.concatenate(frames), min=np.concatenate(mins), fade=np.concatenate(fades),
+                 index=np.full(nF, -1, np.int32), isnull=np.concatenate(nul),
+                 frame_start=fs, seeds=(np.concatenate(seeds) & np.uint64(0xFFFFFFFF)).astype(np.uint32),
                  name="cfg4: %d voice variants x %d utterances" % (n_variants, utt_per_variant), sr=sr)
 
 
+# utterances per GPU of each BASELINE configuration (configs[3] is 10^6 over 8 GPUs, configs[4] 256 x 16384 over 8)
+PER_GPU = {"cfg1": 4096, "cfg2": 65536, "cfg3": 125000, "cfg4": 32 * 16384}
+CFG4_PER_VARIANT = 16384
+
+
 def make(workload, n_utt=None, first=0):
+    """Utterances first .. first + n_utt - 1 of a configuration's (unbounded) utterance list."""
     if workload == "cfg1":
         return cfg1_steady_vowels(n_utt or 4096, first=first)
     if workload == "cfg2":
         return cfg2_ipa_utterances(n_utt or 65536, first=first)
     if workload == "cfg3":
-        return cfg2_ipa_utterances(n_utt or 131072, first=first, max_seconds=0.5)
-    if workload == "cfg4":     # n_utt utterances per variant block of 1024; the full config is 32 variants x 16384 per GPU
-        per = 1024
-        return cfg4_voice_variants(max(1, (n_utt or 32768) // per), per, first_variant=first // per)
+        return cfg2_ipa_utterances(n_utt or PER_GPU["cfg3"], first=first, max_seconds=0.5)
+    if workload == "cfg4":
+        # the flat (variant, utterance) list with 16384 utterances per variant; counts that are not a multiple of
+        # 16384 use blocks of 1024 per variant instead (small tests keep several variants)
+        n = n_utt or PER_GPU["cfg4"]
+        per = CFG4_PER_VARIANT if (n % CFG4_PER_VARIANT == 0 and first % CFG4_PER_VARIANT == 0) or n > 65536 else 1024
+        nv = (first + n + per - 1) // per
+        b = cfg4_voice_variants(nv, per, first_utt=first, n_utt=n)
+        b["name"] = "cfg4: utterances %d..%d of voice variants x %d utterances" % (first, first + n - 1, per)
+        return b
     raise ValueError(workload)
+
+
+def sample_counts(workload, n_utt, first=0):
+    """Samples per utterance of utterances first .. first + n_utt - 1 without building their frames: every recipe's timing
+    repeats with a short period (8 lines x 64 pitch variants; the voice variants of cfg4 change no duration)."""
+    period = 1 if workload == "cfg1" else 512
+    one = make("cfg2" if workload == "cfg4" else workload, period, 0).sample_counts()
+    return one[(first + np.arange(n_utt, dtype=np.int64)) % period]

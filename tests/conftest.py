@@ -12,6 +12,13 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """The tests run against the library built from the sources in the tree: rebuild it when a source, header or
+    generated table is newer (a no-op otherwise; hipcc cross-compiles without a GPU)."""
+    from nvspeechplayer_amd import _native
+    _native.build()
+
+
 def _gpu_present():
     try:
         import torch

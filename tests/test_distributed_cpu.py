@@ -54,3 +54,32 @@ def test_two_rank_sharding_gloo(tmp_path):
         assert float(p["elapsed"]) == 2.0                                        # max over ranks
         assert float(p["samples"]) == float(total)                               # sum over ranks
     assert int(parts[0]["total"]) + int(parts[1]["total"]) == total
+
+
+@pytest.mark.timeout(300)
+def test_bench_starts_its_own_ranks(tmp_path):
+    """`python bench.py --gpus 2` with no launcher around it: the parent starts two rank processes, they rendezvous (gloo here),
+    deal the node's batch (2 x the per-GPU configuration) into two shards of near-equal SAMPLE count, build their shards and
+    reduce; rank 0's JSON line comes back through the parent.  --dry-run leaves out only the GPU launches, so this runs in the
+    CPU container; tests/test_gpu_parity.py::test_bench_two_ranks_on_one_gpu runs the same command for real."""
+    import json
+    import subprocess
+    from nvspeechplayer_amd import workloads
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    for workload, per_gpu in (("cfg2", 300), ("cfg4", 1100)):
+        out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--workload", workload,
+                                       "--utterances", str(per_gpu), "--steps", "3", "--warmup", "1"], env=env, cwd=str(tmp_path), timeout=280)
+        lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+        assert len(lines) == 1, out
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak" and d["dry_run"] is True
+        c = d["config"]
+        assert c["world_size"] == 2 and c["process_group"] == "gloo"
+        assert c["node_utterances"] == 2 * per_gpu
+        counts = workloads.sample_counts(workload, 2 * per_gpu)
+        assert c["node_samples"] == int(counts.sum()) == int(d["total_samples_all_ranks"])        # the shards cover the node batch
+        b = c["shard_bounds"]
+        assert b[0] == 0 and b[2] == 2 * per_gpu and c["utterances_per_gpu"] == b[1]
+        halves = [int(counts[:b[1]].sum()), int(counts[b[1]:].sum())]
+        assert abs(halves[0] - halves[1]) <= 2 * int(counts.max())                                # balanced by samples, not by count
+        assert c["samples_per_gpu"] == halves[0]

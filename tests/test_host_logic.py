@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     _native.build()
     lib = _native.load()
     names = declared_functions("speechPlayer.h") + declared_functions("speechPlayer_batch.h")
-    assert len(names) >= 21
+    assert len(names) >= 34
     for n in names:
         assert hasattr(lib, n), n
     assert set(names) <= set(_native.EXPORTS)
@@ -48,6 +48,26 @@ def test_no_gpu_means_loud_failure_not_fallback():
         eng.SpeechPlayer(22050)
     with pytest.raises(RuntimeError):
         eng.BatchPlayer(22050)
+
+
+def test_failures_carry_an_error_code():
+    """speechPlayer_synthesize returns 0 for "queue drained" and for a failed call alike (the reference has no error
+    convention); speechPlayer_lastErrorCode tells them apart.  Without a GPU every call that needs one fails with
+    SPEECHPLAYER_ERR_NO_DEVICE; calls on invalid handles fail with SPEECHPLAYER_ERR_ARGUMENT; host-only calls succeed."""
+    import ctypes
+    import torch
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    buf = (ctypes.c_short * 16)()
+    assert L.speechPlayer_synthesize(ctypes.c_void_p(12345), 16, buf) == 0          # invalid handle: returns 0 like a drained queue ...
+    assert _native.last_error_code() == 1 and "invalid handle" in _native.last_error()   # ... but says so
+    assert L.speechPlayer_batch_setOption(None, b"mode", 0) == -1
+    if not torch.cuda.is_available():
+        assert not L.speechPlayer_initialize(22050)
+        assert _native.last_error_code() == 2 and "no HIP device" in _native.last_error()
+        assert not L.speechPlayer_batch_create(22050, -1) and _native.last_error_code() == 2
+    assert L.speechPlayer_voiceCount() == 4
+    assert L.speechPlayer_ipa_frames(b"h", 1.0, 100.0, 0.5, 0, None, None, None, None, None, 0) == 1     # host-only producer: no GPU needed
 
 
 def test_product_does_not_import_the_oracle():

@@ -1,8 +1,11 @@
-"""The IPA -> frames producer (nvspeechplayer_amd/ipa.py) against streams captured from the reference's
-own ipa.generateFramesAndTiming (tests/golden/ref_frames.npz): every frame value, NULL flag, duration and
-fade must be identical, for the eight sampleIpa.txt lines x five clause types x two speeds, pitch /
-inflection variants, and ten extra lines with tie bars, length and stress marks and unknown symbols
-(SURVEY.md section 8(f) rank 2)."""
+"""The native IPA -> frames producer (nvspeechplayer_amd/csrc/frame_producer.cpp, called through the C-ABI of
+include/speechPlayer_batch.h) against streams captured from the reference's own ipa.generateFramesAndTiming and
+applyVoiceToFrame (tests/golden/ref_frames.npz, made by tests/golden/make_golden.py): every frame value, NULL flag,
+duration and fade must be identical, for the eight sampleIpa.txt lines x five clause types x two speeds, pitch /
+inflection variants, ten extra lines with tie bars, length and stress marks and unknown symbols, and the four voice
+presets.  Host code: runs without a GPU."""
+import ctypes
+
 import numpy as np
 import pytest
 
@@ -16,23 +19,56 @@ def ref():
     return scenarios.Ref()
 
 
-def test_every_captured_case_is_reproduced_exactly(ref):
+@pytest.fixture(scope="module")
+def golden():
+    return np.load(scenarios.GOLDEN + "/ref_frames.npz")
+
+
+def test_every_captured_case_is_reproduced_exactly(ref, golden):
     from nvspeechplayer_amd import ipa
-    z = np.load(scenarios.GOLDEN + "/ref_frames.npz")
-    lines = [b.decode("utf8") for b in z["ipa_lines"]]
+    lines = [b.decode("utf8") for b in golden["ipa_lines"]]
     n_frames = 0
     for i, meta in enumerate(ref.ipa_meta):
         li, speed, clause, pitch, infl = int(meta[0]), float(meta[1]), CLAUSES[int(meta[2])], float(meta[3]), float(meta[4])
-        got = list(ipa.frame_vectors(lines[li], speed=speed, basePitch=pitch, inflection=infl, clauseType=clause))
+        frames, nul, dur, fade = ipa.frame_arrays(lines[li], speed=speed, basePitch=pitch, inflection=infl, clauseType=clause)
         a, b = ref.ipa_start[i], ref.ipa_start[i + 1]
-        assert len(got) == b - a, (i, len(got), b - a)
-        for k, (vec, dur, fade) in enumerate(got):
-            assert (vec is None) == bool(ref.ipa_isnull[a + k]), (i, k)
-            assert dur == ref.ipa_dur_ms[a + k] and fade == ref.ipa_fade_ms[a + k], (i, k, dur, fade)
-            if vec is not None:
-                assert np.array_equal(vec, ref.ipa_frames[a + k]), (i, k, np.flatnonzero(vec != ref.ipa_frames[a + k]))
-            n_frames += 1
+        assert len(nul) == b - a, (i, len(nul), b - a)
+        assert np.array_equal(nul, ref.ipa_isnull[a:b]), i
+        assert np.array_equal(dur, ref.ipa_dur_ms[a:b]) and np.array_equal(fade, ref.ipa_fade_ms[a:b]), i
+        real = nul == 0
+        assert np.array_equal(frames[real], ref.ipa_frames[a:b][real]), (i, np.argwhere(frames[real] != ref.ipa_frames[a:b][real])[:5])
+        assert not frames[~real].any()
+        n_frames += b - a
     assert n_frames == len(ref.ipa_frames) and len(ref.ipa_meta) == 126
+
+
+def test_voice_presets_match_the_captured_cases(golden):
+    """The four presets of the NVDA driver applied to every frame of the eight sampleIpa lines: through the producer's
+    `voice` argument and through speechPlayer_applyVoiceToFrame on an unvoiced frame."""
+    from nvspeechplayer_amd import Frame, ipa
+    names = [b.decode("utf8") for b in golden["voice_names"]]
+    assert ipa.voices() == names and len(names) == 4
+    lines = [b.decode("utf8") for b in golden["ipa_lines"]]
+    meta, want = golden["voice_case_meta"], golden["voice_case_frames"]
+    k = 0
+    for vi, vname in enumerate(names):
+        for li in range(8):
+            frames, nul, _, _ = ipa.frame_arrays(lines[li], speed=1.0, basePitch=100.0, inflection=0.5, clauseType=".", voice=vname)
+            plain, _, _, _ = ipa.frame_arrays(lines[li], speed=1.0, basePitch=100.0, inflection=0.5, clauseType=".")
+            for j in np.flatnonzero(nul == 0):
+                assert tuple(meta[k]) == (vi, li)
+                assert np.array_equal(frames[j], want[k]), (vname, li, j, np.flatnonzero(frames[j] != want[k]))
+                f = Frame.from_array(plain[j])
+                ipa.applyVoiceToFrame(f, vname)
+                assert np.array_equal(f.as_array(), want[k])
+                k += 1
+    assert k == len(want)
+    assert any(not np.array_equal(a, b) for a, b in zip(want[:50], want[200:250]))       # the presets differ
+    with pytest.raises(KeyError):
+        ipa.frame_arrays("hælou", voice="Nobody")
+    f = Frame.from_array(np.arange(47.0))
+    ipa.applyVoiceToFrame(f, "Caleb")                   # the reference's key carries a trailing blank; both spellings work
+    assert f.voiceAmplitude == 0.0 and f.aspirationAmplitude == 1.0
 
 
 def test_frame_objects_and_batch_packing(ref):
@@ -46,13 +82,33 @@ def test_frame_objects_and_batch_packing(ref):
     assert [int(x) for x in pk["min"][:len(case)]] == [c[1] for c in case]
     assert [int(x) for x in pk["fade"][:len(case)]] == [c[2] for c in case]
     assert pk["isnull"][len(case) - 1] == 1
+    # per-text clause types and pitches, no trailing silence, another sample rate; instanced streams are identical copies
+    texts = ["hæv ju enj wʊl", "ðɪs ɪz veɹj fɑn", "hæv ju enj wʊl", "hæv ju enj wʊl"]
+    pk = ipa.frames_for_batch(texts, sampleRate=16000, speed=0.8, basePitch=[90.0, 120.0, 90.0, 91.0], clauseType=["?", None, "?", "?"],
+                              trailing_silence_ms=None)
+    fs = pk["frame_start"]
+    one = [ipa.frame_arrays(t, speed=0.8, basePitch=p, clauseType=c) for t, p, c in zip(texts, (90.0, 120.0, 90.0, 91.0), ("?", None, "?", "?"))]
+    for u in range(4):
+        fr, nul, dur, fade = one[u]
+        assert fs[u + 1] - fs[u] == len(nul)
+        assert np.array_equal(pk["frames"][fs[u]:fs[u + 1]], fr) and np.array_equal(pk["isnull"][fs[u]:fs[u + 1]], nul)
+        assert [int(x) for x in pk["min"][fs[u]:fs[u + 1]]] == [int(d * (16000 / 1000.0)) for d in dur]      # reference speechPlayer.py:53
+        assert [int(x) for x in pk["fade"][fs[u]:fs[u + 1]]] == [int(d * (16000 / 1000.0)) for d in fade]
+    assert np.array_equal(pk["frames"][fs[0]:fs[1]], pk["frames"][fs[2]:fs[3]])
+    assert not np.array_equal(pk["frames"][fs[0]:fs[1]], pk["frames"][fs[3]:fs[4]])       # 1 Hz apart
 
 
 def test_unknown_symbols_stress_and_ties():
     from nvspeechplayer_amd import ipa
-    # unknown characters are skipped, stress marks move to the syllable head, a tie bar forms an affricate
-    ph = ipa.segment("ˈt͡ʃɑ #ˌpɑː")
-    names = [(p.stop, p.affricate, p.vowel, p.silence, p.stress, p.lengthened) for p in ph]
-    assert any(p.affricate for p in ph) and any(p.lengthened for p in ph)
-    assert ph[0].stress == 1 or ph[1].stress == 1
-    assert len(list(ipa.frame_vectors(""))) == 0
+    # unknown characters are skipped, a tie bar forms an affricate (one frame, 24 ms, preceded by a gap unless it carries the
+    # stress mark), a length mark lengthens by 5 %, an empty text yields nothing
+    fr, nul, dur, fade = ipa.frame_arrays("t͡ʃɑ #pɑː")
+    assert list(nul) == [1, 0, 0, 1, 0, 0, 0]                       # gap t͡ʃ ɑ | gap p (aspiration) ɑː
+    assert dur[1] == 24.0 and fade[1] == 0.001 and dur[0] == 41.0
+    assert dur[5] == 20.0 and dur[6] == 60.0 * 1.05
+    fr2, nul2, dur2, _ = ipa.frame_arrays("ˈt͡ʃɑ")
+    assert list(nul2) == [0, 0] and dur2[0] == 24.0 / (1 / 1.4)     # stressed: no gap, slower syllable
+    assert len(ipa.frame_arrays("")[1]) == 0 and len(ipa.frame_arrays("#7 ")[1]) == 0
+    # invalid UTF-8 is an unknown symbol, not a crash
+    L = __import__("nvspeechplayer_amd")._native.load()
+    assert L.speechPlayer_ipa_frames(b"h\xff\xfe\xe6lou", 1.0, 100.0, 0.5, 0, None, None, None, None, None, 0) >= 3

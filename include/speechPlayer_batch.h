@@ -91,6 +91,35 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
 int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo);
 
 /*
+ * One batch over the GPUs of a node.  Utterances are independent (the reference's only cross-handle coupling
+ * is rand(), src/speechWaveGenerator.cpp:40, replaced by per-utterance noise streams), so the batch is cut into contiguous
+ * shards of near-equal total SAMPLE count, one per device; one host thread per device uploads its shard, the devices
+ * synthesise side by side, nothing is exchanged between them.  Results are addressed by the batch's own utterance numbers.
+ *   devices[nDevices]  HIP device of each shard (NULL: 0 .. nDevices-1; a device may be listed more than once)
+ */
+typedef void* speechPlayer_node_t;
+speechPlayer_node_t speechPlayer_node_create(int sampleRate, int nDevices, const int* devices);
+void speechPlayer_node_destroy(speechPlayer_node_t node);
+int speechPlayer_node_devices(speechPlayer_node_t node);
+int speechPlayer_node_setOption(speechPlayer_node_t node, const char* name, int value);
+/* Arguments as speechPlayer_batch_setUtterances; noiseSeed NULL = the utterance's number in the WHOLE batch. */
+int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtterances, const long long* frameStart,
+	const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration, const unsigned int* fadeDuration,
+	const int* userIndex, const unsigned char* isNull, const unsigned int* noiseSeed);
+int speechPlayer_node_synthesize(speechPlayer_node_t node);   /* asynchronous on every device */
+int speechPlayer_node_wait(speechPlayer_node_t node);
+long long speechPlayer_node_totalSamples(speechPlayer_node_t node);
+long long speechPlayer_node_read(speechPlayer_node_t node, long long utterance, sample* sampleBuf, long long capacity);
+int speechPlayer_node_getLastIndex(speechPlayer_node_t node, long long utterance);
+/* Shard `shard`: its first utterance, utterance count, sample count and device (each pointer may be NULL). */
+int speechPlayer_node_shardInfo(speechPlayer_node_t node, int shard, long long* firstUtterance, long long* nUtterances, long long* samples, int* device);
+/* The shard's own batch object, for everything else (digest, float output, device pointers); utterance numbers are
+ * relative to the shard's first utterance there. */
+speechPlayer_batch_t speechPlayer_node_part(speechPlayer_node_t node, int shard);
+/* `launches` passes over the whole batch, all devices at once; wall-clock milliseconds per pass. */
+int speechPlayer_node_time(speechPlayer_node_t node, int launches, float* msPerLaunch);
+
+/*
  * Many LIVE streams on one GPU: advance nHandles handles created by
  * speechPlayer_initialize by up to sampleCount samples each in ONE kernel launch, one handle per
  * wavefront lane.  Exactly equivalent to calling speechPlayer_synthesize(handles[i], sampleCount,

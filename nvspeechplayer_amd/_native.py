@@ -37,6 +37,10 @@ EXPORTS = [
     "speechPlayer_lastError", "speechPlayer_lastErrorCode", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany",
     "speechPlayer_ipa_frames", "speechPlayer_ipa_pack", "speechPlayer_batch_setIpa",
     "speechPlayer_voiceCount", "speechPlayer_voiceName", "speechPlayer_applyVoiceToFrame",
+    "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
+    "speechPlayer_node_setUtterances", "speechPlayer_node_synthesize", "speechPlayer_node_wait", "speechPlayer_node_totalSamples",
+    "speechPlayer_node_read", "speechPlayer_node_getLastIndex", "speechPlayer_node_shardInfo", "speechPlayer_node_part",
+    "speechPlayer_node_time",
 ]
 
 
@@ -175,6 +179,32 @@ def load():
     L.speechPlayer_ipa_pack.argtypes = [i32, i64, vp, f64, vp, f64, ctypes.c_char_p, ctypes.c_char_p, f64, vp, vp, vp, vp, vp, i64]
     L.speechPlayer_batch_setIpa.restype = i32
     L.speechPlayer_batch_setIpa.argtypes = [vp, i64, vp, f64, vp, f64, ctypes.c_char_p, ctypes.c_char_p, f64, vp]
+    L.speechPlayer_node_create.restype = vp
+    L.speechPlayer_node_create.argtypes = [i32, i32, vp]
+    L.speechPlayer_node_destroy.restype = None
+    L.speechPlayer_node_destroy.argtypes = [vp]
+    L.speechPlayer_node_devices.restype = i32
+    L.speechPlayer_node_devices.argtypes = [vp]
+    L.speechPlayer_node_setOption.restype = i32
+    L.speechPlayer_node_setOption.argtypes = [vp, ctypes.c_char_p, i32]
+    L.speechPlayer_node_setUtterances.restype = i32
+    L.speechPlayer_node_setUtterances.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp]
+    L.speechPlayer_node_synthesize.restype = i32
+    L.speechPlayer_node_synthesize.argtypes = [vp]
+    L.speechPlayer_node_wait.restype = i32
+    L.speechPlayer_node_wait.argtypes = [vp]
+    L.speechPlayer_node_totalSamples.restype = i64
+    L.speechPlayer_node_totalSamples.argtypes = [vp]
+    L.speechPlayer_node_read.restype = i64
+    L.speechPlayer_node_read.argtypes = [vp, i64, vp, i64]
+    L.speechPlayer_node_getLastIndex.restype = i32
+    L.speechPlayer_node_getLastIndex.argtypes = [vp, i64]
+    L.speechPlayer_node_shardInfo.restype = i32
+    L.speechPlayer_node_shardInfo.argtypes = [vp, i32, vp, vp, vp, vp]
+    L.speechPlayer_node_part.restype = vp
+    L.speechPlayer_node_part.argtypes = [vp, i32]
+    L.speechPlayer_node_time.restype = i32
+    L.speechPlayer_node_time.argtypes = [vp, i32, vp]
     L.speechPlayer_voiceCount.restype = i32
     L.speechPlayer_voiceCount.argtypes = []
     L.speechPlayer_voiceName.restype = ctypes.c_char_p

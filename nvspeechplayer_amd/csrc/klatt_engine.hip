@@ -17,7 +17,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <numeric>
 #include <string>
 #include <vector>
@@ -1112,6 +1114,195 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
     HIP_TRY(hipStreamSynchronize(b->stream));
     for (int i = 0; i < launches && !rc; ++i) HIP_TRY(hipEventElapsedTime(&msPerLaunch[i], ev[2 * i], ev[2 * i + 1]));
     return rc;
+}
+
+// ==========================================================================================
+// C-ABI: one batch over several devices of a node
+// ==========================================================================================
+// Utterances are independent, so a node's batch is cut into contiguous shards with near-equal total SAMPLE counts
+// (closed-form lengths; what balances the kernels is samples, not utterance counts), one shard per device, each shard a
+// Batch of its own with its own stream.  One host thread per device uploads its shard; launches are asynchronous, so
+// every device synthesises at the same time; nothing is exchanged between devices (no collective).
+struct Node {
+    int sampleRate = 0;
+    std::vector<Batch*> parts;
+    std::vector<long long> bounds;       // shard d = utterances bounds[d] .. bounds[d + 1] - 1
+};
+
+speechPlayer_node_t speechPlayer_node_create(int sampleRate, int nDevices, const int* devices)
+{
+    begin_call();
+    if (nDevices <= 0) { set_error("node_create: need at least one device"); return nullptr; }
+    Node* n = new Node;
+    n->sampleRate = sampleRate;
+    for (int d = 0; d < nDevices; ++d) {
+        Batch* b = static_cast<Batch*>(speechPlayer_batch_create(sampleRate, devices ? devices[d] : d));
+        if (!b) { speechPlayer_node_destroy(n); return nullptr; }
+        n->parts.push_back(b);
+    }
+    n->bounds.assign((size_t)nDevices + 1, 0);
+    return n;
+}
+
+void speechPlayer_node_destroy(speechPlayer_node_t node)
+{
+    Node* n = static_cast<Node*>(node);
+    if (!n) return;
+    for (Batch* b : n->parts) speechPlayer_batch_destroy(b);
+    delete n;
+}
+
+int speechPlayer_node_devices(speechPlayer_node_t node) { return node ? (int)static_cast<Node*>(node)->parts.size() : -1; }
+
+speechPlayer_batch_t speechPlayer_node_part(speechPlayer_node_t node, int shard)
+{
+    Node* n = static_cast<Node*>(node);
+    return (n && shard >= 0 && shard < (int)n->parts.size()) ? n->parts[shard] : nullptr;
+}
+
+int speechPlayer_node_setOption(speechPlayer_node_t node, const char* name, int value)
+{
+    begin_call();
+    Node* n = static_cast<Node*>(node);
+    if (!n) return -1;
+    for (Batch* b : n->parts)
+        if (speechPlayer_batch_setOption(b, name, value)) return -1;
+    return 0;
+}
+
+int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtterances, const long long* frameStart,
+                                    const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
+                                    const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
+                                    const unsigned int* noiseSeed)
+{
+    begin_call();
+    Node* n = static_cast<Node*>(node);
+    if (!n || nUtterances < 0 || !frameStart) { set_error("node_setUtterances: bad arguments"); return -1; }
+    if (frameStart[0] != 0) { set_error("node_setUtterances: frameStart[0] must be 0"); return -1; }
+    for (long long u = 0; u < nUtterances; ++u)
+        if (frameStart[u + 1] < frameStart[u]) { set_error("node_setUtterances: frameStart not monotone at %lld", u); return -1; }
+    if (frameStart[nUtterances] > 0 && (!minFrameDuration || !fadeDuration)) { set_error("node_setUtterances: bad frame arrays"); return -1; }
+    // samples before each utterance (closed form: a request spans max(M, F + 1) + 1 samples, F clamped to >= 1)
+    std::vector<unsigned long long> before((size_t)nUtterances + 1, 0);
+    for (long long u = 0; u < nUtterances; ++u) {
+        unsigned long long len = 0;
+        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+            const unsigned long long m = minFrameDuration[k], f = std::max(fadeDuration[k], 1u);
+            len += std::max(m, f + 1) + 1;
+        }
+        before[u + 1] = before[u] + len;
+    }
+    const int nd = (int)n->parts.size();
+    const unsigned long long total = before[nUtterances];
+    n->bounds[0] = 0;
+    for (int d = 1; d < nd; ++d) {
+        // first utterance whose start is at or beyond d/nd of the samples (the rule of nvspeechplayer_amd.sharding.shard_bounds)
+        const double target = (double)total * d / (double)nd;
+        long long cut = std::lower_bound(before.begin(), before.end(), target, [](unsigned long long x, double t) { return (double)x < t; }) - before.begin();
+        n->bounds[d] = std::max(n->bounds[d - 1], std::min(cut, nUtterances));
+    }
+    n->bounds[nd] = nUtterances;
+    // one host thread per device: rebase the shard's index array, give every utterance its GLOBAL default seed, upload
+    std::vector<int> rc((size_t)nd, 0), codes((size_t)nd, 0);
+    std::vector<std::string> errors((size_t)nd);
+    std::vector<std::thread> workers;
+    for (int d = 0; d < nd; ++d) {
+        workers.emplace_back([&, d]() {
+            const long long u0 = n->bounds[d], u1 = n->bounds[d + 1], f0 = frameStart[u0];
+            std::vector<long long> fs((size_t)(u1 - u0) + 1);
+            for (long long u = u0; u <= u1; ++u) fs[u - u0] = frameStart[u] - f0;
+            std::vector<unsigned int> seeds((size_t)(u1 - u0));
+            for (long long u = u0; u < u1; ++u) seeds[u - u0] = noiseSeed ? noiseSeed[u] : (unsigned int)u;
+            rc[d] = speechPlayer_batch_setUtterances(n->parts[d], u1 - u0, fs.data(), frames ? frames + f0 : nullptr,
+                                                     minFrameDuration ? minFrameDuration + f0 : nullptr, fadeDuration ? fadeDuration + f0 : nullptr,
+                                                     userIndex ? userIndex + f0 : nullptr, isNull ? isNull + f0 : nullptr, seeds.data());
+            if (rc[d]) { errors[d] = g_lastError; codes[d] = g_lastErrorCode; }
+        });
+    }
+    for (auto& w : workers) w.join();
+    for (int d = 0; d < nd; ++d)
+        if (rc[d]) { set_error_code(codes[d]); set_error("node_setUtterances: shard %d: %s", d, errors[d].c_str()); return -1; }
+    return 0;
+}
+
+int speechPlayer_node_synthesize(speechPlayer_node_t node)
+{
+    begin_call();
+    Node* n = static_cast<Node*>(node);
+    if (!n) return -1;
+    for (Batch* b : n->parts) {       // asynchronous launches: the devices run side by side
+        HIP_TRY(hipSetDevice(b->device));
+        if (batch_launch(b)) return -1;
+    }
+    return 0;
+}
+
+int speechPlayer_node_wait(speechPlayer_node_t node)
+{
+    begin_call();
+    Node* n = static_cast<Node*>(node);
+    if (!n) return -1;
+    for (Batch* b : n->parts) {
+        HIP_TRY(hipSetDevice(b->device));
+        HIP_TRY(hipStreamSynchronize(b->stream));
+    }
+    return 0;
+}
+
+int speechPlayer_node_shardInfo(speechPlayer_node_t node, int shard, long long* firstUtterance, long long* nUtterances, long long* samples, int* device)
+{
+    Node* n = static_cast<Node*>(node);
+    if (!n || shard < 0 || shard >= (int)n->parts.size()) return -1;
+    if (firstUtterance) *firstUtterance = n->bounds[shard];
+    if (nUtterances) *nUtterances = n->bounds[shard + 1] - n->bounds[shard];
+    if (samples) *samples = n->parts[shard]->totalSamples;
+    if (device) *device = n->parts[shard]->device;
+    return 0;
+}
+
+long long speechPlayer_node_totalSamples(speechPlayer_node_t node)
+{
+    Node* n = static_cast<Node*>(node);
+    if (!n) return -1;
+    long long t = 0;
+    for (Batch* b : n->parts) t += b->totalSamples;
+    return t;
+}
+
+static int node_locate(Node* n, long long u)
+{
+    if (!n || u < 0 || u >= n->bounds.back()) return -1;
+    return (int)(std::upper_bound(n->bounds.begin(), n->bounds.end(), u) - n->bounds.begin()) - 1;
+}
+
+long long speechPlayer_node_read(speechPlayer_node_t node, long long u, sample* sampleBuf, long long capacity)
+{
+    Node* n = static_cast<Node*>(node);
+    const int d = node_locate(n, u);
+    if (d < 0) { begin_call(); set_error("node_read: utterance %lld out of range", u); return -1; }
+    return speechPlayer_batch_read(n->parts[d], u - n->bounds[d], sampleBuf, capacity);
+}
+
+int speechPlayer_node_getLastIndex(speechPlayer_node_t node, long long u)
+{
+    Node* n = static_cast<Node*>(node);
+    const int d = node_locate(n, u);
+    return d < 0 ? -1 : speechPlayer_batch_getLastIndex(n->parts[d], u - n->bounds[d]);
+}
+
+// `launches` passes over the node's batch, every device launched before any is waited for; wall-clock milliseconds per pass
+int speechPlayer_node_time(speechPlayer_node_t node, int launches, float* msPerLaunch)
+{
+    begin_call();
+    Node* n = static_cast<Node*>(node);
+    if (!n || launches <= 0 || !msPerLaunch) return -1;
+    if (speechPlayer_node_wait(n)) return -1;
+    for (int i = 0; i < launches; ++i) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (speechPlayer_node_synthesize(n) || speechPlayer_node_wait(n)) return -1;
+        msPerLaunch[i] = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return 0;
 }
 
 // diagnostic builds (-DKLATT_STAMPS): per workgroup and stage {work cycles, barrier-wait cycles} of the last launch

@@ -287,3 +287,86 @@ class BatchPlayer(object):
             self.close()
         except Exception:
             pass
+
+
+class NodePlayer(object):
+    """One batch over several GPUs of a node (speechPlayer_node_*): contiguous shards of near-equal sample count, one
+    per device, synthesised side by side; no exchange between devices.  `devices`: HIP device per shard."""
+
+    def __init__(self, sampleRate, devices, mode=0, layout=None):
+        self.sampleRate = sampleRate
+        self._dll = _native.load()
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        self._h = self._dll.speechPlayer_node_create(sampleRate, len(dev), dev.ctypes.data)
+        if not self._h:
+            raise RuntimeError("speechPlayer_node_create failed: %s" % _native.last_error())
+        self._check(self._dll.speechPlayer_node_setOption(self._h, b"mode", mode))
+        if layout is not None:
+            self._check(self._dll.speechPlayer_node_setOption(self._h, b"layout", layout))
+        self.nUtterances = 0
+        self._lens = None
+
+    def _check(self, rc):
+        if rc is None or rc < 0:
+            raise RuntimeError("speechPlayer node call failed: %s" % _native.last_error())
+        return rc
+
+    def setUtterances(self, frameStart, frames, minSamples, fadeSamples, userIndex=None, isNull=None, noiseSeed=None):
+        fs = np.ascontiguousarray(frameStart, dtype=np.int64)
+        fr = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 47)
+        m = np.ascontiguousarray(minSamples, dtype=np.uint32)
+        f = np.ascontiguousarray(fadeSamples, dtype=np.uint32)
+        assert fs[-1] == len(fr) == len(m) == len(f)
+        ix = None if userIndex is None else np.ascontiguousarray(userIndex, dtype=np.int32)
+        nu = None if isNull is None else np.ascontiguousarray(isNull, dtype=np.uint8)
+        sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
+        p = lambda a: None if a is None else a.ctypes.data
+        self._check(self._dll.speechPlayer_node_setUtterances(self._h, len(fs) - 1, p(fs), p(fr), p(m), p(f), p(ix), p(nu), p(sd)))
+        self.nUtterances = len(fs) - 1
+        per = np.maximum(m.astype(np.int64), np.maximum(f.astype(np.int64), 1) + 1) + 1
+        c = np.concatenate([[0], np.cumsum(per)])
+        self._lens = c[fs[1:]] - c[fs[:-1]]
+
+    @property
+    def totalSamples(self):
+        return self._dll.speechPlayer_node_totalSamples(self._h)
+
+    def shards(self):
+        """[(first utterance, utterances, samples, device)] per shard."""
+        import ctypes
+        out = []
+        for d in range(self._dll.speechPlayer_node_devices(self._h)):
+            a, n, s, dev = ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_longlong(), ctypes.c_int()
+            self._check(self._dll.speechPlayer_node_shardInfo(self._h, d, ctypes.byref(a), ctypes.byref(n), ctypes.byref(s), ctypes.byref(dev)))
+            out.append((a.value, n.value, s.value, dev.value))
+        return out
+
+    def synthesize(self, wait=True):
+        self._check(self._dll.speechPlayer_node_synthesize(self._h))
+        if wait:
+            self._check(self._dll.speechPlayer_node_wait(self._h))
+
+    def read(self, u):
+        n = int(self._lens[u])
+        buf = np.zeros(max(n, 1), dtype=np.int16)
+        got = self._check(self._dll.speechPlayer_node_read(self._h, u, buf.ctypes.data, n))
+        return buf[:got]
+
+    def getLastIndex(self, u):
+        return self._dll.speechPlayer_node_getLastIndex(self._h, u)
+
+    def time(self, launches):
+        ms = np.zeros(launches, dtype=np.float32)
+        self._check(self._dll.speechPlayer_node_time(self._h, launches, ms.ctypes.data))
+        return ms
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._dll.speechPlayer_node_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -847,3 +847,35 @@ def test_error_codes_and_digest(ref):
     p = eng.SpeechPlayer(22050)
     assert p.synthesize(64) is None and _native.last_error_code() == 0
     p.close(); bp.close(); bp2.close()
+
+
+def test_one_batch_over_several_devices(ref, all_scenarios):
+    """speechPlayer_node_*: one ragged batch cut into sample-balanced contiguous shards, one per device entry (this box has
+    one GPU, so the three shards share device 0 -- three Batch objects, three streams, three upload threads): every
+    utterance's PCM and index mark equal the single-device batch's, default seeds are the utterance's number in the WHOLE
+    batch, and the shards' sample counts are balanced."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd.sharding import shard_bounds
+    sel = [s for s in all_scenarios if s.batchable and s.sr == 22050]
+    batch = make_batch(sel)
+    n = len(sel)
+    one = eng.BatchPlayer(22050)
+    one.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], None)
+    one.synthesize()
+    node = eng.NodePlayer(22050, [0, 0, 0])
+    node.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], None)
+    assert node.totalSamples == one.totalSamples
+    sh = node.shards()
+    lens = np.array([one.utteranceSamples(u) for u in range(n)])
+    assert [a for a, _, _, _ in sh] + [n] == list(shard_bounds(lens, 3))                 # the same deal as the Python helper
+    assert sum(c for _, c, _, _ in sh) == n and [s for _, _, s, _ in sh] == [int(lens[a:a + c].sum()) for a, c, _, _ in sh]
+    assert max(s for _, _, s, _ in sh) - min(s for _, _, s, _ in sh) <= 2 * lens.max()
+    node.synthesize()
+    for u in range(n):
+        assert np.array_equal(node.read(u), one.read(u)), u
+        assert node.getLastIndex(u) == one.getLastIndex(u)
+    ms = node.time(2)
+    assert len(ms) == 2 and (ms > 0).all()
+    with pytest.raises(RuntimeError, match="out of range|failed"):
+        node.read(n)
+    node.close(); one.close()

@@ -13,6 +13,53 @@ def find(outdir, sub, suffix):
     return hits[0] if hits else None
 
 
+def pmc_entry(outdir):
+    """Per-launch sums over the klatt kernels of one bench.py launch: VALU instructions, HBM bytes (FETCH_SIZE doubled per the
+    gfx950 note of MI355X_MICROARCH.md; both counters are in KB), and the kernel-trace average durations."""
+    def per_kernel(sub, counter):
+        f = find(outdir, sub, "counter_collection.csv")
+        acc = defaultdict(list)
+        if f:
+            for r in csv.DictReader(open(f)):
+                if "klatt" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+                    acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+        return {k: sum(v) / len(v) for k, v in acc.items()}
+    valu, fetch, write = per_kernel("pmc_insts", "SQ_INSTS_VALU"), per_kernel("pmc_fetch", "FETCH_SIZE"), per_kernel("pmc_write", "WRITE_SIZE")
+    ent = {"kernels": sorted(valu), "valu_insts_per_launch": sum(valu.values()), "valu_insts_by_kernel": valu,
+           "fetch_size_kb": sum(fetch.values()), "write_size_kb": sum(write.values()),
+           "hbm_bytes_per_launch": int((2.0 * sum(fetch.values()) + sum(write.values())) * 1024)}
+    st = find(outdir, "trace", "kernel_stats.csv")
+    if st:
+        ent["kernel_avg_ns"] = {row["Name"]: float(row["AverageNs"]) for row in csv.DictReader(open(st)) if "klatt" in row["Name"]}
+    bj = os.path.join(outdir, "bench_trace.json")
+    if os.path.exists(bj):
+        for line in open(bj):
+            if line.startswith("{"):
+                d = json.loads(line)
+                ent["algorithmic_bytes_per_launch"] = d["roofline"]["algorithmic_bytes_per_launch"]
+                ent["bench_kernel_ms_under_profiler"] = d["roofline"]["kernel_ms"]
+                ent["workload"] = d["config"]["workload"]
+    return ent
+
+
+def merge_json(outdir, key, path):
+    """profiles/r2_pmc.json: one entry per workload, stamped with the digest of the engine sources it was measured on."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    sha = bench.engine_source_digest()
+    data = {}
+    if os.path.exists(path):
+        data = json.load(open(path))
+        if data.get("engine_sources_sha") != sha:
+            data = {}                      # entries measured on other kernels do not mix with this one
+    data["engine_sources_sha"] = sha
+    data["_source"] = "tools/profile.sh: rocprofv3 --pmc passes (SQ_INSTS_VALU; FETCH_SIZE; WRITE_SIZE, each in its own run) + --kernel-trace --stats"
+    data["_correction"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); counters are in KB"
+    data[key] = pmc_entry(outdir)
+    with open(path, "w") as f:
+        json.dump(data, f, indent=1, sort_keys=True)
+
+
 def main(outdir):
     print("# profile summary: %s" % os.path.basename(os.path.normpath(outdir)))
     bj = os.path.join(outdir, "bench_trace.json")
@@ -57,3 +104,5 @@ def main(outdir):
 
 if __name__ == "__main__":
     main(sys.argv[1])
+    if len(sys.argv) >= 4:                 # summarize_prof.py <outdir> <workload key> <pmc json to merge into>
+        merge_json(sys.argv[1], sys.argv[2], sys.argv[3])

@@ -129,6 +129,15 @@ int speechPlayer_node_time(speechPlayer_node_t node, int launches, float* msPerL
  * (nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:62-81); this is that loop for N streams.
  */
 int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced);
+/* The same with the PCM left in HBM: handle i's samples start at *devicePcm + i * *rowStride (device memory, valid until the next
+ * live call on that device).  For consumers on the GPU and for measuring the engine without the PCIe copy of the PCM. */
+int speechPlayer_synthesizeManyDevice(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, const sample** devicePcm,
+	long long* rowStride, int* produced);
+/* Duration in milliseconds of the last live-handle kernel launch on HIP device `device` (HIP events on its stream). */
+float speechPlayer_lastLiveKernelMs(int device);
+/* Process-wide options.  "live_layout": the kernel that advances live handles -- 1 (default): the stage-parallel kernel, four
+ * wavefronts per 64 handles; 0: the lane kernel, one wavefront per 64 handles.  Same saved state, same PCM. */
+int speechPlayer_setGlobalOption(const char* name, int value);
 /* Choose a handle's noise stream (default 0); see DESIGN.md "Noise". */
 int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int seed);
 

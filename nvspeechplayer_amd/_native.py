@@ -34,7 +34,8 @@ EXPORTS = [
     "speechPlayer_batch_synthesize", "speechPlayer_batch_wait", "speechPlayer_batch_read",
     "speechPlayer_batch_readAll", "speechPlayer_batch_readFloat", "speechPlayer_batch_digest", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
     "speechPlayer_batch_deviceOffset", "speechPlayer_batch_time", "speechPlayer_batch_kernelInfo",
-    "speechPlayer_lastError", "speechPlayer_lastErrorCode", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany",
+    "speechPlayer_lastError", "speechPlayer_lastErrorCode", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany", "speechPlayer_setGlobalOption",
+    "speechPlayer_synthesizeManyDevice", "speechPlayer_lastLiveKernelMs",
     "speechPlayer_ipa_frames", "speechPlayer_ipa_pack", "speechPlayer_batch_setIpa",
     "speechPlayer_voiceCount", "speechPlayer_voiceName", "speechPlayer_applyVoiceToFrame",
     "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
@@ -130,6 +131,12 @@ def load():
     L.speechPlayer_setNoiseSeed.argtypes = [vp, u32]
     L.speechPlayer_synthesizeMany.restype = i32
     L.speechPlayer_synthesizeMany.argtypes = [vp, i32, u32, vp, vp]
+    L.speechPlayer_synthesizeManyDevice.restype = i32
+    L.speechPlayer_synthesizeManyDevice.argtypes = [vp, i32, u32, vp, vp, vp]
+    L.speechPlayer_lastLiveKernelMs.restype = ctypes.c_float
+    L.speechPlayer_lastLiveKernelMs.argtypes = [i32]
+    L.speechPlayer_setGlobalOption.restype = i32
+    L.speechPlayer_setGlobalOption.argtypes = [ctypes.c_char_p, i32]
     L.speechPlayer_lastError.restype = ctypes.c_char_p
     L.speechPlayer_lastError.argtypes = []
     L.speechPlayer_lastErrorCode.restype = i32

@@ -471,7 +471,16 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
             s.cnt = (uint32_t)S[215]; s.oldMin = (uint32_t)S[216]; s.newMin = (uint32_t)S[217]; s.newFade = (uint32_t)S[218];
             const uint32_t fl = (uint32_t)S[219];
             s.hasNew = fl & 1; s.oldNull = fl & 2; s.newNull = fl & 4;
-            s.lastIndex = (int32_t)S[220]; s.noiseIdx = (uint32_t)S[221]; s.resMask = (uint32_t)S[222];
+            s.lastIndex = (int32_t)S[220]; s.noiseIdx = (uint32_t)S[221];
+            // which resonators move in the running fade follows from the fade's end points (as event_step derived it); the
+            // state may have been saved by the stage-parallel stream kernel, whose stages keep their own masks
+            uint32_t mk = 0;
+#pragma unroll
+            for (int r = 0; r < kNumRes; ++r) {
+                const bool same = (S[45 + kResF[r] - 1] == S[kResF[r] - 1]) && (S[45 + kResB[r] - 1] == S[kResB[r] - 1]);
+                mk |= same ? 0u : (1u << r);
+            }
+            s.resMask = mk;
         }
         if (A.control && (A.control[u] & 1u)) {
             // purge (reference src/frame.cpp:103-112): cut over from the current interpolated frame
@@ -610,7 +619,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
         S[212] = s.oldInc; S[213] = s.newInc; S[214] = s.invFade;
         S[215] = (double)s.cnt; S[216] = (double)s.oldMin; S[217] = (double)s.newMin; S[218] = (double)s.newFade;
         S[219] = (double)((s.hasNew ? 1u : 0u) | (s.oldNull ? 2u : 0u) | (s.newNull ? 4u : 0u));
-        S[220] = (double)s.lastIndex; S[221] = (double)s.noiseIdx; S[222] = (double)s.resMask;
+        S[220] = (double)s.lastIndex; S[221] = (double)s.noiseIdx;
         S[239] = 1.0;
     }
 }

@@ -191,7 +191,7 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE, int CH, int WPS = 1, bool NASAL = true>
+template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
@@ -204,8 +204,8 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL>); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL>); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM>); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -429,7 +429,8 @@ struct Stream {
     uint32_t seed = 0;
     uintptr_t id = 0;
     std::mutex mu;                       // per call, not per sample (reference locks per sample: src/frame.cpp:122)
-    std::vector<PendingFrame> pending;   // queued, not yet taken by the kernel
+    std::vector<PendingFrame> pending;   // queued, not yet taken by the kernel: pending[head ..]
+    size_t head = 0;                     // frames before it were taken (dropped in bulk, not one erase per pull)
     bool purgePending = false;
     int lastIndex = -1;
     DeviceBuffer<double> dState;         // the stream's saved synthesiser state (kStateDoubles), lives on the GPU
@@ -469,9 +470,16 @@ struct LiveContext {
     std::vector<UttResult> hResult;
     std::vector<size_t> hTake;
     PinnedPair bounce;
+    hipEvent_t kernelStart = nullptr, kernelStop = nullptr;
+    float lastKernelMs = 0.0f;           // the last launch's duration (speechPlayer_lastLiveKernelMs)
+    size_t lastStride = 0;               // samples between the rows of the last launch's PCM in dPcm
 };
 std::mutex g_liveMutex;
 std::vector<LiveContext*> g_live;   // per device
+// Which kernel advances live handles: 1 = the stage-parallel kernel's STREAM instantiation (four wavefronts per 64 handles;
+// default), 0 = the lane kernel's (one wavefront per 64 handles).  Same saved state, same PCM; speechPlayer_setGlobalOption.
+int g_liveLayout = [] { const char* e = getenv("SPEECHPLAYER_LIVE_LAYOUT"); return e ? atoi(e) : 1; }();
+int g_liveCus = 0;
 
 LiveContext* live_context(int device)
 {
@@ -479,7 +487,8 @@ LiveContext* live_context(int device)
     if ((int)g_live.size() <= device) g_live.resize(device + 1, nullptr);
     if (!g_live[device]) {
         LiveContext* c = new LiveContext;
-        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreate(&c->kernelStart) != hipSuccess || hipEventCreate(&c->kernelStop) != hipSuccess) {
             set_error("cannot create a stream on device %d", device);
             delete c;
             return nullptr;
@@ -499,7 +508,9 @@ int stream_init_device(Stream* s)
 
 // Advance n live streams by up to `count` samples each in ONE launch (one stream per wavefront lane).
 // The callers hold every stream's mutex.  produced[i] receives speechPlayer_synthesize's return value.
-int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* const* outs, int* produced)
+// outs == nullptr: the PCM stays on the device (row i at devicePcm + i * stride), for consumers on the GPU.
+int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* const* outs, int* produced,
+                       const int16_t** devicePcm = nullptr, long long* deviceStride = nullptr)
 {
     for (int i = 0; i < n; ++i) produced[i] = 0;
     if (count == 0 || n <= 0) return 0;
@@ -521,9 +532,9 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     for (int i = 0; i < n; ++i) {
         unsigned long long span = 0;
         size_t k = 0;
-        const size_t have = ss[i]->pending.size();
+        const size_t have = ss[i]->pending.size() - ss[i]->head;
         while (k < have && span < count) {
-            const unsigned long long m = ss[i]->pending[k].meta.minSamples, f = ss[i]->pending[k].meta.fadeSamples;
+            const unsigned long long m = ss[i]->pending[ss[i]->head + k].meta.minSamples, f = ss[i]->pending[ss[i]->head + k].meta.fadeSamples;
             span += std::max(m, f + 1) + 1;
             ++k;
         }
@@ -540,8 +551,9 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         memset(&d, 0, sizeof d);
         d.frameStart = (long long)k; d.outStart = (long long)(i * padded); d.nFrames = (uint32_t)take[i];
         d.seed = ss[i]->seed; d.flags = UTT_NEEDS_NOISE;
+        d.length = count;                    // the stage-parallel kernel runs exactly `count` steps (klatt_systolic.h, STREAM)
         for (size_t j = 0; j < take[i]; ++j) {
-            const PendingFrame& f = ss[i]->pending[j];
+            const PendingFrame& f = ss[i]->pending[ss[i]->head + j];
             memcpy(&c->hFrames[k * kNumParams], f.p, sizeof(double) * kNumParams);
             c->hMeta[k] = f.meta;
             ++k;
@@ -568,17 +580,34 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     a.pcm = c->dPcm.ptr; a.result = c->dResult.ptr; a.state = nullptr; a.statePtrs = c->dStatePtrs.ptr; a.control = c->dControl.ptr;
     a.nSlots = n;
     a.maxSamples = count;
-    if (launch<true, true>(a, mode, (n + kLanes - 1) / kLanes, c->stream)) return -1;
+    const long long groups = (n + kLanes - 1) / kLanes;
+    HIP_TRY(hipEventRecord(c->kernelStart, c->stream));
+    if (g_liveLayout == 0) {
+        if (launch<true, true>(a, mode, groups, c->stream)) return -1;
+    } else {
+        if (g_liveCus == 0) {
+            hipDeviceProp_t prop;
+            g_liveCus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+        }
+        // one workgroup per CU while they all fit (16-sample hand-overs), else two per CU (8-sample hand-overs), as for batches
+        if (groups <= g_liveCus ? launch_systolic<true, 16, 1, true, true>(a, mode, groups, c->stream)
+                                : launch_systolic<true, KLATT_NOISY_CH, 2, true, true>(a, mode, groups, c->stream)) return -1;
+    }
+    HIP_TRY(hipEventRecord(c->kernelStop, c->stream));
 
     HIP_TRY(hipMemcpyAsync(c->hResult.data(), c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    (void)hipEventElapsedTime(&c->lastKernelMs, c->kernelStart, c->kernelStop);
+    c->lastStride = padded;
+    if (devicePcm) *devicePcm = c->dPcm.ptr;
+    if (deviceStride) *deviceStride = (long long)padded;
     size_t lastWithData = 0;
     bool any = false;
     for (int i = 0; i < n; ++i) {
         if (c->hResult[i].produced > count) { set_error("kernel produced %u > %u", c->hResult[i].produced, count); return -1; }
         if (c->hResult[i].produced) { lastWithData = i; any = true; }
     }
-    if (any) {
+    if (any && outs) {
         if (n == 1) {
             HIP_TRY(hipMemcpy(outs[0], c->dPcm.ptr, (size_t)c->hResult[0].produced * sizeof(int16_t), hipMemcpyDeviceToHost));
         } else {
@@ -608,7 +637,9 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         Stream* s = ss[i];
         const UttResult& r = c->hResult[i];
         s->purgePending = false;
-        s->pending.erase(s->pending.begin(), s->pending.begin() + std::min<size_t>(r.framesTaken, s->pending.size()));
+        s->head += std::min<size_t>(r.framesTaken, s->pending.size() - s->head);
+        if (s->head == s->pending.size()) { s->pending.clear(); s->head = 0; }
+        else if (s->head >= 64 && s->head * 2 >= s->pending.size()) { s->pending.erase(s->pending.begin(), s->pending.begin() + s->head); s->head = 0; }
         s->lastIndex = r.lastIndex;
         produced[i] = (int)r.produced;
     }
@@ -658,6 +689,7 @@ void speechPlayer_queueFrame(speechPlayer_handle_t playerHandle, speechPlayer_fr
     std::lock_guard<std::mutex> g(s->mu);
     if (purgeQueue) {                                    // reference src/frame.cpp:103-112; the state half of
         s->pending.clear();                              // the purge runs in the kernel before the next sample
+        s->head = 0;
         s->purgePending = true;
     }
     s->pending.push_back(f);
@@ -711,13 +743,52 @@ int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int s
     return 0;
 }
 
+// Additive: process-wide options.  "live_layout": which kernel advances live handles (1: stage-parallel, default; 0: lane kernel).
+int speechPlayer_setGlobalOption(const char* name, int value)
+{
+    begin_call();
+    if (name && !strcmp(name, "live_layout")) { g_liveLayout = value ? 1 : 0; return 0; }
+    set_error("unknown global option %s", name ? name : "(null)");
+    return -1;
+}
+
 // Additive: advance many live handles together -- one kernel launch, one handle per wavefront lane.
 // Equivalent to calling speechPlayer_synthesize(handles[i], sampleCount, sampleBufs[i]) for every i;
 // produced[i] receives each call's return value.  Handles must be distinct and share a sample rate.
+static int synthesize_many(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced,
+                           const int16_t** devicePcm, long long* deviceStride);
+
 int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced)
 {
     begin_call();
-    if (nHandles < 0 || (nHandles > 0 && (!handles || !sampleBufs || !produced))) { set_error("speechPlayer_synthesizeMany: bad arguments"); return -1; }
+    if (nHandles > 0 && !sampleBufs) { set_error("speechPlayer_synthesizeMany: bad arguments"); return -1; }
+    return synthesize_many(handles, nHandles, sampleCount, sampleBufs, produced, nullptr, nullptr);
+}
+
+// The same with the PCM left in HBM: handle i's samples start at *devicePcm + i * *rowStride (valid until the next live call
+// on that device).  For consumers on the GPU, and for measuring the engine without the PCIe copy of the PCM.
+int speechPlayer_synthesizeManyDevice(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, const sample** devicePcm,
+                                      long long* rowStride, int* produced)
+{
+    begin_call();
+    if (!devicePcm || !rowStride) { set_error("speechPlayer_synthesizeManyDevice: bad arguments"); return -1; }
+    const int16_t* p = nullptr;
+    const int rc = synthesize_many(handles, nHandles, sampleCount, nullptr, produced, &p, rowStride);
+    *devicePcm = reinterpret_cast<const sample*>(p);
+    return rc;
+}
+
+// Duration in milliseconds of the last live-handle launch on `device` (HIP events around the kernel on its stream).
+float speechPlayer_lastLiveKernelMs(int device)
+{
+    std::lock_guard<std::mutex> g(g_liveMutex);
+    return (device >= 0 && device < (int)g_live.size() && g_live[device]) ? g_live[device]->lastKernelMs : -1.0f;
+}
+
+static int synthesize_many(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced,
+                           const int16_t** devicePcm, long long* deviceStride)
+{
+    if (nHandles < 0 || (nHandles > 0 && (!handles || !produced))) { set_error("speechPlayer_synthesizeMany: bad arguments"); return -1; }
     std::vector<Stream*> ss((size_t)nHandles);
     for (int i = 0; i < nHandles; ++i) {
         ss[i] = lookup(handles[i]);
@@ -729,7 +800,7 @@ int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, un
     for (size_t i = 1; i < order.size(); ++i)
         if (order[i] == order[i - 1]) { set_error("speechPlayer_synthesizeMany: handle listed twice"); return -1; }
     for (Stream* s : order) s->mu.lock();
-    const int rc = streams_synthesize(ss.data(), nHandles, sampleCount, sampleBufs, produced);
+    const int rc = streams_synthesize(ss.data(), nHandles, sampleCount, sampleBufs, produced, devicePcm, deviceStride);
     for (Stream* s : order) s->mu.unlock();
     return rc;
 }

@@ -303,6 +303,89 @@ __device__ __forceinline__ bool stage_advance(SF& f, PitchState* ps, int32_t* la
     return emit;
 }
 
+// ---- live streams on the stage-parallel kernel ------------------------------------------------------------
+// A handle's saved state is the 240-double block of klatt_device.h (the lane kernel's save block defines the layout).
+// Every stage restores and saves ITS slice of it: its parameters' old / new / current values, its resonators'
+// coefficients and memories, and its copy of the frame state machine's counters (one copy is saved: the stages' copies
+// agree by construction).  Where parameter p's CURRENT value lives in the block:
+__device__ constexpr int stream_cur_slot(int p)
+{
+    if (p == 0) return 137;
+    for (int h = 0; h < kNumHot; ++h) if (kHot[h] == p) return 118 + h;
+    for (int r = 0; r < kNumRes; ++r) { if (kResF[r] == p) return 90 + 2 * r; if (kResB[r] == p) return 91 + 2 * r; }
+    return -1;
+}
+// P: the stage's parameters; GR: its resonators in the block's numbering (N0, NP, c6..c1, p1..p6 = 0..13)
+template <class D, class SF>
+__device__ __forceinline__ void stage_state_load(SF& f, PitchState* ps, const double* S, const int* P, const int* RF, const int* RB, const int* GR, bool purge)
+{
+    if (S[239] != 0.0) {
+#pragma unroll
+        for (int k = 0; k < D::NPARAM; ++k) {
+            f.oldL[k * kLanes] = S[P[k] - 1];
+            f.setNew(k, S[45 + P[k] - 1]);
+            f.cur[k] = S[stream_cur_slot(P[k])];
+        }
+#pragma unroll
+        for (int r = 0; r < D::NRES; ++r) {
+            f.ra[r] = S[138 + GR[r]]; f.rb[r] = S[152 + GR[r]]; f.rc[r] = S[166 + GR[r]]; f.z1[r] = S[180 + GR[r]]; f.z2[r] = S[194 + GR[r]];
+        }
+        f.invFade = S[214];
+        f.cnt = (uint32_t)S[215]; f.oldMin = (uint32_t)S[216]; f.newMin = (uint32_t)S[217]; f.newFade = (uint32_t)S[218];
+        const uint32_t fl = (uint32_t)S[219];
+        f.hasNew = fl & 1; f.oldNull = fl & 2; f.newNull = fl & 4;
+        if (D::PITCH) { ps->old0 = S[135]; ps->new0 = S[136]; ps->cur0 = S[137]; ps->oldInc = S[212]; ps->newInc = S[213]; }
+        // what moves in a running fade follows from its end points, as stage_event derived it
+        uint32_t pm = 0, mk = 0;
+        bool moved[D::NPARAM > 0 ? D::NPARAM : 1];
+#pragma unroll
+        for (int k = 0; k < D::NPARAM; ++k) {
+            const double n = f.getNew(k);
+            moved[k] = !(n == f.oldL[k * kLanes]);
+            pm |= moved[k] ? (1u << k) : 0u;
+            pm |= (n != n) ? kNanTarget : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < D::NRES; ++r) mk |= (moved[RF[r]] || moved[RB[r]]) ? (1u << r) : 0u;
+        if (D::PITCH) pm |= (ps->new0 != ps->new0) ? kNanTarget : 0u;
+        f.parMask = f.hasNew ? pm : 0u;
+        f.resMask = f.hasNew ? mk : 0u;
+    }
+    if (purge) {
+        // reference src/frame.cpp:103-112: the queue was emptied on the host; cut over from the current interpolated frame
+        f.cnt = f.oldMin;
+        if (f.hasNew) {
+            f.oldNull = f.newNull;
+#pragma unroll
+            for (int k = 0; k < D::NPARAM; ++k) f.oldL[k * kLanes] = f.cur[k];
+            if (D::PITCH) ps->old0 = ps->cur0;
+            f.hasNew = false;
+            f.parMask = 0; f.resMask = 0;
+        }
+    }
+}
+template <class D, class SF>
+__device__ __forceinline__ void stage_state_save(const SF& f, const PitchState* ps, double* S, const int* P, const int* GR)
+{
+#pragma unroll
+    for (int k = 0; k < D::NPARAM; ++k) {
+        S[P[k] - 1] = f.oldL[k * kLanes];
+        S[45 + P[k] - 1] = f.getNew(k);
+        S[stream_cur_slot(P[k])] = f.cur[k];
+    }
+#pragma unroll
+    for (int r = 0; r < D::NRES; ++r) {
+        S[138 + GR[r]] = f.ra[r]; S[152 + GR[r]] = f.rb[r]; S[166 + GR[r]] = f.rc[r]; S[180 + GR[r]] = f.z1[r]; S[194 + GR[r]] = f.z2[r];
+    }
+    if (D::PITCH) {
+        S[135] = ps->old0; S[136] = ps->new0; S[137] = ps->cur0; S[212] = ps->oldInc; S[213] = ps->newInc;
+        S[214] = f.invFade;
+        S[215] = (double)f.cnt; S[216] = (double)f.oldMin; S[217] = (double)f.newMin; S[218] = (double)f.newFade;
+        S[219] = (double)((f.hasNew ? 1u : 0u) | (f.oldNull ? 2u : 0u) | (f.newNull ? 4u : 0u));
+        S[239] = 1.0;
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ double resonate(double& z1, double& z2, double a, double b, double c, double in)
 {
@@ -376,10 +459,16 @@ struct Stamps {
 // untouched (reference :151-152: x + (np - x) * 0 == x for finite np) and nothing else reads N0's or NP's memories,
 // so both are skipped and the six formant resonators are spread evenly:
 //   quiet, nasal-free   S0 frame + glottal source | S1 r6, r5, r4 | S2 r3, r2, r1 | S3 gain, clip, int16 -> PCM
-template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true>
+// STREAM (noisy launches only): the lanes are LIVE handles (speechPlayer_synthesizeMany): every stage restores its slice of
+// the handle's saved state, applies a pending purge, the launch advances every handle by exactly A.maxSamples steps (a
+// handle whose queue runs dry stops earlier), and every stage saves its slice again.  Live handles always take the
+// noisy instantiation: the noise generators' memories and counters advance with every sample whatever the gains
+// (reference src/speechWaveGenerator.cpp:39-42), and a handle that is quiet now may be given noisy frames later.
+template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false>
 __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const KernelArgs A)
 {
     static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
+    static_assert(NOISE || !STREAM, "live handles take the noisy instantiation");
     using L = SysLds<NOISE, CH>;
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -434,6 +523,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     const uint32_t maxLen = *maxLenP;
     const int nChunks = (int)((maxLen + kChunk - 1) / kChunk);
     const int nIter = nChunks + (NOISE ? 2 : 3);   // the final stage lags 2 (noisy) or 3 (quiet) chunks; same trip count in every wave
+    // Live handles: every handle that has frames left emits one sample per step, so "at most maxSamples samples per handle" is
+    // "exactly maxSamples steps" for the whole launch (host: UttDesc.length = maxSamples); the last chunk may be a partial one
+    const int fullChunks = STREAM ? (int)(A.maxSamples / (uint32_t)kChunk) : nChunks;
+    double* const streamState = (STREAM && live) ? (A.statePtrs ? A.statePtrs[u] : A.state + (size_t)u * kStateDoubles) : nullptr;
+    const bool streamPurge = STREAM && live && A.control && (A.control[u] & 1u);
 #ifdef KLATT_STAMPS
     Stamps st;
 #endif
@@ -453,7 +547,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         STAMP_BEGIN();                                                                                                             \
         int c = iter - (DEPTH);                                                                                                    \
         if (c >= 0 && c < nChunks) {                                                                                               \
-            int kind = (VIBCHECK) ? -1 : chunk_kind<CH>(FRAMEVAR);                                                                 \
+            const int lim = (STREAM && c >= fullChunks) ? (int)(A.maxSamples - (uint32_t)c * (uint32_t)kChunk) : kChunk;            \
+            int kind = ((VIBCHECK) || lim < kChunk) ? -1 : chunk_kind<CH>(FRAMEVAR);                                               \
             if (kind == 1 && nan_target_live(FRAMEVAR)) kind = -1;   /* "hold" targets: sample by sample, with the NaN test */     \
             bool lerp = false, gainOnly = false;                                                                                   \
             uint32_t wRes = 0;                                                                                                     \
@@ -487,7 +582,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     /* own -- preload, straight-line block, barrier -- with the barrier count of the outer loop; the noisy  */     \
                     /* kernels have no register to spare for the run length.                                                */     \
                     uint32_t run = __any(!FRAMEVAR.done && FRAMEVAR.hasNew) ? 1u : steady_run<CH>(FRAMEVAR);                       \
-                    const uint32_t room = (uint32_t)(nChunks - c);                                                                 \
+                    const uint32_t room = (uint32_t)(fullChunks - c);                                                              \
                     run = run < room ? run : room;                                                                                 \
                     for (uint32_t q = 1; q < run; ++q) {                                                                           \
                         steadyChunk(c);                                                                                            \
@@ -520,7 +615,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 if (KLATT_FADE_TIGHT) {                                                                                            \
                     /* what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too */    \
                     uint32_t run = fade_run<CH>(FRAMEVAR);                                                                         \
-                    const uint32_t room = (uint32_t)(nChunks - c);                                                                 \
+                    const uint32_t room = (uint32_t)(fullChunks - c);                                                              \
                     run = run < room ? run : room;                                                                                 \
                     for (uint32_t q = 1; q < run; ++q) {                                                                           \
                         fadeChunk(c);                                                                                              \
@@ -540,14 +635,14 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 /* lanes of samples left in the stretch run as a rolled loop of the steady / fading body; n by ballot   */         \
                 /* bisection.  Not for the noisy kernels (KLATT_NOISY_RUNS): the extra code costs them more than it saves */         \
                 int i = 0;                                                                                                         \
-                _Pragma("nounroll") while (i < kChunk) {                                                                           \
+                _Pragma("nounroll") while (i < lim) {                                                                              \
                     if ((!NOISE || KLATT_NOISY_RUNS) && !(VIBCHECK)) {                                                             \
                         const bool fad = FRAMEVAR.hasNew;                                                                          \
                         const uint32_t rem = FRAMEVAR.done ? 0xFFFFFFFFu : (fad ? FRAMEVAR.newFade - FRAMEVAR.cnt : (FRAMEVAR.oldMin > FRAMEVAR.cnt ? FRAMEVAR.oldMin - FRAMEVAR.cnt : 0u)); \
                         const bool anyFad = __any(!FRAMEVAR.done && fad), anySteady = __any(!FRAMEVAR.done && !fad);              \
                         int runLen = 0;                                                                                            \
                         if (!(anyFad && anySteady) && !__any(!FRAMEVAR.done && fad && FRAMEVAR.cnt == 0u) && !(anyFad && nan_target_live(FRAMEVAR))) { \
-                            const int cap = kChunk - i;                                                                            \
+                            const int cap = lim - i;                                                                               \
                             _Pragma("unroll") for (int st = kChunk; st >= 1; st >>= 1)                                             \
                                 if (runLen + st <= cap && __all(rem >= (uint32_t)(runLen + st))) runLen += st;                     \
                         }                                                                                                          \
@@ -607,6 +702,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         uint32_t noiseIdx = 0;
         int32_t lastIndex = -1;
         bool vibFrames = false;
+        constexpr int GR0[1] = {0};
+        if (STREAM && live) {
+            if (streamState[239] != 0.0) {
+                pitchPhase = streamState[208]; vibPhase = streamState[209]; aspNoise = streamState[210];
+                lastIndex = (int32_t)streamState[220]; noiseIdx = (uint32_t)streamState[221];
+            }
+            stage_state_load<D>(f, &ps, streamState, P, RF, RB, GR0, streamPurge);
+            vibFrames = f.oldL[0] != 0.0 || f.oldL[kLanes] != 0.0 || f.getNew(0) != 0.0 || f.getNew(1) != 0.0;
+        }
 
         auto source = [&](bool waveVib) __attribute__((always_inline)) -> double {
             double vib = 1.0;
@@ -711,8 +815,13 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
 #define KL_FADE_ALT(c, lerp, gainOnly) false
         if (live) {
             UttResult res;
-            res.produced = f.produced; res.framesTaken = f.nextFrame; res.lastIndex = lastIndex; res.drained = 1u;
+            res.produced = f.produced; res.framesTaken = f.nextFrame; res.lastIndex = lastIndex; res.drained = STREAM ? (f.done ? 1u : 0u) : 1u;
             A.result[u] = res;
+        }
+        if (STREAM && live) {
+            stage_state_save<D>(f, &ps, streamState, P, GR0);
+            streamState[208] = pitchPhase; streamState[209] = vibPhase; streamState[210] = aspNoise;
+            streamState[220] = (double)lastIndex; streamState[221] = (double)noiseIdx;
         }
     } else if (!NOISE && !NASAL && (stage == 1 || stage == 2)) {
         // ================= quiet, nasal-free S1: r6, r5, r4 and S2: r3, r2, r1 =================
@@ -746,6 +855,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         constexpr int CANP = 2 * NR;
         StageFrame<2 * NR + 1, NR> f;
         stage_frame_init(f, live, lds + L::kFrames1, lane);
+        constexpr int GR1[5] = {0, 1, 2, 3, 4};
+        if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR1, streamPurge);
         auto dsp = [&](double x) __attribute__((always_inline)) -> double {
             const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
             f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
@@ -760,6 +871,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         RUN_STAGE(1, f, nullptr, nullptr, D, false, S1_BODY, (void)0, (void)0, S1_EMIT, (void)0, kPre, PIPE(pipeX, c, i))
 #undef S1_BODY
 #undef S1_EMIT
+        if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GR1);
     } else if (NOISE && stage == 3) {
         // ================= noisy S3: frication noise, parallel r1..r4 partial sum =================
         // tracked: (pf, pb) of parallel 1..4, then 24 fricationAmplitude, 44 preFormantGain, pa1..4 (37..40)
@@ -770,6 +882,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         stage_frame_init(f, live, lds + L::kFrames3, lane);
         double fricNoise = 0.0;
         uint32_t noiseIdx = 1;
+        constexpr int GR3[4] = {8, 9, 10, 11};
+        if (STREAM && live) {
+            if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseIdx = (uint32_t)streamState[221] + 1u; }
+            stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR3, streamPurge);
+        }
         auto dsp = [&](double& yOut) __attribute__((always_inline)) -> double {
             fricNoise = noise_uniform(nkey, noiseIdx) + 0.75 * fricNoise;
             noiseIdx += 2u;
@@ -789,6 +906,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         RUN_STAGE(1, f, nullptr, nullptr, D, false, S3_BODY, (void)0, (void)0, S3_EMIT, (void)0, false, 0.0)
 #undef S3_BODY
 #undef S3_EMIT
+        if (STREAM && live) { stage_state_save<D>(f, nullptr, streamState, P, GR3); streamState[211] = fricNoise; }
     } else if (!NOISE && stage == 2) {
         // ================= quiet S2: r5, r4, r3 =================
         using D = StageDesc<6, 3, -1, false, false>;
@@ -821,6 +939,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         constexpr int OUTGAIN = NOISE ? 13 : (NASAL ? 4 : 0);
         StageFrame<NPAR, NR> f;
         stage_frame_init(f, live, lds + (NOISE ? L::kFrames2 : L::kFrames3), lane);
+        constexpr int GRF[5] = {5, 6, 7, 12, 13};
+        if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GRF, streamPurge);
         int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
 
         auto finish = [&](double o, double y, double part) __attribute__((always_inline)) -> uint32_t {
@@ -881,6 +1001,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
 #define FIN_CHUNK do { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); } while (0)
         RUN_STAGE((NOISE ? 2 : 3), f, nullptr, nullptr, D, false, FIN_BODY, (f.produced += runLen), (f.produced += runLen), FIN_EMIT, FIN_CHUNK, kPre, FIN_IN0(c, i))
         if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
+        if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GRF);
 #undef FIN_IN
 #undef FIN_IN0
 #undef FIN_IN12

@@ -9,6 +9,7 @@ interface (include/speechPlayer_batch.h): many frame streams, one kernel launch.
 Everything here calls the HIP library through its C-ABI; there is no CPU path.
 """
 from ctypes import POINTER, Structure, byref, c_double, c_int, c_short, c_void_p, cast
+from ctypes import c_longlong as ctypes_longlong
 
 import numpy as np
 
@@ -89,28 +90,53 @@ class SpeechPlayer(object):
         return self._dll.speechPlayer_getLastIndex(self._speechHandle)
 
     @staticmethod
-    def synthesizeMany(players, numSamples):
+    def synthesizeMany(players, numSamples, out=None):
         """Advance many live players together in one kernel launch (speechPlayer_synthesizeMany).
-        Returns a list with what each player's synthesize(numSamples) would have returned."""
+        Returns a list with what each player's synthesize(numSamples) would have returned.  With `out` (a C-contiguous int16
+        array [len(players), >= numSamples]) the samples land in its rows instead and the return value is the array of
+        per-player sample counts (no buffer is allocated per player and pull)."""
         n = len(players)
         if n == 0:
             return []
         dll = players[0]._dll
         handles = (c_void_p * n)(*[p._speechHandle for p in players])
+        produced = (c_int * n)()
+        if out is not None:
+            if out.dtype != np.int16 or out.ndim != 2 or out.shape[0] < n or out.shape[1] < numSamples or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous int16 array [n, >= numSamples]")
+            ptrs = (out.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(out.strides[0])).astype(np.uint64)
+            rc = dll.speechPlayer_synthesizeMany(handles, n, numSamples, ptrs.ctypes.data, produced)
+            if rc != 0:
+                raise RuntimeError("speechPlayer_synthesizeMany failed: %s" % _native.last_error())
+            return np.frombuffer(produced, dtype=np.int32).copy()
         bufs = [(c_short * numSamples)() for _ in range(n)]
         ptrs = (c_void_p * n)(*[cast(b, c_void_p) for b in bufs])
-        produced = (c_int * n)()
         rc = dll.speechPlayer_synthesizeMany(handles, n, numSamples, ptrs, produced)
         if rc != 0:
             raise RuntimeError("speechPlayer_synthesizeMany failed: %s" % _native.last_error())
-        out = []
+        res = []
         for b, got in zip(bufs, produced):
             if got > 0:
                 b.length = min(got, len(b))
-                out.append(b)
+                res.append(b)
             else:
-                out.append(None)
-        return out
+                res.append(None)
+        return res
+
+    @staticmethod
+    def synthesizeManyDevice(players, numSamples):
+        """The same, PCM left in HBM (speechPlayer_synthesizeManyDevice): -> (device pointer, row stride in samples,
+        produced[n]).  Row i holds produced[i] samples of players[i]."""
+        n = len(players)
+        dll = players[0]._dll
+        handles = (c_void_p * n)(*[p._speechHandle for p in players])
+        produced = (c_int * n)()
+        ptr = c_void_p()
+        stride = ctypes_longlong()
+        rc = dll.speechPlayer_synthesizeManyDevice(handles, n, numSamples, byref(ptr), byref(stride), produced)
+        if rc != 0:
+            raise RuntimeError("speechPlayer_synthesizeManyDevice failed: %s" % _native.last_error())
+        return ptr.value, stride.value, np.frombuffer(produced, dtype=np.int32).copy()
 
     def close(self):
         if getattr(self, "_speechHandle", None):

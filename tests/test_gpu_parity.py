@@ -879,3 +879,73 @@ def test_one_batch_over_several_devices(ref, all_scenarios):
     with pytest.raises(RuntimeError, match="out of range|failed"):
         node.read(n)
     node.close(); one.close()
+
+
+def test_live_handles_on_both_kernels(all_scenarios, ref):
+    """Live handles advance on the stage-parallel kernel's STREAM instantiation by default (every stage restores and saves its slice
+    of the handle's 240-double state) and on the lane kernel when asked (speechPlayer_setGlobalOption("live_layout", 0)).  The
+    saved state is one format: the streaming scenarios (chunked pulls of 1..8192 samples, purge in steady state and inside a
+    fade, drain and resume, vibrato, NaN holds) must equal the oracle call by call on either kernel AND when the kernel
+    changes between pulls of the same handle; 200 handles pulled together (more than three workgroups) likewise."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    names = ("cfg0_a_1s", "stream_chunks", "purge_resume", "vowelchart_pairs", "hannah_vibrato", "nan_hold", "duration_edges")
+    try:
+        for policy in ("stage", "lane", "alternate"):
+            pulls = [0]
+
+            def before_pull():
+                if policy == "alternate":
+                    assert L.speechPlayer_setGlobalOption(b"live_layout", pulls[0] % 2) == 0
+                pulls[0] += 1
+            assert L.speechPlayer_setGlobalOption(b"live_layout", 0 if policy == "lane" else 1) == 0
+            for scn in all_scenarios:
+                if scn.name not in names:
+                    continue
+                exp_pcm, exp_marks = scenarios.play_oracle(scn)
+                p = eng.SpeechPlayer(scn.sr, noiseSeed=scn.seed)
+                got_pcm, got_marks = [], []
+
+                def synth(n):
+                    before_pull()
+                    buf = p.synthesize(n)
+                    return np.zeros(0, np.int16) if buf is None else np.frombuffer(buf, dtype=np.int16)[:buf.length].copy()
+                for op in scn.ops:
+                    if op[0] == "q":
+                        p.queueFrameSamples(None if op[1] is None else eng.Frame.from_array(op[1]), op[2], op[3], op[4], op[5])
+                    elif op[0] == "s":
+                        got_pcm.append(synth(op[1])); got_marks.append(p.getLastIndex())
+                    else:
+                        parts = []
+                        while True:
+                            x = synth(1000 + 37 * len(parts))            # ragged pulls, not multiples of the hand-over size
+                            parts.append(x)
+                            if len(x) < 1000 + 37 * (len(parts) - 1):
+                                break
+                        got_pcm.append(np.concatenate(parts)); got_marks.append(p.getLastIndex())
+                p.close()
+                assert [len(x) for x in got_pcm] == [len(x) for x in exp_pcm], (policy, scn.name)
+                assert got_marks == exp_marks, (policy, scn.name)
+                assert np.array_equal(np.concatenate(got_pcm), np.concatenate(exp_pcm)), (policy, scn.name)
+        # many handles together, the kernel changing between pulls
+        rng = np.random.default_rng(17)
+        cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=200)]
+        players = [eng.SpeechPlayer(22050, noiseSeed=900 + k) for k in range(len(cases))]
+        oracles = [oracle.OraclePlayer(22050, seed=900 + k) for k in range(len(cases))]
+        for k, case in enumerate(cases):
+            for j, (fr, m, f) in enumerate(case):
+                players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, j)
+                oracles[k].queue(fr, m, f, j)
+        for step, n in enumerate((4097, 13, 8192, 8192, 5000, 8192, 8192, 8192)):
+            assert L.speechPlayer_setGlobalOption(b"live_layout", (step + 1) % 2) == 0
+            bufs = eng.SpeechPlayer.synthesizeMany(players, n)
+            for k, b in enumerate(bufs):
+                e = oracles[k].synthesize(n)
+                g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
+                assert np.array_equal(g, e), (step, k, len(g), len(e))
+                assert players[k].getLastIndex() == oracles[k].last_index(), (step, k)
+        for p in players:
+            p.close()
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_layout", 1)

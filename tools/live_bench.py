@@ -1,37 +1,64 @@
 #!/usr/bin/env python3
-"""How fast do N LIVE handles advance when pulled together (speechPlayer_synthesizeMany) vs one by one?"""
+"""How fast do N LIVE handles advance when pulled together (speechPlayer_synthesizeMany)?
+Three figures per run: the kernel alone (HIP events around the launch), the call with the PCM left in HBM
+(speechPlayer_synthesizeManyDevice: upload of the queued frames + kernel + results), and the call that hands every handle
+its samples in a host buffer (PCIe copy of n x 8192 x 2 bytes + a memcpy per handle)."""
 import os
 import sys
 import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import nvspeechplayer_amd as eng
-from nvspeechplayer_amd import ipa
+from nvspeechplayer_amd import ipa, _native
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 chunk = 8192
+pulls = 6
 text = "mɑɪ næɪm ɪz mɑɪkʊl dæɪmɪən kɑɹən"
 frames = list(ipa.generateFramesAndTiming(text, clauseType="."))
-players = [eng.SpeechPlayer(22050, noiseSeed=k) for k in range(n)]
+L = _native.load()
+
+
+def fresh():
+    players = [eng.SpeechPlayer(22050, noiseSeed=k) for k in range(n)]
+    for p in players:
+        for _ in range(3):
+            for fr, d, f in frames:
+                p.queueFrame(fr, d, f)
+    return players
+
+
+players = fresh()
+eng.SpeechPlayer.synthesizeManyDevice(players, 64)      # warm-up
+t0 = time.perf_counter()
+total, kms = 0, 0.0
+for _ in range(pulls):
+    _, _, produced = eng.SpeechPlayer.synthesizeManyDevice(players, chunk)
+    total += int(produced.sum())
+    kms += L.speechPlayer_lastLiveKernelMs(0)
+dt = time.perf_counter() - t0
+print("%d live handles, %d-sample pulls, layout %s: kernel %.2f ms per pull = %.3g samples/s; call with PCM left in HBM %.2f ms = %.3g samples/s" % (
+    n, chunk, os.environ.get("SPEECHPLAYER_LIVE_LAYOUT", "1"), kms / pulls, total / (kms * 1e-3), dt / pulls * 1e3, total / dt), flush=True)
 for p in players:
-    for _ in range(4):
-        for fr, d, f in frames:
-            p.queueFrame(fr, d, f)
-eng.SpeechPlayer.synthesizeMany(players, 64)      # warm-up
+    p.close()
+players = fresh()
+eng.SpeechPlayer.synthesizeMany(players, 64)
+out = np.zeros((n, chunk), dtype=np.int16)
 t0 = time.perf_counter()
 total = 0
-for _ in range(8):
-    bufs = eng.SpeechPlayer.synthesizeMany(players, chunk)
-    total += sum(b.length for b in bufs if b is not None)
+for _ in range(pulls):
+    total += int(eng.SpeechPlayer.synthesizeMany(players, chunk, out=out).sum())
 dt = time.perf_counter() - t0
-print("%d live handles, %d-sample pulls together: %.3g samples/s (%.0f x real time per stream), %.1f ms per pull" % (
-    n, chunk, total / dt, total / dt / n / 22050, dt / 8 * 1e3))
+print("    PCM to per-handle host buffers: %.1f ms per pull = %.3g samples/s (%.0f x real time per stream)" % (dt / pulls * 1e3, total / dt, total / dt / n / 22050), flush=True)
 few = players[:8]
+for p in few:
+    for fr, d, f in frames:
+        p.queueFrame(fr, d, f)
 t0 = time.perf_counter()
 tot2 = 0
-for _ in range(4):
+for _ in range(2):
     for p in few:
         b = p.synthesize(chunk)
         tot2 += b.length if b is not None else 0
 dt2 = time.perf_counter() - t0
-print("one handle per call: %.3g samples/s (%.0f x real time), %.2f ms per 8192-sample pull" % (tot2 / dt2, tot2 / dt2 / 22050, dt2 / (4 * len(few)) * 1e3))
+print("    one handle per call: %.2f ms per 8192-sample pull (%.0f x real time)" % (dt2 / (2 * len(few)) * 1e3, tot2 / dt2 / 22050), flush=True)

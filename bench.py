@@ -60,11 +60,11 @@ def parse(argv=None):
 
 
 def engine_source_digest():
-    """Identifies the kernels a PMC file was collected from: sha1 over csrc/*.h, *.hip, *.inc, *.cpp."""
+    """Identifies the kernels a PMC file was collected from: sha1 over the kernel sources csrc/klatt_*.h and klatt_engine.hip."""
     csrc = os.path.join(ROOT, "nvspeechplayer_amd", "csrc")
     h = hashlib.sha1()
     for f in sorted(os.listdir(csrc)):
-        if f.endswith((".h", ".hip", ".cpp", ".inc")):
+        if f.startswith("klatt_") and f.endswith((".h", ".hip")):
             h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())
     return h.hexdigest()[:16]
 

@@ -373,6 +373,8 @@ class NodePlayer(object):
             self._check(self._dll.speechPlayer_node_wait(self._h))
 
     def read(self, u):
+        if not 0 <= u < self.nUtterances:
+            raise RuntimeError("NodePlayer.read: utterance %d out of range" % u)
         n = int(self._lens[u])
         buf = np.zeros(max(n, 1), dtype=np.int16)
         got = self._check(self._dll.speechPlayer_node_read(self._h, u, buf.ctypes.data, n))

@@ -949,3 +949,37 @@ def test_live_handles_on_both_kernels(all_scenarios, ref):
             p.close()
     finally:
         L.speechPlayer_setGlobalOption(b"live_layout", 1)
+
+
+def test_quiet_classification_needs_finite_parallel_coefficients(ref):
+    """an utterance with zero noise gains skips the parallel bank only while the bank's coefficients stay finite. A large
+    negative parallel bandwidth makes exp(-pi bw / sr) overflow: a = inf, a * 0 = NaN, and the reference's clip turns NaN into
+    32000.  Such utterances must run the full (noisy) kernel -- in every layout -- and equal the oracle."""
+    import nvspeechplayer_amd as eng
+    base = scenarios.vowel_frame(ref, "a", 120.0)
+    assert base[3] == 0 and base[6] == 0 and base[24] == 0                    # a quiet frame
+    cases = []
+    for idx, value in ((31, -8.0e6), (34, -6.0e6), (36, -2.0e7), (33, 2.0e6), (25, 3.0e6), (31, -100.0), (31, 0.0), (25, -5000.0)):
+        f = base.copy(); f[idx] = value
+        cases.append(f)
+    streams = [[(f, 600, 100), (base, 500, 200), (None, 100, 100)] for f in cases] + [[(base, 400, 100), (f, 500, 200), (None, 100, 100)] for f in cases]
+    frames = np.stack([np.zeros(47) if f is None else f for st in streams for f, _, _ in st])
+    m = [x[1] for st in streams for x in st]; fd = [x[2] for st in streams for x in st]
+    nul = [x[0] is None for st in streams for x in st]
+    start = np.arange(len(streams) + 1) * 3
+    exp = []
+    for u, st in enumerate(streams):
+        o = oracle.OraclePlayer(22050, seed=u)
+        for f, mm, ff in st:
+            o.queue(f, mm, ff)
+        exp.append(o.drain())
+    assert sum(bool((e == 32000).any()) for e in exp) >= 6                     # the overflowing ones clip
+    for layout in (-1, 2, 1, 0):
+        bp = eng.BatchPlayer(22050, layout=layout)
+        bp.setUtterances(start, frames, m, fd, None, nul, np.arange(len(streams)))
+        info = bp.kernelInfo()
+        bp.synthesize()
+        for u in range(len(streams)):
+            got = bp.read(u)
+            assert np.array_equal(got, exp[u]), (layout, u, int(np.count_nonzero(got != exp[u])))
+        bp.close()

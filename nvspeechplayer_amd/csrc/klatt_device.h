@@ -156,6 +156,25 @@ struct Coef { double a, b, c; };
 // points (fade_classes in klatt_systolic.h): the ballots and the VALU -> SALU -> branch round trips per evaluation are
 // what the short paths cost most.
 enum { COEF_UNREDUCED = 0, COEF_QUADRANT_M1 = 1, COEF_UNKNOWN = 2 };
+#ifndef KLATT_COLD_CALL
+#define KLATT_COLD_CALL 2
+#endif
+#if KLATT_COLD_CALL
+// exp and cos OUTSIDE the validated range of klatt_math.h (|arg| > 700 / 1e4: no frame a speech front-end produces): the device
+// library's, out of line.  Inlined, its two dozen polynomial and reduction constants are materialised in the kernel's prologue and
+// kept in registers through the hot loops (a 64-bit literal is no VALU operand on gfx950; see profiles/r2_isa_coefficient_block.txt):
+// with the call the noisy stage kernel is 137 KB instead of 262 KB and spills 96 instead of 160 bytes per lane; cfg2 15.05 -> 14.6 ms,
+// rotated 58.5 -> 55 ms, cfg3 14.8 -> 14.3, cfg4 9.84 -> 9.47 (tools/ab_probe.py).  KLATT_COLD_CALL = 1 moves the range-reduced
+// fast_exp / fast_cos out of line as well: better still on aligned batches (14.4 ms), worse where lanes fade apart (62 ms).
+__device__ __attribute__((noinline)) void exp_cos_reduced(double ex, double th, double* rad, double* cs)
+{
+#if KLATT_COLD_CALL == 1
+    if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { *rad = fast_exp(ex); *cs = fast_cos(th); }
+    else
+#endif
+    { *rad = exp(ex); *cs = cos(th); }
+}
+#endif
 template <int MODE>
 __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr,
                                                               int cls = COEF_UNKNOWN)
@@ -173,8 +192,15 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
     else if (cls == COEF_QUADRANT_M1) { rad = exp_unreduced(ex); cs = cos_quadrant_m1(th); }
     else if (__all(eu && cos_is_unreduced(th))) { rad = exp_unreduced(ex); cs = cos_unreduced(th); }
     else if (__all(eu && cos_is_quadrant_m1(th))) { rad = exp_unreduced(ex); cs = cos_quadrant_m1(th); }   // F3 and up
+#if KLATT_COLD_CALL == 1
+    else exp_cos_reduced(ex, th, &rad, &cs);
+#elif KLATT_COLD_CALL == 2
+    else if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
+    else exp_cos_reduced(ex, th, &rad, &cs);
+#else
     else if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
     else { rad = exp(ex); cs = cos(th); }
+#endif
     double cc = -(rad * rad);
     double bb = rad * cs * 2.0;
     double aa = 1.0 - bb - cc;

@@ -18,6 +18,9 @@
  *   src/speechWaveGenerator.cpp:197-214 (mix, gain, clip, int16 store)
  *   src/speechPlayer.cpp:25-53          (C-ABI shim, fade clamp >= 1)
  *
+ * PARITY UNPINNED in the sense of this build's rules: the reference holds no tests, golden vectors or fixtures
+ * for this path, and the reference cannot be compiled here without a stand-in <windows.h>
+ * (not allowed), so neither of the accepted pins exists.  What there is:
  * Pinning: tests/test_oracle_pin.py checks this file against the known-answer
  * values SURVEY.md section 8(c) recorded from the compiled reference (cfg0 SHA-1,
  * first samples, min/max; the eight sampleIpa.txt lines' lengths and SHA-1

@@ -514,6 +514,10 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
 {
     for (int i = 0; i < n; ++i) produced[i] = 0;
     if (count == 0 || n <= 0) return 0;
+    static const bool trace = getenv("SPEECHPLAYER_LIVE_TRACE") != nullptr;     // host-side breakdown of a call on stderr
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const auto t0 = now();
     const int device = ss[0]->device, rate = ss[0]->sampleRate, mode = ss[0]->mode;
     for (int i = 1; i < n; ++i)
         if (ss[i]->device != device || ss[i]->sampleRate != rate || ss[i]->mode != mode) {
@@ -562,6 +566,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         c->hControl[i] = ss[i]->purgePending ? 1u : 0u;
         c->hStatePtrs[i] = ss[i]->dState.ptr;
     }
+    const auto t1 = now();
     if (c->dFrames.reserve(std::max<size_t>(nf, 64) * kNumParams) || c->dMeta.reserve(std::max<size_t>(nf, 64)) ||
         c->dUtt.reserve(n) || c->dOrder.reserve(n) || c->dControl.reserve(n) || c->dResult.reserve(n) ||
         c->dStatePtrs.reserve(n) || c->dPcm.reserve(padded * n))
@@ -597,6 +602,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
 
     HIP_TRY(hipMemcpyAsync(c->hResult.data(), c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    const auto t2 = now();
     (void)hipEventElapsedTime(&c->lastKernelMs, c->kernelStart, c->kernelStop);
     c->lastStride = padded;
     if (devicePcm) *devicePcm = c->dPcm.ptr;
@@ -633,6 +639,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
             }
         }
     }
+    const auto t3 = now();
     for (int i = 0; i < n; ++i) {
         Stream* s = ss[i];
         const UttResult& r = c->hResult[i];
@@ -643,6 +650,9 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         s->lastIndex = r.lastIndex;
         produced[i] = (int)r.produced;
     }
+    if (trace)
+        fprintf(stderr, "[speechPlayer/live] %d handles x %u: stage frames %.2f ms | upload + kernel (%.2f ms) + results %.2f ms | PCM to host %.2f ms | bookkeeping %.2f ms\n",
+                n, count, ms(t0, t1), c->lastKernelMs, ms(t1, t2), ms(t2, t3), ms(t3, now()));
     return 0;
 }
 

@@ -1,0 +1,43 @@
+// Sanitizer run of the frame producer (nvspeechplayer_amd/csrc/frame_producer.cpp) on the CPU: random symbol soup -- tie bars, stress
+// and length marks in any position, unknown symbols, invalid UTF-8, every clause type and voice -- through speechPlayer_ipa_frames and
+// speechPlayer_ipa_pack under AddressSanitizer + UBSan (tests/test_ipa_producer.py builds and runs it).  The two batch entry points the
+// producer calls are stubbed: this links no GPU code.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include <random>
+#include "speechPlayer_batch.h"
+extern "C" int speechPlayer_batch_sampleRate(speechPlayer_batch_t) { return 22050; }
+extern "C" int speechPlayer_batch_setUtterances(speechPlayer_batch_t, long long, const long long*, const speechPlayer_frame_t*, const unsigned int*, const unsigned int*, const int*, const unsigned char*, const unsigned int*) { return 0; }
+int main() {
+    std::mt19937 rng(1);
+    const char* alphabet[] = {"a","h","t","\xcd\xa1","\xca\x83","\xcb\x88","\xcb\x8c","\xcb\x90"," ","p","s","z","m","n","l","j","w","\xc9\x91","\xc3\xa6","i","u","#","\xff","\xc9","d","\xca\x92","k","b","\xc9\xb9","\xc5\x8b"};
+    const int na = sizeof alphabet / sizeof *alphabet;
+    long long total = 0;
+    for (int iter = 0; iter < 40000; ++iter) {
+        std::string s;
+        int len = rng() % 24;
+        for (int i = 0; i < len; ++i) s += alphabet[rng() % na];
+        const char clause = ".,?!\0"[rng() % 5];
+        const char* voices[] = {nullptr, "Adam", "Benjamin", "Caleb", "David", "x"};
+        const char* v = voices[rng() % 6];
+        long long n = speechPlayer_ipa_frames(s.c_str(), 0.5 + (rng() % 20) / 10.0, 60 + rng() % 200, (rng() % 10) / 10.0, clause, v, nullptr, nullptr, nullptr, nullptr, 0);
+        if (n > 0) {
+            std::vector<speechPlayer_frame_t> fr(n); std::vector<unsigned char> nu(n); std::vector<double> d(n), f(n);
+            long long m = speechPlayer_ipa_frames(s.c_str(), 1.0, 100, 0.5, clause, v, fr.data(), nu.data(), d.data(), f.data(), n);
+            if (m != n && !(v && !strcmp(v, "x"))) { printf("mismatch\n"); return 1; }
+            total += n;
+        }
+    }
+    // batch packer with duplicates and empties
+    std::vector<const char*> texts;
+    for (int i = 0; i < 3000; ++i) texts.push_back(alphabet[i % na]);
+    std::vector<long long> start(texts.size() + 1);
+    long long tot = speechPlayer_ipa_pack(16000, (long long)texts.size(), texts.data(), 1.0, nullptr, 0.5, nullptr, "Adam", 150.0, start.data(), nullptr, nullptr, nullptr, nullptr, 0);
+    std::vector<speechPlayer_frame_t> fr(tot); std::vector<unsigned> mi(tot), fa(tot); std::vector<unsigned char> nu(tot);
+    long long tot2 = speechPlayer_ipa_pack(16000, (long long)texts.size(), texts.data(), 1.0, nullptr, 0.5, nullptr, "Adam", 150.0, start.data(), fr.data(), mi.data(), fa.data(), nu.data(), tot);
+    printf("ok %lld frames fuzzed, pack %lld %lld\n", total, tot, tot2);
+    return tot == tot2 ? 0 : 1;
+}

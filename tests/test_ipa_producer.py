@@ -112,3 +112,17 @@ def test_unknown_symbols_stress_and_ties():
     # invalid UTF-8 is an unknown symbol, not a crash
     L = __import__("nvspeechplayer_amd")._native.load()
     assert L.speechPlayer_ipa_frames(b"h\xff\xfe\xe6lou", 1.0, 100.0, 0.5, 0, None, None, None, None, None, 0) >= 3
+
+
+def test_producer_under_sanitizers(tmp_path):
+    """The producer takes text from outside: 40 000 random symbol sequences (invalid UTF-8 included) and a packed batch with
+    duplicates and empty texts run clean under AddressSanitizer + UndefinedBehaviorSanitizer (CPU build of the same source)."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "fuzz_producer")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           "-I", os.path.join(root, "include"), os.path.join(root, "tests", "native", "fuzz_producer.cpp"),
+                           os.path.join(root, "nvspeechplayer_amd", "csrc", "frame_producer.cpp"), "-o", exe])
+    out = subprocess.check_output([exe], stderr=subprocess.STDOUT).decode()
+    assert out.startswith("ok ") and "runtime error" not in out and "AddressSanitizer" not in out, out

@@ -114,6 +114,14 @@ def test_workload_recipes():
     assert np.array_equal(e2["frames"], e["frames"][2 * len(c["min"]):])         # variants are reproducible
     s = c.slice(3, 5)
     assert s.n_utt == 5 and np.array_equal(s.sample_counts(), c.sample_counts()[3:8])
+    # lengths without frames (what the ranks of a node use to deal shards), and pieces of the flat cfg4 list
+    for wl in ("cfg1", "cfg2", "cfg3", "cfg4"):
+        assert np.array_equal(workloads.make(wl, 300, first=1000).sample_counts(), workloads.sample_counts(wl, 300, 1000)), wl
+    whole = workloads.cfg4_voice_variants(3, 1024)
+    piece = workloads.make("cfg4", 1500, first=700)
+    fs = whole["frame_start"]
+    assert np.array_equal(piece["frames"], whole["frames"][fs[700]:fs[2200]]) and np.array_equal(piece["seeds"], whole["seeds"][700:2200])
+    assert workloads.PER_GPU == {"cfg1": 4096, "cfg2": 65536, "cfg3": 125000, "cfg4": 32 * 16384}      # BASELINE configs[3] / 8, configs[4] / 8
 
 
 def test_shard_bounds():

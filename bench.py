@@ -143,13 +143,31 @@ def spawn_ranks(n, argv):
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    sys.stdout.write(out.decode("utf8", "replace"))
-    sys.stdout.flush()
+    # rank 0's output is read on a thread so that the loop below can watch every rank: if one dies, the others would wait
+    # in a barrier for ever -- they are ended (by PID: these are our own children) and the failure is reported
+    import threading
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
     rc = 0
+    while any(p.poll() is None for p in procs):
+        failed = [p for p in procs if p.poll() not in (None, 0)]
+        if failed:
+            rc = max(abs(p.returncode) for p in failed)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
     for p in procs:
-        p.wait()
-        rc = max(rc, abs(p.returncode))
+        try:
+            p.wait(timeout=30)
+        except subprocess.TimeoutExpired:
+            p.kill()
+        rc = max(rc, abs(p.returncode or 0))
+    reader.join(timeout=10)
+    sys.stdout.write(b"".join(c for c in chunks if c).decode("utf8", "replace"))
+    sys.stdout.flush()
     return rc
 
 

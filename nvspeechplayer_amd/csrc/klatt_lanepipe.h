@@ -60,184 +60,9 @@ __device__ __forceinline__ double wave_ror1(double v)
     return __hiloint2double(hi, lo);
 }
 
-// The chunk loop of one pipeline element (a wave).  Same structure and barrier discipline as RUN_STAGE of
-// klatt_systolic.h: `nIter` iterations in every wave, one __syncthreads() each; a wave of depth d works on chunk
-// iter - d.  Per chunk one of three wave-uniform paths: all live lanes steady (unrolled, inputs optionally
-// preloaded), all fading, or sample by sample (events, mixed lanes, lanes still waiting out their start delay).
-//   begin(kind)              before the chunk's samples (wave-uniform set-up); true selects `alt` for a steady chunk
-//   preIn(c, i)              LDS input of sample i (steady path with PRE: all CH loads issued up front)
-//   body(c, i, steady, pre)  one sample in a steady / fading chunk
-//   alt(c, i, pre)           one sample of a steady chunk, alternative straight-line version
-//   fadeAlt(c, lerp, gainOnly)  a whole fading chunk, straight-line; returns false to decline
-//   gen(c, i, emit)          one sample on the general path
-// The steady paths are branch-free so that a whole chunk is one basic block (no EXEC changes: a masked store costs a
-// lone wave ~11 ns), and steady and fading stretches are decided once and then run in tight loops of their own (chunk,
-// barrier, chunk, ...): the structurised three-way chunk loop costs ~6 ns per sample in register shuffles and
-// VALU -> SALU -> branch round trips (tools/ubench_lanepipe.hip, tools/len_probe.py).
-template <class D, int MODE, int CH, bool PRE, class SF, class FForce, class FBegin, class FPre, class FBody, class FAlt, class FFadeAlt, class FGen,
-          class FSteadyDone, class FFadeDone, class FChunk>
-__device__ __forceinline__ void lp_run(int depth, int nIter, int nChunks, SF& f, PitchState* ps, int32_t* lastIndex, uint32_t& delay,
-                                       const int* P, const int* RF, const int* RB, const StageCtx& X,
-                                       FForce forceGeneral, FBegin begin, FPre preIn, FBody body, FAlt alt, FFadeAlt fadeAlt, FGen gen,
-                                       FSteadyDone steadyDone, FFadeDone fadeDone, FChunk perChunk)
-{
-#ifdef KLATT_STAMPS
-    Stamps st;
-#endif
-    // one whole steady chunk (the live lanes): inputs preloaded, CH samples straight-line
-    auto steadyChunk = [&](int c, bool useAlt) __attribute__((always_inline)) {
-        if (!f.done) {
-            double pre[PRE ? CH : 1];
-            if (PRE) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) pre[i] = preIn(c, i);
-            }
-            if (useAlt) {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) alt(c, i, PRE ? pre[i] : 0.0);
-            } else {
-#pragma unroll
-                for (int i = 0; i < CH; ++i) body(c, i, true, PRE ? pre[i] : 0.0);
-            }
-            f.cnt += CH;
-            steadyDone(CH);
-        }
-    };
-    for (int iter = 0; iter < nIter; ++iter) {
-        STAMP_BEGIN();
-        int c = iter - depth;
-        if (c >= 0 && c < nChunks) {
-            int kind = forceGeneral() ? -1 : chunk_kind<CH>(f);
-            if (kind == 1 && nan_target_live(f)) kind = -1;   // "hold" targets: sample by sample, with the NaN test
-            bool lerp = false, gainOnly = false;
-            uint32_t wRes = 0;
-            if (kind == 1) {
-                lerp = __any(!f.done && f.parMask != 0u);
-                gainOnly = D::GAIN >= 0 && !__any(!f.done && (f.parMask & ~(1u << (D::GAIN >= 0 ? D::GAIN : 0))) != 0u);
-                wRes = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(f.done ? 0u : f.resMask);
-                if (!D::PITCH && !lerp && wRes == 0u) kind = 0;   // nothing of this element moves: a steady chunk for it
-            }
-            STAMP_KIND(kind);
-            const bool useAlt = begin(kind);
-            if (kind == 0) {
-                // A steady stretch is decided once (steady_run: the minimum over the live lanes of chunks left in it):
-                // its chunks run in a tight loop of their own -- preload, straight-line block, barrier -- with the
-                // same count of barriers as the outer loop would execute.  (Nothing but the sample counter changes in
-                // a steady chunk, and begin()'s verdict holds for the stretch: a lane's glide increment is constant.)
-                uint32_t run = __any(!f.done && f.hasNew) ? 1u : steady_run<CH>(f);     // a fade that moves nothing here: chunk by chunk
-                const uint32_t room = (uint32_t)(nChunks - c);
-                run = run < room ? run : room;
-                for (uint32_t q = 1; q < run; ++q) {
-                    steadyChunk(c, useAlt);
-                    perChunk();
-                    STAMP_WORKED();
-                    __syncthreads();
-                    STAMP_SYNCED();
-                    STAMP_BEGIN();
-                    ++iter; ++c;
-                }
-                steadyChunk(c, useAlt);
-            } else if (kind == 1) {
-                // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
-                auto fadeChunk = [&](int c) __attribute__((always_inline)) {
-                    if (!f.done) {
-                        if (!fadeAlt(c, lerp, gainOnly)) {
-#pragma unroll 2
-                            for (int i = 0; i < CH; ++i) {
-                                f.cnt++;
-                                stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly);
-                                body(c, i, false, 0.0);
-                            }
-                        }
-                        fadeDone(CH);
-                    }
-                };
-                uint32_t run = fade_run<CH>(f);
-                const uint32_t room = (uint32_t)(nChunks - c);
-                run = run < room ? run : room;
-                for (uint32_t q = 1; q < run; ++q) {
-                    fadeChunk(c);
-                    perChunk();
-                    STAMP_WORKED();
-                    __syncthreads();
-                    STAMP_SYNCED();
-                    STAMP_BEGIN();
-                    ++iter; ++c;
-                }
-                fadeChunk(c);
-            } else {
-                // A chunk with an event in it: [uniform run][event steps][uniform run].  Only the event steps need
-                // the state machine sample by sample; whenever every live lane is inside a steady stretch (or every one
-                // inside a fade, past its first sample) the next n = min over the lanes of samples left in the stretch
-                // run as a rolled loop of the steady / fading body.  n comes from a bisection with ballots.
-                int i = 0;
-#pragma nounroll
-                while (i < CH) {
-                    int n = 0, kr = 0;
-                    if (!forceGeneral()) {
-                        const bool fad = f.hasNew;
-                        const uint32_t rem = f.done ? 0xFFFFFFFFu : (fad ? f.newFade - f.cnt : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
-                        const bool anyFad = __any(!f.done && fad), anySteady = __any(!f.done && !fad);
-                        if (!(anyFad && anySteady) && !__any(!f.done && fad && f.cnt == 0u) && !(anyFad && nan_target_live(f))) {
-                            const int cap = CH - i;
-#pragma unroll
-                            for (int st = CH; st >= 1; st >>= 1)
-                                if (n + st <= cap && __all(rem >= (uint32_t)(n + st))) n += st;
-                            kr = anyFad ? 1 : 0;
-                        }
-                    }
-                    if (n >= 2) {
-                        bool lerpR = false, gainOnlyR = false;
-                        uint32_t wResR = 0;
-                        if (kr == 1) {
-                            lerpR = __any(!f.done && f.parMask != 0u);
-                            gainOnlyR = D::GAIN >= 0 && !__any(!f.done && (f.parMask & ~(1u << (D::GAIN >= 0 ? D::GAIN : 0))) != 0u);
-                            wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(f.done ? 0u : f.resMask);
-                            if (!D::PITCH && !lerpR && wResR == 0u) kr = 0;
-                        }
-                        if (!f.done) {
-                            if (kr == 0) {
-#pragma nounroll
-                                for (int j = i; j < i + n; ++j) body(c, j, true, 0.0);
-                                f.cnt += (uint32_t)n;
-                                steadyDone(n);
-                            } else {
-#pragma nounroll
-                                for (int j = i; j < i + n; ++j) {
-                                    f.cnt++;
-                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR, gainOnlyR);
-                                    body(c, j, false, 0.0);
-                                }
-                                fadeDone(n);
-                            }
-                        }
-                        i += n;
-                        continue;
-                    }
-                    // a lane that has not started yet (pipeline skew) sits this step out
-                    const bool hold = delay > 0u;
-                    const bool wasDone = f.done;
-                    if (hold) { delay--; f.done = true; }
-                    const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
-                    if (hold) f.done = wasDone;
-                    gen(c, i, emit);
-                    ++i;
-                }
-            }
-            perChunk();
-        }
-        STAMP_WORKED();
-        __syncthreads();
-        STAMP_SYNCED();
-    }
-#ifdef KLATT_STAMPS
-    if (X.A.debug && (threadIdx.x & (kLanes - 1)) == 0) {
-        unsigned long long* o = X.A.debug + (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8;
-        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
-    }
-#endif
-}
-
+// The chunk loop of every pipeline element is stage_loop of klatt_systolic.h (steady / fading / sample-by-sample paths, one barrier
+// per chunk).  The steady paths here are branch-free so that a whole chunk is one basic block (no EXEC changes: a masked store
+// costs a lone wave ~11 ns); tools/ubench_lanepipe.hip, tools/len_probe.py and DESIGN.md section 4.3 have the measurements.
 template <int MODE, int CH, int WPS>
 __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const KernelArgs A)
 {
@@ -319,7 +144,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
         auto vib_live_now = [&]() __attribute__((always_inline)) -> bool {
             return vibFrames || f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase;
         };
-        lp_run<D, MODE, CH, false>(0, nIter, nChunks, f, &ps, &lastIndex, delay, P, RF, RB, X,
+        using K0 = LoopKnobs<false, true, true, false, false, CH>;
+        stage_loop<D, MODE, CH, K0>(0, nIter, nChunks, nChunks, wave, f, &ps, &lastIndex, delay, P, RF, RB, X,
             [&]() { return __any(!f.done && vib_live_now()); },
             [&](int kind) -> bool {
                 if (kind != 0 || __any(!f.done && ps.oldInc != 0.0)) return false;
@@ -329,14 +155,18 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
                 incConst = div_by(ps.cur0 * 1.0, srF, invSr);
                 return true;
             },
+            [&](int c) {
+#pragma unroll
+                for (int i = 0; i < CH; ++i) {
+                    pitchPhase = frac_toward_zero(incConst + pitchPhase);
+                    LP_X(c, i) = finishSource();
+                }
+            },
+            [&](int, int, double) {},
             [&](int, int) { return 0.0; },
             [&](int c, int i, bool steady, double) {
                 if (steady) ps.cur0 += ps.oldInc;
                 LP_X(c, i) = source(false);
-            },
-            [&](int c, int i, double) {
-                pitchPhase = frac_toward_zero(incConst + pitchPhase);
-                LP_X(c, i) = finishSource();
             },
             // a fading chunk in which only the gain (and the pitch) move and no target is NaN: fades into and out of
             // silence (reference src/frame.cpp:59-67); same operations as stage_fade + source with the differences and
@@ -400,22 +230,24 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
         // steady chunks store unconditionally (no EXEC juggling inside the block): last lanes into the ring,
         // the others into a scratch area of the same row pitch
         double* const dummyY = reinterpret_cast<double*>(lds + L::kDummy) + lane;
-        lp_run<D, MODE, CH, true>(1, nIter, nChunks, f, nullptr, nullptr, delay, P, RF, RB, X,
+        using KF = LoopKnobs<true, true, true, false, false, CH>;
+        stage_loop<D, MODE, CH, KF>(1, nIter, nChunks, nChunks, wave, f, nullptr, nullptr, delay, P, RF, RB, X,
             [&]() { return __any(!f.done && delay > 0u); },
             [&](int) -> bool { return true; },
-            [&](int c, int i) { return LP_X(c, i); },
-            [&](int c, int i, bool, double) {
-                double in = wave_ror1(out);
-                if (first) in = LP_X(c, i);
-                out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);
-                if (last) LP_Y(c * CH + i) = out;
-            },
+            [&](int) {},
             [&](int c, int i, double pre) {
                 double in = wave_ror1(out);
                 in = first ? pre : in;
                 out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);
                 double* const yRow = last ? &LP_Y(c * CH) : dummyY;
                 yRow[i * kLpUPG] = out;
+            },
+            [&](int c, int i) { return LP_X(c, i); },
+            [&](int c, int i, bool, double) {
+                double in = wave_ror1(out);
+                if (first) in = LP_X(c, i);
+                out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);
+                if (last) LP_Y(c * CH + i) = out;
             },
             [&](int, bool, bool) -> bool { return false; },
             [&](int c, int i, bool emit) {
@@ -473,12 +305,14 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
-        lp_run<D, MODE, CH, true>(3, nIter, nChunks, f, nullptr, nullptr, delay, P, RF, RB, X,
+        using KE = LoopKnobs<true, true, true, false, false, CH>;
+        stage_loop<D, MODE, CH, KE>(3, nIter, nChunks, nChunks, wave, f, nullptr, nullptr, delay, P, RF, RB, X,
             [&]() { return false; },
             [&](int) -> bool { return true; },
+            [&](int) {},
+            [&](int, int i, double pre) { myRow[(it % L::kT) + i] = (int16_t)finish(pre); },
             [&](int c, int i) { return LP_Y(c * CH + i + kLpSkew); },
             [&](int c, int i, bool, double) { myRow[(it % L::kT) + i] = (int16_t)finish(LP_Y(c * CH + i + kLpSkew)); },
-            [&](int, int i, double pre) { myRow[(it % L::kT) + i] = (int16_t)finish(pre); },
             [&](int, bool, bool) -> bool { return false; },
             [&](int c, int i, bool emit) {
                 if (emit) { myRow[(it % L::kT) + i] = (int16_t)finish(LP_Y(c * CH + i + kLpSkew)); f.produced++; }

@@ -453,6 +453,214 @@ struct Stamps {
 #define STAMP_SYNCED()
 #endif
 
+// ---- the chunk loop of one pipeline element (a wave) ---------------------------------------------------------------
+// Barrier discipline: `nIter` iterations in every wave of the workgroup, one __syncthreads() each; a wave of depth d works on
+// chunk iter - d.  Per chunk one of three wave-uniform paths: every live lane steady (straight-line, inputs optionally
+// preloaded), every live lane fading, or sample by sample (events, mixed lanes, start-up skew, the partial last chunk of
+// a launch of live handles).  Steady and fading stretches are decided once and then run in tight loops of their own (chunk,
+// barrier, chunk, ...) with the barrier count of the outer loop.  The element's program is a set of callables:
+//   forceGeneral()             true: this chunk goes sample by sample whatever the lanes do (vibrato live, start-up skew)
+//   begin(kind)                wave-uniform set-up before a chunk's samples; true selects altChunk for a steady stretch
+//   altChunk(c)                a whole steady chunk, the element's own straight-line version (elements without K::PRE)
+//   altSample(c, i, pre)       one sample of such a chunk, input preloaded (elements with K::PRE)
+//   preIn(c, i)                LDS input of sample i (steady path with K::PRE: all CH loads issued up front)
+//   body(c, i, steady, pre)    one sample in a steady / fading chunk
+//   fadeAlt(c, lerp, gainOnly) a whole fading chunk, straight-line; returns false to decline
+//   gen(c, i, emit)            one sample on the sample-by-sample path, after the state machine has stepped
+//   steadyDone(n) / fadeDone(n)  after n samples of a uniform run
+//   perChunk()                 after every chunk
+// K: compile-time knobs (LoopKnobs).  RUNS: a chunk with an event in it runs [uniform run][event steps][uniform run] -- only
+// the event steps need the state machine sample by sample; the run length comes from a bisection with ballots.  (Off for
+// the noisy kernels: the extra code costs them more than the runs save, cfg2 15.8 -> 16.8 ms.)  DELAY: lanes start `delay`
+// steps late (the lane-pipelined kernel's skew).  STREAM: the launch runs exactly A.maxSamples steps (live handles).
+template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_>
+struct LoopKnobs {
+    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_;
+    static constexpr int UNROLL = UNROLL_;
+};
+
+template <class D, int MODE, int CH, class K, class SF, class FForce, class FBegin, class FAltChunk, class FAltSample, class FPre, class FBody, class FFadeAlt,
+          class FGen, class FSteadyDone, class FFadeDone, class FChunk>
+__device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, int fullChunks, int stampSlot, SF& f, PitchState* ps, int32_t* lastIndex,
+                                           uint32_t& delay, const int* P, const int* RF, const int* RB, const StageCtx& X,
+                                           FForce forceGeneral, FBegin begin, FAltChunk altChunk, FAltSample altSample, FPre preIn, FBody body,
+                                           FFadeAlt fadeAlt, FGen gen, FSteadyDone steadyDone, FFadeDone fadeDone, FChunk perChunk)
+{
+#ifdef KLATT_STAMPS
+    Stamps st;
+#endif
+    constexpr int GI = D::GAIN >= 0 ? D::GAIN : 0;
+    // one whole steady chunk (the live lanes)
+    auto steadyChunk = [&](int c, bool useAlt) __attribute__((always_inline)) {
+        if (!f.done) {
+            if (K::PRE) {
+                double pre[K::PRE ? CH : 1];
+#pragma unroll
+                for (int i = 0; i < CH; ++i) pre[i] = preIn(c, i);
+                if (useAlt) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) altSample(c, i, pre[i]);
+                } else {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) body(c, i, true, pre[i]);
+                }
+            } else if (useAlt) {
+                altChunk(c);
+            } else {
+#pragma unroll K::UNROLL
+                for (int i = 0; i < CH; ++i) body(c, i, true, 0.0);
+            }
+            f.cnt += CH;
+            steadyDone(CH);
+        }
+    };
+    for (int iter = 0; iter < nIter; ++iter) {
+        STAMP_BEGIN();
+        int c = iter - depth;
+        if (c >= 0 && c < nChunks) {
+            const int lim = (K::STREAM && c >= fullChunks) ? (int)(X.A.maxSamples - (uint32_t)c * (uint32_t)CH) : CH;
+            int kind = (forceGeneral() || lim < CH) ? -1 : chunk_kind<CH>(f);
+            if (kind == 1 && nan_target_live(f)) kind = -1;   // "hold" targets: sample by sample, with the NaN test
+            bool lerp = false, gainOnly = false;
+            uint32_t wRes = 0;
+            if (kind == 1) {
+                lerp = __any(!f.done && f.parMask != 0u);
+                gainOnly = !K::NOISE && D::GAIN >= 0 && !__any(!f.done && (f.parMask & ~(1u << GI)) != 0u);
+                wRes = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(f.done ? 0u : f.resMask);
+                // a fade in which nothing of THIS element moves is a steady chunk for it (only the counter advances)
+                if (!D::PITCH && !lerp && wRes == 0u) kind = 0;
+            }
+            STAMP_KIND(kind);
+            if (kind == 0) {
+                const bool useAlt = begin(0);
+                // a steady stretch is decided once (steady_run: the minimum over the live lanes of chunks left in it)
+                uint32_t run = 1u;
+                if (!K::NOISE || KLATT_NOISY_TIGHT) {
+                    run = __any(!f.done && f.hasNew) ? 1u : steady_run<CH>(f);   // a fade that moves nothing here: chunk by chunk
+                    const uint32_t room = (uint32_t)(fullChunks - c);
+                    run = run < room ? run : room;
+                }
+                for (uint32_t q = 1; q < run; ++q) {
+                    steadyChunk(c, useAlt);
+                    perChunk();
+                    STAMP_WORKED();
+                    __syncthreads();
+                    STAMP_SYNCED();
+                    STAMP_BEGIN();
+                    ++iter; ++c;
+                }
+                steadyChunk(c, useAlt);
+            } else if (kind == 1) {
+                (void)begin(1);
+                const uint32_t coefCls = fade_classes<D>(f, X.A, RF, RB, wRes);   // once per fade stretch
+                // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
+                auto fadeChunk = [&](int c) __attribute__((always_inline)) {
+                    if (!f.done) {
+                        if (!fadeAlt(c, lerp, gainOnly)) {
+#pragma unroll 2
+                            for (int i = 0; i < CH; ++i) {
+                                f.cnt++;
+                                stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
+                                body(c, i, false, 0.0);
+                            }
+                        }
+                        fadeDone(CH);
+                    }
+                };
+                uint32_t run = 1u;
+                if (KLATT_FADE_TIGHT) {
+                    run = fade_run<CH>(f);
+                    const uint32_t room = (uint32_t)(fullChunks - c);
+                    run = run < room ? run : room;
+                }
+                for (uint32_t q = 1; q < run; ++q) {
+                    fadeChunk(c);
+                    perChunk();
+                    STAMP_WORKED();
+                    __syncthreads();
+                    STAMP_SYNCED();
+                    STAMP_BEGIN();
+                    ++iter; ++c;
+                }
+                fadeChunk(c);
+            } else {
+                (void)begin(-1);
+                int i = 0;
+#pragma nounroll
+                while (i < lim) {
+                    if (K::RUNS && !forceGeneral()) {
+                        // whenever every live lane is inside a steady stretch (or every one inside a fade, past its first sample, no
+                        // NaN target) the next n = min over the lanes of samples left in the stretch run as a rolled loop
+                        const bool fad = f.hasNew;
+                        const uint32_t rem = f.done ? 0xFFFFFFFFu : (fad ? f.newFade - f.cnt : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
+                        const bool anyFad = __any(!f.done && fad), anySteady = __any(!f.done && !fad);
+                        int n = 0;
+                        if (!(anyFad && anySteady) && !__any(!f.done && fad && f.cnt == 0u) && !(anyFad && nan_target_live(f))) {
+                            const int cap = lim - i;
+#pragma unroll
+                            for (int st = CH; st >= 1; st >>= 1)
+                                if (n + st <= cap && __all(rem >= (uint32_t)(n + st))) n += st;
+                        }
+                        if (n >= 2) {
+                            int kr = anyFad ? 1 : 0;
+                            bool lerpR = false, gainOnlyR = false;
+                            uint32_t wResR = 0;
+                            if (kr == 1) {
+                                lerpR = __any(!f.done && f.parMask != 0u);
+                                gainOnlyR = D::GAIN >= 0 && !__any(!f.done && (f.parMask & ~(1u << GI)) != 0u);
+                                wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(f.done ? 0u : f.resMask);
+                                if (!D::PITCH && !lerpR && wResR == 0u) kr = 0;
+                            }
+                            if (!f.done) {
+                                if (kr == 0) {
+#pragma nounroll
+                                    for (int j = i; j < i + n; ++j) body(c, j, true, K::PRE ? preIn(c, j) : 0.0);
+                                    f.cnt += (uint32_t)n;
+                                    steadyDone(n);
+                                } else {
+#pragma nounroll
+                                    for (int j = i; j < i + n; ++j) {
+                                        f.cnt++;
+                                        stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR, gainOnlyR);
+                                        body(c, j, false, 0.0);
+                                    }
+                                    fadeDone(n);
+                                }
+                            }
+                            i += n;
+                            continue;
+                        }
+                    }
+                    if (K::DELAY) {
+                        // a lane that has not started yet (pipeline skew) sits this step out
+                        const bool hold = delay > 0u;
+                        const bool wasDone = f.done;
+                        if (hold) { delay--; f.done = true; }
+                        const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
+                        if (hold) f.done = wasDone;
+                        gen(c, i, emit);
+                    } else {
+                        const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
+                        gen(c, i, emit);
+                    }
+                    ++i;
+                }
+            }
+            perChunk();
+        }
+        STAMP_WORKED();
+        __syncthreads();
+        STAMP_SYNCED();
+    }
+#ifdef KLATT_STAMPS
+    if (X.A.debug && (threadIdx.x & (kLanes - 1)) == 0) {
+        unsigned long long* o = X.A.debug + (blockIdx.x * 4 + stampSlot) * 8;
+        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
+    }
+#endif
+    (void)stampSlot;
+}
+
 // ---- the kernel ---------------------------------------------------------------------------
 // NASAL = false (quiet launches only): every utterance of the launch is nasal-free (UTT_NO_NASAL, classified on the
 // host): caNP == 0 in every frame with bounded, stable N0/NP parameters.  The cascade input then passes the nasal pair
@@ -528,164 +736,19 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     const int fullChunks = STREAM ? (int)(A.maxSamples / (uint32_t)kChunk) : nChunks;
     double* const streamState = (STREAM && live) ? (A.statePtrs ? A.statePtrs[u] : A.state + (size_t)u * kStateDoubles) : nullptr;
     const bool streamPurge = STREAM && live && A.control && (A.control[u] & 1u);
-#ifdef KLATT_STAMPS
-    Stamps st;
-#endif
-
     // pipe slot of sample i of chunk c
 #define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
-
-    // A stage may offer straight-line versions of a whole steady / fading chunk (they return true when they took it);
-    // only S0 of a quiet launch does, see below.
-#define KL_STEADY_ALT(c) false
-#define KL_FADE_ALT(c, lerp, gainOnly) false
-    // Generic chunk loop of a stage.  BODY(c, i, steady) computes sample i of chunk c from the stage's pipe
-    // inputs and writes its outputs; ON_EMIT is the general-step tail (uses `emit`).  One barrier per
-    // iteration, the same number of iterations in every wave.
-#define RUN_STAGE(DEPTH, FRAMEVAR, PSPTR, IDXPTR, DESC, VIBCHECK, BODY, ON_STEADY_DONE, ON_FADE_DONE, ON_EMIT, PER_CHUNK, PRELOAD, PRE_IN)     \
-    for (int iter = 0; iter < nIter; ++iter) {                                                                                     \
-        STAMP_BEGIN();                                                                                                             \
-        int c = iter - (DEPTH);                                                                                                    \
-        if (c >= 0 && c < nChunks) {                                                                                               \
-            const int lim = (STREAM && c >= fullChunks) ? (int)(A.maxSamples - (uint32_t)c * (uint32_t)kChunk) : kChunk;            \
-            int kind = ((VIBCHECK) || lim < kChunk) ? -1 : chunk_kind<CH>(FRAMEVAR);                                               \
-            if (kind == 1 && nan_target_live(FRAMEVAR)) kind = -1;   /* "hold" targets: sample by sample, with the NaN test */     \
-            bool lerp = false, gainOnly = false;                                                                                   \
-            uint32_t wRes = 0;                                                                                                     \
-            if (kind == 1) {                                                                                                       \
-                lerp = __any(!FRAMEVAR.done && FRAMEVAR.parMask != 0u);                                                            \
-                gainOnly = !NOISE && DESC::GAIN >= 0 && !__any(!FRAMEVAR.done && (FRAMEVAR.parMask & ~(1u << (DESC::GAIN >= 0 ? DESC::GAIN : 0))) != 0u); \
-                wRes = wave_or_bits<DESC::NRES>(FRAMEVAR.done ? 0u : FRAMEVAR.resMask);                                            \
-                /* a fade in which nothing of THIS stage moves is a steady chunk for it (only the counter advances) */             \
-                if (!DESC::PITCH && !lerp && wRes == 0u) kind = 0;                                                                 \
-            }                                                                                                                      \
-            STAMP_KIND(kind);                                                                                                      \
-            double pre[PRELOAD ? kChunk : 1];                                                                                      \
-            if (kind == 0) {                                                                                                       \
-                /* one whole steady chunk for the live lanes */                                                                    \
-                auto steadyChunk = [&](int c) __attribute__((always_inline)) {                                                     \
-                    if (!FRAMEVAR.done) {                                                                                          \
-                        [[maybe_unused]] constexpr bool usePre = true; [[maybe_unused]] constexpr int runLen = kChunk;             \
-                        if (KL_STEADY_ALT(c)) {                                                                                    \
-                        } else if (PRELOAD) {                                                                                      \
-                            _Pragma("unroll") for (int i = 0; i < kChunk; ++i) pre[i] = (PRE_IN);                                  \
-                            _Pragma("unroll") for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }                               \
-                        } else {                                                                                                   \
-                            _Pragma(KLATT_STR(unroll KLATT_UNROLL)) for (int i = 0; i < kChunk; ++i) { BODY(c, i, true); }         \
-                        }                                                                                                          \
-                        FRAMEVAR.cnt += runLen;                                                                                    \
-                        ON_STEADY_DONE;                                                                                            \
-                    }                                                                                                              \
-                };                                                                                                                 \
-                if (!NOISE || KLATT_NOISY_TIGHT) {                                                                                 \
-                    /* Quiet launches decide a steady stretch once (steady_run) and run its chunks in a tight loop of their */     \
-                    /* own -- preload, straight-line block, barrier -- with the barrier count of the outer loop; the noisy  */     \
-                    /* kernels have no register to spare for the run length.                                                */     \
-                    uint32_t run = __any(!FRAMEVAR.done && FRAMEVAR.hasNew) ? 1u : steady_run<CH>(FRAMEVAR);                       \
-                    const uint32_t room = (uint32_t)(fullChunks - c);                                                              \
-                    run = run < room ? run : room;                                                                                 \
-                    for (uint32_t q = 1; q < run; ++q) {                                                                           \
-                        steadyChunk(c);                                                                                            \
-                        PER_CHUNK;                                                                                                 \
-                        STAMP_WORKED();                                                                                            \
-                        __syncthreads();                                                                                           \
-                        STAMP_SYNCED();                                                                                            \
-                        STAMP_BEGIN();                                                                                             \
-                        ++iter; ++c;                                                                                               \
-                    }                                                                                                              \
-                }                                                                                                                  \
-                steadyChunk(c);                                                                                                    \
-            } else if (kind == 1) {                                                                                                \
-                const uint32_t coefCls = fade_classes<DESC>(FRAMEVAR, A, RF, RB, wRes);   /* once per fade stretch */              \
-                /* one whole fading chunk for the live lanes */                                                                    \
-                auto fadeChunk = [&](int c) __attribute__((always_inline)) {                                                       \
-                    if (!FRAMEVAR.done) {                                                                                          \
-                        [[maybe_unused]] constexpr bool usePre = false; [[maybe_unused]] constexpr int runLen = kChunk;            \
-                        if (KL_FADE_ALT(c, lerp, gainOnly)) {                                                                      \
-                        } else {                                                                                                   \
-                            _Pragma("unroll 2") for (int i = 0; i < kChunk; ++i) {                                                 \
-                                FRAMEVAR.cnt++;                                                                                    \
-                                stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerp, wRes, gainOnly, coefCls);           \
-                                BODY(c, i, false);                                                                                 \
-                            }                                                                                                      \
-                        }                                                                                                          \
-                        ON_FADE_DONE;                                                                                              \
-                    }                                                                                                              \
-                };                                                                                                                 \
-                if (KLATT_FADE_TIGHT) {                                                                                            \
-                    /* what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too */    \
-                    uint32_t run = fade_run<CH>(FRAMEVAR);                                                                         \
-                    const uint32_t room = (uint32_t)(fullChunks - c);                                                              \
-                    run = run < room ? run : room;                                                                                 \
-                    for (uint32_t q = 1; q < run; ++q) {                                                                           \
-                        fadeChunk(c);                                                                                              \
-                        PER_CHUNK;                                                                                                 \
-                        STAMP_WORKED();                                                                                            \
-                        __syncthreads();                                                                                           \
-                        STAMP_SYNCED();                                                                                            \
-                        STAMP_BEGIN();                                                                                             \
-                        ++iter; ++c;                                                                                               \
-                    }                                                                                                              \
-                }                                                                                                                  \
-                fadeChunk(c);                                                                                                      \
-            } else {                                                                                                               \
-                /* Quiet launches: a chunk with an event in it runs [uniform run][event steps][uniform run]; only the   */         \
-                /* event steps need the state machine sample by sample.  Whenever every live lane is inside a steady    */         \
-                /* stretch (or every one inside a fade, past its first sample, no NaN target) the next n = min over the */         \
-                /* lanes of samples left in the stretch run as a rolled loop of the steady / fading body; n by ballot   */         \
-                /* bisection.  Not for the noisy kernels (KLATT_NOISY_RUNS): the extra code costs them more than it saves */         \
-                int i = 0;                                                                                                         \
-                _Pragma("nounroll") while (i < lim) {                                                                              \
-                    if ((!NOISE || KLATT_NOISY_RUNS) && !(VIBCHECK)) {                                                             \
-                        const bool fad = FRAMEVAR.hasNew;                                                                          \
-                        const uint32_t rem = FRAMEVAR.done ? 0xFFFFFFFFu : (fad ? FRAMEVAR.newFade - FRAMEVAR.cnt : (FRAMEVAR.oldMin > FRAMEVAR.cnt ? FRAMEVAR.oldMin - FRAMEVAR.cnt : 0u)); \
-                        const bool anyFad = __any(!FRAMEVAR.done && fad), anySteady = __any(!FRAMEVAR.done && !fad);              \
-                        int runLen = 0;                                                                                            \
-                        if (!(anyFad && anySteady) && !__any(!FRAMEVAR.done && fad && FRAMEVAR.cnt == 0u) && !(anyFad && nan_target_live(FRAMEVAR))) { \
-                            const int cap = lim - i;                                                                               \
-                            _Pragma("unroll") for (int st = kChunk; st >= 1; st >>= 1)                                             \
-                                if (runLen + st <= cap && __all(rem >= (uint32_t)(runLen + st))) runLen += st;                     \
-                        }                                                                                                          \
-                        if (runLen >= 2) {                                                                                         \
-                            int kr = anyFad ? 1 : 0;                                                                               \
-                            bool lerpR = false, gainOnlyR = false;                                                                 \
-                            uint32_t wResR = 0;                                                                                    \
-                            if (kr == 1) {                                                                                         \
-                                lerpR = __any(!FRAMEVAR.done && FRAMEVAR.parMask != 0u);                                           \
-                                gainOnlyR = DESC::GAIN >= 0 && !__any(!FRAMEVAR.done && (FRAMEVAR.parMask & ~(1u << (DESC::GAIN >= 0 ? DESC::GAIN : 0))) != 0u); \
-                                wResR = wave_or_bits<DESC::NRES>(FRAMEVAR.done ? 0u : FRAMEVAR.resMask);                           \
-                                if (!DESC::PITCH && !lerpR && wResR == 0u) kr = 0;                                                 \
-                            }                                                                                                      \
-                            if (!FRAMEVAR.done) {                                                                                  \
-                                [[maybe_unused]] constexpr bool usePre = false;                                                    \
-                                if (kr == 0) {                                                                                     \
-                                    _Pragma("nounroll") for (int j = i; j < i + runLen; ++j) { BODY(c, j, true); }                 \
-                                    FRAMEVAR.cnt += (uint32_t)runLen;                                                              \
-                                    ON_STEADY_DONE;                                                                                \
-                                } else {                                                                                           \
-                                    _Pragma("nounroll") for (int j = i; j < i + runLen; ++j) {                                     \
-                                        FRAMEVAR.cnt++;                                                                            \
-                                        stage_fade<DESC, MODE, true>(FRAMEVAR, PSPTR, A, RF, RB, lerpR, wResR, gainOnlyR);         \
-                                        BODY(c, j, false);                                                                         \
-                                    }                                                                                              \
-                                    ON_FADE_DONE;                                                                                  \
-                                }                                                                                                  \
-                            }                                                                                                      \
-                            i += runLen;                                                                                           \
-                            continue;                                                                                              \
-                        }                                                                                                          \
-                    }                                                                                                              \
-                    const bool emit = stage_advance<DESC, MODE>(FRAMEVAR, PSPTR, IDXPTR, P, RF, RB, X);                            \
-                    ON_EMIT;                                                                                                       \
-                    ++i;                                                                                                           \
-                }                                                                                                                  \
-            }                                                                                                                      \
-            PER_CHUNK;                                                                                                             \
-        }                                                                                                                          \
-        STAMP_WORKED();                                                                                                            \
-        __syncthreads();                                                                                                           \
-        STAMP_SYNCED();                                                                                                            \
-    }
+    // the chunk loop's knobs: quiet launches preload a steady chunk's inputs and run uniform stretches inside event chunks
+    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;      // stages without a pipe input
+    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;       // stages that read a pipe
+    uint32_t noDelay = 0;
+    auto never = [&]() __attribute__((always_inline)) { return false; };
+    auto noBegin = [&](int) __attribute__((always_inline)) { return false; };
+    auto noAlt = [&](int) __attribute__((always_inline)) {};
+    auto noAltSample = [&](int, int, double) __attribute__((always_inline)) {};
+    auto noFadeAlt = [&](int, bool, bool) __attribute__((always_inline)) { return false; };
+    auto nothing = [&](int) __attribute__((always_inline)) {};
+    auto noChunk = [&]() __attribute__((always_inline)) {};
 
     if (stage == 0) {
         // ================= S0: frame + glottal source (+ aspiration noise) =================
@@ -741,78 +804,74 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         auto vib_live_now = [&]() __attribute__((always_inline)) -> bool {
             return vibFrames || f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase;
         };
-        // Straight-line chunks of the quiet source (vibrato off, checked by VIBCHECK; called with the live lanes active).
-        // Steady chunk without a pitch glide in any lane: cur0 + 0 repeated is cur0 + 0 once, and the phase increment
-        // (cur0 * 1) / sr is one value for the whole chunk.
-        auto s0_steady_alt = [&](int c) __attribute__((always_inline)) -> bool {
-            if (NOISE || __any(ps.oldInc != 0.0)) return false;
-            ps.cur0 += ps.oldInc;
-            const double inc = div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate);
-            // the phase recurrence (three dependent operations per sample) first, then the element-wise rest, whose
-            // operations are independent across samples and fill the recurrence's issue gaps
-            double ph[kChunk];
-#pragma unroll
-            for (int i = 0; i < kChunk; ++i) { pitchPhase = frac_toward_zero(inc + pitchPhase); ph[i] = pitchPhase; }
-#pragma unroll
-            for (int i = 0; i < kChunk; ++i) PIPE(pipeX, c, i) = ((((ph[i] * 2.0) - 1.0) * f.cur[4]) * f.cur[6]) * 0.5;
-            return true;
-        };
-        // Fading chunk in which only the gain (and the pitch) move -- fades into and out of silence, reference
-        // src/frame.cpp:59-67 -- and no target is NaN ("hold", src/utils.h:21): from + ((to - from) * ratio) with the
-        // differences taken once, the old/new values read from LDS once.  Same operations on the same operands as
-        // stage_fade + source, sample by sample.
-        auto s0_fade_alt = [&](int c, bool lerp, bool gainOnly) __attribute__((always_inline)) -> bool {
-            if (NOISE || !gainOnly) return false;
-            constexpr int GI = 6;
-            const double g0 = lerp ? f.oldL[GI * kLanes] : f.cur[GI], g1 = lerp ? f.getNew(GI) : f.cur[GI];
-            if (__any(g1 != g1 || ps.new0 != ps.new0)) return false;
-            const double gd = g1 - g0, p0 = ps.old0, pd = ps.new0 - p0, nf = (double)f.newFade;
-            if (!__any(pd != 0.0 || p0 != p0)) {
-                // the pitch does not move either: p0 + ((p0 - p0) * ratio) == p0 + 0
-                ps.cur0 = p0 + 0.0;
+        stage_loop<D, MODE, CH, KSrc>(0, nIter, nChunks, fullChunks, stage, f, &ps, &lastIndex, noDelay, P, RF, RB, X,
+            [&]() __attribute__((always_inline)) { return __any(!f.done && vib_live_now()); },
+            // Straight-line chunks of the quiet source (vibrato off, checked above).  Steady chunk without a pitch glide in any
+            // live lane: cur0 + 0 repeated is cur0 + 0 once, and the phase increment (cur0 * 1) / sr is one value for the chunk.
+            [&](int kind) __attribute__((always_inline)) -> bool { return !NOISE && kind == 0 && !__any(!f.done && ps.oldInc != 0.0); },
+            [&](int c) __attribute__((always_inline)) {
+                ps.cur0 += ps.oldInc;
                 const double inc = div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate);
+                // the phase recurrence (three dependent operations per sample) first, then the element-wise rest, whose
+                // operations are independent across samples and fill the recurrence's issue gaps
+                double ph[kChunk];
 #pragma unroll
-                for (int i = 0; i < kChunk; ++i) {
-                    f.cnt++;
-                    const double ratio = div_by((double)f.cnt, nf, f.invFade);
-                    const double gain = g0 + (gd * ratio);
-                    pitchPhase = frac_toward_zero(inc + pitchPhase);
-                    PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * gain) * 0.5;
-                    if (i == kChunk - 1) f.cur[GI] = gain;
-                }
-            } else {
+                for (int i = 0; i < kChunk; ++i) { pitchPhase = frac_toward_zero(inc + pitchPhase); ph[i] = pitchPhase; }
 #pragma unroll
-                for (int i = 0; i < kChunk; ++i) {
-                    f.cnt++;
-                    const double ratio = div_by((double)f.cnt, nf, f.invFade);
-                    ps.cur0 = p0 + (pd * ratio);
-                    const double gain = g0 + (gd * ratio);
-                    pitchPhase = frac_toward_zero(div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate) + pitchPhase);
-                    PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * gain) * 0.5;
-                    if (i == kChunk - 1) f.cur[GI] = gain;
+                for (int i = 0; i < kChunk; ++i) PIPE(pipeX, c, i) = ((((ph[i] * 2.0) - 1.0) * f.cur[4]) * f.cur[6]) * 0.5;
+            },
+            noAltSample,
+            [&](int, int) __attribute__((always_inline)) { return 0.0; },
+            [&](int c, int i, bool steady, double) __attribute__((always_inline)) {
+                if (steady) ps.cur0 += ps.oldInc;
+                PIPE(pipeX, c, i) = source(false);
+            },
+            // Fading chunk in which only the gain (and the pitch) move -- fades into and out of silence, reference
+            // src/frame.cpp:59-67 -- and no target is NaN ("hold", src/utils.h:21): from + ((to - from) * ratio) with the
+            // differences taken once, the old/new values read from LDS once.  Same operations on the same operands as
+            // stage_fade + source, sample by sample.
+            [&](int c, bool lerp, bool gainOnly) __attribute__((always_inline)) -> bool {
+                if (NOISE || !gainOnly) return false;
+                constexpr int GI = 6;
+                const double g0 = lerp ? f.oldL[GI * kLanes] : f.cur[GI], g1 = lerp ? f.getNew(GI) : f.cur[GI];
+                if (__any(g1 != g1 || ps.new0 != ps.new0)) return false;
+                const double gd = g1 - g0, p0 = ps.old0, pd = ps.new0 - p0, nf = (double)f.newFade;
+                if (!__any(pd != 0.0 || p0 != p0)) {
+                    // the pitch does not move either: p0 + ((p0 - p0) * ratio) == p0 + 0
+                    ps.cur0 = p0 + 0.0;
+                    const double inc = div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate);
+#pragma unroll
+                    for (int i = 0; i < kChunk; ++i) {
+                        f.cnt++;
+                        const double ratio = div_by((double)f.cnt, nf, f.invFade);
+                        const double gain = g0 + (gd * ratio);
+                        pitchPhase = frac_toward_zero(inc + pitchPhase);
+                        PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * gain) * 0.5;
+                        if (i == kChunk - 1) f.cur[GI] = gain;
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < kChunk; ++i) {
+                        f.cnt++;
+                        const double ratio = div_by((double)f.cnt, nf, f.invFade);
+                        ps.cur0 = p0 + (pd * ratio);
+                        const double gain = g0 + (gd * ratio);
+                        pitchPhase = frac_toward_zero(div_by(ps.cur0 * 1.0, A.sampleRateF, A.invSampleRate) + pitchPhase);
+                        PIPE(pipeX, c, i) = ((((pitchPhase * 2.0) - 1.0) * f.cur[4]) * gain) * 0.5;
+                        if (i == kChunk - 1) f.cur[GI] = gain;
+                    }
                 }
-            }
-            return true;
-        };
-#undef KL_STEADY_ALT
-#undef KL_FADE_ALT
-#define KL_STEADY_ALT(c) s0_steady_alt(c)
-#define KL_FADE_ALT(c, lerp, gainOnly) s0_fade_alt(c, lerp, gainOnly)
-#define S0_BODY(c, i, steady) do { if (steady) ps.cur0 += ps.oldInc; PIPE(pipeX, c, i) = source(false); } while (0)
-#define S0_EMIT do {                                                                                             \
-            if (emit && f.hasNew && f.cnt == 0)                                                                  \
-                vibFrames = f.oldL[0] != 0.0 || f.oldL[kLanes] != 0.0 || f.getNew(0) != 0.0 || f.getNew(1) != 0.0; \
-            const bool waveVib = __any(emit && vib_live_now());                                                  \
-            if (emit) { PIPE(pipeX, c, i) = source(waveVib); f.produced++; }                                     \
-        } while (0)
-        RUN_STAGE(0, f, &ps, &lastIndex, D, __any(!f.done && vib_live_now()), S0_BODY,
-                  (ps.old0 = ps.cur0, f.produced += runLen), (f.produced += runLen), S0_EMIT, (void)0, false, 0.0)
-#undef S0_BODY
-#undef S0_EMIT
-#undef KL_STEADY_ALT
-#undef KL_FADE_ALT
-#define KL_STEADY_ALT(c) false
-#define KL_FADE_ALT(c, lerp, gainOnly) false
+                return true;
+            },
+            [&](int c, int i, bool emit) __attribute__((always_inline)) {
+                if (emit && f.hasNew && f.cnt == 0)
+                    vibFrames = f.oldL[0] != 0.0 || f.oldL[kLanes] != 0.0 || f.getNew(0) != 0.0 || f.getNew(1) != 0.0;
+                const bool waveVib = __any(emit && vib_live_now());
+                if (emit) { PIPE(pipeX, c, i) = source(waveVib); f.produced++; }
+            },
+            [&](int n) __attribute__((always_inline)) { ps.old0 = ps.cur0; f.produced += n; },
+            [&](int n) __attribute__((always_inline)) { f.produced += n; },
+            noChunk);
         if (live) {
             UttResult res;
             res.produced = f.produced; res.framesTaken = f.nextFrame; res.lastIndex = lastIndex; res.drained = STREAM ? (f.done ? 1u : 0u) : 1u;
@@ -838,12 +897,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define SN_BODY(c, i, steady) PIPE(pout, c, i) = dsp((kPre && steady && usePre) ? pre[i] : PIPE(pin, c, i))
-#define SN_EMIT do { if (emit) PIPE(pout, c, i) = dsp(PIPE(pin, c, i)); } while (0)
-        if (s1) { RUN_STAGE(1, f, nullptr, nullptr, D, false, SN_BODY, (void)0, (void)0, SN_EMIT, (void)0, kPre, PIPE(pin, c, i)) }
-        else { RUN_STAGE(2, f, nullptr, nullptr, D, false, SN_BODY, (void)0, (void)0, SN_EMIT, (void)0, kPre, PIPE(pin, c, i)) }
-#undef SN_BODY
-#undef SN_EMIT
+        auto run = [&](int depth) __attribute__((always_inline)) {
+            stage_loop<D, MODE, CH, KFil>(depth, nIter, nChunks, fullChunks, stage, f, nullptr, nullptr, noDelay, P, RF, RB, X, never, noBegin, noAlt, noAltSample,
+                [&](int c, int i) __attribute__((always_inline)) { return PIPE(pin, c, i); },
+                [&](int c, int i, bool steady, double pre) __attribute__((always_inline)) { PIPE(pout, c, i) = dsp((kPre && steady) ? pre : PIPE(pin, c, i)); },
+                noFadeAlt,
+                [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pout, c, i) = dsp(PIPE(pin, c, i)); },
+                nothing, nothing, noChunk);
+        };
+        if (s1) run(1); else run(2);
     } else if (stage == 1) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
         constexpr int NR = NOISE ? 5 : 3;
@@ -866,11 +928,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 2; r < NR; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define S1_BODY(c, i, steady) PIPE(pipeO, c, i) = dsp((kPre && steady && usePre) ? pre[i] : PIPE(pipeX, c, i))
-#define S1_EMIT do { if (emit) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i)); } while (0)
-        RUN_STAGE(1, f, nullptr, nullptr, D, false, S1_BODY, (void)0, (void)0, S1_EMIT, (void)0, kPre, PIPE(pipeX, c, i))
-#undef S1_BODY
-#undef S1_EMIT
+        stage_loop<D, MODE, CH, KFil>(1, nIter, nChunks, fullChunks, stage, f, nullptr, nullptr, noDelay, P, RF, RB, X, never, noBegin, noAlt, noAltSample,
+            [&](int c, int i) __attribute__((always_inline)) { return PIPE(pipeX, c, i); },
+            [&](int c, int i, bool steady, double pre) __attribute__((always_inline)) { PIPE(pipeO, c, i) = dsp((kPre && steady) ? pre : PIPE(pipeX, c, i)); },
+            noFadeAlt,
+            [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i)); },
+            nothing, nothing, noChunk);
         if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GR1);
     } else if (NOISE && stage == 3) {
         // ================= noisy S3: frication noise, parallel r1..r4 partial sum =================
@@ -887,7 +950,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseIdx = (uint32_t)streamState[221] + 1u; }
             stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR3, streamPurge);
         }
-        auto dsp = [&](double& yOut) __attribute__((always_inline)) -> double {
+        auto dsp = [&](int c, int i) __attribute__((always_inline)) {
             fricNoise = noise_uniform(nkey, noiseIdx) + 0.75 * fricNoise;
             noiseIdx += 2u;
             const double fric = fricNoise * 0.3 * f.cur[8];
@@ -898,14 +961,14 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
                 par += (w - y) * f.cur[10 + r];
             }
-            yOut = y;
-            return par;
+            PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
         };
-#define S3_BODY(c, i, steady) do { double y_; const double p_ = dsp(y_); PIPE(pipeA, c, i) = y_; PIPE(pipeB, c, i) = p_; } while (0)
-#define S3_EMIT do { if (emit) { double y_; const double p_ = dsp(y_); PIPE(pipeA, c, i) = y_; PIPE(pipeB, c, i) = p_; } } while (0)
-        RUN_STAGE(1, f, nullptr, nullptr, D, false, S3_BODY, (void)0, (void)0, S3_EMIT, (void)0, false, 0.0)
-#undef S3_BODY
-#undef S3_EMIT
+        stage_loop<D, MODE, CH, KSrc>(1, nIter, nChunks, fullChunks, stage, f, nullptr, nullptr, noDelay, P, RF, RB, X, never, noBegin, noAlt, noAltSample,
+            [&](int, int) __attribute__((always_inline)) { return 0.0; },
+            [&](int c, int i, bool, double) __attribute__((always_inline)) { dsp(c, i); },
+            noFadeAlt,
+            [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) dsp(c, i); },
+            nothing, nothing, noChunk);
         if (STREAM && live) { stage_state_save<D>(f, nullptr, streamState, P, GR3); streamState[211] = fricNoise; }
     } else if (!NOISE && stage == 2) {
         // ================= quiet S2: r5, r4, r3 =================
@@ -919,11 +982,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
-#define S2_BODY(c, i, steady) PIPE(pipeA, c, i) = dsp((kPre && steady && usePre) ? pre[i] : PIPE(pipeO, c, i))
-#define S2_EMIT do { if (emit) PIPE(pipeA, c, i) = dsp(PIPE(pipeO, c, i)); } while (0)
-        RUN_STAGE(2, f, nullptr, nullptr, D, false, S2_BODY, (void)0, (void)0, S2_EMIT, (void)0, kPre, PIPE(pipeO, c, i))
-#undef S2_BODY
-#undef S2_EMIT
+        stage_loop<D, MODE, CH, KFil>(2, nIter, nChunks, fullChunks, stage, f, nullptr, nullptr, noDelay, P, RF, RB, X, never, noBegin, noAlt, noAltSample,
+            [&](int c, int i) __attribute__((always_inline)) { return PIPE(pipeO, c, i); },
+            [&](int c, int i, bool steady, double pre) __attribute__((always_inline)) { PIPE(pipeA, c, i) = dsp((kPre && steady) ? pre : PIPE(pipeO, c, i)); },
+            noFadeAlt,
+            [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pipeA, c, i) = dsp(PIPE(pipeO, c, i)); },
+            nothing, nothing, noChunk);
     } else {
         // ================= final stage: rest of the cascade, (parallel r5, r6 + bypass), gain, clip, PCM ===
         // noisy (stage 2): r3, r2, r1 | parallel 5, 6 | pa5, pa6, parallelBypass, outputGain
@@ -993,31 +1057,24 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         };
 
         uint32_t it = 0;   // samples stepped so far (wave-uniform); the chunk being processed starts at `it`
-#define FIN_IN0(c, i) (NOISE ? PIPE(pipeO, c, i) : PIPE(pipeA, c, i))
-#define FIN_IN12(c, i) (NOISE ? PIPE(pipeA, c, i) : 0.0), (NOISE ? PIPE(pipeB, c, i) : 0.0)
-#define FIN_IN(c, i) FIN_IN0(c, i), FIN_IN12(c, i)
-#define FIN_BODY(c, i, steady) myRow[(it % kTile) + i] = (int16_t)finish((kPre && steady && usePre) ? pre[i] : FIN_IN0(c, i), FIN_IN12(c, i))
-#define FIN_EMIT do { if (emit) { myRow[(it % kTile) + i] = (int16_t)finish(FIN_IN(c, i)); f.produced++; } } while (0)
-#define FIN_CHUNK do { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); } while (0)
-        RUN_STAGE((NOISE ? 2 : 3), f, nullptr, nullptr, D, false, FIN_BODY, (f.produced += runLen), (f.produced += runLen), FIN_EMIT, FIN_CHUNK, kPre, FIN_IN0(c, i))
+        auto in0 = [&](int c, int i) __attribute__((always_inline)) -> double { return NOISE ? PIPE(pipeO, c, i) : PIPE(pipeA, c, i); };
+        auto inY = [&](int c, int i) __attribute__((always_inline)) -> double { return NOISE ? PIPE(pipeA, c, i) : 0.0; };
+        auto inP = [&](int c, int i) __attribute__((always_inline)) -> double { return NOISE ? PIPE(pipeB, c, i) : 0.0; };
+        stage_loop<D, MODE, CH, KFil>((NOISE ? 2 : 3), nIter, nChunks, fullChunks, stage, f, nullptr, nullptr, noDelay, P, RF, RB, X, never, noBegin, noAlt, noAltSample,
+            in0,
+            [&](int c, int i, bool steady, double pre) __attribute__((always_inline)) {
+                myRow[(it % kTile) + i] = (int16_t)finish((kPre && steady) ? pre : in0(c, i), inY(c, i), inP(c, i));
+            },
+            noFadeAlt,
+            [&](int c, int i, bool emit) __attribute__((always_inline)) {
+                if (emit) { myRow[(it % kTile) + i] = (int16_t)finish(in0(c, i), inY(c, i), inP(c, i)); f.produced++; }
+            },
+            [&](int n) __attribute__((always_inline)) { f.produced += n; },
+            [&](int n) __attribute__((always_inline)) { f.produced += n; },
+            [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
         if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
         if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GRF);
-#undef FIN_IN
-#undef FIN_IN0
-#undef FIN_IN12
-#undef FIN_BODY
-#undef FIN_EMIT
-#undef FIN_CHUNK
     }
-#ifdef KLATT_STAMPS
-    if (A.debug && lane == 0) {
-        unsigned long long* o = A.debug + (blockIdx.x * 4 + stage) * 8;
-        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
-    }
-#endif
-#undef RUN_STAGE
-#undef KL_STEADY_ALT
-#undef KL_FADE_ALT
 #undef PIPE
 }
 

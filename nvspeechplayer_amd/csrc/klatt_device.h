@@ -166,16 +166,22 @@ enum { COEF_UNREDUCED = 0, COEF_QUADRANT_M1 = 1, COEF_UNKNOWN = 2 };
 // with the call the noisy stage kernel is 137 KB instead of 262 KB and spills 96 instead of 160 bytes per lane; cfg2 15.05 -> 14.6 ms,
 // rotated 58.5 -> 55 ms, cfg3 14.8 -> 14.3, cfg4 9.84 -> 9.47 (tools/ab_probe.py).  KLATT_COLD_CALL = 1 moves the range-reduced
 // fast_exp / fast_cos out of line as well: better still on aligned batches (14.4 ms), worse where lanes fade apart (62 ms).
-__device__ __attribute__((noinline)) void exp_cos_reduced(double ex, double th, double* rad, double* cs)
+// Results come back by value (registers): no address of a caller's local is taken.  Only the kernels call it (one level deep); the
+// lane kernel's out-of-line resonator_coefficients() keeps the library calls inline (NESTED = false) -- a noinline function calling
+// this one from inside a divergent branch gave wrong coefficients now and then (tests: MODE_FAST, layout 0, NaN parameters).
+struct RadCos { double rad, cs; };
+__device__ __attribute__((noinline)) RadCos exp_cos_reduced(double ex, double th)
 {
+    RadCos o;
 #if KLATT_COLD_CALL == 1
-    if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { *rad = fast_exp(ex); *cs = fast_cos(th); }
+    if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { o.rad = fast_exp(ex); o.cs = fast_cos(th); }
     else
 #endif
-    { *rad = exp(ex); *cs = cos(th); }
+    { o.rad = exp(ex); o.cs = cos(th); }
+    return o;
 }
 #endif
-template <int MODE>
+template <int MODE, bool NESTED = true>
 __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr,
                                                               int cls = COEF_UNKNOWN)
 {
@@ -193,14 +199,13 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
     else if (__all(eu && cos_is_unreduced(th))) { rad = exp_unreduced(ex); cs = cos_unreduced(th); }
     else if (__all(eu && cos_is_quadrant_m1(th))) { rad = exp_unreduced(ex); cs = cos_quadrant_m1(th); }   // F3 and up
 #if KLATT_COLD_CALL == 1
-    else exp_cos_reduced(ex, th, &rad, &cs);
-#elif KLATT_COLD_CALL == 2
-    else if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
-    else exp_cos_reduced(ex, th, &rad, &cs);
-#else
-    else if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
-    else { rad = exp(ex); cs = cos(th); }
+    else if (NESTED) { const RadCos o = exp_cos_reduced(ex, th); rad = o.rad; cs = o.cs; }
 #endif
+    else if (__builtin_fabs(ex) <= 700.0 && __builtin_fabs(th) <= 1.0e4) { rad = fast_exp(ex); cs = fast_cos(th); }
+#if KLATT_COLD_CALL == 2
+    else if (NESTED) { const RadCos o = exp_cos_reduced(ex, th); rad = o.rad; cs = o.cs; }
+#endif
+    else { rad = exp(ex); cs = cos(th); }
     double cc = -(rad * rad);
     double bb = rad * cs * 2.0;
     double aa = 1.0 - bb - cc;
@@ -216,7 +221,7 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
 template <int MODE>
 __device__ __attribute__((noinline)) Coef resonator_coefficients(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr)
 {
-    return resonator_coefficients_inline<MODE>(f, bw, anti, negPiOverSr, twoPiOverSr);
+    return resonator_coefficients_inline<MODE, false>(f, bw, anti, negPiOverSr, twoPiOverSr);
 }
 
 // LDS per workgroup (one wavefront):

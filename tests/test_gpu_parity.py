@@ -983,3 +983,24 @@ def test_quiet_classification_needs_finite_parallel_coefficients(ref):
             got = bp.read(u)
             assert np.array_equal(got, exp[u]), (layout, u, int(np.count_nonzero(got != exp[u])))
         bp.close()
+
+
+def test_wild_batch_repeated_in_fresh_batches():
+    """The same wild batch (NaN parameters: the coefficient code takes its device-library path, an out-of-line call) through fresh
+    batch objects again and again, every layout and arithmetic mode: each run must equal the oracle.  Catches results that depend on
+    what earlier launches left behind in scratch memory or registers -- round 2 had one (MODE_FAST, lane kernel: a nested out-of-line
+    call from a divergent branch, ~70 % of the runs wrong in one or more utterances after a few launches)."""
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(2)
+    batch = random_batch(rng, 1500, wild=True)
+    exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
+    for rep in range(12):
+        for layout in (0, 1):
+            for mode in (0, 1):
+                bp = eng.BatchPlayer(22050, mode=mode, layout=layout)
+                bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
+                bp.synthesize()
+                got, _ = bp.readAll()
+                bad = np.flatnonzero(got != exp)
+                assert len(bad) == 0, (rep, layout, mode, len(bad), sorted(set(int(x) for x in np.searchsorted(exp_start, bad, side="right") - 1))[:5])
+                bp.close()

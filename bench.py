@@ -60,9 +60,11 @@ def parse(argv=None):
 
 
 def engine_source_digest():
-    """Identifies the kernels a PMC file was collected from: sha1 over the kernel sources csrc/klatt_*.h and klatt_engine.hip."""
+    """Identifies the kernels a PMC file was collected from: sha1 over the kernel sources csrc/klatt_*.h and klatt_engine.hip
+    and the compiler flags they are built with."""
+    from nvspeechplayer_amd import _native
     csrc = os.path.join(ROOT, "nvspeechplayer_amd", "csrc")
-    h = hashlib.sha1()
+    h = hashlib.sha1(" ".join(_native.HIPCC_FLAGS).encode())
     for f in sorted(os.listdir(csrc)):
         if f.startswith("klatt_") and f.endswith((".h", ".hip")):
             h.update(f.encode()); h.update(open(os.path.join(csrc, f), "rb").read())

@@ -19,7 +19,11 @@ LIB_PATH = os.path.join(LIB_DIR, "libspeechPlayer.so")
 SOURCES = ["klatt_engine.hip", "frame_producer.cpp"]
 INCLUDE_DIR = os.path.join(os.path.dirname(PKG_DIR), "include")
 OBJ_DIR = os.path.join(PKG_DIR, "build_tmp")
-HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function"]
+# -amdgpu-sched-strategy=max-memory-clause: the machine scheduler keeps memory operations together instead of chasing occupancy
+# (the kernels' occupancy is fixed by __launch_bounds__ and LDS anyway).  Same PCM; cfg2 14.65 -> 14.2 ms, cfg4 -3 %, the quiet
+# kernels within 1 % (tools/ab_probe.py, profiles/r2_ab_noisy_variants.txt; max-ilp: +1.5 %, machine LICM off: +5 %).
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
+               "-mllvm", "-amdgpu-sched-strategy=max-memory-clause"]
 CXX_FLAGS = ["-O2", "-ffp-contract=off", "-fPIC", "-std=c++17", "-Wall", "-Wextra"]
 LINK_FLAGS = ["-shared", "-fPIC", "--offload-arch=gfx950", "-Wl,-rpath,/opt/rocm/lib"]
 

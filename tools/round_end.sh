@@ -1,3 +1,7 @@
+#!/bin/bash
+# What produced the round's numbers, in one GPU call (`gpurun -- 'bash tools/round_end.sh'`): the GPU test suite, the rocprofv3
+# profiles of the two single-GPU configurations (which also write the PMC file bench.py reads), the bench lines, the probes.
+# Everything lands under gpurun_out/; the summaries are then copied into profiles/ (see profiles/README.md).
 mkdir -p gpurun_out
 timeout -k 10 1000 python -m pytest tests -m gpu -x -q > gpurun_out/r2_gputests8.log 2>&1; tail -3 gpurun_out/r2_gputests8.log
 rm -f gpurun_out/r2_pmc.json

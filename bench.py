@@ -304,14 +304,14 @@ def main():
                 # same batch in MODE_FAST (fused multiply-adds; identical PCM on every test so far, not guaranteed bit-exact)
                 bp.setOption("mode", 1)
                 bp.time(1)
-                fast_ms = float(np.mean(bp.time(max(3, args.steps // 4))))
+                fast_ms = float(np.mean(bp.time(max(20, args.steps))))
                 bp.setOption("mode", 0)
                 out["mode_fast"] = {"value": samples / (fast_ms * 1e-3), "unit": "samples/s", "kernel_ms": fast_ms,
                                     "roofline_frac": alg_bytes / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if world == 1 and not args.utterances and not args.no_extras:
                 # the other single-GPU configuration (BASELINE configs[1], 4096 steady vowels) and its recipe at 65 536 utterances
                 bp.close()
-                for key, wl, n, reps in (("cfg1", "cfg1", 4096, 50), ("cfg1_recipe_at_batch_65536", "cfg1", 65536, 10)):
+                for key, wl, n, reps in (("cfg1", "cfg1", 4096, 400), ("cfg1_recipe_at_batch_65536", "cfg1", 65536, 60)):
                     if key == "cfg1" and args.workload == "cfg1":
                         continue
                     xb = workloads.make(wl, n)

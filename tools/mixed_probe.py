@@ -7,6 +7,8 @@ sentences, so after the sort by length every wavefront holds 64 copies of one se
                similar delays side by side again: lanes end up skewed by ~100 samples only)
   rotated    : sorted, every utterance's frame list rotated by a random amount (same lengths, fully de-aligned
                fades) -- the stand-in for 64 different sentences per wave
+  jittered   : every frame's duration and fade scaled by its own random factor in [0.7, 1.3]: no two utterances of the batch
+               share a timing or a length (what a batch of unrelated sentences looks like to the kernel)
 """
 import os
 import sys
@@ -51,6 +53,15 @@ def rotate(b, seed=1):
     return workloads.Batch(frame_start=fs, seeds=b["seeds"], name=b["name"] + " rotated", sr=b["sr"], **out)
 
 
+def jitter(b, seed=1):
+    rng = np.random.default_rng(seed)
+    k = rng.uniform(0.7, 1.3, size=len(b["min"]))
+    out = {key: b[key] for key in ("frames", "index", "isnull")}
+    out["min"] = np.maximum(1, (b["min"] * k)).astype(np.uint32)
+    out["fade"] = (b["fade"] * k).astype(np.uint32)
+    return workloads.Batch(frame_start=b["frame_start"], seeds=b["seeds"], name=b["name"] + " jittered", sr=b["sr"], **out)
+
+
 def run(name, b, sort, mode=0):
     bp = BatchPlayer(b["sr"], mode=mode)
     bp.setOption("sort", sort)
@@ -68,3 +79,4 @@ if __name__ == "__main__":
     run("unsorted", b, 0)
     run("staggered", stagger(b), 1)
     run("rotated", rotate(b), 1)
+    run("jittered", jitter(b), 1)

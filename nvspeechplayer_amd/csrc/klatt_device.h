@@ -49,6 +49,7 @@ constexpr int MODE_FAST = 1;
 
 constexpr uint32_t FRAME_NULL = 1u;       // FrameMeta.flags
 constexpr uint32_t UTT_NEEDS_NOISE = 1u;  // UttDesc.flags
+constexpr uint32_t UTT_TRACKED = 4u;      // UttDesc.flags: noisy, every parameter finite, coefficient tracks planned (2u: UTT_NO_NASAL, klatt_lanepipe.h)
 
 struct FrameMeta {           // 16 B per frame; with the 376-B parameter vector: 392 B/frame read
     uint32_t minSamples;
@@ -73,7 +74,36 @@ struct UttResult {           // written by the kernel
     uint32_t drained;        // 1: the queue ran dry (short count)
 };
 
+// ---- coefficient tracks (klatt_tracks.h) ------------------------------------------------------------------
+// A resonator's coefficients are a pure function of (f, bw) (reference src/speechWaveGenerator.cpp:112-127), and during a
+// fade (f, bw) are a pure function of the fade's two end frames and the sample counter (reference src/frame.cpp:48-53): the
+// coefficient values of a fade do not depend on the signal.  The tracked kernels therefore take them from a TRACK --
+// evaluated densely (lanes = entries) by klatt_tracks before the synthesis launch -- instead of evaluating exp/cos inside
+// the sample recurrence.  A track is an array of 16-byte entries:
+//   fade sample 1 (every resonator is re-evaluated there, see fade_update below): 15 entries,
+//       [0] N0 (b, c)  [1] N0 (a, -)  [2..14] NP, c6..c1, p1..p6 (b, c)            (a = 1 - b - c except for the anti-resonator)
+//   fade samples 2..F: one entry per MOVING resonator (mask, ascending; N0 takes two), nSlots entries per sample.
+// Fades with the same end values of all 28 (f, bw) parameters and the same length share one track (host, setUtterances).
+constexpr int kTrackFirst = 15;              // entries of a fade's first sample
+struct TrackRef {            // 16 B per frame, read by the tracked stages at a dequeue
+    unsigned long long off;  // first entry of the fade's track
+    uint32_t mask;           // resonators that move in the fade (bit r of N0, NP, c6..c1, p1..p6)
+    uint32_t nSlots;         // entries per fade sample after the first: popcount(mask) + (mask & 1)
+};
+struct TrackJob {            // one distinct track, read by klatt_tracks
+    unsigned long long off;
+    long long oldFrame, newFrame;   // frames (index into KernelArgs.frames) the fade starts from / goes to; -1 = all zero
+    uint32_t fadeSamples;
+    uint32_t mask;
+};
+__host__ __device__ inline uint32_t track_slots(uint32_t mask) { return (uint32_t)__builtin_popcount(mask) + (mask & 1u); }
+// slot of resonator r among the entries of a later fade sample / of the first one
+__host__ __device__ inline uint32_t track_slot(uint32_t mask, int r) { return (uint32_t)__builtin_popcount(mask & ((1u << r) - 1u)) + ((r > 0) ? (mask & 1u) : 0u); }
+constexpr int track_first_slot(int r) { return r + (r > 0 ? 1 : 0); }
+
 struct KernelArgs {
+    const TrackRef* trackRef;    // [nFrames] tracked launches only
+    const double2* track;        // the launch's coefficient tracks
     const double* frames;        // [nFrames][47]
     const FrameMeta* meta;       // [nFrames]
     const UttDesc* utt;          // [nUtt]

@@ -10,6 +10,7 @@
 #include "klatt_device.h"
 #include "klatt_systolic.h"
 #include "klatt_lanepipe.h"
+#include "klatt_tracks.h"
 
 #include <algorithm>
 #include <cmath>
@@ -22,6 +23,7 @@
 #include <thread>
 #include <numeric>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/speechPlayer_batch.h"
@@ -191,12 +193,12 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false>
+template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false, bool TRACK = false>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = SysLds<NOISE, CH>::kBytes;
+    constexpr int ldsBytes = SysLds<NOISE, CH, TRACK>::kBytes;
     auto go = [&](auto kernel) -> int {
         if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a);
@@ -204,8 +206,8 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM>); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM>); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM, TRACK>); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM, TRACK>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -311,10 +313,14 @@ struct Batch {
     int layout = -1;                       // -1: choose per group (plan_group); 2: lane-pipelined where eligible; 1: stage-parallel workgroups; 0: one wave per 64 utterances
     int cus = 256;
     hipStream_t stream = nullptr;
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};   // the quiet groups run beside the noisy one (batch_launch)
-    hipEvent_t forkEvent = nullptr, join[3] = {nullptr, nullptr, nullptr};
+    int tracks = 1;                        // 1: noisy utterances with finite parameters take their coefficients from tracks (klatt_tracks.h)
+    long long trackBudgetMB = 16384;       // the tracks of a batch may take this much device memory; utterances beyond it run untracked
+    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
+    hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     long long nUtt = 0, nFrames = 0, nSlots = 0;
     long long nQuiet = 0;                  // order[0..nQuiet) = utterances without noise, the rest with
+    long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with coefficient tracks
+    long long nJobs = 0, trackEntries = 0; // distinct tracks of the batch, their entries (16 B each)
     long long nNoNasal = 0;                // order[0..nNoNasal) = quiet utterances that never couple the nasal pair (UTT_NO_NASAL)
     long long totalSamples = 0, poolSamples = 0;
     std::vector<uint32_t> lens;
@@ -327,6 +333,9 @@ struct Batch {
     DeviceBuffer<uint32_t> dOrder;
     DeviceBuffer<int16_t> dPcm;
     DeviceBuffer<UttResult> dResult;
+    DeviceBuffer<TrackRef> dTrackRef;          // [nFrames]
+    DeviceBuffer<TrackJob> dJobs;
+    DeviceBuffer<double2> dTrack;
     DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
     DeviceBuffer<unsigned long long> dDigest;  // per-utterance digests (speechPlayer_batch_digest)
@@ -347,6 +356,16 @@ long long lanepipe_count(const Batch* b)
     return groups <= b->cus ? b->nNoNasal : 0;
 }
 
+// How many of the noisy utterances (the head of the noisy part of `order`) take their coefficients from tracks: those the
+// host planned tracks for, under the stage-parallel layouts.
+#ifndef KLATT_TRACK_WPS
+#define KLATT_TRACK_WPS 2
+#endif
+// host copies of kResF / kResB (klatt_device.h): the frequency and bandwidth parameter of resonator r
+constexpr int kResFHost[kNumRes] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
+constexpr int kResBHost[kNumRes] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
+long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
+
 int batch_launch(Batch* b)
 {
     KernelArgs a = base_args(b->sampleRate);
@@ -364,12 +383,14 @@ int batch_launch(Batch* b)
     //   order[nLp, nNoNasal)       quiet, nasal-free -> stage-parallel kernel without the nasal pair (NASAL = false)
     //   order[nNoNasal, nQuiet)    quiet             -> stage-parallel (or lane) kernel, NOISE = false
     //   order[nQuiet, nSlots)      noisy             -> stage-parallel (or lane) kernel, NOISE = true
-    const long long nNoisy = b->nSlots - b->nQuiet;
+    //   order[nQuiet, nQuiet + nTr)  noisy, tracked  -> klatt_tracks, then the stage-parallel kernel with TRACK = true
     const long long nLp = lanepipe_count(b);
     const bool laneKernel = b->layout == 0;
+    const long long nTr = tracked_count(b);
+    const long long nNoisy = b->nSlots - b->nQuiet - nTr;
     const long long nNn = laneKernel ? 0 : b->nNoNasal - nLp;
     const long long nQ = b->nQuiet - nLp - nNn;
-    const int parts = (nLp > 0) + (nNn > 0) + (nQ > 0) + (nNoisy > 0);
+    const int parts = (nLp > 0) + (nNn > 0) + (nQ > 0) + (nNoisy > 0) + (nTr > 0);
     const bool fork = parts > 1;
     if (fork) HIP_TRY(hipEventRecord(b->forkEvent, b->stream));
     int sideUsed = 0, seen = 0;
@@ -400,9 +421,26 @@ int batch_launch(Batch* b)
         if (plq.systolic ? (plq.chunk == 32 ? launch_systolic<false, 32>(a, b->mode, g, st) : launch_systolic<false, 16>(a, b->mode, g, st))
                          : launch<false, false>(a, b->mode, g, st)) return -1;
     }
+    if (nTr > 0) {
+        hipStream_t st = next_stream();
+        TrackArgs t;
+        t.jobs = b->dJobs.ptr; t.nJobs = b->nJobs; t.frames = b->dFrames.ptr; t.track = b->dTrack.ptr;
+        t.negPiOverSr = a.negPiOverSr; t.twoPiOverSr = a.twoPiOverSr;
+        const long long tg = (b->nJobs + kTrackWaves - 1) / kTrackWaves;
+        if (tg > 0x7FFFFFFF) { set_error("too many coefficient tracks: %lld", b->nJobs); return -1; }
+        hipLaunchKernelGGL(klatt_tracks, dim3((unsigned)tg), dim3(kLanes * kTrackWaves), 0, st, t);
+        HIP_TRY(hipGetLastError());
+        a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nTr;
+        a.trackRef = b->dTrackRef.ptr; a.track = b->dTrack.ptr;
+        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
+        const long long g = (nTr + kLanes - 1) / kLanes;
+        if (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
+                          : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
+        a.trackRef = nullptr; a.track = nullptr;
+    }
     if (nNoisy > 0) {
-        a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nNoisy;
-        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nNoisy, b->cus);
+        a.order = b->dOrder.ptr + b->nQuiet + nTr; a.nSlots = nNoisy;
+        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nNoisy + kLanes - 1) / kLanes;
         if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, 2>(a, b->mode, g, b->stream) : launch_systolic<true, 16>(a, b->mode, g, b->stream))
                         : launch<false, true>(a, b->mode, g, b->stream)) return -1;
@@ -829,7 +867,8 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) b->cus = prop.multiProcessorCount; }
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess;
-    for (int i = 0; i < 3 && ok; ++i)
+    { const char* e = getenv("SPEECHPLAYER_TRACKS"); if (e) b->tracks = atoi(e) ? 1 : 0; }
+    for (int i = 0; i < 4 && ok; ++i)
         ok = hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&b->join[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -846,13 +885,14 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    for (int i = 0; i < 3; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (b->side[i]) { (void)hipStreamSynchronize(b->side[i]); (void)hipStreamDestroy(b->side[i]); }
         if (b->join[i]) (void)hipEventDestroy(b->join[i]);
     }
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
+    b->dTrackRef.release(); b->dJobs.release(); b->dTrack.release();
     delete b;
 }
 
@@ -868,6 +908,9 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     }
     if (!strcmp(name, "sort")) { b->sortByLength = value ? 1 : 0; return 0; }
     if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value > 2 ? 1 : value); return 0; }
+    // coefficient tracks: planned by setUtterances (set the option before it), used by the stage-parallel layouts
+    if (!strcmp(name, "tracks")) { b->tracks = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "track_budget_mb")) { b->trackBudgetMB = value < 0 ? 0 : value; return 0; }
     set_error("unknown option %s", name);
     return -1;
 }
@@ -958,6 +1001,82 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         pool += ((long long)len + kTile - 1) / kTile * kTile;
     }
     outStart[nUtterances] = pool;
+    // ---- coefficient tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite -------------------
+    // Per frame: which resonators its fade moves and where the fade's coefficients will be.  The state walked here is the
+    // part of the frame state machine that decides a fade's (f, bw) end points (reference src/frame.cpp:55-72, restated by
+    // stage_event): silence keeps the shape of the last spoken frame, the first frame after silence starts from its own
+    // shape, any other frame fades from the last spoken frame's values.  Fades with bitwise equal end points of all 28
+    // (f, bw) parameters and the same length share one track.
+    std::vector<TrackRef> trackRef;
+    std::vector<TrackJob> jobs;
+    unsigned long long trackEntries = 0;
+    if (b->tracks && nF > 0) {
+        trackRef.assign((size_t)nF, TrackRef{0, 0, 0});
+        struct Shape { unsigned long long w[2 * kNumRes]; bool operator==(const Shape& o) const { return !memcmp(w, o.w, sizeof w); } };
+        struct ShapeHash { size_t operator()(const Shape& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (unsigned long long v : k.w) { h ^= v; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
+        struct Fade { uint32_t from, to, len; bool operator==(const Fade& o) const { return from == o.from && to == o.to && len == o.len; } };
+        struct FadeHash { size_t operator()(const Fade& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
+        std::unordered_map<Shape, uint32_t, ShapeHash> shapes;      // (f, bw) vector -> id
+        std::vector<long long> shapeFrame;                          // id -> a frame that has it (-1: all zero)
+        std::unordered_map<Fade, unsigned long long, FadeHash> fades;   // (from, to, length) -> first entry
+        Shape zero; memset(&zero, 0, sizeof zero);
+        shapes.emplace(zero, 0u); shapeFrame.push_back(-1);
+        const unsigned long long budget = (unsigned long long)b->trackBudgetMB * (1ull << 20) / sizeof(double2);
+        std::vector<Fade> added;
+        for (long long u = 0; u < nUtterances; ++u) {
+            if (!(utt[u].flags & UTT_NEEDS_NOISE)) continue;
+            bool finite = true;
+            for (long long k = frameStart[u]; k < frameStart[u + 1] && finite; ++k) {
+                if (meta[k].flags & FRAME_NULL) continue;
+                const double* p = reinterpret_cast<const double*>(frames + k);
+                for (int i = 0; i < kNumParams && finite; ++i) finite = std::isfinite(p[i]);
+            }
+            if (!finite) continue;     // "hold" targets and overflowing coefficients stay with the untracked kernel
+            added.clear();
+            const unsigned long long before = trackEntries;
+            const size_t jobsBefore = jobs.size();
+            bool fits = true, prevNull = true;
+            uint32_t shapeId = 0;      // the last spoken frame's shape (0: none yet, all parameters zero)
+            long long shapeAt = -1;
+            for (long long k = frameStart[u]; k < frameStart[u + 1] && fits; ++k) {
+                uint32_t from = shapeId, to = shapeId, mask = 0;
+                if (!(meta[k].flags & FRAME_NULL)) {
+                    const double* p = reinterpret_cast<const double*>(frames + k);
+                    Shape sh;
+                    for (int r = 0; r < kNumRes; ++r) { memcpy(&sh.w[2 * r], &p[kResFHost[r]], 8); memcpy(&sh.w[2 * r + 1], &p[kResBHost[r]], 8); }
+                    auto it = shapes.find(sh);
+                    if (it == shapes.end()) { it = shapes.emplace(sh, (uint32_t)shapeFrame.size()).first; shapeFrame.push_back(k); }
+                    to = it->second;
+                    if (prevNull) from = to;
+                    else {
+                        const double* q = reinterpret_cast<const double*>(frames + shapeAt);
+                        for (int r = 0; r < kNumRes; ++r)
+                            if (!(p[kResFHost[r]] == q[kResFHost[r]]) || !(p[kResBHost[r]] == q[kResBHost[r]])) mask |= 1u << r;
+                    }
+                    shapeId = to; shapeAt = k; prevNull = false;
+                } else prevNull = true;
+                const uint32_t nSlots = track_slots(mask);
+                const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
+                if (n >= (1ull << 27)) { fits = false; break; }
+                const Fade key{from, to, meta[k].fadeSamples};
+                auto f = fades.find(key);
+                if (f == fades.end()) {
+                    if (trackEntries + n > budget) { fits = false; break; }
+                    f = fades.emplace(key, trackEntries).first;
+                    added.push_back(key);
+                    jobs.push_back(TrackJob{trackEntries, shapeFrame[from], shapeFrame[to], meta[k].fadeSamples, mask});
+                    trackEntries += n;
+                }
+                trackRef[k] = TrackRef{f->second, mask, nSlots};
+            }
+            if (fits) utt[u].flags |= UTT_TRACKED;
+            else {
+                for (const Fade& key : added) fades.erase(key);
+                jobs.resize(jobsBefore);
+                trackEntries = before;
+            }
+        }
+    }
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
     // (within the quiet group and within the noisy group, which are launched as separate kernels)
     std::vector<uint32_t> order((size_t)nUtterances);
@@ -966,11 +1085,14 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     const long long nQuiet = quietEnd - order.begin();
     auto noNasalEnd = std::stable_partition(order.begin(), quietEnd, [&](uint32_t x) { return (utt[x].flags & UTT_NO_NASAL) != 0; });
     const long long nNoNasal = noNasalEnd - order.begin();
+    auto trackedEnd = std::stable_partition(quietEnd, order.end(), [&](uint32_t x) { return (utt[x].flags & UTT_TRACKED) != 0; });
+    const long long nTracked = trackedEnd - quietEnd;
     if (b->sortByLength) {
         auto longer = [&](uint32_t x, uint32_t y) { return lens[x] > lens[y]; };
         std::stable_sort(order.begin(), noNasalEnd, longer);
         std::stable_sort(noNasalEnd, quietEnd, longer);
-        std::stable_sort(quietEnd, order.end(), longer);
+        std::stable_sort(quietEnd, trackedEnd, longer);
+        std::stable_sort(trackedEnd, order.end(), longer);
     }
 
     auto upload = [&]() -> int {
@@ -978,6 +1100,11 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
             b->dUtt.reserve(std::max<size_t>(nUtterances, 1)) || b->dOrder.reserve(std::max<size_t>(nUtterances, 1)) ||
             b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
+        if (nTracked > 0) {
+            if (b->dTrackRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dTrack.reserve((size_t)trackEntries)) return -1;
+            HIP_TRY(hipMemcpyAsync(b->dTrackRef.ptr, trackRef.data(), (size_t)nF * sizeof(TrackRef), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dJobs.ptr, jobs.data(), jobs.size() * sizeof(TrackJob), hipMemcpyHostToDevice, b->stream));
+        }
         if (nF) {
             HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dMeta.ptr, meta.data(), (size_t)nF * sizeof(FrameMeta), hipMemcpyHostToDevice, b->stream));
@@ -993,11 +1120,13 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     if (upload()) {
         // the device buffers may hold a mix of the old and the new batch now: the object becomes an empty batch
         b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
+        b->nTracked = 0; b->nJobs = 0; b->trackEntries = 0;
         b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
         return -1;
     }
     b->nUtt = nUtterances; b->nFrames = nF; b->nSlots = nUtterances;
     b->nQuiet = nQuiet; b->nNoNasal = nNoNasal;
+    b->nTracked = nTracked; b->nJobs = nTracked > 0 ? (long long)jobs.size() : 0; b->trackEntries = nTracked > 0 ? (long long)trackEntries : 0;
     b->totalSamples = total; b->poolSamples = pool;
     b->lens.swap(lens); b->outStart.swap(outStart);
     b->results.clear();
@@ -1411,6 +1540,8 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     const bool noisy = !lanepipe && !nasalFree && nNoisy >= nQ;
     const GroupPlan pl = plan_group(b->layout, noisy, b->nSlots, nNoisy, b->cus);
     const bool fast = b->mode == MODE_FAST;
+    const long long nTr = tracked_count(b);
+    const bool tracked = noisy && nTr > 0 && nTr >= nNoisy - nTr;
     const void* fn;
     int ldsBytes = LdsLayout<false>::kBytes, chunk = 0, wavesPerGroup = 1;
     long long groups = (nNn + kLanes - 1) / kLanes + (nQ + kLanes - 1) / kLanes + (nNoisy + kLanes - 1) / kLanes;
@@ -1425,6 +1556,11 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         else { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 16, 2> : (const void*)klatt_lanepipe<MODE_EXACT, 16, 2>; ldsBytes = LpLds<16>::kBytes; chunk = 16; }
         wavesPerGroup = kStages;
         groups = g;
+    } else if (tracked) {
+        if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_NOISY_CH, true>::kBytes; }
+        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>; ldsBytes = SysLds<true, 16, true>::kBytes; }
+        chunk = pl.chunk;
+        wavesPerGroup = kStages;
     } else if (pl.systolic) {
         if (noisy && pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 8, 2> : (const void*)klatt_systolic<MODE_EXACT, true, 8, 2>; ldsBytes = SysLds<true, 8>::kBytes; }
         else if (noisy) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16> : (const void*)klatt_systolic<MODE_EXACT, true, 16>; ldsBytes = SysLds<true, 16>::kBytes; }
@@ -1448,6 +1584,10 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     if (nInfo >= 8) { info[6] = chunk; info[7] = noisy ? 1 : 0; }
     if (nInfo >= 10) { info[8] = lanepipe ? 1 : 0; info[9] = (int)std::min<long long>(nLp, 0x7FFFFFFF); }
     if (nInfo >= 12) { info[10] = nasalFree ? 1 : 0; info[11] = (int)std::min<long long>(nNn, 0x7FFFFFFF); }
+    if (nInfo >= 16) {
+        info[12] = (int)std::min<long long>(nTr, 0x7FFFFFFF); info[13] = (int)std::min<long long>(b->nJobs, 0x7FFFFFFF);
+        info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? 1 : 0;
+    }
     return 0;
 }
 

@@ -61,7 +61,7 @@ constexpr int kStages = 4;
 
 // LDS per workgroup: pipes [2 buffers][CH][64 lanes] f64 (4 noisy / 3 quiet), the PCM tile and row
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
-template <bool NOISE, int CH>
+template <bool NOISE, int CH, bool TRACK = false>
 struct SysLds {
     static constexpr int kPipeBytes = 2 * CH * kLanes * 8;
     static constexpr int kNumPipes = NOISE ? 4 : 3;
@@ -70,8 +70,9 @@ struct SysLds {
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
     static constexpr int kFrames = kMaxLen + 16;
-    // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
-    static constexpr int kParams0 = 7, kParams1 = NOISE ? 11 : 7, kParams2 = NOISE ? 14 : 6, kParams3 = NOISE ? 14 : 5;
+    // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5; tracked (noisy, no f/bw pairs) 7, 1, 4, 6
+    static constexpr int kParams0 = 7, kParams1 = NOISE ? (TRACK ? 1 : 11) : 7, kParams2 = NOISE ? (TRACK ? 4 : 14) : 6,
+                         kParams3 = NOISE ? (TRACK ? 6 : 14) : 5;
     static constexpr int kFrames1 = kFrames + 1 * kParams0 * kLanes * 8;    // S0 keeps its target values in registers
     static constexpr int kFrames2 = kFrames1 + 2 * kParams1 * kLanes * 8;
     static constexpr int kFrames3 = kFrames2 + 2 * kParams2 * kLanes * 8;
@@ -93,6 +94,10 @@ struct StageFrame {
     double invFade;
     uint32_t cnt, oldMin, newMin, newFade, nextFrame, resMask, parMask, produced;
     bool hasNew, oldNull, newNull, done;
+    // tracked stages (StageDesc::TRACK): the running fade's coefficient track, its resonator mask in the track's numbering
+    // (N0, NP, c6..c1, p1..p6) and its entries per fade sample
+    const double2* tBase;
+    uint32_t gmask, nSlots;
 };
 
 // pitch (parameter 0) needs the glide state; only the source stage has it
@@ -112,14 +117,17 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
     f.invFade = 1.0;
     f.cnt = 0; f.oldMin = 0; f.newMin = 0; f.newFade = 1; f.nextFrame = 0; f.resMask = 0; f.parMask = 0; f.produced = 0;
     f.hasNew = false; f.oldNull = true; f.newNull = false; f.done = !live;
+    f.tBase = nullptr; f.gmask = 0; f.nSlots = 0;
 }
 
 // Stage descriptor.  GAIN = index into P of parameter 44 (or -1): NULL frames force it to 0
 // (reference src/frame.cpp:61,66).  ANTI0: resonator 0 is the anti-resonator N0.
-template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false>
+// TRACK: the stage tracks no (f, bw) parameters; its resonators' coefficients come from the fade's coefficient track
+// (klatt_tracks.h), and the RF argument of the stage functions lists the resonators' numbers in the track (RB is unused).
+template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false, bool TRACK_ = false>
 struct StageDesc {
     static constexpr int NPARAM = NPARAM_, NRES = NRES_, GAIN = GAIN_;
-    static constexpr bool PITCH = PITCH_, ANTI0 = ANTI0_, INLINE_COEF = INLINE_COEF_;
+    static constexpr bool PITCH = PITCH_, ANTI0 = ANTI0_, INLINE_COEF = INLINE_COEF_, TRACK = TRACK_;
 };
 
 struct StageCtx {          // what every stage needs from the launch
@@ -127,6 +135,7 @@ struct StageCtx {          // what every stage needs from the launch
     const UttDesc& d;
     const double* myFrames;
     const FrameMeta* myMeta;
+    const TrackRef* myTrack;   // tracked launches: the utterance's per-frame track references
 };
 
 // OR over the wavefront of the low NBITS bits of a per-lane mask, as a wave-uniform (scalar) value.
@@ -192,8 +201,10 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
                 pm |= moved[k] ? (1u << k) : 0u;
                 pm |= (v != v) ? kNanTarget : 0u;
             }
+            if constexpr (!D::TRACK) {
 #pragma unroll
-            for (int r = 0; r < D::NRES; ++r) mk |= (moved[RF[r]] || moved[RB[r]]) ? (1u << r) : 0u;
+                for (int r = 0; r < D::NRES; ++r) mk |= (moved[RF[r]] || moved[RB[r]]) ? (1u << r) : 0u;
+            }
         }
         if (D::PITCH) {
             const double g0 = g[0], g46 = g[46];
@@ -202,6 +213,17 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
             if (f.oldNull) ps->old0 = g0;
         }
         f.resMask = mk; f.parMask = pm;
+    }
+    if (D::TRACK) {
+        // which resonators move, and where the fade's coefficients are, was worked out on the host (setUtterances) with the
+        // comparisons above: silence and the first frame after it move none
+        const TrackRef tr = X.myTrack[f.nextFrame - 1];
+        f.tBase = X.A.track + tr.off;
+        f.gmask = tr.mask; f.nSlots = tr.nSlots;
+        uint32_t mk = 0;
+#pragma unroll
+        for (int r = 0; r < D::NRES; ++r) mk |= ((tr.mask >> RF[r]) & 1u) << r;
+        f.resMask = mk;
     }
     if (lastIndex && m.userIndex != -1) *lastIndex = m.userIndex;   // (:69)
     f.cnt = 0;                                                       // (:70)
@@ -230,7 +252,7 @@ template <class D, class SF>
 __device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& A, const int* RF, const int* RB, uint32_t wRes)
 {
     uint32_t bits = kCoefAllUnknown;
-    if (!D::INLINE_COEF) return bits;
+    if constexpr (D::INLINE_COEF) {
 #pragma unroll
     for (int r = 0; r < D::NRES; ++r) {
         if (!(wRes & (1u << r))) continue;
@@ -242,6 +264,7 @@ __device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& 
         const uint32_t cls = __all(f.done || (eu && c0)) ? COEF_UNREDUCED : (__all(f.done || (eu && c1)) ? COEF_QUADRANT_M1 : COEF_UNKNOWN);
         bits = (bits & ~(3u << (2 * r))) | (cls << (2 * r));
     }
+    }
     return bits;
 }
 
@@ -249,7 +272,7 @@ template <class D, int MODE, bool PLAIN = false, class SF>
 __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelArgs& A, const int* RF, const int* RB,
                                            bool lerp, uint32_t wRes, bool gainOnly = false, uint32_t coefCls = kCoefAllUnknown)
 {
-    if (!D::PITCH && !lerp) return;
+    if (!D::PITCH && !lerp && !(D::TRACK && wRes != 0u)) return;
     const double ratio = div_by((double)f.cnt, (double)f.newFade, f.invFade);
     if (D::PITCH) ps->cur0 = fade_value(ps->old0, ps->new0, ratio);
     constexpr int GI = D::GAIN >= 0 ? D::GAIN : 0;
@@ -263,16 +286,34 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = PLAIN ? o[k] + ((n[k] - o[k]) * ratio) : fade_value(o[k], n[k], ratio);   // PLAIN: no NaN target in any live lane
     }
+    if constexpr (D::TRACK) {
+        // the coefficients of this fade sample, evaluated by klatt_tracks from the same (f, bw) the untracked stages interpolate:
+        // a lane takes an entry for each of its resonators that moves (all of them on the fade's first sample)
+        const bool first = !PLAIN && f.cnt == 1u;     // the whole-chunk paths start past a fade's first sample
+        const uint32_t base = first ? 0u : (uint32_t)kTrackFirst + (f.cnt - 2u) * f.nSlots;
 #pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        if (wRes & (1u << r)) {
-            // inlined where fades dominate (speech); the quiet kernels keep one out-of-line copy, which keeps
-            // their loops small (measured: cfg1 1.72 ms vs 1.86 ms inlined; cfg2 29.2 ms inlined vs 36.6 ms called)
-            const Coef k = D::INLINE_COEF
-                ? resonator_coefficients_inline<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr,
-                                                      (int)((coefCls >> (2 * r)) & 3u))
-                : resonator_coefficients<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr);
-            f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
+        for (int r = 0; r < D::NRES; ++r) {
+            if (wRes & (1u << r)) {
+                if (first || ((f.resMask >> r) & 1u)) {
+                    const uint32_t slot = base + (first ? (uint32_t)track_first_slot(RF[r]) : track_slot(f.gmask, RF[r]));
+                    const double2 bc = f.tBase[slot];
+                    f.ra[r] = (D::ANTI0 && r == 0) ? f.tBase[slot + 1u].x : (1.0 - bc.x - bc.y);
+                    f.rb[r] = bc.x; f.rc[r] = bc.y;
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int r = 0; r < D::NRES; ++r) {
+            if (wRes & (1u << r)) {
+                // inlined where fades dominate (speech); the quiet kernels keep one out-of-line copy, which keeps
+                // their loops small (measured: cfg1 1.72 ms vs 1.86 ms inlined; cfg2 29.2 ms inlined vs 36.6 ms called)
+                const Coef k = D::INLINE_COEF
+                    ? resonator_coefficients_inline<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr,
+                                                          (int)((coefCls >> (2 * r)) & 3u))
+                    : resonator_coefficients<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr);
+                f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
+            }
         }
     }
 }
@@ -672,12 +713,16 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
 // handle whose queue runs dry stops earlier), and every stage saves its slice again.  Live handles always take the
 // noisy instantiation: the noise generators' memories and counters advance with every sample whatever the gains
 // (reference src/speechWaveGenerator.cpp:39-42), and a handle that is quiet now may be given noisy frames later.
-template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false>
+// TRACK (noisy batch launches only): the utterances of the launch have coefficient tracks (klatt_tracks.h; host: UTT_TRACKED).
+// S1, S2 and S3 then track no (f, bw) parameters -- 1, 4 and 6 parameters instead of 11, 14 and 14 -- and pick their
+// resonators' coefficients up from the track on fade samples instead of evaluating exp and cos.
+template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false, bool TRACK = false>
 __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const KernelArgs A)
 {
     static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
     static_assert(NOISE || !STREAM, "live handles take the noisy instantiation");
-    using L = SysLds<NOISE, CH>;
+    static_assert(!TRACK || (NOISE && !STREAM), "coefficient tracks: noisy batch launches");
+    using L = SysLds<NOISE, CH, TRACK>;
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     double* const pipeX = reinterpret_cast<double*>(lds);                           // S0 -> S1
@@ -698,7 +743,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     UttDesc d;
     d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
-    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart};
+    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart, TRACK ? A.trackRef + d.frameStart : nullptr};
     const uint32_t nkey = noise_key(d.seed);
     constexpr int FINAL = NOISE ? 2 : 3;
     // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out
@@ -766,7 +811,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         int32_t lastIndex = -1;
         bool vibFrames = false;
         constexpr int GR0[1] = {0};
-        if (STREAM && live) {
+        if constexpr (STREAM) if (live) {
             if (streamState[239] != 0.0) {
                 pitchPhase = streamState[208]; vibPhase = streamState[209]; aspNoise = streamState[210];
                 lastIndex = (int32_t)streamState[220]; noiseIdx = (uint32_t)streamState[221];
@@ -877,7 +922,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             res.produced = f.produced; res.framesTaken = f.nextFrame; res.lastIndex = lastIndex; res.drained = STREAM ? (f.done ? 1u : 0u) : 1u;
             A.result[u] = res;
         }
-        if (STREAM && live) {
+        if constexpr (STREAM) if (live) {
             stage_state_save<D>(f, &ps, streamState, P, GR0);
             streamState[208] = pitchPhase; streamState[209] = vibPhase; streamState[210] = aspNoise;
             streamState[220] = (double)lastIndex; streamState[221] = (double)noiseIdx;
@@ -909,16 +954,17 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (stage == 1) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
         constexpr int NR = NOISE ? 5 : 3;
-        using D = StageDesc<2 * NR + 1, NR, -1, false, true, NOISE>;
-        // parameter list: (f, bw) of N0, NP, r6 [, r5, r4], then caNP
-        constexpr int P[11] = {13, 21, 14, 22, 12, 20, NOISE ? 11 : 23, 19, 10, 18, 23};
-        constexpr int RF[5] = {0, 2, 4, 6, 8};
+        constexpr int NPAR = TRACK ? 1 : 2 * NR + 1;
+        using D = StageDesc<NPAR, NR, -1, false, true, NOISE && !TRACK, TRACK>;
+        // parameter list: (f, bw) of N0, NP, r6 [, r5, r4], then caNP; tracked: caNP alone, RF = the resonators' track numbers
+        constexpr int P[11] = {TRACK ? 23 : 13, 21, 14, 22, 12, 20, NOISE ? 11 : 23, 19, 10, 18, 23};
+        constexpr int RF[5] = {0, TRACK ? 1 : 2, TRACK ? 2 : 4, TRACK ? 3 : 6, TRACK ? 4 : 8};
         constexpr int RB[5] = {1, 3, 5, 7, 9};
-        constexpr int CANP = 2 * NR;
-        StageFrame<2 * NR + 1, NR> f;
+        constexpr int CANP = NPAR - 1;
+        StageFrame<NPAR, NR> f;
         stage_frame_init(f, live, lds + L::kFrames1, lane);
         constexpr int GR1[5] = {0, 1, 2, 3, 4};
-        if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR1, streamPurge);
+        if constexpr (STREAM) if (live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR1, streamPurge);
         auto dsp = [&](double x) __attribute__((always_inline)) -> double {
             const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
             f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
@@ -934,32 +980,35 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             noFadeAlt,
             [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i)); },
             nothing, nothing, noChunk);
-        if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GR1);
+        if constexpr (STREAM) if (live) stage_state_save<D>(f, nullptr, streamState, P, GR1);
     } else if (NOISE && stage == 3) {
         // ================= noisy S3: frication noise, parallel r1..r4 partial sum =================
         // tracked: (pf, pb) of parallel 1..4, then 24 fricationAmplitude, 44 preFormantGain, pa1..4 (37..40)
-        using D = StageDesc<14, 4, 9, false, false, true>;
-        constexpr int P[14] = {25, 31, 26, 32, 27, 33, 28, 34, 24, 44, 37, 38, 39, 40};
-        constexpr int RF[4] = {0, 2, 4, 6}, RB[4] = {1, 3, 5, 7};
-        StageFrame<14, 4> f;
+        // tracked: the six gains alone, RF = the track numbers of parallel 1..4
+        constexpr int NPAR = TRACK ? 6 : 14;
+        constexpr int G0 = NPAR - 6;      // where 24 fricationAmplitude sits in P
+        using D = StageDesc<NPAR, 4, G0 + 1, false, false, !TRACK, TRACK>;
+        constexpr int P[14] = {TRACK ? 24 : 25, TRACK ? 44 : 31, TRACK ? 37 : 26, TRACK ? 38 : 32, TRACK ? 39 : 27, TRACK ? 40 : 33, 28, 34, 24, 44, 37, 38, 39, 40};
+        constexpr int RF[4] = {TRACK ? 8 : 0, TRACK ? 9 : 2, TRACK ? 10 : 4, TRACK ? 11 : 6}, RB[4] = {1, 3, 5, 7};
+        StageFrame<NPAR, 4> f;
         stage_frame_init(f, live, lds + L::kFrames3, lane);
         double fricNoise = 0.0;
         uint32_t noiseIdx = 1;
         constexpr int GR3[4] = {8, 9, 10, 11};
-        if (STREAM && live) {
+        if constexpr (STREAM) if (live) {
             if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseIdx = (uint32_t)streamState[221] + 1u; }
             stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR3, streamPurge);
         }
         auto dsp = [&](int c, int i) __attribute__((always_inline)) {
             fricNoise = noise_uniform(nkey, noiseIdx) + 0.75 * fricNoise;
             noiseIdx += 2u;
-            const double fric = fricNoise * 0.3 * f.cur[8];
-            const double y = (fric * f.cur[9]) * 0.5;
+            const double fric = fricNoise * 0.3 * f.cur[G0];
+            const double y = (fric * f.cur[G0 + 1]) * 0.5;
             double par = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
-                par += (w - y) * f.cur[10 + r];
+                par += (w - y) * f.cur[G0 + 2 + r];
             }
             PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
         };
@@ -969,7 +1018,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             noFadeAlt,
             [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) dsp(c, i); },
             nothing, nothing, noChunk);
-        if (STREAM && live) { stage_state_save<D>(f, nullptr, streamState, P, GR3); streamState[211] = fricNoise; }
+        if constexpr (STREAM) if (live) { stage_state_save<D>(f, nullptr, streamState, P, GR3); streamState[211] = fricNoise; }
     } else if (!NOISE && stage == 2) {
         // ================= quiet S2: r5, r4, r3 =================
         using D = StageDesc<6, 3, -1, false, false>;
@@ -994,17 +1043,19 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // quiet (stage 3): r2, r1 | outputGain          quiet, nasal-free (stage 3): outputGain only
         constexpr int NC = NOISE ? 3 : (NASAL ? 2 : 0);   // cascade resonators here
         constexpr int NR = NOISE ? 5 : NC;
-        constexpr int NPAR = NOISE ? 14 : (NASAL ? 5 : 1);
-        using D = StageDesc<NPAR, NR, -1, false, false, NOISE>;
-        constexpr int P[14] = {NOISE ? 9 : (NASAL ? 8 : 45), NOISE ? 17 : 16, NOISE ? 8 : 7, NOISE ? 16 : 15, NOISE ? 7 : 45, 15,
-                               29, 35, 30, 36, 41, 42, 43, 45};
-        constexpr int RF[5] = {0, 2, NOISE ? 4 : 0, 6, 8};
+        // tracked (noisy): pa5, pa6, parallelBypass, outputGain alone, RF = the track numbers of c3, c2, c1, p5, p6
+        constexpr int NPAR = NOISE ? (TRACK ? 4 : 14) : (NASAL ? 5 : 1);
+        using D = StageDesc<NPAR, NR, -1, false, false, NOISE && !TRACK, TRACK>;
+        constexpr int P[14] = {TRACK ? 41 : (NOISE ? 9 : (NASAL ? 8 : 45)), TRACK ? 42 : (NOISE ? 17 : 16), TRACK ? 43 : (NOISE ? 8 : 7),
+                               TRACK ? 45 : (NOISE ? 16 : 15), NOISE ? 7 : 45, 15, 29, 35, 30, 36, 41, 42, 43, 45};
+        constexpr int RF[5] = {TRACK ? 5 : 0, TRACK ? 6 : 2, TRACK ? 7 : (NOISE ? 4 : 0), TRACK ? 12 : 6, TRACK ? 13 : 8};
         constexpr int RB[5] = {1, 3, NOISE ? 5 : 0, 7, 9};
-        constexpr int OUTGAIN = NOISE ? 13 : (NASAL ? 4 : 0);
+        constexpr int OUTGAIN = NOISE ? NPAR - 1 : (NASAL ? 4 : 0);
+        constexpr int PA5 = NOISE ? NPAR - 4 : 0;
         StageFrame<NPAR, NR> f;
         stage_frame_init(f, live, lds + (NOISE ? L::kFrames2 : L::kFrames3), lane);
         constexpr int GRF[5] = {5, 6, 7, 12, 13};
-        if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GRF, streamPurge);
+        if constexpr (STREAM) if (live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GRF, streamPurge);
         int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
 
         auto finish = [&](double o, double y, double part) __attribute__((always_inline)) -> uint32_t {
@@ -1016,9 +1067,9 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
 #pragma unroll
                 for (int r = 3; r < 5; ++r) {
                     const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
-                    par += (w - y) * f.cur[10 + (r - 3)];
+                    par += (w - y) * f.cur[PA5 + (r - 3)];
                 }
-                par = fade_value(par, y, f.cur[12]);
+                par = fade_value(par, y, f.cur[PA5 + 2]);
                 mix = o + par;
             }
             const double v = (mix * f.cur[OUTGAIN]) * 4000.0;
@@ -1073,7 +1124,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             [&](int n) __attribute__((always_inline)) { f.produced += n; },
             [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
         if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
-        if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GRF);
+        if constexpr (STREAM) if (live) stage_state_save<D>(f, nullptr, streamState, P, GRF);
     }
 #undef PIPE
 }

@@ -1,0 +1,74 @@
+// klatt_tracks.h -- coefficient tracks: the resonator coefficients of every fade sample, evaluated densely.
+//
+// The reference recomputes a resonator's coefficients whenever its frequency or bandwidth changed (reference
+// src/speechWaveGenerator.cpp:112-127), i.e. on every sample of a fade for every resonator the fade moves (reference
+// src/frame.cpp:48-53): one exp and one cos per resonator and fade sample, inside the sample recurrence.  Inside the synthesis
+// kernels that evaluation runs with lanes = utterances, so a wavefront pays for it on every sample in which ANY of its 64
+// utterances is fading -- always, once the utterances of a wavefront are not copies of one sentence -- and the polynomial
+// constants and temporaries of exp/cos share the register budget of the filter stages.
+//
+// But the values do not depend on the signal: (f, bw) on fade sample n are
+//     from + ((to - from) * (n / fadeSamples))                       (reference src/utils.h:20-23)
+// of the fade's two end frames.  This kernel evaluates them with lanes = ENTRIES of a track (a fade's samples x its moving
+// resonators; layout in klatt_device.h), every lane busy whatever the utterances' alignment, with the very functions the
+// untracked stages call (fade_value, resonator_coefficients_inline: same operations, operands and rounding, so the tracked
+// kernels produce the same PCM bit for bit).  The host gives equal fades ONE track (setUtterances: a voice has a few dozen
+// formant targets, so the fades of a batch are few distinct transitions, whatever the text), which makes the tracks a small,
+// cache-resident table and this launch a fraction of a millisecond.
+#pragma once
+
+#include "klatt_device.h"
+
+namespace klatt {
+
+struct TrackArgs {
+    const TrackJob* jobs;
+    long long nJobs;
+    const double* frames;        // [nFrames][47]
+    double2* track;
+    double negPiOverSr, twoPiOverSr;
+};
+
+constexpr int kTrackWaves = 4;   // wavefronts (jobs) per workgroup
+
+__global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const TrackArgs T)
+{
+    const int lane = threadIdx.x & (kLanes - 1);
+    const long long j = (long long)blockIdx.x * kTrackWaves + (threadIdx.x >> 6);
+    if (j >= T.nJobs) return;     // whole waves
+    const TrackJob job = T.jobs[j];
+    const uint32_t mask = job.mask, nSlots = track_slots(mask), div = nSlots ? nSlots : 1u;
+    const double nf = (double)job.fadeSamples, invFade = 1.0 / nf;
+    const double* const fo = job.oldFrame >= 0 ? T.frames + job.oldFrame * kNumParams : nullptr;
+    const double* const fn = job.newFrame >= 0 ? T.frames + job.newFrame * kNumParams : nullptr;
+    const uint32_t total = (uint32_t)kTrackFirst + (job.fadeSamples - 1u) * nSlots;   // host: below 2^27
+    double2* const out = T.track + job.off;
+    for (uint32_t e0 = 0; e0 < total; e0 += kLanes) {
+        // every lane evaluates (the last pass repeats the track's last entry in its idle lanes): the wave-uniform short cuts of
+        // resonator_coefficients_inline ballot over a full wavefront
+        const uint32_t e = min(e0 + (uint32_t)lane, total - 1u);
+        uint32_t cnt, r;
+        bool second;              // N0's second entry: its a
+        if (e < (uint32_t)kTrackFirst) {
+            cnt = 1u; r = e <= 1u ? 0u : e - 1u; second = (e == 1u);
+        } else {
+            const uint32_t q = e - (uint32_t)kTrackFirst, n = q / div, s = q - n * div;
+            cnt = 2u + n; r = 0u; second = false;
+            uint32_t acc = 0;
+            for (int k = 0; k < kNumRes; ++k) {
+                if (!((mask >> k) & 1u)) continue;     // wave-uniform
+                const uint32_t w = k == 0 ? 2u : 1u;
+                if (s >= acc && s < acc + w) { r = (uint32_t)k; second = (k == 0 && s == acc + 1u); }
+                acc += w;
+            }
+        }
+        const int pf = kResF[r], pb = kResB[r];
+        const double f0 = fo ? fo[pf] : 0.0, f1 = fn ? fn[pf] : 0.0, b0 = fo ? fo[pb] : 0.0, b1 = fn ? fn[pb] : 0.0;
+        const double ratio = div_by((double)cnt, nf, invFade);
+        const double f = fade_value(f0, f1, ratio), bw = fade_value(b0, b1, ratio);
+        const Coef k = resonator_coefficients_inline<MODE_EXACT>(f, bw, r == 0u, T.negPiOverSr, T.twoPiOverSr);
+        if (e0 + (uint32_t)lane < total) out[e] = second ? make_double2(k.a, 0.0) : make_double2(k.b, k.c);
+    }
+}
+
+}  // namespace klatt

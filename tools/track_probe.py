@@ -1,0 +1,47 @@
+#!/usr/bin/env python3
+"""Coefficient tracks on / off: kernel time and PCM digest of cfg2 as benchmarked, with rotated frame lists, with jittered
+durations and without the sort by length (tools/mixed_probe.py), plus cfg3 / cfg4 on request.  The digests of a row must agree.
+
+    python tools/track_probe.py [utterances] [+cfg3] [+cfg4] [+unsorted]
+"""
+import os
+import sys
+import time
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+from nvspeechplayer_amd import BatchPlayer, workloads
+from mixed_probe import rotate, jitter
+
+
+def run(b, tracks, sort=1, mode=0, launches=4):
+    bp = BatchPlayer(b["sr"], mode=mode)
+    bp.setOption("sort", sort)
+    bp.setOption("tracks", tracks)
+    t0 = time.time()
+    bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+    host = time.time() - t0
+    bp.time(1)
+    ms = float(np.mean(bp.time(launches)))
+    dg = bp.digest()
+    info = bp.kernelInfo()
+    bp.close()
+    return ms, dg, host, info
+
+
+if __name__ == "__main__":
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("+") else 65536
+    extra = [a[1:] for a in sys.argv[1:] if a.startswith("+")]
+    base = workloads.make("cfg2", n)
+    cases = [("cfg2", base, 1), ("rotated", rotate(base), 1), ("jittered", jitter(base), 1)]
+    if "unsorted" in extra:
+        cases.append(("unsorted", base, 0))
+    if "cfg3" in extra:
+        cases.append(("cfg3", workloads.make("cfg3", 125000), 1))
+    if "cfg4" in extra:
+        cases.append(("cfg4", workloads.make("cfg4", 32768), 1))
+    for name, b, sort in cases:
+        off = run(b, 0, sort)
+        on = run(b, 1, sort)
+        same = "same PCM" if off[1] == on[1] else "PCM DIFFERS (%016x vs %016x)" % (off[1], on[1])
+        print("%-9s %6d utt  untracked %7.2f ms  tracked %7.2f ms  (%.2fx)  %s  setUtterances %.2f -> %.2f s  vgprs %s scratch %s" % (
+            name, b.n_utt, off[0], on[0], off[0] / on[0], same, off[2], on[2], on[3].get("vgprs"), on[3].get("scratch_bytes")), flush=True)

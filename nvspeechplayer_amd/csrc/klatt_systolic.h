@@ -98,6 +98,9 @@ struct StageFrame {
     // (N0, NP, c6..c1, p1..p6) and its entries per fade sample
     const double2* tBase;
     uint32_t gmask, nSlots;
+    double2 pk[NRES > 0 ? NRES : 1];   // the entries of the lane's next fade sample (track_issue / track_apply)
+    double pkA0;
+    bool pkValid;
 };
 
 // pitch (parameter 0) needs the glide state; only the source stage has it
@@ -117,7 +120,7 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
     f.invFade = 1.0;
     f.cnt = 0; f.oldMin = 0; f.newMin = 0; f.newFade = 1; f.nextFrame = 0; f.resMask = 0; f.parMask = 0; f.produced = 0;
     f.hasNew = false; f.oldNull = true; f.newNull = false; f.done = !live;
-    f.tBase = nullptr; f.gmask = 0; f.nSlots = 0;
+    f.tBase = nullptr; f.gmask = 0; f.nSlots = 0; f.pkValid = false;
 }
 
 // Stage descriptor.  GAIN = index into P of parameter 44 (or -1): NULL frames force it to 0
@@ -268,11 +271,67 @@ __device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& 
     return bits;
 }
 
+// ---- tracked stages: a fade sample's coefficients, read one sample ahead -------------------------------------------
+// The entries of a fade are at known addresses (klatt_device.h: 15 entries for the first fade sample, then a row of nSlots
+// entries per sample), so a tracked stage never waits for the entries of the sample it is working on: a lane's NEXT fade
+// sample's entries are always in flight -- issued at the dequeue (the fade's first row, together with the frame's own loads)
+// and at every fade sample (the following row), into the `pk*` registers of its StageFrame -- and are applied when the state
+// machine reaches that sample.  `pkValid` says the registers hold (or will hold) the entries of counter f.cnt + 1.
+// wRes (wave-uniform): the stage's resonators some lane of the wave may need; `all`: the target is a fade's first sample.
+#ifndef KLATT_TRACK_AHEAD
+#define KLATT_TRACK_AHEAD 1     // 0: a fade sample loads its own entries and waits for them
+#endif
+template <class D, class SF>
+__device__ __forceinline__ void track_issue(SF& f, const int* GR, uint32_t wRes, uint32_t cnt)
+{
+    const bool first = cnt == 1u;
+    const double2* row = f.tBase + (first ? 0u : (uint32_t)kTrackFirst + (cnt - 2u) * f.nSlots);
+#pragma unroll
+    for (int r = 0; r < D::NRES; ++r) {
+        if ((wRes & (1u << r)) && (first || ((f.resMask >> r) & 1u))) {
+            const uint32_t slot = first ? (uint32_t)track_first_slot(GR[r]) : track_slot(f.gmask, GR[r]);
+            f.pk[r] = row[slot];
+            if (D::ANTI0 && r == 0) f.pkA0 = row[slot + 1u].x;
+        }
+    }
+}
+// the entries of the sample the state machine has just reached (counter f.cnt) become the resonators' coefficients
+template <class D, class SF>
+__device__ __forceinline__ void track_apply(SF& f, uint32_t wRes)
+{
+    const bool first = f.cnt == 1u;
+#pragma unroll
+    for (int r = 0; r < D::NRES; ++r) {
+        if ((wRes & (1u << r)) && (first || ((f.resMask >> r) & 1u))) {
+            f.ra[r] = (D::ANTI0 && r == 0) ? f.pkA0 : (1.0 - f.pk[r].x - f.pk[r].y);
+            f.rb[r] = f.pk[r].x; f.rc[r] = f.pk[r].y;
+        }
+    }
+}
+// one fade sample of a tracked stage, counter already advanced: take this sample's entries (a lane without them in flight
+// loads them now), then send for the next sample's.  wNext: resonators that move in some lane (rows after the first).
+template <class D, class SF>
+__device__ __forceinline__ void track_step(SF& f, const int* GR, uint32_t wRes, uint32_t wNext)
+{
+#if KLATT_TRACK_AHEAD
+    const bool late = !f.pkValid && (f.cnt == 1u || f.resMask != 0u);
+    if (__any(late)) { if (late) track_issue<D>(f, GR, wRes, f.cnt); }
+    track_apply<D>(f, wRes);
+    f.pkValid = f.cnt < f.newFade && f.resMask != 0u;
+    if (f.pkValid) track_issue<D>(f, GR, wNext, f.cnt + 1u);
+#else
+    (void)wNext;
+    track_issue<D>(f, GR, wRes, f.cnt);
+    track_apply<D>(f, wRes);
+#endif
+}
+
+// (tracked stages: the parameters only; the caller takes the coefficients with track_step)
 template <class D, int MODE, bool PLAIN = false, class SF>
 __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelArgs& A, const int* RF, const int* RB,
                                            bool lerp, uint32_t wRes, bool gainOnly = false, uint32_t coefCls = kCoefAllUnknown)
 {
-    if (!D::PITCH && !lerp && !(D::TRACK && wRes != 0u)) return;
+    if (!D::PITCH && !lerp) return;
     const double ratio = div_by((double)f.cnt, (double)f.newFade, f.invFade);
     if (D::PITCH) ps->cur0 = fade_value(ps->old0, ps->new0, ratio);
     constexpr int GI = D::GAIN >= 0 ? D::GAIN : 0;
@@ -286,23 +345,7 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = PLAIN ? o[k] + ((n[k] - o[k]) * ratio) : fade_value(o[k], n[k], ratio);   // PLAIN: no NaN target in any live lane
     }
-    if constexpr (D::TRACK) {
-        // the coefficients of this fade sample, evaluated by klatt_tracks from the same (f, bw) the untracked stages interpolate:
-        // a lane takes an entry for each of its resonators that moves (all of them on the fade's first sample)
-        const bool first = !PLAIN && f.cnt == 1u;     // the whole-chunk paths start past a fade's first sample
-        const uint32_t base = first ? 0u : (uint32_t)kTrackFirst + (f.cnt - 2u) * f.nSlots;
-#pragma unroll
-        for (int r = 0; r < D::NRES; ++r) {
-            if (wRes & (1u << r)) {
-                if (first || ((f.resMask >> r) & 1u)) {
-                    const uint32_t slot = base + (first ? (uint32_t)track_first_slot(RF[r]) : track_slot(f.gmask, RF[r]));
-                    const double2 bc = f.tBase[slot];
-                    f.ra[r] = (D::ANTI0 && r == 0) ? f.tBase[slot + 1u].x : (1.0 - bc.x - bc.y);
-                    f.rb[r] = bc.x; f.rc[r] = bc.y;
-                }
-            }
-        }
-    } else {
+    if constexpr (!D::TRACK) {
 #pragma unroll
         for (int r = 0; r < D::NRES; ++r) {
             if (wRes & (1u << r)) {
@@ -335,11 +378,23 @@ __device__ __forceinline__ bool stage_advance(SF& f, PitchState* ps, int32_t* la
             emit = stage_event<D>(f, ps, lastIndex, P, RF, RB, X);
         }
     }
+    if constexpr (D::TRACK) {
+        // a lane that has just dequeued sends for its fade's first row (every resonator of the stage)
+        const bool deq = !f.done && f.hasNew && f.cnt == 0u;
+        if (KLATT_TRACK_AHEAD && __any(deq)) {
+            if (deq) { track_issue<D>(f, RF, 0xFFFFFFFFu, 1u); f.pkValid = true; }
+        }
+    }
     if (__any(fading)) {
         // first fade sample of a lane: everything; later: what moves in some fading lane
         const bool lerp = __any(fading && (f.cnt == 1 || f.parMask != 0u));
         const uint32_t wRes = wave_or_bits<D::NRES>(fading ? ((f.cnt == 1) ? 0xFFFFFFFFu : f.resMask) : 0u);
-        if (fading) stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes);
+        if (fading) {
+            stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes);
+            if constexpr (D::TRACK) {
+                if (wRes != 0u) track_step<D>(f, RF, wRes, wave_or_bits<D::NRES>(f.resMask));
+            }
+        }
     }
     return emit;
 }
@@ -514,9 +569,16 @@ struct Stamps {
 // the event steps need the state machine sample by sample; the run length comes from a bisection with ballots.  (Off for
 // the noisy kernels: the extra code costs them more than the runs save, cfg2 15.8 -> 16.8 ms.)  DELAY: lanes start `delay`
 // steps late (the lane-pipelined kernel's skew).  STREAM: the launch runs exactly A.maxSamples steps (live handles).
-template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_>
+// MIXED (tracked launches): stretches in which no live lane has an event run as a rolled loop whatever the lanes are doing --
+// steady lanes count, fading lanes interpolate their parameters and take their coefficients from the track -- with the
+// wave-level decisions (what to interpolate, which resonators to look at) taken once per stretch.  With the coefficients
+// evaluated elsewhere a fading lane is cheap enough for this to pay when the lanes of a wave do not fade together.
+#ifndef KLATT_MIXED_RUNS
+#define KLATT_MIXED_RUNS 1
+#endif
+template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_, bool MIXED_ = false>
 struct LoopKnobs {
-    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_;
+    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_, MIXED = MIXED_;
     static constexpr int UNROLL = UNROLL_;
 };
 
@@ -598,11 +660,21 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {
                     if (!f.done) {
                         if (!fadeAlt(c, lerp, gainOnly)) {
+                            if constexpr (D::TRACK) {
 #pragma unroll 2
-                            for (int i = 0; i < CH; ++i) {
-                                f.cnt++;
-                                stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
-                                body(c, i, false, 0.0);
+                                for (int i = 0; i < CH; ++i) {
+                                    f.cnt++;
+                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
+                                    if (wRes != 0u) track_step<D>(f, RF, wRes, wRes);
+                                    body(c, i, false, 0.0);
+                                }
+                            } else {
+#pragma unroll 2
+                                for (int i = 0; i < CH; ++i) {
+                                    f.cnt++;
+                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
+                                    body(c, i, false, 0.0);
+                                }
                             }
                         }
                         fadeDone(CH);
@@ -670,6 +742,40 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                             }
                             i += n;
                             continue;
+                        }
+                    }
+                    if constexpr (K::MIXED) {
+                        if (!forceGeneral()) {
+                            const bool fad = !f.done && f.hasNew;
+                            const uint32_t rem = f.done ? 0xFFFFFFFFu : (f.hasNew ? f.newFade - f.cnt : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
+                            const int cap = lim - i;
+                            int n = 0;
+#pragma unroll
+                            for (int st = CH; st >= 1; st >>= 1)
+                                if (n + st <= cap && __all(rem >= (uint32_t)(n + st))) n += st;
+                            if (n >= 2 && !nan_target_live(f)) {
+                                // a lane that has just dequeued (counter 0) has its first fade sample in the stretch: everything moves there
+                                const bool lerpR = __any(fad && (f.cnt == 0u || f.parMask != 0u));
+                                const uint32_t wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? (f.cnt == 0u ? 0xFFFFFFFFu : f.resMask) : 0u);
+                                const uint32_t wNextR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? f.resMask : 0u);
+                                const bool anyFad = __any(fad);
+#pragma nounroll
+                                for (int j = i; j < i + n; ++j) {
+                                    if (!f.done) {
+                                        f.cnt++;
+                                        if (anyFad) {
+                                            if (fad) {
+                                                stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR);
+                                                if constexpr (D::TRACK) { if (wResR != 0u) track_step<D>(f, RF, wResR, wNextR); }
+                                            }
+                                        }
+                                        if (D::PITCH) { if (!fad) { ps->cur0 += ps->oldInc; ps->old0 = ps->cur0; } }
+                                    }
+                                    gen(c, j, !f.done);
+                                }
+                                i += n;
+                                continue;
+                            }
                         }
                     }
                     if (K::DELAY) {
@@ -784,8 +890,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // pipe slot of sample i of chunk c
 #define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
     // the chunk loop's knobs: quiet launches preload a steady chunk's inputs and run uniform stretches inside event chunks
-    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;      // stages without a pipe input
-    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;       // stages that read a pipe
+    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, TRACK && KLATT_MIXED_RUNS>;      // stages without a pipe input
+    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, TRACK && KLATT_MIXED_RUNS>;       // stages that read a pipe
     uint32_t noDelay = 0;
     auto never = [&]() __attribute__((always_inline)) { return false; };
     auto noBegin = [&](int) __attribute__((always_inline)) { return false; };

@@ -98,9 +98,8 @@ struct StageFrame {
     // (N0, NP, c6..c1, p1..p6) and its entries per fade sample
     const double2* tBase;
     uint32_t gmask, nSlots;
-    double2 pk[NRES > 0 ? NRES : 1];   // the entries of the lane's next fade sample (track_issue / track_apply)
-    double pkA0;
-    bool pkValid;
+    const double2* tp[NRES > 0 ? NRES : 1];   // per resonator: its entry of the next fade sample (track_first / track_next)
+    uint32_t ts[NRES > 0 ? NRES : 1];         //                and how far that moves per sample (0: the resonator does not move)
 };
 
 // pitch (parameter 0) needs the glide state; only the source stage has it
@@ -120,7 +119,7 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
     f.invFade = 1.0;
     f.cnt = 0; f.oldMin = 0; f.newMin = 0; f.newFade = 1; f.nextFrame = 0; f.resMask = 0; f.parMask = 0; f.produced = 0;
     f.hasNew = false; f.oldNull = true; f.newNull = false; f.done = !live;
-    f.tBase = nullptr; f.gmask = 0; f.nSlots = 0; f.pkValid = false;
+    f.tBase = nullptr; f.gmask = 0; f.nSlots = 0;
 }
 
 // Stage descriptor.  GAIN = index into P of parameter 44 (or -1): NULL frames force it to 0
@@ -271,59 +270,61 @@ __device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& 
     return bits;
 }
 
-// ---- tracked stages: a fade sample's coefficients, read one sample ahead -------------------------------------------
+// ---- tracked stages: a fade sample's coefficients ---------------------------------------------------------------------
 // The entries of a fade are at known addresses (klatt_device.h: 15 entries for the first fade sample, then a row of nSlots
-// entries per sample), so a tracked stage never waits for the entries of the sample it is working on: a lane's NEXT fade
-// sample's entries are always in flight -- issued at the dequeue (the fade's first row, together with the frame's own loads)
-// and at every fade sample (the following row), into the `pk*` registers of its StageFrame -- and are applied when the state
-// machine reaches that sample.  `pkValid` says the registers hold (or will hold) the entries of counter f.cnt + 1.
-// wRes (wave-uniform): the stage's resonators some lane of the wave may need; `all`: the target is a fade's first sample.
-#ifndef KLATT_TRACK_AHEAD
-#define KLATT_TRACK_AHEAD 1     // 0: a fade sample loads its own entries and waits for them
-#endif
+// entries per sample).  On the fade's first sample a lane takes the entry of every resonator of its stage (track_first) and
+// sets up one pointer per resonator: to the resonator's slot in the first later row, advancing by a row per sample, if the
+// fade moves it -- and to the entry just read, not advancing, if it does not.  Every later fade sample then loads through the
+// pointers of the resonators that move in SOME lane of the wave (wRes, wave-uniform) without a per-lane test: a lane whose
+// resonator does not move reads the value it already holds (track_next).  Five instructions per resonator and fade sample.
 template <class D, class SF>
-__device__ __forceinline__ void track_issue(SF& f, const int* GR, uint32_t wRes, uint32_t cnt)
+__device__ __forceinline__ void track_take(SF& f, int r, const double2* p)
 {
-    const bool first = cnt == 1u;
-    const double2* row = f.tBase + (first ? 0u : (uint32_t)kTrackFirst + (cnt - 2u) * f.nSlots);
+    const double2 bc = p[0];
+    f.ra[r] = (D::ANTI0 && r == 0) ? p[1].x : (1.0 - bc.x - bc.y);
+    f.rb[r] = bc.x; f.rc[r] = bc.y;
+}
+template <class D, class SF>
+__device__ __forceinline__ void track_first(SF& f, const int* GR)
+{
 #pragma unroll
     for (int r = 0; r < D::NRES; ++r) {
-        if ((wRes & (1u << r)) && (first || ((f.resMask >> r) & 1u))) {
-            const uint32_t slot = first ? (uint32_t)track_first_slot(GR[r]) : track_slot(f.gmask, GR[r]);
-            f.pk[r] = row[slot];
-            if (D::ANTI0 && r == 0) f.pkA0 = row[slot + 1u].x;
+        const double2* p = f.tBase + track_first_slot(GR[r]);
+        track_take<D>(f, r, p);
+        const bool moves = (f.resMask >> r) & 1u;
+        f.tp[r] = moves ? f.tBase + ((uint32_t)kTrackFirst + track_slot(f.gmask, GR[r])) : p;
+        f.ts[r] = moves ? f.nSlots : 0u;
+    }
+}
+template <class D, class SF>
+__device__ __forceinline__ void track_next(SF& f, uint32_t wRes)
+{
+    // every load first, then the uses: one wait for the memory latency instead of one per resonator
+    double2 bc[D::NRES > 0 ? D::NRES : 1];
+    double a0 = 0.0;
+#pragma unroll
+    for (int r = 0; r < D::NRES; ++r) {
+        if (wRes & (1u << r)) {
+            bc[r] = f.tp[r][0];
+            if (D::ANTI0 && r == 0) a0 = f.tp[r][1].x;
+            f.tp[r] += f.ts[r];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < D::NRES; ++r) {
+        if (wRes & (1u << r)) {
+            f.ra[r] = (D::ANTI0 && r == 0) ? a0 : (1.0 - bc[r].x - bc[r].y);
+            f.rb[r] = bc[r].x; f.rc[r] = bc[r].y;
         }
     }
 }
-// the entries of the sample the state machine has just reached (counter f.cnt) become the resonators' coefficients
+// one fade sample of a tracked stage in any mix of lanes, counter already advanced
 template <class D, class SF>
-__device__ __forceinline__ void track_apply(SF& f, uint32_t wRes)
+__device__ __forceinline__ void track_step(SF& f, const int* GR, uint32_t wRes)
 {
     const bool first = f.cnt == 1u;
-#pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        if ((wRes & (1u << r)) && (first || ((f.resMask >> r) & 1u))) {
-            f.ra[r] = (D::ANTI0 && r == 0) ? f.pkA0 : (1.0 - f.pk[r].x - f.pk[r].y);
-            f.rb[r] = f.pk[r].x; f.rc[r] = f.pk[r].y;
-        }
-    }
-}
-// one fade sample of a tracked stage, counter already advanced: take this sample's entries (a lane without them in flight
-// loads them now), then send for the next sample's.  wNext: resonators that move in some lane (rows after the first).
-template <class D, class SF>
-__device__ __forceinline__ void track_step(SF& f, const int* GR, uint32_t wRes, uint32_t wNext)
-{
-#if KLATT_TRACK_AHEAD
-    const bool late = !f.pkValid && (f.cnt == 1u || f.resMask != 0u);
-    if (__any(late)) { if (late) track_issue<D>(f, GR, wRes, f.cnt); }
-    track_apply<D>(f, wRes);
-    f.pkValid = f.cnt < f.newFade && f.resMask != 0u;
-    if (f.pkValid) track_issue<D>(f, GR, wNext, f.cnt + 1u);
-#else
-    (void)wNext;
-    track_issue<D>(f, GR, wRes, f.cnt);
-    track_apply<D>(f, wRes);
-#endif
+    if (__any(first)) { if (first) track_first<D>(f, GR); }
+    if (!first) track_next<D>(f, wRes);
 }
 
 // (tracked stages: the parameters only; the caller takes the coefficients with track_step)
@@ -378,13 +379,6 @@ __device__ __forceinline__ bool stage_advance(SF& f, PitchState* ps, int32_t* la
             emit = stage_event<D>(f, ps, lastIndex, P, RF, RB, X);
         }
     }
-    if constexpr (D::TRACK) {
-        // a lane that has just dequeued sends for its fade's first row (every resonator of the stage)
-        const bool deq = !f.done && f.hasNew && f.cnt == 0u;
-        if (KLATT_TRACK_AHEAD && __any(deq)) {
-            if (deq) { track_issue<D>(f, RF, 0xFFFFFFFFu, 1u); f.pkValid = true; }
-        }
-    }
     if (__any(fading)) {
         // first fade sample of a lane: everything; later: what moves in some fading lane
         const bool lerp = __any(fading && (f.cnt == 1 || f.parMask != 0u));
@@ -392,7 +386,7 @@ __device__ __forceinline__ bool stage_advance(SF& f, PitchState* ps, int32_t* la
         if (fading) {
             stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes);
             if constexpr (D::TRACK) {
-                if (wRes != 0u) track_step<D>(f, RF, wRes, wave_or_bits<D::NRES>(f.resMask));
+                if (wRes != 0u) track_step<D>(f, RF, wRes);
             }
         }
     }
@@ -665,7 +659,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                 for (int i = 0; i < CH; ++i) {
                                     f.cnt++;
                                     stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
-                                    if (wRes != 0u) track_step<D>(f, RF, wRes, wRes);
+                                    if (wRes != 0u) track_next<D>(f, wRes);
                                     body(c, i, false, 0.0);
                                 }
                             } else {
@@ -747,17 +741,16 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                     if constexpr (K::MIXED) {
                         if (!forceGeneral()) {
                             const bool fad = !f.done && f.hasNew;
-                            const uint32_t rem = f.done ? 0xFFFFFFFFu : (f.hasNew ? f.newFade - f.cnt : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
+                            // (a lane that has just dequeued takes its fade's first sample, where everything moves, on the general step)
+                            const uint32_t rem = f.done ? 0xFFFFFFFFu : (f.hasNew ? (f.cnt == 0u ? 0u : f.newFade - f.cnt) : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
                             const int cap = lim - i;
                             int n = 0;
 #pragma unroll
                             for (int st = CH; st >= 1; st >>= 1)
                                 if (n + st <= cap && __all(rem >= (uint32_t)(n + st))) n += st;
                             if (n >= 2 && !nan_target_live(f)) {
-                                // a lane that has just dequeued (counter 0) has its first fade sample in the stretch: everything moves there
-                                const bool lerpR = __any(fad && (f.cnt == 0u || f.parMask != 0u));
-                                const uint32_t wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? (f.cnt == 0u ? 0xFFFFFFFFu : f.resMask) : 0u);
-                                const uint32_t wNextR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? f.resMask : 0u);
+                                const bool lerpR = __any(fad && f.parMask != 0u);
+                                const uint32_t wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? f.resMask : 0u);
                                 const bool anyFad = __any(fad);
 #pragma nounroll
                                 for (int j = i; j < i + n; ++j) {
@@ -766,7 +759,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                         if (anyFad) {
                                             if (fad) {
                                                 stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR);
-                                                if constexpr (D::TRACK) { if (wResR != 0u) track_step<D>(f, RF, wResR, wNextR); }
+                                                if constexpr (D::TRACK) { if (wResR != 0u) track_next<D>(f, wResR); }
                                             }
                                         }
                                         if (D::PITCH) { if (!fad) { ps->cur0 += ps->oldInc; ps->old0 = ps->cur0; } }

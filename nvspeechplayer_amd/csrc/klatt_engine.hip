@@ -362,6 +362,7 @@ long long lanepipe_count(const Batch* b)
 #define KLATT_TRACK_WPS 2
 #endif
 // host copies of kResF / kResB (klatt_device.h): the frequency and bandwidth parameter of resonator r
+constexpr size_t kTrackPad = 64;   // entries past the last track: the tracked stages read one row ahead (KLATT_TRACK_PIPE), a row is at most 15
 constexpr int kResFHost[kNumRes] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
 constexpr int kResBHost[kNumRes] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
@@ -1101,7 +1102,7 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
             b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
         if (nTracked > 0) {
-            if (b->dTrackRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dTrack.reserve((size_t)trackEntries)) return -1;
+            if (b->dTrackRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dTrack.reserve((size_t)trackEntries + kTrackPad)) return -1;
             HIP_TRY(hipMemcpyAsync(b->dTrackRef.ptr, trackRef.data(), (size_t)nF * sizeof(TrackRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dJobs.ptr, jobs.data(), jobs.size() * sizeof(TrackJob), hipMemcpyHostToDevice, b->stream));
         }

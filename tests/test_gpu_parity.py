@@ -1004,3 +1004,62 @@ def test_wild_batch_repeated_in_fresh_batches():
                 bad = np.flatnonzero(got != exp)
                 assert len(bad) == 0, (rep, layout, mode, len(bad), sorted(set(int(x) for x in np.searchsorted(exp_start, bad, side="right") - 1))[:5])
                 bp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,wild", [(11, False), (12, True)])
+def test_coefficient_tracks_change_nothing(seed, wild):
+    """Coefficient tracks (klatt_tracks.h: the resonator coefficients of every fade sample evaluated densely, one track per
+    distinct fade, picked up by the tracked stages) against the same batch without them: the PCM must be the same bytes, in
+    both arithmetic modes, sorted and unsorted, with a track budget that only some utterances fit in, and with utterances
+    repeated (shared tracks).  Random ragged timing: NULL frames anywhere (also first, also in a row), fades longer than
+    their frame, 1-sample fades; wild: NaN "hold" parameters, whose utterances must stay untracked."""
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(seed)
+    one = random_batch(rng, 700, quiet_fraction=0.15, wild=wild)
+    # the same utterances again with other seeds: every fade of the second half has its track already
+    batch = dict(frames=np.concatenate([one["frames"], one["frames"]]), min=np.concatenate([one["min"], one["min"]]),
+                 fade=np.concatenate([one["fade"], one["fade"]]), index=np.concatenate([one["index"], one["index"]]),
+                 isnull=np.concatenate([one["isnull"], one["isnull"]]),
+                 frame_start=np.concatenate([one["frame_start"], one["frame_start"][1:] + one["frame_start"][-1]]),
+                 seeds=np.concatenate([one["seeds"], one["seeds"] ^ np.uint32(0x5bd1e995)]))
+    n_utt = len(batch["seeds"])
+
+    def run(mode, tracks, sort=1, budget=None):
+        bp = eng.BatchPlayer(22050, mode=mode)
+        bp.setOption("tracks", tracks)
+        bp.setOption("sort", sort)
+        if budget is not None:
+            bp.setOption("track_budget_mb", budget)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
+        bp.synthesize()
+        pcm, start = bp.readAll()
+        info = bp.kernelInfo()
+        bp.close()
+        return pcm, start, info
+
+    for mode in (0, 1):
+        ref_pcm, ref_start, info0 = run(mode, 0)
+        assert info0["tracked_utterances"] == 0
+        for sort, budget in ((1, None), (0, None), (1, 1)):
+            pcm, start, info = run(mode, 1, sort, budget)
+            assert np.array_equal(start, ref_start)
+            assert np.array_equal(pcm, ref_pcm), "mode %d sort %d budget %s: %d samples differ" % (
+                mode, sort, budget, int(np.count_nonzero(pcm != ref_pcm)))
+            print("mode %d sort %d budget %s: %d of %d utterances tracked, %d tracks, %d MB" % (
+                mode, sort, budget, info["tracked_utterances"], n_utt, info["tracks"], info["track_mbytes"]))
+            if budget is None:
+                assert info["tracked_utterances"] > n_utt // (4 if wild else 2)   # the noisy utterances with finite parameters
+                # the second copy of every utterance shares the first one's tracks: at most one track per frame of the first
+                assert info["tracks"] <= len(one["min"])
+            else:
+                assert 0 < info["tracked_utterances"] < n_utt // 4       # 1 MB holds the tracks of a few utterances only
+            if wild:
+                nan_utts = sum(1 for u in range(n_utt) if np.isnan(batch["frames"][batch["frame_start"][u]:batch["frame_start"][u + 1]]).any())
+                assert nan_utts > 0 and info["tracked_utterances"] <= n_utt - nan_utts
+    # and against the oracle, utterance by utterance
+    exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
+    pcm, start, _ = run(0, 1)
+    d = pcm.astype(np.int32) - exp.astype(np.int32)
+    assert np.array_equal(start, exp_start) and np.abs(d).max() <= 1
+    assert int(np.count_nonzero(d)) <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)

@@ -323,7 +323,7 @@ __device__ __forceinline__ void track_next(SF& f, uint32_t wRes)
 // stepping the pointers back over the one row read too far (a row past a fade's end is still inside the track buffer: the host
 // pads it).  The wait for the memory latency then happens once per run instead of once per sample.
 #ifndef KLATT_TRACK_PIPE
-#define KLATT_TRACK_PIPE 1
+#define KLATT_TRACK_PIPE 0      // measured slower: the entries in flight cost registers (192 instead of 24 bytes of scratch; cfg2 11.4 -> 11.6 ms, rotated 27 -> 30)
 #endif
 template <class D>
 struct TrackAhead { double2 bc[D::NRES > 0 ? D::NRES : 1]; double a0; };
@@ -573,12 +573,15 @@ struct Stamps {
     unsigned long long work = 0, wait = 0, t0 = 0, t1 = 0, n[3] = {0, 0, 0}, c[3] = {0, 0, 0};
     int kind = 3;
 };
+// every chunk is counted under the kind its stretch was decided as (the chunks of a tight run keep the run's kind)
 #define STAMP_BEGIN() st.t0 = __builtin_amdgcn_s_memtime()
-#define STAMP_KIND(k) do { st.kind = (k) < 0 ? 2 : (k); st.n[st.kind]++; } while (0)
-#define STAMP_WORKED() do { st.t1 = __builtin_amdgcn_s_memtime(); st.work += st.t1 - st.t0; if (st.kind < 3) st.c[st.kind] += st.t1 - st.t0; st.kind = 3; } while (0)
+#define STAMP_KIND(k) do { st.kind = (k) < 0 ? 2 : (k); } while (0)
+#define STAMP_WORKED() do { st.t1 = __builtin_amdgcn_s_memtime(); st.work += st.t1 - st.t0; if (st.kind < 3) { st.c[st.kind] += st.t1 - st.t0; st.n[st.kind]++; } } while (0)
+#define STAMP_IDLE() st.kind = 3
 #define STAMP_SYNCED() do { st.wait += __builtin_amdgcn_s_memtime() - st.t1; } while (0)
 #else
 #define STAMP_BEGIN()
+#define STAMP_IDLE()
 #define STAMP_KIND(k)
 #define STAMP_WORKED()
 #define STAMP_SYNCED()
@@ -654,6 +657,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
     };
     for (int iter = 0; iter < nIter; ++iter) {
         STAMP_BEGIN();
+        STAMP_IDLE();
         int c = iter - depth;
         if (c >= 0 && c < nChunks) {
             const int lim = (K::STREAM && c >= fullChunks) ? (int)(X.A.maxSamples - (uint32_t)c * (uint32_t)CH) : CH;
@@ -817,9 +821,11 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                             }
                                         }
                                         if (D::PITCH) { if (!fad) { ps->cur0 += ps->oldInc; ps->old0 = ps->cur0; } }
+                                        // no event in the stretch: what forceGeneral() ruled out at its start (vibrato) stays out
+                                        body(c, j, false, 0.0);
                                     }
-                                    gen(c, j, !f.done);
                                 }
+                                if (!f.done) fadeDone(n);
                                 if constexpr (D::TRACK && KLATT_TRACK_PIPE) { if (wResR != 0u && fad) track_unload<D>(f, wResR); }
                                 i += n;
                                 continue;
@@ -949,7 +955,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     auto nothing = [&](int) __attribute__((always_inline)) {};
     auto noChunk = [&]() __attribute__((always_inline)) {};
 
-    if (stage == 0) {
+#ifndef KLATT_ONLY_STAGE
+#define KLATT_ONLY_STAGE -1
+#endif
+    if (stage == 0 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 0)) {
         // ================= S0: frame + glottal source (+ aspiration noise) =================
         // tracked: 1 vibratoPitchOffset, 2 vibratoSpeed, 3 turbulence, 4 openQuotient, 5 voiceAmplitude,
         //          6 aspirationAmplitude, 44 preFormantGain (quiet launches never read 3, 4, 6)
@@ -1105,7 +1114,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 nothing, nothing, noChunk);
         };
         if (s1) run(1); else run(2);
-    } else if (stage == 1) {
+    } else if (stage == 1 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 1)) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
         constexpr int NR = NOISE ? 5 : 3;
         constexpr int NPAR = TRACK ? 1 : 2 * NR + 1;
@@ -1135,7 +1144,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i)); },
             nothing, nothing, noChunk);
         if constexpr (STREAM) if (live) stage_state_save<D>(f, nullptr, streamState, P, GR1);
-    } else if (NOISE && stage == 3) {
+    } else if (NOISE && stage == 3 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 3)) {
         // ================= noisy S3: frication noise, parallel r1..r4 partial sum =================
         // tracked: (pf, pb) of parallel 1..4, then 24 fricationAmplitude, 44 preFormantGain, pa1..4 (37..40)
         // tracked: the six gains alone, RF = the track numbers of parallel 1..4
@@ -1191,7 +1200,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             noFadeAlt,
             [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pipeA, c, i) = dsp(PIPE(pipeO, c, i)); },
             nothing, nothing, noChunk);
-    } else {
+    } else if (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 2) {
         // ================= final stage: rest of the cascade, (parallel r5, r6 + bypass), gain, clip, PCM ===
         // noisy (stage 2): r3, r2, r1 | parallel 5, 6 | pa5, pa6, parallelBypass, outputGain
         // quiet (stage 3): r2, r1 | outputGain          quiet, nasal-free (stage 3): outputGain only

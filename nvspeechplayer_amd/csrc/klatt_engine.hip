@@ -362,7 +362,7 @@ long long lanepipe_count(const Batch* b)
 #define KLATT_TRACK_WPS 2
 #endif
 // host copies of kResF / kResB (klatt_device.h): the frequency and bandwidth parameter of resonator r
-constexpr size_t kTrackPad = 64;   // entries past the last track: the tracked stages read one row ahead (KLATT_TRACK_PIPE), a row is at most 15
+constexpr size_t kTrackPad = 64;   // slack past the last track
 constexpr int kResFHost[kNumRes] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
 constexpr int kResBHost[kNumRes] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
@@ -1024,6 +1024,12 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         shapes.emplace(zero, 0u); shapeFrame.push_back(-1);
         const unsigned long long budget = (unsigned long long)b->trackBudgetMB * (1ull << 20) / sizeof(double2);
         std::vector<Fade> added;
+        // Tracks pay when (nearly) the whole noisy group has them: a batch whose fades share nothing may need more memory than
+        // the budget, and splitting such a batch into a tracked and an untracked launch measured slower than either kernel
+        // alone (tools/track_probe.py +distinct).  So once more than a tenth of the eligible utterances did not fit, nothing
+        // is tracked.
+        std::vector<unsigned char> eligible((size_t)nUtterances, 0);
+        long long nEligible = 0, nMissed = 0;
         for (long long u = 0; u < nUtterances; ++u) {
             if (!(utt[u].flags & UTT_NEEDS_NOISE)) continue;
             bool finite = true;
@@ -1032,7 +1038,10 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
                 const double* p = reinterpret_cast<const double*>(frames + k);
                 for (int i = 0; i < kNumParams && finite; ++i) finite = std::isfinite(p[i]);
             }
-            if (!finite) continue;     // "hold" targets and overflowing coefficients stay with the untracked kernel
+            if (finite) { eligible[u] = 1; ++nEligible; }     // "hold" targets and overflowing coefficients stay with the untracked kernel
+        }
+        for (long long u = 0; u < nUtterances && nMissed * 10 <= nEligible; ++u) {
+            if (!eligible[u]) continue;
             added.clear();
             const unsigned long long before = trackEntries;
             const size_t jobsBefore = jobs.size();
@@ -1075,7 +1084,13 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
                 for (const Fade& key : added) fades.erase(key);
                 jobs.resize(jobsBefore);
                 trackEntries = before;
+                ++nMissed;
             }
+        }
+        if (nMissed * 10 > nEligible) {
+            for (long long u = 0; u < nUtterances; ++u) utt[u].flags &= ~UTT_TRACKED;
+            jobs.clear();
+            trackEntries = 0;
         }
     }
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together

@@ -318,47 +318,10 @@ __device__ __forceinline__ void track_next(SF& f, uint32_t wRes)
         }
     }
 }
-// Inside a run (a fade's chunks in their tight loop, a mixed stretch) the entries are read one sample ahead: the run starts by
-// loading its first sample's entries, every sample uses what the previous one loaded and sends for the next, and the run ends by
-// stepping the pointers back over the one row read too far (a row past a fade's end is still inside the track buffer: the host
-// pads it).  The wait for the memory latency then happens once per run instead of once per sample.
-#ifndef KLATT_TRACK_PIPE
-#define KLATT_TRACK_PIPE 0      // measured slower: the entries in flight cost registers (192 instead of 24 bytes of scratch; cfg2 11.4 -> 11.6 ms, rotated 27 -> 30)
-#endif
-template <class D>
-struct TrackAhead { double2 bc[D::NRES > 0 ? D::NRES : 1]; double a0; };
-template <class D, class SF>
-__device__ __forceinline__ void track_load(SF& f, uint32_t wRes, TrackAhead<D>& t)
-{
-#pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        if (wRes & (1u << r)) {
-            t.bc[r] = f.tp[r][0];
-            if (D::ANTI0 && r == 0) t.a0 = f.tp[r][1].x;
-            f.tp[r] += f.ts[r];
-        }
-    }
-}
-template <class D, class SF>
-__device__ __forceinline__ void track_use(SF& f, uint32_t wRes, const TrackAhead<D>& t)
-{
-#pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        if (wRes & (1u << r)) {
-            f.ra[r] = (D::ANTI0 && r == 0) ? t.a0 : (1.0 - t.bc[r].x - t.bc[r].y);
-            f.rb[r] = t.bc[r].x; f.rc[r] = t.bc[r].y;
-        }
-    }
-}
-template <class D, class SF>
-__device__ __forceinline__ void track_unload(SF& f, uint32_t wRes)
-{
-#pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        if (wRes & (1u << r)) f.tp[r] -= f.ts[r];
-    }
-}
-
+// (Reading a run's entries one sample ahead was built twice and measured slower both times -- through registers, where the
+// entries in flight pushed the kernel from 24 to 192 bytes of scratch: cfg2 11.4 -> 11.6 ms, rotated 27 -> 30; and straight
+// into LDS rows with global_load_lds_dwordx4, no registers involved: cfg2 11.2 -> 11.9, rotated 25.9 -> 28.9.  With two
+// waves per SIMD the second wave already covers the loads' latency; the extra waits and instructions do not pay.)
 // one fade sample of a tracked stage in any mix of lanes, counter already advanced
 template <class D, class SF>
 __device__ __forceinline__ void track_step(SF& f, const int* GR, uint32_t wRes)
@@ -696,8 +659,6 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 (void)begin(1);
                 const uint32_t coefCls = fade_classes<D>(f, X.A, RF, RB, wRes);   // once per fade stretch
                 // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
-                TrackAhead<D> ta;
-                if constexpr (D::TRACK && KLATT_TRACK_PIPE) { if (wRes != 0u && !f.done) track_load<D>(f, wRes, ta); }
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {
                     if (!f.done) {
                         if (!fadeAlt(c, lerp, gainOnly)) {
@@ -706,10 +667,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                 for (int i = 0; i < CH; ++i) {
                                     f.cnt++;
                                     stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
-                                    if (wRes != 0u) {
-                                        if (KLATT_TRACK_PIPE) { track_use<D>(f, wRes, ta); track_load<D>(f, wRes, ta); }
-                                        else track_next<D>(f, wRes);
-                                    }
+                                    if (wRes != 0u) track_next<D>(f, wRes);
                                     body(c, i, false, 0.0);
                                 }
                             } else {
@@ -740,7 +698,6 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                     ++iter; ++c;
                 }
                 fadeChunk(c);
-                if constexpr (D::TRACK && KLATT_TRACK_PIPE) { if (wRes != 0u && !f.done) track_unload<D>(f, wRes); }
             } else {
                 (void)begin(-1);
                 int i = 0;
@@ -803,8 +760,6 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                 const bool lerpR = __any(fad && f.parMask != 0u);
                                 const uint32_t wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? f.resMask : 0u);
                                 const bool anyFad = __any(fad);
-                                TrackAhead<D> ta;
-                                if constexpr (D::TRACK && KLATT_TRACK_PIPE) { if (wResR != 0u && fad) track_load<D>(f, wResR, ta); }
 #pragma nounroll
                                 for (int j = i; j < i + n; ++j) {
                                     if (!f.done) {
@@ -813,10 +768,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                             if (fad) {
                                                 stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR);
                                                 if constexpr (D::TRACK) {
-                                                    if (wResR != 0u) {
-                                                        if (KLATT_TRACK_PIPE) { track_use<D>(f, wResR, ta); track_load<D>(f, wResR, ta); }
-                                                        else track_next<D>(f, wResR);
-                                                    }
+                                                    if (wResR != 0u) track_next<D>(f, wResR);
                                                 }
                                             }
                                         }
@@ -826,7 +778,6 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                     }
                                 }
                                 if (!f.done) fadeDone(n);
-                                if constexpr (D::TRACK && KLATT_TRACK_PIPE) { if (wResR != 0u && fad) track_unload<D>(f, wResR); }
                                 i += n;
                                 continue;
                             }

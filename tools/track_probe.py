@@ -10,7 +10,7 @@ import time
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from nvspeechplayer_amd import BatchPlayer, workloads
-from mixed_probe import rotate, jitter
+from mixed_probe import rotate, jitter, distinct
 
 
 def run(b, tracks, sort=1, mode=0, launches=4):
@@ -35,6 +35,9 @@ if __name__ == "__main__":
     cases = [("cfg2", base, 1), ("rotated", rotate(base), 1), ("jittered", jitter(base), 1)]
     if "unsorted" in extra:
         cases.append(("unsorted", base, 0))
+    if "distinct" in extra:
+        cases.append(("distinct", distinct(base), 1))
+        cases.append(("dist+rot", rotate(distinct(base)), 1))
     if "cfg3" in extra:
         cases.append(("cfg3", workloads.make("cfg3", 125000), 1))
     if "cfg4" in extra:
@@ -43,5 +46,5 @@ if __name__ == "__main__":
         off = run(b, 0, sort)
         on = run(b, 1, sort)
         same = "same PCM" if off[1] == on[1] else "PCM DIFFERS (%016x vs %016x)" % (off[1], on[1])
-        print("%-9s %6d utt  untracked %7.2f ms  tracked %7.2f ms  (%.2fx)  %s  setUtterances %.2f -> %.2f s  vgprs %s scratch %s" % (
-            name, b.n_utt, off[0], on[0], off[0] / on[0], same, off[2], on[2], on[3].get("vgprs"), on[3].get("scratch_bytes")), flush=True)
+        print("%-9s %6d utt  untracked %7.2f ms  tracked %7.2f ms  (%.2fx)  %s  setUtterances %.2f -> %.2f s  tracked %d utt, %d tracks, %d MB" % (
+            name, b.n_utt, off[0], on[0], off[0] / on[0], same, off[2], on[2], on[3].get("tracked_utterances"), on[3].get("tracks"), on[3].get("track_mbytes")), flush=True)

@@ -76,8 +76,10 @@ def kernel_name(info):
     if info.get("lane_pipelined"):
         return "klatt_lanepipe (cascade across lanes, %d-sample hand-overs)" % info["stage_parallel_chunk"]
     if info["stage_parallel_chunk"]:
-        return "klatt_systolic (stage-parallel%s%s, %d-sample hand-overs)" % (", noisy" if info.get("noisy_group") else "",
-                                                                             ", nasal-free" if info.get("nasal_free") else "", info["stage_parallel_chunk"])
+        return "klatt_systolic (stage-parallel%s%s%s, %d-sample hand-overs)" % (
+            ", noisy" if info.get("noisy_group") else "", ", nasal-free" if info.get("nasal_free") else "",
+            ", coefficients from %d tracks (klatt_tracks, %d MB)" % (info["tracks"], info["track_mbytes"]) if info.get("tracked") else "",
+            info["stage_parallel_chunk"])
     return "klatt_synthesize (lane kernel)"
 
 
@@ -262,6 +264,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": batch["name"], "utterances_per_gpu": shard["utterances"], "samples_per_gpu": samples,
                        "frames_per_gpu": int(len(batch["min"])), "sample_rate": batch["sr"], "mode": args.mode, "layout": args.layout,
+                       "coefficient_tracks": None if dry else {"tracked_utterances": info["tracked_utterances"], "tracks": info["tracks"], "mbytes": info["track_mbytes"]},
                        "node_utterances": shard["node_utterances"], "node_samples": shard["node_samples"],
                        "shard_bounds": shard["bounds"], "process_group": None if dist is None else dist.get_backend(),
                        "world_size": 1 if dist is None else dist.get_world_size(),
@@ -308,6 +311,21 @@ def main():
                 bp.setOption("mode", 0)
                 out["mode_fast"] = {"value": samples / (fast_ms * 1e-3), "unit": "samples/s", "kernel_ms": fast_ms,
                                     "roofline_frac": alg_bytes / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+            if world == 1 and args.mode == 0 and not args.no_extras and info.get("tracked"):
+                # the same batch without coefficient tracks (every stage evaluates exp/cos itself, as in round 1), and with every
+                # utterance's frame list rotated by a random amount -- same lengths, but no two lanes of a wavefront fade together:
+                # what a batch of unrelated sentences looks like to the kernel (the BASELINE recipe repeats eight sentences)
+                def timed(b, tracks):
+                    x = BatchPlayer(b["sr"], device=device, mode=args.mode, layout=args.layout)
+                    x.setOption("tracks", tracks)
+                    x.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+                    x.time(1)
+                    ms = float(np.mean(x.time(10)))
+                    x.close()
+                    return {"value": samples / (ms * 1e-3), "unit": "samples/s", "kernel_ms": ms, "roofline_frac": alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                out["tracks_off"] = timed(batch, 0)
+                rot = workloads.rotated(batch)
+                out["rotated_frame_lists"] = dict(timed(rot, 1), tracks_off=timed(rot, 0))
             if world == 1 and not args.utterances and not args.no_extras:
                 # the other single-GPU configuration (BASELINE configs[1], 4096 steady vowels) and its recipe at 65 536 utterances
                 bp.close()

@@ -187,3 +187,19 @@ def sample_counts(workload, n_utt, first=0):
     period = 1 if workload == "cfg1" else 512
     one = make("cfg2" if workload == "cfg4" else workload, period, 0).sample_counts()
     return one[(first + np.arange(n_utt, dtype=np.int64)) % period]
+
+
+def rotated(b, seed=1):
+    """Every utterance keeps its frames (and so its length) but starts at a random one of them: waves still hold
+    64 utterances of equal length after the sort, yet no two lanes fade at the same time -- the closest cheap
+    stand-in for a batch of 64 different sentences of similar length."""
+    rng = np.random.default_rng(seed)
+    fs = b["frame_start"]
+    perm = np.arange(len(b["min"]))
+    for u in range(b.n_utt):
+        a, e = int(fs[u]), int(fs[u + 1]) - 1          # the last frame (the closing NULL frame) stays last
+        if e - a > 1:
+            k = int(rng.integers(0, e - a))
+            perm[a:e] = np.roll(np.arange(a, e), -k)
+    out = {k: b[k][perm] for k in ("frames", "min", "fade", "index", "isnull")}
+    return Batch(frame_start=fs, seeds=b["seeds"], name=b["name"] + " rotated", sr=b["sr"], **out)

@@ -37,20 +37,7 @@ def stagger(b, seed=1):
     return workloads.Batch(frame_start=new_fs, seeds=b["seeds"], name=b["name"] + " staggered", sr=b["sr"], **out)
 
 
-def rotate(b, seed=1):
-    """Every utterance keeps its frames (and so its length) but starts at a random one of them: waves still hold
-    64 utterances of equal length after the sort, yet no two lanes fade at the same time -- the closest cheap
-    stand-in for a batch of 64 different sentences of similar length."""
-    rng = np.random.default_rng(seed)
-    fs = b["frame_start"]
-    perm = np.arange(len(b["min"]))
-    for u in range(b.n_utt):
-        a, e = int(fs[u]), int(fs[u + 1]) - 1          # the last frame (the closing NULL frame) stays last
-        if e - a > 1:
-            k = int(rng.integers(0, e - a))
-            perm[a:e] = np.roll(np.arange(a, e), -k)
-    out = {k: b[k][perm] for k in ("frames", "min", "fade", "index", "isnull")}
-    return workloads.Batch(frame_start=fs, seeds=b["seeds"], name=b["name"] + " rotated", sr=b["sr"], **out)
+rotate = workloads.rotated
 
 
 def jitter(b, seed=1):

@@ -126,10 +126,23 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
 // (reference src/frame.cpp:61,66).  ANTI0: resonator 0 is the anti-resonator N0.
 // TRACK: the stage tracks no (f, bw) parameters; its resonators' coefficients come from the fade's coefficient track
 // (klatt_tracks.h), and the RF argument of the stage functions lists the resonators' numbers in the track (RB is unused).
-template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false, bool TRACK_ = false>
+// WUSUAL (tracked stages): the set of the stage's resonators that usually moves in speech (the first three formants and their
+// parallel twins; the nasal pair): when exactly that set moves in a run, the run's loop is compiled for it -- no tests, the
+// loads back to back -- instead of testing the wave's set resonator by resonator on every sample.
+#ifndef KLATT_FADE_UNROLL
+#define KLATT_FADE_UNROLL 2
+#endif
+#ifndef KLATT_USUAL_FADE
+#define KLATT_USUAL_FADE 1
+#endif
+#ifndef KLATT_USUAL_MIXED
+#define KLATT_USUAL_MIXED 0
+#endif
+template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false, bool TRACK_ = false, uint32_t WUSUAL_ = 0>
 struct StageDesc {
     static constexpr int NPARAM = NPARAM_, NRES = NRES_, GAIN = GAIN_;
     static constexpr bool PITCH = PITCH_, ANTI0 = ANTI0_, INLINE_COEF = INLINE_COEF_, TRACK = TRACK_;
+    static constexpr uint32_t WUSUAL = WUSUAL_;
 };
 
 struct StageCtx {          // what every stage needs from the launch
@@ -541,6 +554,12 @@ struct Stamps {
 #define STAMP_KIND(k) do { st.kind = (k) < 0 ? 2 : (k); } while (0)
 #define STAMP_WORKED() do { st.t1 = __builtin_amdgcn_s_memtime(); st.work += st.t1 - st.t0; if (st.kind < 3) { st.c[st.kind] += st.t1 - st.t0; st.n[st.kind]++; } } while (0)
 #define STAMP_IDLE() st.kind = 3
+#if KLATT_STAMPS == 2
+#undef STAMP_WORKED
+#define STAMP_WORKED() do { st.t1 = __builtin_amdgcn_s_memtime(); st.work += st.t1 - st.t0; } while (0)
+#define STAMP_SUB_BEGIN() const unsigned long long tSub = __builtin_amdgcn_s_memtime()
+#define STAMP_SUB_END(slot, count) do { st.c[slot] += __builtin_amdgcn_s_memtime() - tSub; st.n[slot] += (count); } while (0)
+#endif
 #define STAMP_SYNCED() do { st.wait += __builtin_amdgcn_s_memtime() - st.t1; } while (0)
 #else
 #define STAMP_BEGIN()
@@ -548,6 +567,10 @@ struct Stamps {
 #define STAMP_KIND(k)
 #define STAMP_WORKED()
 #define STAMP_SYNCED()
+#endif
+#ifndef STAMP_SUB_BEGIN
+#define STAMP_SUB_BEGIN()
+#define STAMP_SUB_END(slot, count)
 #endif
 
 // ---- the chunk loop of one pipeline element (a wave) ---------------------------------------------------------------
@@ -663,13 +686,18 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                     if (!f.done) {
                         if (!fadeAlt(c, lerp, gainOnly)) {
                             if constexpr (D::TRACK) {
-#pragma unroll 2
-                                for (int i = 0; i < CH; ++i) {
-                                    f.cnt++;
-                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
-                                    if (wRes != 0u) track_next<D>(f, wRes);
-                                    body(c, i, false, 0.0);
-                                }
+                                auto samples = [&](auto usual) __attribute__((always_inline)) {
+                                    const uint32_t w = decltype(usual)::value ? decltype(usual)::value : wRes;
+#pragma unroll KLATT_FADE_UNROLL
+                                    for (int i = 0; i < CH; ++i) {
+                                        f.cnt++;
+                                        stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
+                                        if (w != 0u) track_next<D>(f, w);
+                                        body(c, i, false, 0.0);
+                                    }
+                                };
+                                if (KLATT_USUAL_FADE && D::WUSUAL != 0u && wRes == D::WUSUAL) samples(std::integral_constant<uint32_t, D::WUSUAL>());
+                                else samples(std::integral_constant<uint32_t, 0u>());
                             } else {
 #pragma unroll 2
                                 for (int i = 0; i < CH; ++i) {
@@ -747,6 +775,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                         }
                     }
                     if constexpr (K::MIXED) {
+                        STAMP_SUB_BEGIN();
                         if (!forceGeneral()) {
                             const bool fad = !f.done && f.hasNew;
                             // (a lane that has just dequeued takes its fade's first sample, where everything moves, on the general step)
@@ -760,29 +789,38 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                 const bool lerpR = __any(fad && f.parMask != 0u);
                                 const uint32_t wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? f.resMask : 0u);
                                 const bool anyFad = __any(fad);
+                                auto stretch = [&](auto usual) __attribute__((always_inline)) {
+                                    const uint32_t w = decltype(usual)::value ? decltype(usual)::value : wResR;
 #pragma nounroll
-                                for (int j = i; j < i + n; ++j) {
-                                    if (!f.done) {
-                                        f.cnt++;
-                                        if (anyFad) {
-                                            if (fad) {
-                                                stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR);
-                                                if constexpr (D::TRACK) {
-                                                    if (wResR != 0u) track_next<D>(f, wResR);
+                                    for (int j = i; j < i + n; ++j) {
+                                        if (!f.done) {
+                                            f.cnt++;
+                                            if (anyFad) {
+                                                if (fad) {
+                                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR);
+                                                    if constexpr (D::TRACK) {
+                                                        if (w != 0u) track_next<D>(f, w);
+                                                    }
                                                 }
                                             }
+                                            if (D::PITCH) { if (!fad) { ps->cur0 += ps->oldInc; ps->old0 = ps->cur0; } }
+                                            // no event in the stretch: what forceGeneral() ruled out at its start (vibrato) stays out
+                                            body(c, j, false, 0.0);
                                         }
-                                        if (D::PITCH) { if (!fad) { ps->cur0 += ps->oldInc; ps->old0 = ps->cur0; } }
-                                        // no event in the stretch: what forceGeneral() ruled out at its start (vibrato) stays out
-                                        body(c, j, false, 0.0);
                                     }
-                                }
+                                };
+                                if (KLATT_USUAL_MIXED && D::TRACK && D::WUSUAL != 0u && wResR == D::WUSUAL) stretch(std::integral_constant<uint32_t, D::WUSUAL>());
+                                else stretch(std::integral_constant<uint32_t, 0u>());
                                 if (!f.done) fadeDone(n);
                                 i += n;
+                                STAMP_SUB_END(0, n);
                                 continue;
                             }
                         }
+                        STAMP_SUB_END(2, 1);
                     }
+                    {
+                    STAMP_SUB_BEGIN();
                     if (K::DELAY) {
                         // a lane that has not started yet (pipeline skew) sits this step out
                         const bool hold = delay > 0u;
@@ -794,6 +832,8 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                     } else {
                         const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
                         gen(c, i, emit);
+                    }
+                    STAMP_SUB_END(1, 1);
                     }
                     ++i;
                 }
@@ -1069,7 +1109,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
         constexpr int NR = NOISE ? 5 : 3;
         constexpr int NPAR = TRACK ? 1 : 2 * NR + 1;
-        using D = StageDesc<NPAR, NR, -1, false, true, NOISE && !TRACK, TRACK>;
+        using D = StageDesc<NPAR, NR, -1, false, true, NOISE && !TRACK, TRACK, 0x03u>;    // usually N0 and NP, when anything
         // parameter list: (f, bw) of N0, NP, r6 [, r5, r4], then caNP; tracked: caNP alone, RF = the resonators' track numbers
         constexpr int P[11] = {TRACK ? 23 : 13, 21, 14, 22, 12, 20, NOISE ? 11 : 23, 19, 10, 18, 23};
         constexpr int RF[5] = {0, TRACK ? 1 : 2, TRACK ? 2 : 4, TRACK ? 3 : 6, TRACK ? 4 : 8};
@@ -1101,7 +1141,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // tracked: the six gains alone, RF = the track numbers of parallel 1..4
         constexpr int NPAR = TRACK ? 6 : 14;
         constexpr int G0 = NPAR - 6;      // where 24 fricationAmplitude sits in P
-        using D = StageDesc<NPAR, 4, G0 + 1, false, false, !TRACK, TRACK>;
+        using D = StageDesc<NPAR, 4, G0 + 1, false, false, !TRACK, TRACK, 0x07u>;       // usually parallel 1..3
         constexpr int P[14] = {TRACK ? 24 : 25, TRACK ? 44 : 31, TRACK ? 37 : 26, TRACK ? 38 : 32, TRACK ? 39 : 27, TRACK ? 40 : 33, 28, 34, 24, 44, 37, 38, 39, 40};
         constexpr int RF[4] = {TRACK ? 8 : 0, TRACK ? 9 : 2, TRACK ? 10 : 4, TRACK ? 11 : 6}, RB[4] = {1, 3, 5, 7};
         StageFrame<NPAR, 4> f;
@@ -1159,7 +1199,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         constexpr int NR = NOISE ? 5 : NC;
         // tracked (noisy): pa5, pa6, parallelBypass, outputGain alone, RF = the track numbers of c3, c2, c1, p5, p6
         constexpr int NPAR = NOISE ? (TRACK ? 4 : 14) : (NASAL ? 5 : 1);
-        using D = StageDesc<NPAR, NR, -1, false, false, NOISE && !TRACK, TRACK>;
+        using D = StageDesc<NPAR, NR, -1, false, false, NOISE && !TRACK, TRACK, 0x07u>;  // usually c3, c2, c1
         constexpr int P[14] = {TRACK ? 41 : (NOISE ? 9 : (NASAL ? 8 : 45)), TRACK ? 42 : (NOISE ? 17 : 16), TRACK ? 43 : (NOISE ? 8 : 7),
                                TRACK ? 45 : (NOISE ? 16 : 15), NOISE ? 7 : 45, 15, 29, 35, 30, 36, 41, 42, 43, 45};
         constexpr int RF[5] = {TRACK ? 5 : 0, TRACK ? 6 : 2, TRACK ? 7 : (NOISE ? 4 : 0), TRACK ? 12 : 6, TRACK ? 13 : 8};

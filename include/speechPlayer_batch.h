@@ -34,7 +34,12 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
 /* Options: "mode" (see above); "sort" (1: pack wavefronts by utterance length, default 1);
  * "layout" (-1: chosen per batch, default; 2: lane-pipelined workgroups for the quiet, nasal-free utterances
  * whatever the batch size; 1: stage-parallel workgroups, four wavefronts per 64 utterances; 0: one wavefront
- * per 64 utterances).  No option changes the PCM. */
+ * per 64 utterances);
+ * "tracks" (1, default: noisy utterances whose parameters are all finite take their resonator coefficients from
+ * coefficient tracks -- every fade's coefficients evaluated densely by a kernel of its own before the synthesis kernel,
+ * one track per distinct fade of the batch -- instead of evaluating exp/cos inside the sample recurrence; 0: never) and
+ * "track_budget_mb" (device memory the tracks of a batch may take, default 16384; a batch whose tracks do not fit runs
+ * without them): both are read by speechPlayer_batch_setUtterances, set them before it.  No option changes the PCM. */
 int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value);
 
 /*
@@ -89,6 +94,18 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
 
 /* Kernel resource facts for reports: fills vgprs, ldsBytes, wavefronts launched, workgroups per CU. */
 int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo);
+/* info[12..15] (nInfo >= 16): utterances that take their coefficients from tracks, distinct tracks of the batch, their size in
+ * MB, 1 if the reported kernel is the tracked instantiation. */
+
+/* Host-only view of the coefficient-track planning of speechPlayer_batch_setUtterances (tests, tools; touches no device):
+ * the plan for these utterances under a budget of budgetMB.  eligible[u] != 0: utterance u may be tracked (NULL: all; the
+ * engine itself tracks the noisy utterances whose parameters are all finite).  Per frame: first entry and resonator mask
+ * (bit r of N0, NP, c6..c1, p1..p6) of its fade's track; per utterance: tracked or not (nothing is, once a tenth of the
+ * eligible utterances did not fit).  Returns the number of distinct tracks, *nEntries their 16-byte entries; -1 on bad
+ * arguments.  A fade's end points follow reference src/frame.cpp:55-72; equal fades share a track. */
+long long speechPlayer_planTracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,
+	const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible, long long budgetMB,
+	unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked, unsigned long long* nEntries);
 
 /*
  * One batch over the GPUs of a node.  Utterances are independent (the reference's only cross-handle coupling

@@ -45,7 +45,7 @@ EXPORTS = [
     "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
     "speechPlayer_node_setUtterances", "speechPlayer_node_synthesize", "speechPlayer_node_wait", "speechPlayer_node_totalSamples",
     "speechPlayer_node_read", "speechPlayer_node_getLastIndex", "speechPlayer_node_shardInfo", "speechPlayer_node_part",
-    "speechPlayer_node_time",
+    "speechPlayer_node_time", "speechPlayer_planTracks",
 ]
 
 
@@ -222,6 +222,8 @@ def load():
     L.speechPlayer_voiceName.argtypes = [i32]
     L.speechPlayer_applyVoiceToFrame.restype = i32
     L.speechPlayer_applyVoiceToFrame.argtypes = [vp, ctypes.c_char_p]
+    L.speechPlayer_planTracks.restype = i64
+    L.speechPlayer_planTracks.argtypes = [i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     _lib = L
     return L
 

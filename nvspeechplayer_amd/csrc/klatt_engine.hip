@@ -365,6 +365,96 @@ long long lanepipe_count(const Batch* b)
 constexpr size_t kTrackPad = 64;   // slack past the last track
 constexpr int kResFHost[kNumRes] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
 constexpr int kResBHost[kNumRes] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
+// ---- planning the coefficient tracks of a batch (host only; klatt_tracks.h, klatt_device.h for the track layout) -----------
+// Per frame of an eligible utterance: which resonators its fade moves and where the fade's coefficients will be.  The state
+// walked here is the part of the frame state machine that decides a fade's (f, bw) end points (reference src/frame.cpp:55-72,
+// restated by stage_event): silence keeps the shape of the last spoken frame, the first frame after silence starts from its
+// own shape, any other frame fades from the last spoken frame's values.  Fades with bitwise equal end points of all 28
+// (f, bw) parameters and the same length share one track.
+// Tracks pay when (nearly) the whole noisy group has them: a batch whose fades share nothing may need more memory than the
+// budget, and splitting such a batch into a tracked and an untracked launch measured slower than either kernel alone
+// (tools/track_probe.py +distinct).  So once more than a tenth of the eligible utterances did not fit, nothing is tracked.
+struct TrackPlan {
+    std::vector<TrackRef> ref;              // [nFrames]
+    std::vector<TrackJob> jobs;             // one per distinct track
+    std::vector<unsigned char> tracked;     // [nUtterances]
+    unsigned long long entries = 0;
+};
+void plan_tracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameMeta* meta,
+                 const unsigned char* eligible, long long budgetMB, TrackPlan& out)
+{
+    const long long nF = frameStart[nUtterances];
+    out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
+    out.jobs.clear();
+    out.tracked.assign((size_t)nUtterances, 0);
+    out.entries = 0;
+    struct Shape { unsigned long long w[2 * kNumRes]; bool operator==(const Shape& o) const { return !memcmp(w, o.w, sizeof w); } };
+    struct ShapeHash { size_t operator()(const Shape& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (unsigned long long v : k.w) { h ^= v; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
+    struct Fade { uint32_t from, to, len; bool operator==(const Fade& o) const { return from == o.from && to == o.to && len == o.len; } };
+    struct FadeHash { size_t operator()(const Fade& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
+    std::unordered_map<Shape, uint32_t, ShapeHash> shapes;      // (f, bw) vector -> id
+    std::vector<long long> shapeFrame;                          // id -> a frame that has it (-1: all zero)
+    std::unordered_map<Fade, unsigned long long, FadeHash> fades;   // (from, to, length) -> first entry
+    Shape zero; memset(&zero, 0, sizeof zero);
+    shapes.emplace(zero, 0u); shapeFrame.push_back(-1);
+    const unsigned long long budget = (unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2);
+    std::vector<Fade> added;
+    long long nEligible = 0, nMissed = 0;
+    for (long long u = 0; u < nUtterances; ++u) nEligible += eligible[u] ? 1 : 0;
+    for (long long u = 0; u < nUtterances && nMissed * 10 <= nEligible; ++u) {
+        if (!eligible[u]) continue;
+        added.clear();
+        const unsigned long long before = out.entries;
+        const size_t jobsBefore = out.jobs.size();
+        bool fits = true, prevNull = true;
+        uint32_t shapeId = 0;      // the last spoken frame's shape (0: none yet, all parameters zero)
+        long long shapeAt = -1;
+        for (long long k = frameStart[u]; k < frameStart[u + 1] && fits; ++k) {
+            uint32_t from = shapeId, to = shapeId, mask = 0;
+            if (!(meta[k].flags & FRAME_NULL)) {
+                const double* p = reinterpret_cast<const double*>(frames + k);
+                Shape sh;
+                for (int r = 0; r < kNumRes; ++r) { memcpy(&sh.w[2 * r], &p[kResFHost[r]], 8); memcpy(&sh.w[2 * r + 1], &p[kResBHost[r]], 8); }
+                auto it = shapes.find(sh);
+                if (it == shapes.end()) { it = shapes.emplace(sh, (uint32_t)shapeFrame.size()).first; shapeFrame.push_back(k); }
+                to = it->second;
+                if (prevNull) from = to;
+                else {
+                    const double* q = reinterpret_cast<const double*>(frames + shapeAt);
+                    for (int r = 0; r < kNumRes; ++r)
+                        if (!(p[kResFHost[r]] == q[kResFHost[r]]) || !(p[kResBHost[r]] == q[kResBHost[r]])) mask |= 1u << r;
+                }
+                shapeId = to; shapeAt = k; prevNull = false;
+            } else prevNull = true;
+            const uint32_t nSlots = track_slots(mask);
+            const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
+            if (n >= (1ull << 27)) { fits = false; break; }
+            const Fade key{from, to, meta[k].fadeSamples};
+            auto f = fades.find(key);
+            if (f == fades.end()) {
+                if (out.entries + n > budget) { fits = false; break; }
+                f = fades.emplace(key, out.entries).first;
+                added.push_back(key);
+                out.jobs.push_back(TrackJob{out.entries, shapeFrame[from], shapeFrame[to], meta[k].fadeSamples, mask});
+                out.entries += n;
+            }
+            out.ref[k] = TrackRef{f->second, mask, nSlots};
+        }
+        if (fits) out.tracked[u] = 1;
+        else {
+            for (const Fade& key : added) fades.erase(key);
+            out.jobs.resize(jobsBefore);
+            out.entries = before;
+            ++nMissed;
+        }
+    }
+    if (nMissed * 10 > nEligible) {
+        out.tracked.assign((size_t)nUtterances, 0);
+        out.jobs.clear();
+        out.entries = 0;
+    }
+}
+
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
 
 int batch_launch(Batch* b)
@@ -1002,34 +1092,10 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         pool += ((long long)len + kTile - 1) / kTile * kTile;
     }
     outStart[nUtterances] = pool;
-    // ---- coefficient tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite -------------------
-    // Per frame: which resonators its fade moves and where the fade's coefficients will be.  The state walked here is the
-    // part of the frame state machine that decides a fade's (f, bw) end points (reference src/frame.cpp:55-72, restated by
-    // stage_event): silence keeps the shape of the last spoken frame, the first frame after silence starts from its own
-    // shape, any other frame fades from the last spoken frame's values.  Fades with bitwise equal end points of all 28
-    // (f, bw) parameters and the same length share one track.
-    std::vector<TrackRef> trackRef;
-    std::vector<TrackJob> jobs;
-    unsigned long long trackEntries = 0;
+    // ---- coefficient tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite: plan_tracks -----
+    TrackPlan plan;
     if (b->tracks && nF > 0) {
-        trackRef.assign((size_t)nF, TrackRef{0, 0, 0});
-        struct Shape { unsigned long long w[2 * kNumRes]; bool operator==(const Shape& o) const { return !memcmp(w, o.w, sizeof w); } };
-        struct ShapeHash { size_t operator()(const Shape& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (unsigned long long v : k.w) { h ^= v; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
-        struct Fade { uint32_t from, to, len; bool operator==(const Fade& o) const { return from == o.from && to == o.to && len == o.len; } };
-        struct FadeHash { size_t operator()(const Fade& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
-        std::unordered_map<Shape, uint32_t, ShapeHash> shapes;      // (f, bw) vector -> id
-        std::vector<long long> shapeFrame;                          // id -> a frame that has it (-1: all zero)
-        std::unordered_map<Fade, unsigned long long, FadeHash> fades;   // (from, to, length) -> first entry
-        Shape zero; memset(&zero, 0, sizeof zero);
-        shapes.emplace(zero, 0u); shapeFrame.push_back(-1);
-        const unsigned long long budget = (unsigned long long)b->trackBudgetMB * (1ull << 20) / sizeof(double2);
-        std::vector<Fade> added;
-        // Tracks pay when (nearly) the whole noisy group has them: a batch whose fades share nothing may need more memory than
-        // the budget, and splitting such a batch into a tracked and an untracked launch measured slower than either kernel
-        // alone (tools/track_probe.py +distinct).  So once more than a tenth of the eligible utterances did not fit, nothing
-        // is tracked.
         std::vector<unsigned char> eligible((size_t)nUtterances, 0);
-        long long nEligible = 0, nMissed = 0;
         for (long long u = 0; u < nUtterances; ++u) {
             if (!(utt[u].flags & UTT_NEEDS_NOISE)) continue;
             bool finite = true;
@@ -1038,61 +1104,15 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
                 const double* p = reinterpret_cast<const double*>(frames + k);
                 for (int i = 0; i < kNumParams && finite; ++i) finite = std::isfinite(p[i]);
             }
-            if (finite) { eligible[u] = 1; ++nEligible; }     // "hold" targets and overflowing coefficients stay with the untracked kernel
+            eligible[u] = finite ? 1 : 0;     // "hold" targets and overflowing coefficients stay with the untracked kernel
         }
-        for (long long u = 0; u < nUtterances && nMissed * 10 <= nEligible; ++u) {
-            if (!eligible[u]) continue;
-            added.clear();
-            const unsigned long long before = trackEntries;
-            const size_t jobsBefore = jobs.size();
-            bool fits = true, prevNull = true;
-            uint32_t shapeId = 0;      // the last spoken frame's shape (0: none yet, all parameters zero)
-            long long shapeAt = -1;
-            for (long long k = frameStart[u]; k < frameStart[u + 1] && fits; ++k) {
-                uint32_t from = shapeId, to = shapeId, mask = 0;
-                if (!(meta[k].flags & FRAME_NULL)) {
-                    const double* p = reinterpret_cast<const double*>(frames + k);
-                    Shape sh;
-                    for (int r = 0; r < kNumRes; ++r) { memcpy(&sh.w[2 * r], &p[kResFHost[r]], 8); memcpy(&sh.w[2 * r + 1], &p[kResBHost[r]], 8); }
-                    auto it = shapes.find(sh);
-                    if (it == shapes.end()) { it = shapes.emplace(sh, (uint32_t)shapeFrame.size()).first; shapeFrame.push_back(k); }
-                    to = it->second;
-                    if (prevNull) from = to;
-                    else {
-                        const double* q = reinterpret_cast<const double*>(frames + shapeAt);
-                        for (int r = 0; r < kNumRes; ++r)
-                            if (!(p[kResFHost[r]] == q[kResFHost[r]]) || !(p[kResBHost[r]] == q[kResBHost[r]])) mask |= 1u << r;
-                    }
-                    shapeId = to; shapeAt = k; prevNull = false;
-                } else prevNull = true;
-                const uint32_t nSlots = track_slots(mask);
-                const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
-                if (n >= (1ull << 27)) { fits = false; break; }
-                const Fade key{from, to, meta[k].fadeSamples};
-                auto f = fades.find(key);
-                if (f == fades.end()) {
-                    if (trackEntries + n > budget) { fits = false; break; }
-                    f = fades.emplace(key, trackEntries).first;
-                    added.push_back(key);
-                    jobs.push_back(TrackJob{trackEntries, shapeFrame[from], shapeFrame[to], meta[k].fadeSamples, mask});
-                    trackEntries += n;
-                }
-                trackRef[k] = TrackRef{f->second, mask, nSlots};
-            }
-            if (fits) utt[u].flags |= UTT_TRACKED;
-            else {
-                for (const Fade& key : added) fades.erase(key);
-                jobs.resize(jobsBefore);
-                trackEntries = before;
-                ++nMissed;
-            }
-        }
-        if (nMissed * 10 > nEligible) {
-            for (long long u = 0; u < nUtterances; ++u) utt[u].flags &= ~UTT_TRACKED;
-            jobs.clear();
-            trackEntries = 0;
-        }
+        plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible.data(), b->trackBudgetMB, plan);
+        for (long long u = 0; u < nUtterances; ++u)
+            if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED;
     }
+    std::vector<TrackRef>& trackRef = plan.ref;
+    std::vector<TrackJob>& jobs = plan.jobs;
+    const unsigned long long trackEntries = plan.entries;
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
     // (within the quiet group and within the noisy group, which are launched as separate kernels)
     std::vector<uint32_t> order((size_t)nUtterances);
@@ -1605,6 +1625,46 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? 1 : 0;
     }
     return 0;
+}
+
+
+// Host-only view of the track planning (tests, tools): the plan speechPlayer_batch_setUtterances would make for these
+// utterances (eligible[u] != 0: utterance u may be tracked; NULL: all).  Per frame: first entry and resonator mask of its
+// fade's track (0 / 0 in utterances that are not tracked); per utterance: tracked or not.  Returns the number of distinct
+// tracks, *nEntries the 16-byte entries they hold; -1 on bad arguments.  Touches no device.
+long long speechPlayer_planTracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,
+                                  const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible,
+                                  long long budgetMB, unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked,
+                                  unsigned long long* nEntries)
+{
+    begin_call();
+    if (nUtterances < 0 || !frameStart || frameStart[0] != 0) { set_error("planTracks: bad arguments"); return -1; }
+    for (long long u = 0; u < nUtterances; ++u)
+        if (frameStart[u + 1] < frameStart[u]) { set_error("planTracks: frameStart not monotone at %lld", u); return -1; }
+    const long long nF = frameStart[nUtterances];
+    if (nF > 0 && (!frames || !fadeDuration)) { set_error("planTracks: bad frame arrays"); return -1; }
+    std::vector<FrameMeta> meta((size_t)nF);
+    for (long long k = 0; k < nF; ++k) {
+        meta[k].minSamples = 0; meta[k].userIndex = -1;
+        meta[k].fadeSamples = std::max(fadeDuration[k], 1u);
+        meta[k].flags = (isNull && isNull[k]) ? FRAME_NULL : 0u;
+    }
+    std::vector<unsigned char> all;
+    if (!eligible) { all.assign((size_t)nUtterances, 1); eligible = all.data(); }
+    TrackPlan plan;
+    plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible, budgetMB, plan);
+    for (long long k = 0; k < nF; ++k) {
+        if (trackOff) trackOff[k] = plan.ref[k].off;
+        if (trackMask) trackMask[k] = plan.ref[k].mask;
+    }
+    // references of utterances that ended up untracked mean nothing: clear them
+    for (long long u = 0; u < nUtterances; ++u) {
+        if (tracked) tracked[u] = plan.tracked[u];
+        if (!plan.tracked[u])
+            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) { if (trackOff) trackOff[k] = 0; if (trackMask) trackMask[k] = 0; }
+    }
+    if (nEntries) *nEntries = plan.entries;
+    return (long long)plan.jobs.size();
 }
 
 }  // extern "C"

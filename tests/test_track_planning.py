@@ -1,0 +1,113 @@
+"""Host logic of the coefficient tracks (speechPlayer_planTracks: what speechPlayer_batch_setUtterances plans; no GPU needed):
+which resonators a fade moves, which fades share a track, where the tracks lie, and the all-or-nothing budget rule -- against a
+plain Python walk of the reference's frame rules (src/frame.cpp:55-72: silence keeps the last spoken shape, the first frame
+after silence starts from its own shape, any other frame fades from the last spoken frame's values)."""
+import ctypes
+
+import numpy as np
+
+from nvspeechplayer_amd import _native
+
+RES_F = [13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30]      # N0, NP, c6..c1, p1..p6 (frame.h:24-42 order)
+RES_B = [21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36]
+FIRST = 15                                                          # entries of a fade's first sample (klatt_device.h)
+
+
+def plan(frame_start, frames, fade, isnull, eligible=None, budget_mb=16384):
+    L = _native.load()
+    nu, nf = len(frame_start) - 1, len(fade)
+    off = np.zeros(nf, np.uint64); mask = np.zeros(nf, np.uint32); tracked = np.zeros(nu, np.uint8)
+    entries = ctypes.c_ulonglong(0)
+    frames = np.ascontiguousarray(frames, np.float64); fade = np.ascontiguousarray(fade, np.uint32)
+    isnull = np.ascontiguousarray(isnull, np.uint8); frame_start = np.ascontiguousarray(frame_start, np.int64)
+    el = None if eligible is None else np.ascontiguousarray(eligible, np.uint8)
+    n = L.speechPlayer_planTracks(nu, frame_start.ctypes.data, frames.ctypes.data, fade.ctypes.data, isnull.ctypes.data,
+                                  None if el is None else el.ctypes.data, budget_mb, off.ctypes.data, mask.ctypes.data,
+                                  tracked.ctypes.data, ctypes.byref(entries))
+    return n, int(entries.value), off, mask, tracked
+
+
+def expected(frame_start, frames, fade, isnull):
+    """(mask, key) per frame; key = (old f/bw bytes, new f/bw bytes, fade length)"""
+    zero = np.zeros(28).tobytes()
+    masks, keys = [], []
+    for u in range(len(frame_start) - 1):
+        prev_null, shape = True, None
+        for k in range(frame_start[u], frame_start[u + 1]):
+            F = max(int(fade[k]), 1)
+            if isnull[k]:
+                s = zero if shape is None else shape[1]
+                masks.append(0); keys.append((s, s, F)); prev_null = True
+                continue
+            fb = np.array([v for r in range(14) for v in (frames[k][RES_F[r]], frames[k][RES_B[r]])])
+            if prev_null:
+                masks.append(0); keys.append((fb.tobytes(), fb.tobytes(), F))
+            else:
+                m = 0
+                for r in range(14):
+                    if frames[k][RES_F[r]] != shape[0][2 * r] or frames[k][RES_B[r]] != shape[0][2 * r + 1]:
+                        m |= 1 << r
+                masks.append(m); keys.append((shape[1], fb.tobytes(), F))
+            shape = (fb, fb.tobytes()); prev_null = False
+    return masks, keys
+
+
+def random_frames(rng, n_utt):
+    """few distinct shapes, so that fades repeat across utterances; NULL frames anywhere; -0.0 against 0.0"""
+    shapes = rng.uniform(100, 5000, size=(6, 47))
+    shapes[1] = shapes[0]; shapes[1][9] += 1.0            # differs from shape 0 in one formant only
+    shapes[2][13] = 0.0; shapes[3] = shapes[2]; shapes[3][13] = -0.0   # equal by value, different bits
+    frames, fade, nul, start = [], [], [], [0]
+    for _ in range(n_utt):
+        n = int(rng.integers(1, 7))
+        for _ in range(n):
+            frames.append(shapes[rng.integers(0, 6)].copy()); fade.append(int(rng.choice([0, 1, 2, 50, 300])))
+            nul.append(rng.random() < 0.25)
+        start.append(start[-1] + n)
+    return np.array(start, np.int64), np.array(frames), np.array(fade, np.uint32), np.array(nul, np.uint8)
+
+
+def test_masks_sharing_and_layout():
+    rng = np.random.default_rng(5)
+    fs, frames, fade, nul = random_frames(rng, 300)
+    n_tracks, entries, off, mask, tracked = plan(fs, frames, fade, nul)
+    assert tracked.all()
+    masks, keys = expected(fs, frames, fade, nul)
+    assert [int(m) for m in mask] == masks
+    # equal fades share a track, different fades do not; tracks tile [0, entries) without overlap, sized 15 + (F - 1) * slots
+    by_key, spans = {}, {}
+    for k, key in enumerate(keys):
+        assert by_key.setdefault(key, int(off[k])) == int(off[k])
+        slots = bin(masks[k]).count("1") + (masks[k] & 1)
+        spans[int(off[k])] = FIRST + (key[2] - 1) * slots
+    assert len(by_key) == n_tracks == len(set(by_key.values()))
+    pos = 0
+    for o in sorted(spans):
+        assert o == pos
+        pos += spans[o]
+    assert pos == entries
+    # the anti-resonator takes two entries per sample
+    k = next(k for k, m in enumerate(masks) if m & 1 and fade[k] > 1)
+    assert spans[int(off[k])] == FIRST + (max(int(fade[k]), 1) - 1) * (bin(masks[k]).count("1") + 1)
+
+
+def test_eligibility_and_budget():
+    rng = np.random.default_rng(6)
+    fs, frames, fade, nul = random_frames(rng, 200)
+    el = (rng.random(200) < 0.7).astype(np.uint8)
+    n_tracks, entries, off, mask, tracked = plan(fs, frames, fade, nul, eligible=el)
+    assert np.array_equal(tracked, el)
+    for u in range(200):
+        if not el[u]:
+            assert not off[fs[u]:fs[u + 1]].any() and not mask[fs[u]:fs[u + 1]].any()
+    # a budget that cannot hold the batch: nothing is tracked (a split batch measured slower than either kernel alone)
+    n0, e0, off0, mask0, tracked0 = plan(fs, frames, fade, nul, budget_mb=0)
+    assert n0 == 0 and e0 == 0 and not tracked0.any() and not off0.any()
+    # a budget that holds everything but a few utterances keeps the rest tracked: make one utterance enormous
+    fade2 = fade.copy(); frames2 = frames.copy()
+    k = int(fs[7])
+    frames2[k + 0] = rng.uniform(100, 5000, 47)
+    if fs[8] - fs[7] > 1:
+        frames2[k + 1] = rng.uniform(100, 5000, 47); nul2 = nul.copy(); nul2[k] = 0; nul2[k + 1] = 0; fade2[k + 1] = 50_000_000
+        n2, e2, off2, mask2, tracked2 = plan(fs, frames2, fade2, nul2, budget_mb=64)
+        assert not tracked2[7] and tracked2.sum() == 199

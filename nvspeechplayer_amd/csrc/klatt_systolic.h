@@ -138,6 +138,9 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
 #ifndef KLATT_USUAL_MIXED
 #define KLATT_USUAL_MIXED 0
 #endif
+#ifndef KLATT_MIXED_ALL
+#define KLATT_MIXED_ALL 0      // measured: no gain (rotated 27.0 -> 27.1 ms, cfg2 10.5 -> 10.7: 200 instead of 88 bytes of scratch)
+#endif
 template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false, bool TRACK_ = false, uint32_t WUSUAL_ = 0>
 struct StageDesc {
     static constexpr int NPARAM = NPARAM_, NRES = NRES_, GAIN = GAIN_;
@@ -809,7 +812,10 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                         }
                                     }
                                 };
-                                if (KLATT_USUAL_MIXED && D::TRACK && D::WUSUAL != 0u && wResR == D::WUSUAL) stretch(std::integral_constant<uint32_t, D::WUSUAL>());
+                                // KLATT_MIXED_ALL: a mixed stretch loads through ALL the stage's pointers on every fade sample instead of
+                                // testing the wave's moving set resonator by resonator (a resonator that does not move re-reads its value)
+                                if (KLATT_MIXED_ALL && D::TRACK) { if (wResR != 0u) stretch(std::integral_constant<uint32_t, (1u << (D::NRES > 0 ? D::NRES : 1)) - 1u>()); else stretch(std::integral_constant<uint32_t, 0u>()); }
+                                else if (KLATT_USUAL_MIXED && D::TRACK && D::WUSUAL != 0u && wResR == D::WUSUAL) stretch(std::integral_constant<uint32_t, D::WUSUAL>());
                                 else stretch(std::integral_constant<uint32_t, 0u>());
                                 if (!f.done) fadeDone(n);
                                 i += n;

@@ -517,7 +517,7 @@ int batch_launch(Batch* b)
         TrackArgs t;
         t.jobs = b->dJobs.ptr; t.nJobs = b->nJobs; t.frames = b->dFrames.ptr; t.track = b->dTrack.ptr;
         t.negPiOverSr = a.negPiOverSr; t.twoPiOverSr = a.twoPiOverSr;
-        const long long tg = (b->nJobs + kTrackWaves - 1) / kTrackWaves;
+        const long long tg = b->nJobs;     // one workgroup per track
         if (tg > 0x7FFFFFFF) { set_error("too many coefficient tracks: %lld", b->nJobs); return -1; }
         hipLaunchKernelGGL(klatt_tracks, dim3((unsigned)tg), dim3(kLanes * kTrackWaves), 0, st, t);
         HIP_TRY(hipGetLastError());

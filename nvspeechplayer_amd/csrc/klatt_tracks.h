@@ -29,13 +29,13 @@ struct TrackArgs {
     double negPiOverSr, twoPiOverSr;
 };
 
-constexpr int kTrackWaves = 4;   // wavefronts (jobs) per workgroup
+constexpr int kTrackWaves = 16;  // wavefronts per workgroup; a workgroup evaluates ONE track, wave w the entries [64 w, 64 w + 64), + 1024, ...
+                                 // (BASELINE configs[2] has 94 tracks of a few thousand entries: one wave per track took 59 us)
 
 __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const TrackArgs T)
 {
     const int lane = threadIdx.x & (kLanes - 1);
-    const long long j = (long long)blockIdx.x * kTrackWaves + (threadIdx.x >> 6);
-    if (j >= T.nJobs) return;     // whole waves
+    const long long j = blockIdx.x;
     const TrackJob job = T.jobs[j];
     const uint32_t mask = job.mask, nSlots = track_slots(mask), div = nSlots ? nSlots : 1u;
     const double nf = (double)job.fadeSamples, invFade = 1.0 / nf;
@@ -43,7 +43,7 @@ __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const Track
     const double* const fn = job.newFrame >= 0 ? T.frames + job.newFrame * kNumParams : nullptr;
     const uint32_t total = (uint32_t)kTrackFirst + (job.fadeSamples - 1u) * nSlots;   // host: below 2^27
     double2* const out = T.track + job.off;
-    for (uint32_t e0 = 0; e0 < total; e0 += kLanes) {
+    for (uint32_t e0 = (threadIdx.x >> 6) * kLanes; e0 < total; e0 += kLanes * kTrackWaves) {
         // every lane evaluates (the last pass repeats the track's last entry in its idle lanes): the wave-uniform short cuts of
         // resonator_coefficients_inline ballot over a full wavefront
         const uint32_t e = min(e0 + (uint32_t)lane, total - 1u);

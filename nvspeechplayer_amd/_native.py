@@ -95,7 +95,15 @@ def build(force=False, verbose=False, extra_hipcc_flags=(), lib_path=None):
         own = variant and is_hip
         o = os.path.join(OBJ_DIR, os.path.basename(out) + "." + os.path.splitext(src)[0] + ".o") if own else _obj(src)
         if force or own or _obj_stale(src):
-            cmd = ([hipcc] + HIPCC_FLAGS + list(extra_hipcc_flags) if is_hip else ["g++"] + CXX_FLAGS) + ["-c", os.path.join(CSRC, src), "-o", o]
+            flags = list(HIPCC_FLAGS)
+            extra = list(extra_hipcc_flags)
+            for f in [f for f in extra if f.startswith("--sched=")]:      # A/B builds: another machine-scheduler strategy ("none": the default)
+                extra.remove(f)
+                i = flags.index("-mllvm")
+                del flags[i:i + 2]
+                if f != "--sched=none":
+                    flags += ["-mllvm", "-amdgpu-sched-strategy=" + f[len("--sched="):]]
+            cmd = ([hipcc] + flags + extra if is_hip else ["g++"] + CXX_FLAGS) + ["-c", os.path.join(CSRC, src), "-o", o]
             if verbose:
                 print(" ".join(cmd))
             subprocess.check_call(cmd)

@@ -337,7 +337,12 @@ __device__ __forceinline__ void track_next(SF& f, uint32_t wRes)
 // (Reading a run's entries one sample ahead was built twice and measured slower both times -- through registers, where the
 // entries in flight pushed the kernel from 24 to 192 bytes of scratch: cfg2 11.4 -> 11.6 ms, rotated 27 -> 30; and straight
 // into LDS rows with global_load_lds_dwordx4, no registers involved: cfg2 11.2 -> 11.9, rotated 25.9 -> 28.9.  With two
-// waves per SIMD the second wave already covers the loads' latency; the extra waits and instructions do not pay.)
+// waves per SIMD the second wave already covers the loads' latency; the extra waits and instructions do not pay -- not even on a
+// batch whose 353 MB of tracks miss the L2: jittered durations 46.9 -> 47.2 ms with the LDS form.)
+// (Letting a mixed stretch span fade ends and first fade samples too, so that only dequeues break it -- a fade's end is mere
+// bookkeeping, its first sample a load through the first-row slots -- was also built: bit-identical, fewer single steps, and
+// slower: rotated 26.7 -> 30.0 ms, jittered 46.8 -> 47.7.  Two more ballots and branches on every sample of every stretch cost
+// more than the saved steps: the stretch body is bound by the instructions it issues.)
 // one fade sample of a tracked stage in any mix of lanes, counter already advanced
 template <class D, class SF>
 __device__ __forceinline__ void track_step(SF& f, const int* GR, uint32_t wRes)

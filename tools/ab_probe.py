@@ -36,11 +36,11 @@ def measure(workloads_wanted):
     import numpy as np
     from nvspeechplayer_amd import BatchPlayer, workloads
     sys.path.insert(0, os.path.join(ROOT, "tools"))
-    from mixed_probe import rotate
+    from mixed_probe import rotate, jitter
     out = {}
     base = workloads.make("cfg2", 65536)
     for key in workloads_wanted:
-        b = {"cfg2": lambda: base, "rot": lambda: rotate(base), "cfg2_16k": lambda: base.slice(0, 16384),
+        b = {"cfg2": lambda: base, "rot": lambda: rotate(base), "cfg2_16k": lambda: base.slice(0, 16384), "jit": lambda: jitter(base),
              "cfg4": lambda: workloads.make("cfg4", 32768), "cfg3": lambda: workloads.make("cfg3", 125000)}[key]()
         bp = BatchPlayer(b["sr"])
         bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])

@@ -138,6 +138,9 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
 #ifndef KLATT_USUAL_MIXED
 #define KLATT_USUAL_MIXED 0
 #endif
+#ifndef KLATT_STRETCH_UNROLL
+#define KLATT_STRETCH_UNROLL 1
+#endif
 #ifndef KLATT_MIXED_ALL
 #define KLATT_MIXED_ALL 0      // measured: no gain (rotated 27.0 -> 27.1 ms, cfg2 10.5 -> 10.7: 200 instead of 88 bytes of scratch)
 #endif
@@ -799,7 +802,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                 const bool anyFad = __any(fad);
                                 auto stretch = [&](auto usual) __attribute__((always_inline)) {
                                     const uint32_t w = decltype(usual)::value ? decltype(usual)::value : wResR;
-#pragma nounroll
+#pragma unroll KLATT_STRETCH_UNROLL
                                     for (int j = i; j < i + n; ++j) {
                                         if (!f.done) {
                                             f.cnt++;

@@ -313,8 +313,8 @@ def main():
                                     "roofline_frac": alg_bytes / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if world == 1 and args.mode == 0 and not args.no_extras and info.get("tracked"):
                 # the same batch without coefficient tracks (every stage evaluates exp/cos itself, as in round 1), and with every
-                # utterance's frame list rotated by a random amount -- same lengths, but no two lanes of a wavefront fade together:
-                # what a batch of unrelated sentences looks like to the kernel (the BASELINE recipe repeats eight sentences)
+                # utterance's frame list rotated by a random amount -- same lengths, ~24 different timings per sentence in random
+                # order: the lane packing puts equally timed utterances side by side again
                 def timed(b, tracks):
                     x = BatchPlayer(b["sr"], device=device, mode=args.mode, layout=args.layout)
                     x.setOption("tracks", tracks)
@@ -326,6 +326,10 @@ def main():
                 out["tracks_off"] = timed(batch, 0)
                 rot = workloads.rotated(batch)
                 out["rotated_frame_lists"] = dict(timed(rot, 1), tracks_off=timed(rot, 0))
+                # and with every frame's duration scaled by its own random factor: no two utterances share a timing or a length, so
+                # no wavefront can be packed with equally timed utterances -- a batch of unrelated sentences
+                jit = workloads.jittered(batch)
+                out["jittered_durations"] = dict(timed(jit, 1), tracks_off=timed(jit, 0))
             if world == 1 and not args.utterances and not args.no_extras:
                 # the other single-GPU configuration (BASELINE configs[1], 4096 steady vowels) and its recipe at 65 536 utterances
                 bp.close()

@@ -319,7 +319,8 @@ struct Batch {
     hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     long long nUtt = 0, nFrames = 0, nSlots = 0;
     long long nQuiet = 0;                  // order[0..nQuiet) = utterances without noise, the rest with
-    long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with coefficient tracks
+    long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with coefficient tracks (slots: utterances + padding)
+    long long nTrackedUtt = 0;             // the utterances among them
     long long nJobs = 0, trackEntries = 0; // distinct tracks of the batch, their entries (16 B each)
     long long nNoNasal = 0;                // order[0..nNoNasal) = quiet utterances that never couple the nasal pair (UTT_NO_NASAL)
     long long totalSamples = 0, poolSamples = 0;
@@ -358,6 +359,9 @@ long long lanepipe_count(const Batch* b)
 
 // How many of the noisy utterances (the head of the noisy part of `order`) take their coefficients from tracks: those the
 // host planned tracks for, under the stage-parallel layouts.
+#ifndef KLATT_TRACK_ALWAYS_CH8
+#define KLATT_TRACK_ALWAYS_CH8 0
+#endif
 #ifndef KLATT_TRACK_WPS
 #define KLATT_TRACK_WPS 2
 #endif
@@ -525,7 +529,7 @@ int batch_launch(Batch* b)
         a.trackRef = b->dTrackRef.ptr; a.track = b->dTrack.ptr;
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
-        if (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
+        if ((pl.chunk == 8 || KLATT_TRACK_ALWAYS_CH8) ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
                           : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
         a.trackRef = nullptr; a.track = nullptr;
     }
@@ -1122,21 +1126,62 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     auto noNasalEnd = std::stable_partition(order.begin(), quietEnd, [&](uint32_t x) { return (utt[x].flags & UTT_NO_NASAL) != 0; });
     const long long nNoNasal = noNasalEnd - order.begin();
     auto trackedEnd = std::stable_partition(quietEnd, order.end(), [&](uint32_t x) { return (utt[x].flags & UTT_TRACKED) != 0; });
-    const long long nTracked = trackedEnd - quietEnd;
+    const long long nTrackedUtt = trackedEnd - quietEnd;
+    long long nTracked = nTrackedUtt;      // slots of the tracked group (utterances + padding, below)
     if (b->sortByLength) {
-        auto longer = [&](uint32_t x, uint32_t y) { return lens[x] > lens[y]; };
-        std::stable_sort(order.begin(), noNasalEnd, longer);
-        std::stable_sort(noNasalEnd, quietEnd, longer);
-        std::stable_sort(quietEnd, trackedEnd, longer);
-        std::stable_sort(trackedEnd, order.end(), longer);
+        // Within a group: longest first, and utterances with the same TIMING (the same sequence of frame durations, fades and
+        // silences: the same text at the same speed, whatever the pitch, the voice or the noise seed) side by side.  Lanes
+        // with one timing dequeue and fade on the same samples, so their wavefront runs whole chunks on the uniform paths.
+        std::vector<unsigned long long> timing((size_t)nUtterances);
+        for (long long u = 0; u < nUtterances; ++u) {
+            unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(frameStart[u + 1] - frameStart[u]);
+            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+                h ^= ((unsigned long long)meta[k].minSamples << 32) ^ meta[k].fadeSamples ^ ((unsigned long long)(meta[k].flags & FRAME_NULL) << 63);
+                h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29;
+            }
+            timing[u] = h;
+        }
+        auto before = [&](uint32_t x, uint32_t y) { return lens[x] != lens[y] ? lens[x] > lens[y] : timing[x] < timing[y]; };
+        std::stable_sort(order.begin(), noNasalEnd, before);
+        std::stable_sort(noNasalEnd, quietEnd, before);
+        std::stable_sort(quietEnd, trackedEnd, before);
+        std::stable_sort(trackedEnd, order.end(), before);
+        // The noisy groups (64 utterances per wavefront): a wavefront that holds two timings runs every chunk on the general
+        // path -- ~2.6 times the time of a pure one for the whole length of its utterances, and it is the last to finish.  So a
+        // run of equally timed utterances that filled at least a quarter of its last wavefront, or that is followed by a run
+        // of 64 or more, ends its wavefront there: the remaining lanes stay empty (order slot 0xFFFFFFFF).  Batches of
+        // utterances that are all different (runs of 1) are packed densely, as before.
+        auto pad_runs = [&](std::vector<uint32_t>::iterator first, std::vector<uint32_t>::iterator last, std::vector<uint32_t>& out) {
+            size_t lanesOfRun = 0;     // lanes the current run occupies in the wavefront being filled
+            for (auto it = first; it != last;) {
+                auto runEnd = it;
+                while (runEnd != last && timing[*runEnd] == timing[*it] && lens[*runEnd] == lens[*it]) ++runEnd;
+                const size_t runSize = (size_t)(runEnd - it), fill = out.size() % kLanes;
+                if (fill != 0 && (lanesOfRun >= (size_t)kLanes / 4 || runSize >= (size_t)kLanes))
+                    out.insert(out.end(), kLanes - fill, 0xFFFFFFFFu);
+                out.insert(out.end(), it, runEnd);
+                const size_t tail = out.size() % kLanes;
+                lanesOfRun = tail == 0 ? 0 : std::min(runSize, tail);
+                it = runEnd;
+            }
+        };
+        std::vector<uint32_t> tracked, untracked;
+        pad_runs(quietEnd, trackedEnd, tracked);
+        if (!tracked.empty() && trackedEnd != order.end()) tracked.insert(tracked.end(), (kLanes - tracked.size() % kLanes) % kLanes, 0xFFFFFFFFu);   // the untracked group starts its own wavefront
+        pad_runs(trackedEnd, order.end(), untracked);
+        nTracked = (long long)tracked.size();
+        order.resize((size_t)nQuiet);
+        order.insert(order.end(), tracked.begin(), tracked.end());
+        order.insert(order.end(), untracked.begin(), untracked.end());
     }
+    const long long nSlotsAll = (long long)order.size();
 
     auto upload = [&]() -> int {
         if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>(nF, 1)) ||
-            b->dUtt.reserve(std::max<size_t>(nUtterances, 1)) || b->dOrder.reserve(std::max<size_t>(nUtterances, 1)) ||
+            b->dUtt.reserve(std::max<size_t>(nUtterances, 1)) || b->dOrder.reserve(std::max<size_t>(nSlotsAll, 1)) ||
             b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
-        if (nTracked > 0) {
+        if (nTrackedUtt > 0) {
             if (b->dTrackRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dTrack.reserve((size_t)trackEntries + kTrackPad)) return -1;
             HIP_TRY(hipMemcpyAsync(b->dTrackRef.ptr, trackRef.data(), (size_t)nF * sizeof(TrackRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dJobs.ptr, jobs.data(), jobs.size() * sizeof(TrackJob), hipMemcpyHostToDevice, b->stream));
@@ -1147,7 +1192,7 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         }
         if (nUtterances) {
             HIP_TRY(hipMemcpyAsync(b->dUtt.ptr, utt.data(), (size_t)nUtterances * sizeof(UttDesc), hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->dOrder.ptr, order.data(), (size_t)nUtterances * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dOrder.ptr, order.data(), (size_t)nSlotsAll * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nUtterances * sizeof(UttResult), b->stream));
         }
         HIP_TRY(hipStreamSynchronize(b->stream));
@@ -1156,13 +1201,14 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     if (upload()) {
         // the device buffers may hold a mix of the old and the new batch now: the object becomes an empty batch
         b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
-        b->nTracked = 0; b->nJobs = 0; b->trackEntries = 0;
+        b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0;
         b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
         return -1;
     }
-    b->nUtt = nUtterances; b->nFrames = nF; b->nSlots = nUtterances;
+    b->nUtt = nUtterances; b->nFrames = nF; b->nSlots = nSlotsAll;
     b->nQuiet = nQuiet; b->nNoNasal = nNoNasal;
-    b->nTracked = nTracked; b->nJobs = nTracked > 0 ? (long long)jobs.size() : 0; b->trackEntries = nTracked > 0 ? (long long)trackEntries : 0;
+    b->nTracked = nTrackedUtt > 0 ? nTracked : 0; b->nTrackedUtt = nTrackedUtt;
+    b->nJobs = nTrackedUtt > 0 ? (long long)jobs.size() : 0; b->trackEntries = nTrackedUtt > 0 ? (long long)trackEntries : 0;
     b->totalSamples = total; b->poolSamples = pool;
     b->lens.swap(lens); b->outStart.swap(outStart);
     b->results.clear();
@@ -1621,7 +1667,7 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     if (nInfo >= 10) { info[8] = lanepipe ? 1 : 0; info[9] = (int)std::min<long long>(nLp, 0x7FFFFFFF); }
     if (nInfo >= 12) { info[10] = nasalFree ? 1 : 0; info[11] = (int)std::min<long long>(nNn, 0x7FFFFFFF); }
     if (nInfo >= 16) {
-        info[12] = (int)std::min<long long>(nTr, 0x7FFFFFFF); info[13] = (int)std::min<long long>(b->nJobs, 0x7FFFFFFF);
+        info[12] = (int)std::min<long long>(nTr > 0 ? b->nTrackedUtt : 0, 0x7FFFFFFF); info[13] = (int)std::min<long long>(b->nJobs, 0x7FFFFFFF);
         info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? 1 : 0;
     }
     return 0;

@@ -203,3 +203,14 @@ def rotated(b, seed=1):
             perm[a:e] = np.roll(np.arange(a, e), -k)
     out = {k: b[k][perm] for k in ("frames", "min", "fade", "index", "isnull")}
     return Batch(frame_start=fs, seeds=b["seeds"], name=b["name"] + " rotated", sr=b["sr"], **out)
+
+
+def jittered(b, seed=1):
+    """Every frame's duration and fade scaled by its own random factor in [0.7, 1.3]: no two utterances of the batch share a
+    timing or a length -- what a batch of unrelated sentences looks like to the kernels."""
+    rng = np.random.default_rng(seed)
+    k = rng.uniform(0.7, 1.3, size=len(b["min"]))
+    out = {key: b[key] for key in ("frames", "index", "isnull")}
+    out["min"] = np.maximum(1, (b["min"] * k)).astype(np.uint32)
+    out["fade"] = (b["fade"] * k).astype(np.uint32)
+    return Batch(frame_start=b["frame_start"], seeds=b["seeds"], name=b["name"] + " jittered", sr=b["sr"], **out)

@@ -1023,6 +1023,18 @@ def test_coefficient_tracks_change_nothing(seed, wild):
                  isnull=np.concatenate([one["isnull"], one["isnull"]]),
                  frame_start=np.concatenate([one["frame_start"], one["frame_start"][1:] + one["frame_start"][-1]]),
                  seeds=np.concatenate([one["seeds"], one["seeds"] ^ np.uint32(0x5bd1e995)]))
+    # and five of them forty more times each: runs of equally timed utterances that do not fill whole wavefronts, so the
+    # lane packing ends wavefronts early (empty lanes) -- the PCM must not care (sort = 0 packs densely in the given order)
+    extra = [u for u in range(5) for _ in range(40)]
+    fs, parts = [int(batch["frame_start"][-1])], {k: [batch[k]] for k in ("frames", "min", "fade", "index", "isnull")}
+    for u in extra:
+        a0, a1 = int(one["frame_start"][u]), int(one["frame_start"][u + 1])
+        for k in parts:
+            parts[k].append(one[k][a0:a1])
+        fs.append(fs[-1] + a1 - a0)
+    batch = dict({k: np.concatenate(v) for k, v in parts.items()},
+                 frame_start=np.concatenate([batch["frame_start"], np.array(fs[1:], np.int64)]),
+                 seeds=np.concatenate([batch["seeds"], rng.integers(0, 2 ** 32, len(extra)).astype(np.uint32)]))
     n_utt = len(batch["seeds"])
 
     def run(mode, tracks, sort=1, budget=None):
@@ -1039,6 +1051,7 @@ def test_coefficient_tracks_change_nothing(seed, wild):
         return pcm, start, info
 
     for mode in (0, 1):
+        waves = {}
         ref_pcm, ref_start, info0 = run(mode, 0)
         assert info0["tracked_utterances"] == 0
         for sort, budget in ((1, None), (0, None), (1, 1)):
@@ -1052,8 +1065,11 @@ def test_coefficient_tracks_change_nothing(seed, wild):
                 assert info["tracked_utterances"] > n_utt // (4 if wild else 2)   # the noisy utterances with finite parameters
                 # the second copy of every utterance shares the first one's tracks: at most one track per frame of the first
                 assert info["tracks"] <= len(one["min"])
+                waves[sort] = info["wavefronts"]
             else:
                 assert info["tracked_utterances"] == 0                   # 1 MB holds the tracks of a few utterances only: all or nothing
+            if budget is None and len(waves) == 2:
+                assert waves[1] > waves[0]       # runs of equal timing end their wavefronts early: more wavefronts than the dense packing
             if wild:
                 nan_utts = sum(1 for u in range(n_utt) if np.isnan(batch["frames"][batch["frame_start"][u]:batch["frame_start"][u + 1]]).any())
                 assert nan_utts > 0 and info["tracked_utterances"] <= n_utt - nan_utts

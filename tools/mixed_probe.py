@@ -40,13 +40,7 @@ def stagger(b, seed=1):
 rotate = workloads.rotated
 
 
-def jitter(b, seed=1):
-    rng = np.random.default_rng(seed)
-    k = rng.uniform(0.7, 1.3, size=len(b["min"]))
-    out = {key: b[key] for key in ("frames", "index", "isnull")}
-    out["min"] = np.maximum(1, (b["min"] * k)).astype(np.uint32)
-    out["fade"] = (b["fade"] * k).astype(np.uint32)
-    return workloads.Batch(frame_start=b["frame_start"], seeds=b["seeds"], name=b["name"] + " jittered", sr=b["sr"], **out)
+jitter = workloads.jittered
 
 
 def distinct(b, seed=1):

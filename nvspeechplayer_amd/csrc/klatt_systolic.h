@@ -345,7 +345,9 @@ __device__ __forceinline__ void track_next(SF& f, uint32_t wRes)
 // (Letting a mixed stretch span fade ends and first fade samples too, so that only dequeues break it -- a fade's end is mere
 // bookkeeping, its first sample a load through the first-row slots -- was also built: bit-identical, fewer single steps, and
 // slower: rotated 26.7 -> 30.0 ms, jittered 46.8 -> 47.7.  Two more ballots and branches on every sample of every stretch cost
-// more than the saved steps: the stretch body is bound by the instructions it issues.)
+// more than the saved steps: the stretch body is bound by the instructions it issues.  A lighter form -- the bookkeeping of
+// a fade's end done at the stretch decision, the sample itself run as a steady one -- changed nothing either way: 47.0 -> 47.2 ms
+// on the jittered batch, where single steps are 35 % of the parallel stage's time, `-DKLATT_STAMPS=2`.)
 // one fade sample of a tracked stage in any mix of lanes, counter already advanced
 template <class D, class SF>
 __device__ __forceinline__ void track_step(SF& f, const int* GR, uint32_t wRes)

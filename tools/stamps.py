@@ -13,6 +13,9 @@ per = 20 if layout == 2 else 64
 if wl == "staggered":          # cfg2 with per-utterance leading silence: lanes of a wave do not fade together
     from mixed_probe import stagger
     batch = stagger(workloads.make("cfg2", n))
+elif wl == "jittered":
+    from mixed_probe import jitter
+    batch = jitter(workloads.make("cfg2", n))
 elif wl == "rotated":
     from mixed_probe import rotate
     batch = rotate(workloads.make("cfg2", n))

@@ -359,9 +359,6 @@ long long lanepipe_count(const Batch* b)
 
 // How many of the noisy utterances (the head of the noisy part of `order`) take their coefficients from tracks: those the
 // host planned tracks for, under the stage-parallel layouts.
-#ifndef KLATT_TRACK_ALWAYS_CH8
-#define KLATT_TRACK_ALWAYS_CH8 0
-#endif
 #ifndef KLATT_TRACK_WPS
 #define KLATT_TRACK_WPS 2
 #endif
@@ -529,7 +526,7 @@ int batch_launch(Batch* b)
         a.trackRef = b->dTrackRef.ptr; a.track = b->dTrack.ptr;
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
-        if ((pl.chunk == 8 || KLATT_TRACK_ALWAYS_CH8) ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
+        if (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
                           : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
         a.trackRef = nullptr; a.track = nullptr;
     }

@@ -135,15 +135,6 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
 #ifndef KLATT_USUAL_FADE
 #define KLATT_USUAL_FADE 1
 #endif
-#ifndef KLATT_USUAL_MIXED
-#define KLATT_USUAL_MIXED 0
-#endif
-#ifndef KLATT_STRETCH_UNROLL
-#define KLATT_STRETCH_UNROLL 1
-#endif
-#ifndef KLATT_MIXED_ALL
-#define KLATT_MIXED_ALL 0      // measured: no gain (rotated 27.0 -> 27.1 ms, cfg2 10.5 -> 10.7: 200 instead of 88 bytes of scratch)
-#endif
 template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false, bool TRACK_ = false, uint32_t WUSUAL_ = 0>
 struct StageDesc {
     static constexpr int NPARAM = NPARAM_, NRES = NRES_, GAIN = GAIN_;
@@ -804,7 +795,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                 const bool anyFad = __any(fad);
                                 auto stretch = [&](auto usual) __attribute__((always_inline)) {
                                     const uint32_t w = decltype(usual)::value ? decltype(usual)::value : wResR;
-#pragma unroll KLATT_STRETCH_UNROLL
+#pragma nounroll
                                     for (int j = i; j < i + n; ++j) {
                                         if (!f.done) {
                                             f.cnt++;
@@ -822,11 +813,9 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                         }
                                     }
                                 };
-                                // KLATT_MIXED_ALL: a mixed stretch loads through ALL the stage's pointers on every fade sample instead of
-                                // testing the wave's moving set resonator by resonator (a resonator that does not move re-reads its value)
-                                if (KLATT_MIXED_ALL && D::TRACK) { if (wResR != 0u) stretch(std::integral_constant<uint32_t, (1u << (D::NRES > 0 ? D::NRES : 1)) - 1u>()); else stretch(std::integral_constant<uint32_t, 0u>()); }
-                                else if (KLATT_USUAL_MIXED && D::TRACK && D::WUSUAL != 0u && wResR == D::WUSUAL) stretch(std::integral_constant<uint32_t, D::WUSUAL>());
-                                else stretch(std::integral_constant<uint32_t, 0u>());
+                                // (compiled for the usual moving set like the fade chunks, or loading through all the stage's pointers without tests:
+                                //  both measured slower -- 208 / 200 bytes of scratch, profiles/r2_ab_track_variants.txt)
+                                stretch(std::integral_constant<uint32_t, 0u>());
                                 if (!f.done) fadeDone(n);
                                 i += n;
                                 STAMP_SUB_END(0, n);

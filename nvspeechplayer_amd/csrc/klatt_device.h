@@ -74,32 +74,55 @@ struct UttResult {           // written by the kernel
     uint32_t drained;        // 1: the queue ran dry (short count)
 };
 
-// ---- coefficient tracks (klatt_tracks.h) ------------------------------------------------------------------
+// ---- tracks (klatt_tracks.h) ---------------------------------------------------------------------------------
 // A resonator's coefficients are a pure function of (f, bw) (reference src/speechWaveGenerator.cpp:112-127), and during a
-// fade (f, bw) are a pure function of the fade's two end frames and the sample counter (reference src/frame.cpp:48-53): the
-// coefficient values of a fade do not depend on the signal.  The tracked kernels therefore take them from a TRACK --
-// evaluated densely (lanes = entries) by klatt_tracks before the synthesis launch -- instead of evaluating exp/cos inside
-// the sample recurrence.  A track is an array of 16-byte entries:
-//   fade sample 1 (every resonator is re-evaluated there, see fade_update below): 15 entries,
-//       [0] N0 (b, c)  [1] N0 (a, -)  [2..14] NP, c6..c1, p1..p6 (b, c)            (a = 1 - b - c except for the anti-resonator)
-//   fade samples 2..F: one entry per MOVING resonator (mask, ascending; N0 takes two), nSlots entries per sample.
-// Fades with the same end values of all 28 (f, bw) parameters and the same length share one track (host, setUtterances).
-constexpr int kTrackFirst = 15;              // entries of a fade's first sample
+// fade every parameter is a pure function of the fade's two end frames and the sample counter (reference src/frame.cpp:48-53):
+// what the filter stages need on a fade sample does not depend on the signal.  The tracked kernels therefore take it from a
+// TRACK -- evaluated densely (lanes = entries) by klatt_tracks before the synthesis launch -- instead of interpolating and
+// evaluating exp/cos inside the sample recurrence.  A track is an array of 16-byte entries, kTrackEntries kinds of them:
+//   0..13   resonator r (N0, NP, c6..c1, p1..p6): (b, c); a = 1 - b - c, except for the anti-resonator N0, whose a is a
+//           second entry (a, -) right after its (b, c)
+//   14..19  the interpolated gains of the filter stages, in pairs: (caNP, -) | (pa5, pa6) (parallelBypass, outputGain) |
+//           (fricationAmplitude, preFormantGain) (pa1, pa2) (pa3, pa4)          -- S1 | final stage | parallel stage
+//   20..23  the source stage's parameters: (vibratoPitchOffset, vibratoSpeed) (voiceTurbulenceAmplitude, glottalOpenQuotient)
+//           (voiceAmplitude, aspirationAmplitude) (preFormantGain, -)           -- S0 (the pitch itself glides: not in a track)
+// Fade sample 1 (everything is re-evaluated there, see fade_update below): all of them, kTrackFirst entries in the order above.
+// Fade samples 2..F: one entry per kind that MOVES in the fade (mask, ascending; N0 takes two), nSlots entries per sample.
+// Fades with bitwise equal end values of all 39 parameters involved and the same length share one track (host, plan_tracks).
+constexpr int kTrackEntries = 24;
+constexpr int kTrackFirst = kTrackEntries + 1;   // entries of a fade's first sample (N0 takes two)
+constexpr int kShapeValues = 45;                 // a SHAPE: the parameter values a track depends on at one end of the fade
+constexpr int kShapeStride = 46;
+// where the values of a shape come from in a frame: (f, bw) of resonator r at 2r, 2r + 1; then the gains
+__host__ __device__ constexpr int shape_param(int i)
+{
+    constexpr int kF[14] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
+    constexpr int kB[14] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
+    constexpr int kG[17] = {23, 41, 42, 43, 45, 24, 44, 37, 38, 39, 40, 1, 2, 3, 4, 5, 6};
+    return i < 28 ? ((i & 1) ? kB[i >> 1] : kF[i >> 1]) : kG[i - 28];
+}
+constexpr int kShapePreGain = 28 + 6;            // preFormantGain (parameter 44): silence gates it (reference src/frame.cpp:61,66)
+// the two shape values of gain entry e (14..19); -1: none
+__host__ __device__ constexpr int entry_value(int e, int half)
+{
+    constexpr int kV[10][2] = {{28, -1}, {29, 30}, {31, 32}, {33, 34}, {35, 36}, {37, 38}, {39, 40}, {41, 42}, {43, 44}, {34, -1}};
+    return kV[e - 14][half];
+}
 struct TrackRef {            // 16 B per frame, read by the tracked stages at a dequeue
     unsigned long long off;  // first entry of the fade's track
-    uint32_t mask;           // resonators that move in the fade (bit r of N0, NP, c6..c1, p1..p6)
+    uint32_t mask;           // entry kinds that move in the fade (bit e)
     uint32_t nSlots;         // entries per fade sample after the first: popcount(mask) + (mask & 1)
 };
 struct TrackJob {            // one distinct track, read by klatt_tracks
     unsigned long long off;
-    long long oldFrame, newFrame;   // frames (index into KernelArgs.frames) the fade starts from / goes to; -1 = all zero
+    uint32_t fromShape, toShape;    // the fade's end points (index into TrackArgs.shapes)
     uint32_t fadeSamples;
     uint32_t mask;
 };
 __host__ __device__ inline uint32_t track_slots(uint32_t mask) { return (uint32_t)__builtin_popcount(mask) + (mask & 1u); }
-// slot of resonator r among the entries of a later fade sample / of the first one
-__host__ __device__ inline uint32_t track_slot(uint32_t mask, int r) { return (uint32_t)__builtin_popcount(mask & ((1u << r) - 1u)) + ((r > 0) ? (mask & 1u) : 0u); }
-constexpr int track_first_slot(int r) { return r + (r > 0 ? 1 : 0); }
+// slot of entry kind e among the entries of a later fade sample / of the first one
+__host__ __device__ inline uint32_t track_slot(uint32_t mask, int e) { return (uint32_t)__builtin_popcount(mask & ((1u << e) - 1u)) + ((e > 0) ? (mask & 1u) : 0u); }
+constexpr int track_first_slot(int e) { return e + (e > 0 ? 1 : 0); }
 
 struct KernelArgs {
     const TrackRef* trackRef;    // [nFrames] tracked launches only

@@ -193,12 +193,12 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false, bool TRACK = false>
+template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false, bool TRACK = false, bool FLAT = false>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = SysLds<NOISE, CH, TRACK>::kBytes;
+    constexpr int ldsBytes = SysLds<NOISE, CH, TRACK, FLAT>::kBytes;
     auto go = [&](auto kernel) -> int {
         if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a);
@@ -206,8 +206,8 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM, TRACK>); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM, TRACK>); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM, TRACK, FLAT>); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM, TRACK, FLAT>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -314,6 +314,7 @@ struct Batch {
     int cus = 256;
     hipStream_t stream = nullptr;
     int tracks = 1;                        // 1: noisy utterances with finite parameters take their coefficients from tracks (klatt_tracks.h)
+    int flat = 0;                          // 1: the tracked launch runs flat filter stages (gains from the tracks too, no frame state machine in S1..S3)
     long long trackBudgetMB = 16384;       // the tracks of a batch may take this much device memory; utterances beyond it run untracked
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
     hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -336,6 +337,7 @@ struct Batch {
     DeviceBuffer<UttResult> dResult;
     DeviceBuffer<TrackRef> dTrackRef;          // [nFrames]
     DeviceBuffer<TrackJob> dJobs;
+    DeviceBuffer<double> dShapes;              // [nShapes][kShapeStride]
     DeviceBuffer<double2> dTrack;
     DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
@@ -362,22 +364,26 @@ long long lanepipe_count(const Batch* b)
 #ifndef KLATT_TRACK_WPS
 #define KLATT_TRACK_WPS 2
 #endif
-// host copies of kResF / kResB (klatt_device.h): the frequency and bandwidth parameter of resonator r
+#ifndef KLATT_FLAT_WPS
+#define KLATT_FLAT_WPS 2
+#endif
 constexpr size_t kTrackPad = 64;   // slack past the last track
 constexpr int kResFHost[kNumRes] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
 constexpr int kResBHost[kNumRes] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
-// ---- planning the coefficient tracks of a batch (host only; klatt_tracks.h, klatt_device.h for the track layout) -----------
-// Per frame of an eligible utterance: which resonators its fade moves and where the fade's coefficients will be.  The state
-// walked here is the part of the frame state machine that decides a fade's (f, bw) end points (reference src/frame.cpp:55-72,
-// restated by stage_event): silence keeps the shape of the last spoken frame, the first frame after silence starts from its
-// own shape, any other frame fades from the last spoken frame's values.  Fades with bitwise equal end points of all 28
-// (f, bw) parameters and the same length share one track.
+// ---- planning the tracks of a batch (host only; klatt_tracks.h, klatt_device.h for the track layout) --------------------
+// Per frame of an eligible utterance: which entry kinds its fade moves and where the fade's track will be.  The state walked
+// here is the part of the frame state machine that decides a fade's end points (reference src/frame.cpp:55-72, restated by
+// stage_event): silence keeps the last request's values with the gain gated off, the first frame after silence starts from its
+// own values with the gain gated off, any other frame fades from the previous request's values.  A SHAPE is the vector of
+// the 39 parameter values a track depends on (klatt_device.h); fades with bitwise equal shapes at both ends and the same
+// length share one track.
 // Tracks pay when (nearly) the whole noisy group has them: a batch whose fades share nothing may need more memory than the
 // budget, and splitting such a batch into a tracked and an untracked launch measured slower than either kernel alone
 // (tools/track_probe.py +distinct).  So once more than a tenth of the eligible utterances did not fit, nothing is tracked.
 struct TrackPlan {
     std::vector<TrackRef> ref;              // [nFrames]
     std::vector<TrackJob> jobs;             // one per distinct track
+    std::vector<double> shapes;             // [nShapes][kShapeStride]
     std::vector<unsigned char> tracked;     // [nUtterances]
     unsigned long long entries = 0;
 };
@@ -387,17 +393,26 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     const long long nF = frameStart[nUtterances];
     out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
     out.jobs.clear();
+    out.shapes.clear();
     out.tracked.assign((size_t)nUtterances, 0);
     out.entries = 0;
-    struct Shape { unsigned long long w[2 * kNumRes]; bool operator==(const Shape& o) const { return !memcmp(w, o.w, sizeof w); } };
-    struct ShapeHash { size_t operator()(const Shape& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (unsigned long long v : k.w) { h ^= v; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
+    struct Shape { double v[kShapeValues]; bool operator==(const Shape& o) const { return !memcmp(v, o.v, sizeof v); } };
+    struct ShapeHash { size_t operator()(const Shape& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (double d : k.v) { unsigned long long w; memcpy(&w, &d, 8); h ^= w; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
     struct Fade { uint32_t from, to, len; bool operator==(const Fade& o) const { return from == o.from && to == o.to && len == o.len; } };
     struct FadeHash { size_t operator()(const Fade& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
-    std::unordered_map<Shape, uint32_t, ShapeHash> shapes;      // (f, bw) vector -> id
-    std::vector<long long> shapeFrame;                          // id -> a frame that has it (-1: all zero)
+    std::unordered_map<Shape, uint32_t, ShapeHash> shapes;          // values -> id (row of out.shapes)
     std::unordered_map<Fade, unsigned long long, FadeHash> fades;   // (from, to, length) -> first entry
+    auto shape_id = [&](const Shape& sh) -> uint32_t {
+        auto it = shapes.find(sh);
+        if (it != shapes.end()) return it->second;
+        const uint32_t id = (uint32_t)shapes.size();
+        shapes.emplace(sh, id);
+        out.shapes.resize((size_t)(id + 1) * kShapeStride, 0.0);
+        memcpy(&out.shapes[(size_t)id * kShapeStride], sh.v, sizeof sh.v);
+        return id;
+    };
     Shape zero; memset(&zero, 0, sizeof zero);
-    shapes.emplace(zero, 0u); shapeFrame.push_back(-1);
+    shape_id(zero);
     const unsigned long long budget = (unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2);
     std::vector<Fade> added;
     long long nEligible = 0, nMissed = 0;
@@ -408,35 +423,36 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
         const unsigned long long before = out.entries;
         const size_t jobsBefore = out.jobs.size();
         bool fits = true, prevNull = true;
-        uint32_t shapeId = 0;      // the last spoken frame's shape (0: none yet, all parameters zero)
-        long long shapeAt = -1;
+        Shape prev = zero;         // the previous request's values (a fresh handle: all zero)
         for (long long k = frameStart[u]; k < frameStart[u + 1] && fits; ++k) {
-            uint32_t from = shapeId, to = shapeId, mask = 0;
-            if (!(meta[k].flags & FRAME_NULL)) {
+            Shape from = prev, to = prev;
+            if (meta[k].flags & FRAME_NULL) {
+                to.v[kShapePreGain] = 0.0;                     // silence: the old values, the gain gated off (:59-63)
+                prevNull = true;
+            } else {
                 const double* p = reinterpret_cast<const double*>(frames + k);
-                Shape sh;
-                for (int r = 0; r < kNumRes; ++r) { memcpy(&sh.w[2 * r], &p[kResFHost[r]], 8); memcpy(&sh.w[2 * r + 1], &p[kResBHost[r]], 8); }
-                auto it = shapes.find(sh);
-                if (it == shapes.end()) { it = shapes.emplace(sh, (uint32_t)shapeFrame.size()).first; shapeFrame.push_back(k); }
-                to = it->second;
-                if (prevNull) from = to;
-                else {
-                    const double* q = reinterpret_cast<const double*>(frames + shapeAt);
-                    for (int r = 0; r < kNumRes; ++r)
-                        if (!(p[kResFHost[r]] == q[kResFHost[r]]) || !(p[kResBHost[r]] == q[kResBHost[r]])) mask |= 1u << r;
-                }
-                shapeId = to; shapeAt = k; prevNull = false;
-            } else prevNull = true;
+                for (int i = 0; i < kShapeValues; ++i) to.v[i] = p[shape_param(i)];
+                if (prevNull) { from = to; from.v[kShapePreGain] = 0.0; }   // out of silence: the new values, from gain 0 (:64-67)
+                prevNull = false;
+            }
+            prev = to;
+            uint32_t mask = 0;
+            for (int r = 0; r < kNumRes; ++r)
+                if (!(to.v[2 * r] == from.v[2 * r]) || !(to.v[2 * r + 1] == from.v[2 * r + 1])) mask |= 1u << r;
+            for (int e = kNumRes; e < kTrackEntries; ++e) {
+                const int a = entry_value(e, 0), c = entry_value(e, 1);
+                if (!(to.v[a] == from.v[a]) || (c >= 0 && !(to.v[c] == from.v[c]))) mask |= 1u << e;
+            }
             const uint32_t nSlots = track_slots(mask);
             const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
             if (n >= (1ull << 27)) { fits = false; break; }
-            const Fade key{from, to, meta[k].fadeSamples};
+            const Fade key{shape_id(from), shape_id(to), meta[k].fadeSamples};
             auto f = fades.find(key);
             if (f == fades.end()) {
                 if (out.entries + n > budget) { fits = false; break; }
                 f = fades.emplace(key, out.entries).first;
                 added.push_back(key);
-                out.jobs.push_back(TrackJob{out.entries, shapeFrame[from], shapeFrame[to], meta[k].fadeSamples, mask});
+                out.jobs.push_back(TrackJob{out.entries, key.from, key.to, meta[k].fadeSamples, mask});
                 out.entries += n;
             }
             out.ref[k] = TrackRef{f->second, mask, nSlots};
@@ -516,7 +532,7 @@ int batch_launch(Batch* b)
     if (nTr > 0) {
         hipStream_t st = next_stream();
         TrackArgs t;
-        t.jobs = b->dJobs.ptr; t.nJobs = b->nJobs; t.frames = b->dFrames.ptr; t.track = b->dTrack.ptr;
+        t.jobs = b->dJobs.ptr; t.nJobs = b->nJobs; t.shapes = b->dShapes.ptr; t.track = b->dTrack.ptr;
         t.negPiOverSr = a.negPiOverSr; t.twoPiOverSr = a.twoPiOverSr;
         const long long tg = b->nJobs;     // one workgroup per track
         if (tg > 0x7FFFFFFF) { set_error("too many coefficient tracks: %lld", b->nJobs); return -1; }
@@ -526,8 +542,10 @@ int batch_launch(Batch* b)
         a.trackRef = b->dTrackRef.ptr; a.track = b->dTrack.ptr;
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
-        if (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
-                          : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
+        if (b->flat ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true, true>(a, b->mode, g, st)
+                                     : launch_systolic<true, 16, 1, true, false, true, true>(a, b->mode, g, st))
+                    : (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
+                                     : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st))) return -1;
         a.trackRef = nullptr; a.track = nullptr;
     }
     if (nNoisy > 0) {
@@ -960,6 +978,7 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess;
     { const char* e = getenv("SPEECHPLAYER_TRACKS"); if (e) b->tracks = atoi(e) ? 1 : 0; }
+    { const char* e = getenv("SPEECHPLAYER_FLAT"); if (e) b->flat = atoi(e) ? 1 : 0; }
     for (int i = 0; i < 4 && ok; ++i)
         ok = hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&b->join[i], hipEventDisableTiming) == hipSuccess;
@@ -984,7 +1003,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
-    b->dTrackRef.release(); b->dJobs.release(); b->dTrack.release();
+    b->dTrackRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
     delete b;
 }
 
@@ -1002,6 +1021,7 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value > 2 ? 1 : value); return 0; }
     // coefficient tracks: planned by setUtterances (set the option before it), used by the stage-parallel layouts
     if (!strcmp(name, "tracks")) { b->tracks = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "flat")) { b->flat = value ? 1 : 0; return 0; }
     if (!strcmp(name, "track_budget_mb")) { b->trackBudgetMB = value < 0 ? 0 : value; return 0; }
     set_error("unknown option %s", name);
     return -1;
@@ -1179,7 +1199,9 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
             b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
         if (nTrackedUtt > 0) {
-            if (b->dTrackRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dTrack.reserve((size_t)trackEntries + kTrackPad)) return -1;
+            if (b->dTrackRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
+                b->dTrack.reserve((size_t)trackEntries + kTrackPad)) return -1;
+            HIP_TRY(hipMemcpyAsync(b->dShapes.ptr, plan.shapes.data(), plan.shapes.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dTrackRef.ptr, trackRef.data(), (size_t)nF * sizeof(TrackRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dJobs.ptr, jobs.data(), jobs.size() * sizeof(TrackJob), hipMemcpyHostToDevice, b->stream));
         }

@@ -58,10 +58,13 @@ namespace klatt {
 #define KLATT_STR(x) KLATT_STR2(x)
 
 constexpr int kStages = 4;
+#ifndef KLATT_FLAT_SOURCE
+#define KLATT_FLAT_SOURCE 1     // FLAT launches: S0 is a flat stage too (0: the tracked launch's S0, with the frame state machine)
+#endif
 
 // LDS per workgroup: pipes [2 buffers][CH][64 lanes] f64 (4 noisy / 3 quiet), the PCM tile and row
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
-template <bool NOISE, int CH, bool TRACK = false>
+template <bool NOISE, int CH, bool TRACK = false, bool FLAT = false>
 struct SysLds {
     static constexpr int kPipeBytes = 2 * CH * kLanes * 8;
     static constexpr int kNumPipes = NOISE ? 4 : 3;
@@ -71,8 +74,9 @@ struct SysLds {
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
     static constexpr int kFrames = kMaxLen + 16;
     // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5; tracked (noisy, no f/bw pairs) 7, 1, 4, 6
-    static constexpr int kParams0 = 7, kParams1 = NOISE ? (TRACK ? 1 : 11) : 7, kParams2 = NOISE ? (TRACK ? 4 : 14) : 6,
-                         kParams3 = NOISE ? (TRACK ? 6 : 14) : 5;
+    // flat (FLAT: the filter stages take their gains from the tracks too and keep no fade end points at all) 7, 0, 0, 0
+    static constexpr int kParams0 = 7, kParams1 = FLAT ? 0 : (NOISE ? (TRACK ? 1 : 11) : 7), kParams2 = FLAT ? 0 : (NOISE ? (TRACK ? 4 : 14) : 6),
+                         kParams3 = FLAT ? 0 : (NOISE ? (TRACK ? 6 : 14) : 5);
     static constexpr int kFrames1 = kFrames + 1 * kParams0 * kLanes * 8;    // S0 keeps its target values in registers
     static constexpr int kFrames2 = kFrames1 + 2 * kParams1 * kLanes * 8;
     static constexpr int kFrames3 = kFrames2 + 2 * kParams2 * kLanes * 8;
@@ -858,6 +862,177 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
     (void)stampSlot;
 }
 
+// ---- flat filter stages (FLAT launches) ---------------------------------------------------------------------------
+// With the gains in the tracks as well (entry kinds 14..19, klatt_device.h) a filter stage needs no frame state machine: what
+// changes its state is a list of fades at sample positions that follow from the frame durations alone.  Frame k of an
+// utterance is dequeued on sample T_k (T_0 = 0, T_k+1 = T_k + max(min_k, fade_k + 1) + 1; reference src/frame.cpp:41-80) and its
+// fade's rows apply to samples T_k + 1 .. T_k + fade_k.  So a flat stage keeps per lane: the sample on which its next fade starts,
+// the rows left of the running one, one pointer and stride per entry kind it uses -- and per sample does
+//     a lane whose fade starts: reads the frame's TrackRef and durations, takes the first row, points at the later rows
+//     a lane inside a fade:     loads through its pointers (an entry kind that does not move re-reads its first-row value)
+//     every lane that still has samples: the filters
+// with no dequeue / fade-end events, no interpolation, no end points in LDS.  A chunk in which no lane of the wave starts, runs
+// or ends anything is the straight-line steady chunk of the other kernels.  (S0, which glides the pitch, keeps its state machine.)
+template <int NRES_, int NGAIN_, bool ANTI0_>
+struct FlatDesc { static constexpr int NRES = NRES_, NGAIN = NGAIN_, NE = NRES_ + NGAIN_; static constexpr bool ANTI0 = ANTI0_; };
+template <class FD>
+struct FlatState {
+    static constexpr int NR = FD::NRES > 0 ? FD::NRES : 1;
+    double ra[NR], rb[NR], rc[NR], z1[NR], z2[NR];
+    double cur[2 * FD::NGAIN];
+    const double2* tp[FD::NE];
+    uint32_t ts[FD::NE];
+    uint32_t startAt, left, next, nFrames, length, produced;
+    bool live;
+};
+template <class FD>
+__device__ __forceinline__ void flat_init(FlatState<FD>& f, bool live, const UttDesc& d)
+{
+#pragma unroll
+    for (int r = 0; r < FD::NRES; ++r) { f.ra[r] = 0.0; f.rb[r] = 2.0; f.rc[r] = -1.0; f.z1[r] = 0.0; f.z2[r] = 0.0; }
+#pragma unroll
+    for (int k = 0; k < 2 * FD::NGAIN; ++k) f.cur[k] = 0.0;
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) { f.tp[e] = nullptr; f.ts[e] = 0; }
+    f.live = live && d.length > 0u;
+    f.nFrames = d.nFrames; f.length = d.length; f.next = 0; f.left = 0; f.produced = 0;
+    f.startAt = (live && d.nFrames > 0u) ? 1u : 0xFFFFFFFFu;      // frame 0 is dequeued on sample 0, its fade's first row applies to sample 1
+}
+template <class FD>
+__device__ __forceinline__ void flat_take(FlatState<FD>& f, int e, const double2 v, double a0)
+{
+    if (e < FD::NRES) {
+        f.ra[e] = (FD::ANTI0 && e == 0) ? a0 : (1.0 - v.x - v.y);
+        f.rb[e] = v.x; f.rc[e] = v.y;
+    } else {
+        f.cur[2 * (e - FD::NRES)] = v.x; f.cur[2 * (e - FD::NRES) + 1] = v.y;
+    }
+}
+// a fade starts on this sample: its first row (every entry kind), then the pointers for the rows that follow
+template <class FD>
+__device__ __forceinline__ void flat_begin(FlatState<FD>& f, const StageCtx& X, const int* GE)
+{
+    const FrameMeta m = X.myMeta[f.next];
+    const TrackRef tr = X.myTrack[f.next];
+    const double2* const base = X.A.track + tr.off;
+    double2 v[FD::NE];
+    double a0 = 0.0;
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) v[e] = base[track_first_slot(GE[e])];
+    if (FD::ANTI0) a0 = base[track_first_slot(GE[0]) + 1].x;
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) {
+        flat_take<FD>(f, e, v[e], a0);
+        const bool moves = (tr.mask >> GE[e]) & 1u;
+        f.tp[e] = base + (moves ? (uint32_t)kTrackFirst + track_slot(tr.mask, GE[e]) : (uint32_t)track_first_slot(GE[e]));
+        f.ts[e] = moves ? tr.nSlots : 0u;
+    }
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) mine |= (tr.mask >> GE[e]) & 1u;
+    f.left = mine ? m.fadeSamples - 1u : 0u;       // a fade that moves nothing of this stage has no further rows for it
+    const uint32_t span = (m.minSamples > m.fadeSamples + 1u ? m.minSamples : m.fadeSamples + 1u) + 1u;
+    f.next++;
+    f.startAt = f.next < f.nFrames ? f.startAt + span : 0xFFFFFFFFu;
+}
+// one later row of the running fade
+template <class FD>
+__device__ __forceinline__ void flat_next(FlatState<FD>& f)
+{
+    double2 v[FD::NE];
+    double a0 = 0.0;
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) { v[e] = f.tp[e][0]; if (FD::ANTI0 && e == 0) a0 = f.tp[e][1].x; f.tp[e] += f.ts[e]; }
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) flat_take<FD>(f, e, v[e], a0);
+    f.left--;
+}
+// the chunk loop of a flat stage: same barrier discipline as stage_loop (nIter iterations, one barrier each, chunk iter - depth)
+template <class FD, int CH, class FBody, class FChunk>
+__device__ __forceinline__ void flat_loop(int depth, int nIter, int nChunks, int stampSlot, FlatState<FD>& f, const StageCtx& X, const int* GE, FBody body, FChunk perChunk)
+{
+#ifdef KLATT_STAMPS
+    Stamps st;
+#endif
+    for (int iter = 0; iter < nIter; ++iter) {
+        STAMP_BEGIN();
+        STAMP_IDLE();
+        const int c = iter - depth;
+        if (c >= 0 && c < nChunks) {
+            const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
+            if (f.length <= t0) f.live = false;                               // this lane has emitted its last sample
+            const bool busy = f.live && (f.left > 0u || f.startAt < t1 || f.length < t1);
+            if (!__any(busy)) {
+                // a steady stretch is decided once: the chunks until some live lane starts a fade or ends run in a tight loop
+                // (chunk, barrier, chunk, ...) with the barrier count of the outer loop
+                uint32_t run = 0xFFFFFFFFu;
+                if (f.live) { const uint32_t until = f.startAt < f.length ? f.startAt : f.length; run = (until - t0) / (uint32_t)CH; }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
+                run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                const uint32_t room = (uint32_t)(nChunks - c);
+                run = run < room ? run : room;
+                int cc = c;
+                STAMP_KIND(0);
+                for (uint32_t q = 1; q < run; ++q) {
+                    if (f.live) {
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) body(cc, i);
+                    }
+                    if (f.live) f.produced = (uint32_t)(cc + 1) * (uint32_t)CH;
+                    perChunk();
+                    STAMP_WORKED();
+                    __syncthreads();
+                    STAMP_SYNCED();
+                    STAMP_BEGIN();
+                    ++iter; ++cc;
+                }
+                if (f.live) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) body(cc, i);
+                }
+                if (f.live) f.produced = (uint32_t)(cc + 1) * (uint32_t)CH;
+                perChunk();
+                STAMP_WORKED();
+                __syncthreads();
+                STAMP_SYNCED();
+                continue;
+            } else if (!__any(f.live && (f.left < (uint32_t)CH || f.startAt < t1 || f.length < t1))) {
+                // every live lane is inside a fade for the whole chunk: no tests per sample
+                STAMP_KIND(1);
+                if (f.live) {
+#pragma unroll 2
+                    for (int i = 0; i < CH; ++i) { flat_next<FD>(f); body(c, i); }
+                }
+            } else {
+                STAMP_KIND(-1);
+#pragma nounroll
+                for (int i = 0; i < CH; ++i) {
+                    const uint32_t t = t0 + (uint32_t)i;
+                    const bool emit = f.live && t < f.length;
+                    const bool starting = emit && t == f.startAt;
+                    if (__any(starting)) { if (starting) flat_begin<FD>(f, X, GE); }
+                    const bool fading = emit && !starting && f.left > 0u;
+                    if (__any(fading)) { if (fading) flat_next<FD>(f); }
+                    if (emit) body(c, i);
+                }
+            }
+            f.produced = f.length < t1 ? f.length : t1;
+            perChunk();
+        }
+        STAMP_WORKED();
+        __syncthreads();
+        STAMP_SYNCED();
+    }
+#ifdef KLATT_STAMPS
+    if (X.A.debug && (threadIdx.x & (kLanes - 1)) == 0) {
+        unsigned long long* o = X.A.debug + (blockIdx.x * 4 + stampSlot) * 8;
+        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
+    }
+#endif
+    (void)stampSlot;
+}
+
 // ---- the kernel ---------------------------------------------------------------------------
 // NASAL = false (quiet launches only): every utterance of the launch is nasal-free (UTT_NO_NASAL, classified on the
 // host): caNP == 0 in every frame with bounded, stable N0/NP parameters.  The cascade input then passes the nasal pair
@@ -872,13 +1047,15 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
 // TRACK (noisy batch launches only): the utterances of the launch have coefficient tracks (klatt_tracks.h; host: UTT_TRACKED).
 // S1, S2 and S3 then track no (f, bw) parameters -- 1, 4 and 6 parameters instead of 11, 14 and 14 -- and pick their
 // resonators' coefficients up from the track on fade samples instead of evaluating exp and cos.
-template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false, bool TRACK = false>
+// FLAT (tracked launches): S1, S2 and S3 are flat stages (above); S0 is the tracked launch's S0.
+template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false, bool TRACK = false, bool FLAT = false>
 __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const KernelArgs A)
 {
+    static_assert(!FLAT || TRACK, "flat stages read tracks");
     static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
     static_assert(NOISE || !STREAM, "live handles take the noisy instantiation");
     static_assert(!TRACK || (NOISE && !STREAM), "coefficient tracks: noisy batch launches");
-    using L = SysLds<NOISE, CH, TRACK>;
+    using L = SysLds<NOISE, CH, TRACK, FLAT>;
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     double* const pipeX = reinterpret_cast<double*>(lds);                           // S0 -> S1
@@ -954,7 +1131,169 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
 #ifndef KLATT_ONLY_STAGE
 #define KLATT_ONLY_STAGE -1
 #endif
-    if (stage == 0 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 0)) {
+    if (FLAT && KLATT_FLAT_SOURCE && stage == 0) {
+        // ================= flat S0: the source stage without the chunk machinery of stage_loop =================
+        // Its seven parameters come from the tracks (entry kinds 20..23); what stays here is the pitch, which glides with the sample
+        // count of THIS utterance (reference src/frame.cpp:76-79, :98, :71) and so cannot be shared: per lane the sample of the next
+        // dequeue, of the running fade's end, the fade rows left.  Per sample a lane is dequeuing (sets up the pitch fade; the sample
+        // is emitted unchanged), fading (pitch interpolated, a row taken), ending its fade (bookkeeping), or steady (glide).
+        if constexpr (FLAT) {
+            using FD = FlatDesc<0, 4, false>;
+            constexpr int GE[4] = {20, 21, 22, 23};     // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain
+            FlatState<FD> f;
+            flat_init<FD>(f, live, d);
+            PitchState ps;
+            ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
+            double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, invFade = 1.0, nfD = 1.0;
+            uint32_t noiseIdx = 0, cntF = 0, fmask = 0, fslots = 0;
+            uint32_t deqAt = (live && d.nFrames > 0u) ? 0u : 0xFFFFFFFFu, fadeEndAt = 0xFFFFFFFFu;
+            const double2* tBase = nullptr;
+            int32_t lastIndex = -1;
+            bool oldNull = true, newNull = false, first = false, rows = false;   // rows: the running fade moves some parameter of this stage
+            auto source = [&](bool waveVib) __attribute__((always_inline)) -> double {
+                double vib = 1.0;
+                if (waveVib) {
+                    const double vs = f.cur[1];
+                    const double adv = frac_toward_zero(div_by(vs, A.sampleRateF, A.invSampleRate) + vibPhase);
+                    vibPhase = (vs != 0.0) ? adv : vibPhase;
+                    vib = (sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[0]) + 1.0;
+                }
+                pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
+                double voice = (pitchPhase * 2.0) - 1.0;
+                aspNoise = noise_uniform(nkey, noiseIdx) + 0.75 * aspNoise;
+                noiseIdx += 2u;
+                double asp = aspNoise * 0.2;
+                double turb = asp * f.cur[2];
+                turb = (pitchPhase >= f.cur[3]) ? turb : turb * 0.01;
+                voice += turb;
+                voice *= f.cur[4];
+                asp *= f.cur[5];
+                const double src = asp + voice;
+                return (src * f.cur[6]) * 0.5;
+            };
+            auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase; };
+#ifdef KLATT_STAMPS
+            Stamps st;
+#endif
+            for (int iter = 0; iter < nIter; ++iter) {
+                STAMP_BEGIN();
+                STAMP_IDLE();
+                const int c = iter;
+                if (c < nChunks) {
+                    const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
+                    if (f.length <= t0) f.live = false;
+                    const bool busy = f.live && (f.left > 0u || deqAt < t1 || fadeEndAt < t1 || f.length < t1 || vib_live());
+                    STAMP_KIND(__any(busy) ? -1 : 0);
+                    if (!__any(busy)) {
+                        // steady stretch, decided once (as in flat_loop): the pitch glides, nothing else changes
+                        uint32_t run = 0xFFFFFFFFu;
+                        if (f.live) { const uint32_t until = deqAt < f.length ? deqAt : f.length; run = (until - t0) / (uint32_t)CH; }
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
+                        run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                        const uint32_t room = (uint32_t)(nChunks - c);
+                        run = run < room ? run : room;
+                        int cc = c;
+                        for (uint32_t q = 0; q < run; ++q) {
+                            if (f.live) {
+#pragma unroll
+                                for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; PIPE(pipeX, cc, i) = source(false); }
+                                ps.old0 = ps.cur0;
+                            }
+                            if (q + 1 < run) { STAMP_WORKED(); __syncthreads(); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; }
+                        }
+                    } else if (!__any(f.live && (f.left < (uint32_t)CH || first || deqAt < t1 || f.length < t1 || vib_live()))) {
+                        // every live lane is inside a fade (past its first row) for the whole chunk, no vibrato: no tests per sample
+                        const bool anyRows = __any(f.live && rows);
+                        if (f.live) {
+#pragma unroll 2
+                            for (int i = 0; i < CH; ++i) {
+                                cntF++;
+                                const double ratio = div_by((double)cntF, nfD, invFade);
+                                ps.cur0 = fade_value(ps.old0, ps.new0, ratio);
+                                if (anyRows) flat_next<FD>(f); else f.left--;
+                                PIPE(pipeX, c, i) = source(false);
+                            }
+                        }
+                    } else {
+#pragma nounroll
+                        for (int i = 0; i < CH; ++i) {
+                            const uint32_t t = t0 + (uint32_t)i;
+                            const bool emit = f.live && t < f.length;
+                            const bool deq = emit && t == deqAt;
+                            if (__any(deq)) {
+                                if (deq) {   // reference src/frame.cpp:55-72 (stage_event restates it); the sample itself is emitted as it is
+                                    const FrameMeta m = X.myMeta[f.next];
+                                    const TrackRef tr = X.myTrack[f.next];
+                                    const double* g = X.myFrames + (size_t)f.next * kNumParams;
+                                    newNull = (m.flags & FRAME_NULL) != 0;
+                                    if (newNull) { ps.new0 = ps.cur0; ps.newInc = 0.0; }
+                                    else {
+                                        const double g0 = g[0], g46 = g[46];
+                                        ps.new0 = g0;
+                                        ps.newInc = (g46 - g0) / (double)m.minSamples;   // reference src/frame.cpp:98
+                                        if (oldNull) ps.old0 = g0;
+                                    }
+                                    if (m.userIndex != -1) lastIndex = m.userIndex;       // (:69)
+                                    nfD = (double)m.fadeSamples;
+                                    ps.new0 += ps.newInc * nfD;                           // (:71)
+                                    invFade = 1.0 / nfD;
+                                    cntF = 0;
+                                    tBase = X.A.track + tr.off; fmask = tr.mask; fslots = tr.nSlots;
+#pragma unroll
+                                    for (int e = 0; e < FD::NE; ++e) { f.tp[e] = tBase + track_first_slot(GE[e]); f.ts[e] = 0u; }
+                                    f.left = m.fadeSamples; first = true; rows = true;
+                                    fadeEndAt = t + m.fadeSamples + 1u;
+                                    const uint32_t span = (m.minSamples > m.fadeSamples + 1u ? m.minSamples : m.fadeSamples + 1u) + 1u;
+                                    f.next++;
+                                    deqAt = f.next < f.nFrames ? t + span : 0xFFFFFFFFu;
+                                }
+                            }
+                            const bool fad = emit && !deq && f.left > 0u;
+                            if (__any(fad)) {
+                                if (fad) {
+                                    cntF++;
+                                    const double ratio = div_by((double)cntF, nfD, invFade);
+                                    ps.cur0 = fade_value(ps.old0, ps.new0, ratio);
+                                    if (rows) flat_next<FD>(f); else f.left--;
+                                    if (first) {   // the first row read: from here on the rows that follow
+                                        first = false;
+                                        uint32_t mine = 0;
+#pragma unroll
+                                        for (int e = 0; e < FD::NE; ++e) {
+                                            const bool moves = (fmask >> GE[e]) & 1u;
+                                            mine |= moves ? 1u : 0u;
+                                            if (moves) { f.tp[e] = tBase + ((uint32_t)kTrackFirst + track_slot(fmask, GE[e])); f.ts[e] = fslots; }
+                                        }
+                                        rows = mine != 0u;
+                                    }
+                                }
+                            }
+                            const bool ending = emit && !deq && !fad && t == fadeEndAt;
+                            if (__any(ending)) { if (ending) { ps.old0 = ps.new0; ps.oldInc = ps.newInc; oldNull = newNull; fadeEndAt = 0xFFFFFFFFu; } }
+                            if (emit && !deq && !fad && !ending) { ps.cur0 += ps.oldInc; ps.old0 = ps.cur0; }   // glide (reference src/frame.cpp:76-79)
+                            const bool waveVib = __any(emit && vib_live());
+                            if (emit) PIPE(pipeX, c, i) = source(waveVib);
+                        }
+                    }
+                }
+                STAMP_WORKED();
+                __syncthreads();
+                STAMP_SYNCED();
+            }
+#ifdef KLATT_STAMPS
+            if (A.debug && lane == 0) {
+                unsigned long long* o = A.debug + (blockIdx.x * 4 + 0) * 8;
+                o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
+            }
+#endif
+            if (live) {
+                UttResult res;
+                res.produced = d.length; res.framesTaken = f.next; res.lastIndex = lastIndex; res.drained = 1u;
+                A.result[u] = res;
+            }
+        }
+    } else if (stage == 0 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 0)) {
         // ================= S0: frame + glottal source (+ aspiration noise) =================
         // tracked: 1 vibratoPitchOffset, 2 vibratoSpeed, 3 turbulence, 4 openQuotient, 5 voiceAmplitude,
         //          6 aspirationAmplitude, 44 preFormantGain (quiet launches never read 3, 4, 6)
@@ -1085,6 +1424,110 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             stage_state_save<D>(f, &ps, streamState, P, GR0);
             streamState[208] = pitchPhase; streamState[209] = vibPhase; streamState[210] = aspNoise;
             streamState[220] = (double)lastIndex; streamState[221] = (double)noiseIdx;
+        }
+    } else if (FLAT && stage == 1) {
+        // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 =================
+        if constexpr (FLAT) {
+            using FD = FlatDesc<5, 1, true>;
+            constexpr int GE[6] = {0, 1, 2, 3, 4, 14};
+            FlatState<FD> f;
+            flat_init<FD>(f, live, d);
+            flat_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
+                [&](int c, int i) __attribute__((always_inline)) {
+                    const double x = PIPE(pipeX, c, i);
+                    const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
+                    f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
+                    const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
+                    double o = fade_value(x, np, f.cur[0]);
+#pragma unroll
+                    for (int r = 2; r < 5; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
+                    PIPE(pipeO, c, i) = o;
+                },
+                noChunk);
+        }
+    } else if (FLAT && stage == 3) {
+        // ================= flat S3: frication noise, parallel r1..r4 partial sum =================
+        if constexpr (FLAT) {
+            using FD = FlatDesc<4, 3, false>;
+            constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // cur: fricationAmplitude, preFormantGain, pa1..pa4
+            FlatState<FD> f;
+            flat_init<FD>(f, live, d);
+            double fricNoise = 0.0;
+            uint32_t noiseIdx = 1;
+            flat_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
+                [&](int c, int i) __attribute__((always_inline)) {
+                    fricNoise = noise_uniform(nkey, noiseIdx) + 0.75 * fricNoise;
+                    noiseIdx += 2u;
+                    const double fric = fricNoise * 0.3 * f.cur[0];
+                    const double y = (fric * f.cur[1]) * 0.5;
+                    double par = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
+                        par += (w - y) * f.cur[2 + r];
+                    }
+                    PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
+                },
+                noChunk);
+        }
+    } else if (FLAT && stage == 2) {
+        // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
+        if constexpr (FLAT) {
+            using FD = FlatDesc<5, 2, false>;
+            constexpr int GE[7] = {5, 6, 7, 12, 13, 15, 16};      // cur: pa5, pa6, parallelBypass, outputGain
+            FlatState<FD> f;
+            flat_init<FD>(f, live, d);
+            int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
+            uint32_t it = 0;
+            auto flush_tile = [&](uint32_t tileStart, uint32_t validTo) __attribute__((always_inline)) {
+                rowCount[lane] = f.produced;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave alone owns the tile: wave-level ordering is enough
+                constexpr int kChunksPerRow = kTile / 8;
+                constexpr int kRowsPerPass = kLanes / kChunksPerRow;
+                constexpr int kPasses = kLanes / kRowsPerPass;
+                const int chunk = lane % kChunksPerRow;
+                const uint32_t first = tileStart + (uint32_t)chunk * 8u;
+                uint2 lo[kPasses], hi[kPasses];
+                uint32_t cnt[kPasses];
+                long long base[kPasses];
+#pragma unroll
+                for (int p = 0; p < kPasses; ++p) {
+                    const int row = p * kRowsPerPass + lane / kChunksPerRow;
+                    const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
+                    lo[p] = src[0]; hi[p] = src[1];
+                    cnt[p] = rowCount[row];
+                    base[p] = rowBase[row];
+                }
+#pragma unroll
+                for (int p = 0; p < kPasses; ++p) {
+                    if (cnt[p] > first && first < validTo) {
+                        uint4* dst = reinterpret_cast<uint4*>(A.pcm + base[p] + first);
+                        *dst = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+                    }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            };
+            flat_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
+                [&](int c, int i) __attribute__((always_inline)) {
+                    double o = PIPE(pipeO, c, i);
+                    const double y = PIPE(pipeA, c, i);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
+                    double par = PIPE(pipeB, c, i);
+#pragma unroll
+                    for (int r = 3; r < 5; ++r) {
+                        const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
+                        par += (w - y) * f.cur[r - 3];
+                    }
+                    par = fade_value(par, y, f.cur[2]);
+                    const double mix = o + par;
+                    const double v = (mix * f.cur[3]) * 4000.0;
+                    const double lo = (v < 32000.0) ? v : 32000.0;       // windows.h min(): NaN -> 32000
+                    const double cl = (lo > -32000.0) ? lo : -32000.0;
+                    myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (:208)
+                },
+                [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
+            if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
         }
     } else if (!NOISE && !NASAL && (stage == 1 || stage == 2)) {
         // ================= quiet, nasal-free S1: r6, r5, r4 and S2: r3, r2, r1 =================

@@ -24,7 +24,7 @@ namespace klatt {
 struct TrackArgs {
     const TrackJob* jobs;
     long long nJobs;
-    const double* frames;        // [nFrames][47]
+    const double* shapes;        // [nShapes][kShapeStride]: the parameter values at the end points of the fades (host, plan_tracks)
     double2* track;
     double negPiOverSr, twoPiOverSr;
 };
@@ -39,15 +39,15 @@ __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const Track
     const TrackJob job = T.jobs[j];
     const uint32_t mask = job.mask, nSlots = track_slots(mask), div = nSlots ? nSlots : 1u;
     const double nf = (double)job.fadeSamples, invFade = 1.0 / nf;
-    const double* const fo = job.oldFrame >= 0 ? T.frames + job.oldFrame * kNumParams : nullptr;
-    const double* const fn = job.newFrame >= 0 ? T.frames + job.newFrame * kNumParams : nullptr;
+    const double* const fo = T.shapes + (size_t)job.fromShape * kShapeStride;
+    const double* const fn = T.shapes + (size_t)job.toShape * kShapeStride;
     const uint32_t total = (uint32_t)kTrackFirst + (job.fadeSamples - 1u) * nSlots;   // host: below 2^27
     double2* const out = T.track + job.off;
     for (uint32_t e0 = (threadIdx.x >> 6) * kLanes; e0 < total; e0 += kLanes * kTrackWaves) {
         // every lane evaluates (the last pass repeats the track's last entry in its idle lanes): the wave-uniform short cuts of
         // resonator_coefficients_inline ballot over a full wavefront
         const uint32_t e = min(e0 + (uint32_t)lane, total - 1u);
-        uint32_t cnt, r;
+        uint32_t cnt, r;          // r: the entry's kind
         bool second;              // N0's second entry: its a
         if (e < (uint32_t)kTrackFirst) {
             cnt = 1u; r = e <= 1u ? 0u : e - 1u; second = (e == 1u);
@@ -55,19 +55,30 @@ __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const Track
             const uint32_t q = e - (uint32_t)kTrackFirst, n = q / div, s = q - n * div;
             cnt = 2u + n; r = 0u; second = false;
             uint32_t acc = 0;
-            for (int k = 0; k < kNumRes; ++k) {
+            for (int k = 0; k < kTrackEntries; ++k) {
                 if (!((mask >> k) & 1u)) continue;     // wave-uniform
                 const uint32_t w = k == 0 ? 2u : 1u;
                 if (s >= acc && s < acc + w) { r = (uint32_t)k; second = (k == 0 && s == acc + 1u); }
                 acc += w;
             }
         }
-        const int pf = kResF[r], pb = kResB[r];
-        const double f0 = fo ? fo[pf] : 0.0, f1 = fn ? fn[pf] : 0.0, b0 = fo ? fo[pb] : 0.0, b1 = fn ? fn[pb] : 0.0;
         const double ratio = div_by((double)cnt, nf, invFade);
-        const double f = fade_value(f0, f1, ratio), bw = fade_value(b0, b1, ratio);
+        // a resonator's (f, bw), or a gain entry's two values (a resonator's path is taken by the gain lanes too, on the values
+        // of resonator 0, so that the wave-uniform short cuts of resonator_coefficients_inline see a full wavefront)
+        const bool gain = r >= (uint32_t)kNumRes;
+        const int i0 = gain ? 0 : 2 * (int)r, i1 = gain ? 1 : 2 * (int)r + 1;
+        const double f = fade_value(fo[i0], fn[i0], ratio), bw = fade_value(fo[i1], fn[i1], ratio);
         const Coef k = resonator_coefficients_inline<MODE_EXACT>(f, bw, r == 0u, T.negPiOverSr, T.twoPiOverSr);
-        if (e0 + (uint32_t)lane < total) out[e] = second ? make_double2(k.a, 0.0) : make_double2(k.b, k.c);
+        double2 v = second ? make_double2(k.a, 0.0) : make_double2(k.b, k.c);
+        if (gain) {
+            int ga = 28, gb = -1;
+#pragma unroll
+            for (int g = kNumRes; g < kTrackEntries; ++g)
+                if (r == (uint32_t)g) { ga = entry_value(g, 0); gb = entry_value(g, 1); }
+            v.x = fade_value(fo[ga], fn[ga], ratio);
+            v.y = gb >= 0 ? fade_value(fo[gb], fn[gb], ratio) : 0.0;
+        }
+        if (e0 + (uint32_t)lane < total) out[e] = v;
     }
 }
 

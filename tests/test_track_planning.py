@@ -10,7 +10,10 @@ from nvspeechplayer_amd import _native
 
 RES_F = [13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30]      # N0, NP, c6..c1, p1..p6 (frame.h:24-42 order)
 RES_B = [21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36]
-FIRST = 15                                                          # entries of a fade's first sample (klatt_device.h)
+# entry kinds 14..23: pairs of parameters (-1: none); 44 = preFormantGain, which silence gates off (frame.cpp:61,66)
+PAIRS = [(23, -1), (41, 42), (43, 45), (24, 44), (37, 38), (39, 40), (1, 2), (3, 4), (5, 6), (44, -1)]
+SHAPE = [p for r in range(14) for p in (RES_F[r], RES_B[r])] + [23, 41, 42, 43, 45, 24, 44, 37, 38, 39, 40, 1, 2, 3, 4, 5, 6]
+FIRST = 25                                                          # entries of a fade's first sample: 24 kinds, N0 takes two
 
 
 def plan(frame_start, frames, fade, isnull, eligible=None, budget_mb=16384):
@@ -28,35 +31,44 @@ def plan(frame_start, frames, fade, isnull, eligible=None, budget_mb=16384):
 
 
 def expected(frame_start, frames, fade, isnull):
-    """(mask, key) per frame; key = (old f/bw bytes, new f/bw bytes, fade length)"""
-    zero = np.zeros(28).tobytes()
+    """(mask, key) per frame; key = (values at the fade's start, at its end, fade length).  The end points follow
+    reference src/frame.cpp:55-72: silence = the previous request's values with the gain gated off; the first frame after
+    silence (or the first of all) starts from its own values with the gain gated off; else from the previous request's values."""
     masks, keys = [], []
     for u in range(len(frame_start) - 1):
-        prev_null, shape = True, None
+        prev, prev_null = {p: 0.0 for p in range(47)}, True
         for k in range(frame_start[u], frame_start[u + 1]):
             F = max(int(fade[k]), 1)
             if isnull[k]:
-                s = zero if shape is None else shape[1]
-                masks.append(0); keys.append((s, s, F)); prev_null = True
-                continue
-            fb = np.array([v for r in range(14) for v in (frames[k][RES_F[r]], frames[k][RES_B[r]])])
-            if prev_null:
-                masks.append(0); keys.append((fb.tobytes(), fb.tobytes(), F))
+                old, new = dict(prev), dict(prev)
+                new[44] = 0.0
+                prev_null = True
             else:
-                m = 0
-                for r in range(14):
-                    if frames[k][RES_F[r]] != shape[0][2 * r] or frames[k][RES_B[r]] != shape[0][2 * r + 1]:
-                        m |= 1 << r
-                masks.append(m); keys.append((shape[1], fb.tobytes(), F))
-            shape = (fb, fb.tobytes()); prev_null = False
+                new = {p: float(frames[k][p]) for p in range(47)}
+                old = dict(new) if prev_null else dict(prev)
+                if prev_null:
+                    old[44] = 0.0
+                prev_null = False
+            prev = new
+            m = 0
+            for r in range(14):
+                if old[RES_F[r]] != new[RES_F[r]] or old[RES_B[r]] != new[RES_B[r]]:
+                    m |= 1 << r
+            for e, (a, b) in enumerate(PAIRS):
+                if old[a] != new[a] or (b >= 0 and old[b] != new[b]):
+                    m |= 1 << (14 + e)
+            masks.append(m)
+            keys.append((np.array([old[p] for p in SHAPE]).tobytes(), np.array([new[p] for p in SHAPE]).tobytes(), F))
     return masks, keys
 
 
 def random_frames(rng, n_utt):
     """few distinct shapes, so that fades repeat across utterances; NULL frames anywhere; -0.0 against 0.0"""
     shapes = rng.uniform(100, 5000, size=(6, 47))
-    shapes[1] = shapes[0]; shapes[1][9] += 1.0            # differs from shape 0 in one formant only
-    shapes[2][13] = 0.0; shapes[3] = shapes[2]; shapes[3][13] = -0.0   # equal by value, different bits
+    shapes[1] = shapes[0].copy(); shapes[1][9] += 1.0     # differs from shape 0 in one formant only
+    shapes[2][13] = 0.0; shapes[3] = shapes[2].copy(); shapes[3][13] = -0.0   # equal by value, different bits
+    shapes[4] = shapes[0].copy(); shapes[4][44] += 0.25   # differs from shape 0 in the gain only
+    shapes[5] = shapes[0].copy(); shapes[5][5] *= 0.5     # ... in a source parameter only
     frames, fade, nul, start = [], [], [], [0]
     for _ in range(n_utt):
         n = int(rng.integers(1, 7))

@@ -314,7 +314,7 @@ struct Batch {
     int cus = 256;
     hipStream_t stream = nullptr;
     int tracks = 1;                        // 1: noisy utterances with finite parameters take their coefficients from tracks (klatt_tracks.h)
-    int flat = 0;                          // 1: the tracked launch runs flat filter stages (gains from the tracks too, no frame state machine in S1..S3)
+    int flat = 1;                          // 1: the tracked launch runs flat stages (gains from the tracks too, no frame state machine in S1..S3)
     long long trackBudgetMB = 16384;       // the tracks of a batch may take this much device memory; utterances beyond it run untracked
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
     hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1657,6 +1657,11 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         else { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 16, 2> : (const void*)klatt_lanepipe<MODE_EXACT, 16, 2>; ldsBytes = LpLds<16>::kBytes; chunk = 16; }
         wavesPerGroup = kStages;
         groups = g;
+    } else if (tracked && b->flat) {
+        if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true, true>; ldsBytes = SysLds<true, KLATT_NOISY_CH, true, true>::kBytes; }
+        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true, true>; ldsBytes = SysLds<true, 16, true, true>::kBytes; }
+        chunk = pl.chunk;
+        wavesPerGroup = kStages;
     } else if (tracked) {
         if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_NOISY_CH, true>::kBytes; }
         else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>; ldsBytes = SysLds<true, 16, true>::kBytes; }
@@ -1687,7 +1692,7 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     if (nInfo >= 12) { info[10] = nasalFree ? 1 : 0; info[11] = (int)std::min<long long>(nNn, 0x7FFFFFFF); }
     if (nInfo >= 16) {
         info[12] = (int)std::min<long long>(nTr > 0 ? b->nTrackedUtt : 0, 0x7FFFFFFF); info[13] = (int)std::min<long long>(b->nJobs, 0x7FFFFFFF);
-        info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? 1 : 0;
+        info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? (b->flat ? 2 : 1) : 0;
     }
     return 0;
 }

@@ -873,8 +873,10 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
 //     every lane that still has samples: the filters
 // with no dequeue / fade-end events, no interpolation, no end points in LDS.  A chunk in which no lane of the wave starts, runs
 // or ends anything is the straight-line steady chunk of the other kernels.  (S0, which glides the pitch, keeps its state machine.)
-template <int NRES_, int NGAIN_, bool ANTI0_>
-struct FlatDesc { static constexpr int NRES = NRES_, NGAIN = NGAIN_, NE = NRES_ + NGAIN_; static constexpr bool ANTI0 = ANTI0_; };
+// USUAL: the entry kinds of the stage (bit e of its list) that usually move in speech -- a chunk in which every lane fades and
+// nothing outside this set moves loads through these pointers only (compiled in: no tests)
+template <int NRES_, int NGAIN_, bool ANTI0_, uint32_t USUAL_ = 0>
+struct FlatDesc { static constexpr int NRES = NRES_, NGAIN = NGAIN_, NE = NRES_ + NGAIN_; static constexpr bool ANTI0 = ANTI0_; static constexpr uint32_t USUAL = USUAL_; };
 template <class FD>
 struct FlatState {
     static constexpr int NR = FD::NRES > 0 ? FD::NRES : 1;
@@ -935,16 +937,18 @@ __device__ __forceinline__ void flat_begin(FlatState<FD>& f, const StageCtx& X, 
     f.next++;
     f.startAt = f.next < f.nFrames ? f.startAt + span : 0xFFFFFFFFu;
 }
-// one later row of the running fade
-template <class FD>
+// one later row of the running fade; SET (compile time): the entry kinds to load (those outside it do not move in any lane)
+template <class FD, uint32_t SET = 0xFFFFFFFFu>
 __device__ __forceinline__ void flat_next(FlatState<FD>& f)
 {
     double2 v[FD::NE];
     double a0 = 0.0;
 #pragma unroll
-    for (int e = 0; e < FD::NE; ++e) { v[e] = f.tp[e][0]; if (FD::ANTI0 && e == 0) a0 = f.tp[e][1].x; f.tp[e] += f.ts[e]; }
+    for (int e = 0; e < FD::NE; ++e)
+        if (SET & (1u << e)) { v[e] = f.tp[e][0]; if (FD::ANTI0 && e == 0) a0 = f.tp[e][1].x; f.tp[e] += f.ts[e]; }
 #pragma unroll
-    for (int e = 0; e < FD::NE; ++e) flat_take<FD>(f, e, v[e], a0);
+    for (int e = 0; e < FD::NE; ++e)
+        if (SET & (1u << e)) flat_take<FD>(f, e, v[e], a0);
     f.left--;
 }
 // the chunk loop of a flat stage: same barrier discipline as stage_loop (nIter iterations, one barrier each, chunk iter - depth)
@@ -1000,9 +1004,19 @@ __device__ __forceinline__ void flat_loop(int depth, int nIter, int nChunks, int
             } else if (!__any(f.live && (f.left < (uint32_t)CH || f.startAt < t1 || f.length < t1))) {
                 // every live lane is inside a fade for the whole chunk: no tests per sample
                 STAMP_KIND(1);
+                uint32_t wMove = 0;     // entry kinds that move in some live lane
+                if (FD::USUAL != 0u) {
+#pragma unroll
+                    for (int e = 0; e < FD::NE; ++e) wMove |= __any(f.live && f.ts[e] != 0u) ? (1u << e) : 0u;
+                }
                 if (f.live) {
+                    if (FD::USUAL != 0u && (wMove & ~FD::USUAL) == 0u) {
 #pragma unroll 2
-                    for (int i = 0; i < CH; ++i) { flat_next<FD>(f); body(c, i); }
+                        for (int i = 0; i < CH; ++i) { flat_next<FD, FD::USUAL>(f); body(c, i); }
+                    } else {
+#pragma unroll 2
+                        for (int i = 0; i < CH; ++i) { flat_next<FD>(f); body(c, i); }
+                    }
                 }
             } else {
                 STAMP_KIND(-1);
@@ -1428,7 +1442,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (FLAT && stage == 1) {
         // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 =================
         if constexpr (FLAT) {
-            using FD = FlatDesc<5, 1, true>;
+            using FD = FlatDesc<5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
             constexpr int GE[6] = {0, 1, 2, 3, 4, 14};
             FlatState<FD> f;
             flat_init<FD>(f, live, d);
@@ -1448,7 +1462,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (FLAT && stage == 3) {
         // ================= flat S3: frication noise, parallel r1..r4 partial sum =================
         if constexpr (FLAT) {
-            using FD = FlatDesc<4, 3, false>;
+            using FD = FlatDesc<4, 3, false, 0x77u>;                // usually parallel 1..3 and the gains
             constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // cur: fricationAmplitude, preFormantGain, pa1..pa4
             FlatState<FD> f;
             flat_init<FD>(f, live, d);
@@ -1473,7 +1487,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (FLAT && stage == 2) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
         if constexpr (FLAT) {
-            using FD = FlatDesc<5, 2, false>;
+            using FD = FlatDesc<5, 2, false, 0x67u>;                // usually c3, c2, c1 and the gains
             constexpr int GE[7] = {5, 6, 7, 12, 13, 15, 16};      // cur: pa5, pa6, parallelBypass, outputGain
             FlatState<FD> f;
             flat_init<FD>(f, live, d);

@@ -875,8 +875,13 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
 // or ends anything is the straight-line steady chunk of the other kernels.  (S0, which glides the pitch, keeps its state machine.)
 // USUAL: the entry kinds of the stage (bit e of its list) that usually move in speech -- a chunk in which every lane fades and
 // nothing outside this set moves loads through these pointers only (compiled in: no tests)
-template <int NRES_, int NGAIN_, bool ANTI0_, uint32_t USUAL_ = 0>
-struct FlatDesc { static constexpr int NRES = NRES_, NGAIN = NGAIN_, NE = NRES_ + NGAIN_; static constexpr bool ANTI0 = ANTI0_; static constexpr uint32_t USUAL = USUAL_; };
+// (USUAL: with the stage's gains; USUAL2: the resonators alone, when no gain moves either)
+template <int NRES_, int NGAIN_, bool ANTI0_, uint32_t USUAL_ = 0, uint32_t USUAL2_ = 0>
+struct FlatDesc {
+    static constexpr int NRES = NRES_, NGAIN = NGAIN_, NE = NRES_ + NGAIN_;
+    static constexpr bool ANTI0 = ANTI0_;
+    static constexpr uint32_t USUAL = USUAL_, USUAL2 = USUAL2_;
+};
 template <class FD>
 struct FlatState {
     static constexpr int NR = FD::NRES > 0 ? FD::NRES : 1;
@@ -1010,7 +1015,10 @@ __device__ __forceinline__ void flat_loop(int depth, int nIter, int nChunks, int
                     for (int e = 0; e < FD::NE; ++e) wMove |= __any(f.live && f.ts[e] != 0u) ? (1u << e) : 0u;
                 }
                 if (f.live) {
-                    if (FD::USUAL != 0u && (wMove & ~FD::USUAL) == 0u) {
+                    if (FD::USUAL2 != 0u && (wMove & ~FD::USUAL2) == 0u) {
+#pragma unroll 2
+                        for (int i = 0; i < CH; ++i) { flat_next<FD, FD::USUAL2>(f); body(c, i); }
+                    } else if (FD::USUAL != 0u && (wMove & ~FD::USUAL) == 0u) {
 #pragma unroll 2
                         for (int i = 0; i < CH; ++i) { flat_next<FD, FD::USUAL>(f); body(c, i); }
                     } else {
@@ -1462,7 +1470,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (FLAT && stage == 3) {
         // ================= flat S3: frication noise, parallel r1..r4 partial sum =================
         if constexpr (FLAT) {
-            using FD = FlatDesc<4, 3, false, 0x77u>;                // usually parallel 1..3 and the gains
+            using FD = FlatDesc<4, 3, false, 0x77u, 0x07u>;         // usually parallel 1..3 and the gains
             constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // cur: fricationAmplitude, preFormantGain, pa1..pa4
             FlatState<FD> f;
             flat_init<FD>(f, live, d);
@@ -1487,7 +1495,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (FLAT && stage == 2) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
         if constexpr (FLAT) {
-            using FD = FlatDesc<5, 2, false, 0x67u>;                // usually c3, c2, c1 and the gains
+            using FD = FlatDesc<5, 2, false, 0x67u, 0x07u>;         // usually c3, c2, c1 and the gains
             constexpr int GE[7] = {5, 6, 7, 12, 13, 15, 16};      // cur: pa5, pa6, parallelBypass, outputGain
             FlatState<FD> f;
             flat_init<FD>(f, live, d);

@@ -78,7 +78,7 @@ def kernel_name(info):
     if info["stage_parallel_chunk"]:
         return "klatt_systolic (stage-parallel%s%s%s, %d-sample hand-overs)" % (
             ", noisy" if info.get("noisy_group") else "", ", nasal-free" if info.get("nasal_free") else "",
-            ", %s from %d tracks (klatt_tracks, %d MB)" % ("flat stages: parameters and coefficients" if info.get("flat") else "coefficients", info["tracks"], info["track_mbytes"]) if info.get("tracked") else "",
+            ", flat stages: parameters and coefficients from %d tracks (klatt_tracks, %d MB)" % (info["tracks"], info["track_mbytes"]) if info.get("tracked") else "",
             info["stage_parallel_chunk"])
     return "klatt_synthesize (lane kernel)"
 

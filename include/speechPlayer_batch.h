@@ -95,7 +95,7 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
 /* Kernel resource facts for reports: fills vgprs, ldsBytes, wavefronts launched, workgroups per CU. */
 int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo);
 /* info[12..15] (nInfo >= 16): utterances that take their coefficients from tracks, distinct tracks of the batch, their size in
- * MB, 1 if the reported kernel is the tracked instantiation, 2 if it is the flat one. */
+ * MB, 1 if the reported kernel is the tracked (flat-stage) instantiation. */
 
 /* Host-only view of the coefficient-track planning of speechPlayer_batch_setUtterances (tests, tools; touches no device):
  * the plan for these utterances under a budget of budgetMB.  eligible[u] != 0: utterance u may be tracked (NULL: all; the

@@ -193,12 +193,12 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false, bool TRACK = false, bool FLAT = false>
+template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false, bool FLAT = false>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = SysLds<NOISE, CH, TRACK, FLAT>::kBytes;
+    constexpr int ldsBytes = SysLds<NOISE, CH, FLAT>::kBytes;
     auto go = [&](auto kernel) -> int {
         if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a);
@@ -206,8 +206,8 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM, TRACK, FLAT>); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM, TRACK, FLAT>); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM, FLAT>); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM, FLAT>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -314,7 +314,6 @@ struct Batch {
     int cus = 256;
     hipStream_t stream = nullptr;
     int tracks = 1;                        // 1: noisy utterances with finite parameters take their coefficients from tracks (klatt_tracks.h)
-    int flat = 1;                          // 1: the tracked launch runs flat stages (gains from the tracks too, no frame state machine in S1..S3)
     long long trackBudgetMB = 16384;       // the tracks of a batch may take this much device memory; utterances beyond it run untracked
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
     hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -361,9 +360,6 @@ long long lanepipe_count(const Batch* b)
 
 // How many of the noisy utterances (the head of the noisy part of `order`) take their coefficients from tracks: those the
 // host planned tracks for, under the stage-parallel layouts.
-#ifndef KLATT_TRACK_WPS
-#define KLATT_TRACK_WPS 2
-#endif
 #ifndef KLATT_FLAT_WPS
 #define KLATT_FLAT_WPS 2
 #endif
@@ -491,7 +487,7 @@ int batch_launch(Batch* b)
     //   order[nLp, nNoNasal)       quiet, nasal-free -> stage-parallel kernel without the nasal pair (NASAL = false)
     //   order[nNoNasal, nQuiet)    quiet             -> stage-parallel (or lane) kernel, NOISE = false
     //   order[nQuiet, nSlots)      noisy             -> stage-parallel (or lane) kernel, NOISE = true
-    //   order[nQuiet, nQuiet + nTr)  noisy, tracked  -> klatt_tracks, then the stage-parallel kernel with TRACK = true
+    //   order[nQuiet, nQuiet + nTr)  noisy, tracked  -> klatt_tracks, then the stage-parallel kernel with flat stages (FLAT = true)
     const long long nLp = lanepipe_count(b);
     const bool laneKernel = b->layout == 0;
     const long long nTr = tracked_count(b);
@@ -542,10 +538,8 @@ int batch_launch(Batch* b)
         a.trackRef = b->dTrackRef.ptr; a.track = b->dTrack.ptr;
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
-        if (b->flat ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true, true>(a, b->mode, g, st)
-                                     : launch_systolic<true, 16, 1, true, false, true, true>(a, b->mode, g, st))
-                    : (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>(a, b->mode, g, st)
-                                     : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st))) return -1;
+        if (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true>(a, b->mode, g, st)
+                          : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
         a.trackRef = nullptr; a.track = nullptr;
     }
     if (nNoisy > 0) {
@@ -978,7 +972,6 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess;
     { const char* e = getenv("SPEECHPLAYER_TRACKS"); if (e) b->tracks = atoi(e) ? 1 : 0; }
-    { const char* e = getenv("SPEECHPLAYER_FLAT"); if (e) b->flat = atoi(e) ? 1 : 0; }
     for (int i = 0; i < 4 && ok; ++i)
         ok = hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&b->join[i], hipEventDisableTiming) == hipSuccess;
@@ -1021,7 +1014,6 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value > 2 ? 1 : value); return 0; }
     // coefficient tracks: planned by setUtterances (set the option before it), used by the stage-parallel layouts
     if (!strcmp(name, "tracks")) { b->tracks = value ? 1 : 0; return 0; }
-    if (!strcmp(name, "flat")) { b->flat = value ? 1 : 0; return 0; }
     if (!strcmp(name, "track_budget_mb")) { b->trackBudgetMB = value < 0 ? 0 : value; return 0; }
     set_error("unknown option %s", name);
     return -1;
@@ -1657,13 +1649,8 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         else { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 16, 2> : (const void*)klatt_lanepipe<MODE_EXACT, 16, 2>; ldsBytes = LpLds<16>::kBytes; chunk = 16; }
         wavesPerGroup = kStages;
         groups = g;
-    } else if (tracked && b->flat) {
-        if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true, true>; ldsBytes = SysLds<true, KLATT_NOISY_CH, true, true>::kBytes; }
-        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true, true>; ldsBytes = SysLds<true, 16, true, true>::kBytes; }
-        chunk = pl.chunk;
-        wavesPerGroup = kStages;
     } else if (tracked) {
-        if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_NOISY_CH, KLATT_TRACK_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_NOISY_CH, true>::kBytes; }
+        if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_NOISY_CH, true>::kBytes; }
         else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>; ldsBytes = SysLds<true, 16, true>::kBytes; }
         chunk = pl.chunk;
         wavesPerGroup = kStages;
@@ -1692,7 +1679,7 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     if (nInfo >= 12) { info[10] = nasalFree ? 1 : 0; info[11] = (int)std::min<long long>(nNn, 0x7FFFFFFF); }
     if (nInfo >= 16) {
         info[12] = (int)std::min<long long>(nTr > 0 ? b->nTrackedUtt : 0, 0x7FFFFFFF); info[13] = (int)std::min<long long>(b->nJobs, 0x7FFFFFFF);
-        info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? (b->flat ? 2 : 1) : 0;
+        info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? 1 : 0;
     }
     return 0;
 }

@@ -59,12 +59,12 @@ namespace klatt {
 
 constexpr int kStages = 4;
 #ifndef KLATT_FLAT_SOURCE
-#define KLATT_FLAT_SOURCE 1     // FLAT launches: S0 is a flat stage too (0: the tracked launch's S0, with the frame state machine)
+#define KLATT_FLAT_SOURCE 1     // flat launches: S0 is a flat stage too (0: the source stage of the noisy launches, with its frame state machine)
 #endif
 
 // LDS per workgroup: pipes [2 buffers][CH][64 lanes] f64 (4 noisy / 3 quiet), the PCM tile and row
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
-template <bool NOISE, int CH, bool TRACK = false, bool FLAT = false>
+template <bool NOISE, int CH, bool FLAT = false>
 struct SysLds {
     static constexpr int kPipeBytes = 2 * CH * kLanes * 8;
     static constexpr int kNumPipes = NOISE ? 4 : 3;
@@ -73,10 +73,9 @@ struct SysLds {
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
     static constexpr int kFrames = kMaxLen + 16;
-    // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5; tracked (noisy, no f/bw pairs) 7, 1, 4, 6
-    // flat (FLAT: the filter stages take their gains from the tracks too and keep no fade end points at all) 7, 0, 0, 0
-    static constexpr int kParams0 = 7, kParams1 = FLAT ? 0 : (NOISE ? (TRACK ? 1 : 11) : 7), kParams2 = FLAT ? 0 : (NOISE ? (TRACK ? 4 : 14) : 6),
-                         kParams3 = FLAT ? 0 : (NOISE ? (TRACK ? 6 : 14) : 5);
+    // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
+    // flat launches (FLAT): the filter stages take everything from the tracks and keep no fade end points: 7, 0, 0, 0
+    static constexpr int kParams0 = 7, kParams1 = FLAT ? 0 : (NOISE ? 11 : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
     static constexpr int kFrames1 = kFrames + 1 * kParams0 * kLanes * 8;    // S0 keeps its target values in registers
     static constexpr int kFrames2 = kFrames1 + 2 * kParams1 * kLanes * 8;
     static constexpr int kFrames3 = kFrames2 + 2 * kParams2 * kLanes * 8;
@@ -98,12 +97,6 @@ struct StageFrame {
     double invFade;
     uint32_t cnt, oldMin, newMin, newFade, nextFrame, resMask, parMask, produced;
     bool hasNew, oldNull, newNull, done;
-    // tracked stages (StageDesc::TRACK): the running fade's coefficient track, its resonator mask in the track's numbering
-    // (N0, NP, c6..c1, p1..p6) and its entries per fade sample
-    const double2* tBase;
-    uint32_t gmask, nSlots;
-    const double2* tp[NRES > 0 ? NRES : 1];   // per resonator: its entry of the next fade sample (track_first / track_next)
-    uint32_t ts[NRES > 0 ? NRES : 1];         //                and how far that moves per sample (0: the resonator does not move)
 };
 
 // pitch (parameter 0) needs the glide state; only the source stage has it
@@ -123,27 +116,14 @@ __device__ __forceinline__ void stage_frame_init(StageFrame<NPARAM, NRES, NWREG>
     f.invFade = 1.0;
     f.cnt = 0; f.oldMin = 0; f.newMin = 0; f.newFade = 1; f.nextFrame = 0; f.resMask = 0; f.parMask = 0; f.produced = 0;
     f.hasNew = false; f.oldNull = true; f.newNull = false; f.done = !live;
-    f.tBase = nullptr; f.gmask = 0; f.nSlots = 0;
 }
 
 // Stage descriptor.  GAIN = index into P of parameter 44 (or -1): NULL frames force it to 0
 // (reference src/frame.cpp:61,66).  ANTI0: resonator 0 is the anti-resonator N0.
-// TRACK: the stage tracks no (f, bw) parameters; its resonators' coefficients come from the fade's coefficient track
-// (klatt_tracks.h), and the RF argument of the stage functions lists the resonators' numbers in the track (RB is unused).
-// WUSUAL (tracked stages): the set of the stage's resonators that usually moves in speech (the first three formants and their
-// parallel twins; the nasal pair): when exactly that set moves in a run, the run's loop is compiled for it -- no tests, the
-// loads back to back -- instead of testing the wave's set resonator by resonator on every sample.
-#ifndef KLATT_FADE_UNROLL
-#define KLATT_FADE_UNROLL 2
-#endif
-#ifndef KLATT_USUAL_FADE
-#define KLATT_USUAL_FADE 1
-#endif
-template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false, bool TRACK_ = false, uint32_t WUSUAL_ = 0>
+template <int NPARAM_, int NRES_, int GAIN_, bool PITCH_, bool ANTI0_, bool INLINE_COEF_ = false>
 struct StageDesc {
     static constexpr int NPARAM = NPARAM_, NRES = NRES_, GAIN = GAIN_;
-    static constexpr bool PITCH = PITCH_, ANTI0 = ANTI0_, INLINE_COEF = INLINE_COEF_, TRACK = TRACK_;
-    static constexpr uint32_t WUSUAL = WUSUAL_;
+    static constexpr bool PITCH = PITCH_, ANTI0 = ANTI0_, INLINE_COEF = INLINE_COEF_;
 };
 
 struct StageCtx {          // what every stage needs from the launch
@@ -151,7 +131,7 @@ struct StageCtx {          // what every stage needs from the launch
     const UttDesc& d;
     const double* myFrames;
     const FrameMeta* myMeta;
-    const TrackRef* myTrack;   // tracked launches: the utterance's per-frame track references
+    const TrackRef* myTrack;   // flat launches: the utterance's per-frame track references
 };
 
 // OR over the wavefront of the low NBITS bits of a per-lane mask, as a wave-uniform (scalar) value.
@@ -217,10 +197,8 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
                 pm |= moved[k] ? (1u << k) : 0u;
                 pm |= (v != v) ? kNanTarget : 0u;
             }
-            if constexpr (!D::TRACK) {
 #pragma unroll
-                for (int r = 0; r < D::NRES; ++r) mk |= (moved[RF[r]] || moved[RB[r]]) ? (1u << r) : 0u;
-            }
+            for (int r = 0; r < D::NRES; ++r) mk |= (moved[RF[r]] || moved[RB[r]]) ? (1u << r) : 0u;
         }
         if (D::PITCH) {
             const double g0 = g[0], g46 = g[46];
@@ -229,17 +207,6 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
             if (f.oldNull) ps->old0 = g0;
         }
         f.resMask = mk; f.parMask = pm;
-    }
-    if (D::TRACK) {
-        // which resonators move, and where the fade's coefficients are, was worked out on the host (setUtterances) with the
-        // comparisons above: silence and the first frame after it move none
-        const TrackRef tr = X.myTrack[f.nextFrame - 1];
-        f.tBase = X.A.track + tr.off;
-        f.gmask = tr.mask; f.nSlots = tr.nSlots;
-        uint32_t mk = 0;
-#pragma unroll
-        for (int r = 0; r < D::NRES; ++r) mk |= ((tr.mask >> RF[r]) & 1u) << r;
-        f.resMask = mk;
     }
     if (lastIndex && m.userIndex != -1) *lastIndex = m.userIndex;   // (:69)
     f.cnt = 0;                                                       // (:70)
@@ -268,7 +235,7 @@ template <class D, class SF>
 __device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& A, const int* RF, const int* RB, uint32_t wRes)
 {
     uint32_t bits = kCoefAllUnknown;
-    if constexpr (D::INLINE_COEF) {
+    if (!D::INLINE_COEF) return bits;
 #pragma unroll
     for (int r = 0; r < D::NRES; ++r) {
         if (!(wRes & (1u << r))) continue;
@@ -280,79 +247,9 @@ __device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& 
         const uint32_t cls = __all(f.done || (eu && c0)) ? COEF_UNREDUCED : (__all(f.done || (eu && c1)) ? COEF_QUADRANT_M1 : COEF_UNKNOWN);
         bits = (bits & ~(3u << (2 * r))) | (cls << (2 * r));
     }
-    }
     return bits;
 }
 
-// ---- tracked stages: a fade sample's coefficients ---------------------------------------------------------------------
-// The entries of a fade are at known addresses (klatt_device.h: 15 entries for the first fade sample, then a row of nSlots
-// entries per sample).  On the fade's first sample a lane takes the entry of every resonator of its stage (track_first) and
-// sets up one pointer per resonator: to the resonator's slot in the first later row, advancing by a row per sample, if the
-// fade moves it -- and to the entry just read, not advancing, if it does not.  Every later fade sample then loads through the
-// pointers of the resonators that move in SOME lane of the wave (wRes, wave-uniform) without a per-lane test: a lane whose
-// resonator does not move reads the value it already holds (track_next).  Five instructions per resonator and fade sample.
-template <class D, class SF>
-__device__ __forceinline__ void track_take(SF& f, int r, const double2* p)
-{
-    const double2 bc = p[0];
-    f.ra[r] = (D::ANTI0 && r == 0) ? p[1].x : (1.0 - bc.x - bc.y);
-    f.rb[r] = bc.x; f.rc[r] = bc.y;
-}
-template <class D, class SF>
-__device__ __forceinline__ void track_first(SF& f, const int* GR)
-{
-#pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        const double2* p = f.tBase + track_first_slot(GR[r]);
-        track_take<D>(f, r, p);
-        const bool moves = (f.resMask >> r) & 1u;
-        f.tp[r] = moves ? f.tBase + ((uint32_t)kTrackFirst + track_slot(f.gmask, GR[r])) : p;
-        f.ts[r] = moves ? f.nSlots : 0u;
-    }
-}
-template <class D, class SF>
-__device__ __forceinline__ void track_next(SF& f, uint32_t wRes)
-{
-    // every load first, then the uses: one wait for the memory latency instead of one per resonator
-    double2 bc[D::NRES > 0 ? D::NRES : 1];
-    double a0 = 0.0;
-#pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        if (wRes & (1u << r)) {
-            bc[r] = f.tp[r][0];
-            if (D::ANTI0 && r == 0) a0 = f.tp[r][1].x;
-            f.tp[r] += f.ts[r];
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < D::NRES; ++r) {
-        if (wRes & (1u << r)) {
-            f.ra[r] = (D::ANTI0 && r == 0) ? a0 : (1.0 - bc[r].x - bc[r].y);
-            f.rb[r] = bc[r].x; f.rc[r] = bc[r].y;
-        }
-    }
-}
-// (Reading a run's entries one sample ahead was built twice and measured slower both times -- through registers, where the
-// entries in flight pushed the kernel from 24 to 192 bytes of scratch: cfg2 11.4 -> 11.6 ms, rotated 27 -> 30; and straight
-// into LDS rows with global_load_lds_dwordx4, no registers involved: cfg2 11.2 -> 11.9, rotated 25.9 -> 28.9.  With two
-// waves per SIMD the second wave already covers the loads' latency; the extra waits and instructions do not pay -- not even on a
-// batch whose 353 MB of tracks miss the L2: jittered durations 46.9 -> 47.2 ms with the LDS form.)
-// (Letting a mixed stretch span fade ends and first fade samples too, so that only dequeues break it -- a fade's end is mere
-// bookkeeping, its first sample a load through the first-row slots -- was also built: bit-identical, fewer single steps, and
-// slower: rotated 26.7 -> 30.0 ms, jittered 46.8 -> 47.7.  Two more ballots and branches on every sample of every stretch cost
-// more than the saved steps: the stretch body is bound by the instructions it issues.  A lighter form -- the bookkeeping of
-// a fade's end done at the stretch decision, the sample itself run as a steady one -- changed nothing either way: 47.0 -> 47.2 ms
-// on the jittered batch, where single steps are 35 % of the parallel stage's time, `-DKLATT_STAMPS=2`.)
-// one fade sample of a tracked stage in any mix of lanes, counter already advanced
-template <class D, class SF>
-__device__ __forceinline__ void track_step(SF& f, const int* GR, uint32_t wRes)
-{
-    const bool first = f.cnt == 1u;
-    if (__any(first)) { if (first) track_first<D>(f, GR); }
-    if (!first) track_next<D>(f, wRes);
-}
-
-// (tracked stages: the parameters only; the caller takes the coefficients with track_step)
 template <class D, int MODE, bool PLAIN = false, class SF>
 __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelArgs& A, const int* RF, const int* RB,
                                            bool lerp, uint32_t wRes, bool gainOnly = false, uint32_t coefCls = kCoefAllUnknown)
@@ -371,18 +268,16 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = PLAIN ? o[k] + ((n[k] - o[k]) * ratio) : fade_value(o[k], n[k], ratio);   // PLAIN: no NaN target in any live lane
     }
-    if constexpr (!D::TRACK) {
 #pragma unroll
-        for (int r = 0; r < D::NRES; ++r) {
-            if (wRes & (1u << r)) {
-                // inlined where fades dominate (speech); the quiet kernels keep one out-of-line copy, which keeps
-                // their loops small (measured: cfg1 1.72 ms vs 1.86 ms inlined; cfg2 29.2 ms inlined vs 36.6 ms called)
-                const Coef k = D::INLINE_COEF
-                    ? resonator_coefficients_inline<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr,
-                                                          (int)((coefCls >> (2 * r)) & 3u))
-                    : resonator_coefficients<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr);
-                f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
-            }
+    for (int r = 0; r < D::NRES; ++r) {
+        if (wRes & (1u << r)) {
+            // inlined where fades dominate (speech); the quiet kernels keep one out-of-line copy, which keeps
+            // their loops small (measured: cfg1 1.72 ms vs 1.86 ms inlined; cfg2 29.2 ms inlined vs 36.6 ms called)
+            const Coef k = D::INLINE_COEF
+                ? resonator_coefficients_inline<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr,
+                                                      (int)((coefCls >> (2 * r)) & 3u))
+                : resonator_coefficients<MODE>(f.cur[RF[r]], f.cur[RB[r]], D::ANTI0 && r == 0, A.negPiOverSr, A.twoPiOverSr);
+            f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
         }
     }
 }
@@ -408,12 +303,7 @@ __device__ __forceinline__ bool stage_advance(SF& f, PitchState* ps, int32_t* la
         // first fade sample of a lane: everything; later: what moves in some fading lane
         const bool lerp = __any(fading && (f.cnt == 1 || f.parMask != 0u));
         const uint32_t wRes = wave_or_bits<D::NRES>(fading ? ((f.cnt == 1) ? 0xFFFFFFFFu : f.resMask) : 0u);
-        if (fading) {
-            stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes);
-            if constexpr (D::TRACK) {
-                if (wRes != 0u) track_step<D>(f, RF, wRes);
-            }
-        }
+        if (fading) stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes);
     }
     return emit;
 }
@@ -562,12 +452,6 @@ struct Stamps {
 #define STAMP_KIND(k) do { st.kind = (k) < 0 ? 2 : (k); } while (0)
 #define STAMP_WORKED() do { st.t1 = __builtin_amdgcn_s_memtime(); st.work += st.t1 - st.t0; if (st.kind < 3) { st.c[st.kind] += st.t1 - st.t0; st.n[st.kind]++; } } while (0)
 #define STAMP_IDLE() st.kind = 3
-#if KLATT_STAMPS == 2
-#undef STAMP_WORKED
-#define STAMP_WORKED() do { st.t1 = __builtin_amdgcn_s_memtime(); st.work += st.t1 - st.t0; } while (0)
-#define STAMP_SUB_BEGIN() const unsigned long long tSub = __builtin_amdgcn_s_memtime()
-#define STAMP_SUB_END(slot, count) do { st.c[slot] += __builtin_amdgcn_s_memtime() - tSub; st.n[slot] += (count); } while (0)
-#endif
 #define STAMP_SYNCED() do { st.wait += __builtin_amdgcn_s_memtime() - st.t1; } while (0)
 #else
 #define STAMP_BEGIN()
@@ -575,10 +459,6 @@ struct Stamps {
 #define STAMP_KIND(k)
 #define STAMP_WORKED()
 #define STAMP_SYNCED()
-#endif
-#ifndef STAMP_SUB_BEGIN
-#define STAMP_SUB_BEGIN()
-#define STAMP_SUB_END(slot, count)
 #endif
 
 // ---- the chunk loop of one pipeline element (a wave) ---------------------------------------------------------------
@@ -601,16 +481,9 @@ struct Stamps {
 // the event steps need the state machine sample by sample; the run length comes from a bisection with ballots.  (Off for
 // the noisy kernels: the extra code costs them more than the runs save, cfg2 15.8 -> 16.8 ms.)  DELAY: lanes start `delay`
 // steps late (the lane-pipelined kernel's skew).  STREAM: the launch runs exactly A.maxSamples steps (live handles).
-// MIXED (tracked launches): stretches in which no live lane has an event run as a rolled loop whatever the lanes are doing --
-// steady lanes count, fading lanes interpolate their parameters and take their coefficients from the track -- with the
-// wave-level decisions (what to interpolate, which resonators to look at) taken once per stretch.  With the coefficients
-// evaluated elsewhere a fading lane is cheap enough for this to pay when the lanes of a wave do not fade together.
-#ifndef KLATT_MIXED_RUNS
-#define KLATT_MIXED_RUNS 1
-#endif
-template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_, bool MIXED_ = false>
+template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_>
 struct LoopKnobs {
-    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_, MIXED = MIXED_;
+    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_;
     static constexpr int UNROLL = UNROLL_;
 };
 
@@ -693,26 +566,11 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {
                     if (!f.done) {
                         if (!fadeAlt(c, lerp, gainOnly)) {
-                            if constexpr (D::TRACK) {
-                                auto samples = [&](auto usual) __attribute__((always_inline)) {
-                                    const uint32_t w = decltype(usual)::value ? decltype(usual)::value : wRes;
-#pragma unroll KLATT_FADE_UNROLL
-                                    for (int i = 0; i < CH; ++i) {
-                                        f.cnt++;
-                                        stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
-                                        if (w != 0u) track_next<D>(f, w);
-                                        body(c, i, false, 0.0);
-                                    }
-                                };
-                                if (KLATT_USUAL_FADE && D::WUSUAL != 0u && wRes == D::WUSUAL) samples(std::integral_constant<uint32_t, D::WUSUAL>());
-                                else samples(std::integral_constant<uint32_t, 0u>());
-                            } else {
 #pragma unroll 2
-                                for (int i = 0; i < CH; ++i) {
-                                    f.cnt++;
-                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
-                                    body(c, i, false, 0.0);
-                                }
+                            for (int i = 0; i < CH; ++i) {
+                                f.cnt++;
+                                stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerp, wRes, gainOnly, coefCls);
+                                body(c, i, false, 0.0);
                             }
                         }
                         fadeDone(CH);
@@ -782,54 +640,6 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                             continue;
                         }
                     }
-                    if constexpr (K::MIXED) {
-                        STAMP_SUB_BEGIN();
-                        if (!forceGeneral()) {
-                            const bool fad = !f.done && f.hasNew;
-                            // (a lane that has just dequeued takes its fade's first sample, where everything moves, on the general step)
-                            const uint32_t rem = f.done ? 0xFFFFFFFFu : (f.hasNew ? (f.cnt == 0u ? 0u : f.newFade - f.cnt) : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
-                            const int cap = lim - i;
-                            int n = 0;
-#pragma unroll
-                            for (int st = CH; st >= 1; st >>= 1)
-                                if (n + st <= cap && __all(rem >= (uint32_t)(n + st))) n += st;
-                            if (n >= 2 && !nan_target_live(f)) {
-                                const bool lerpR = __any(fad && f.parMask != 0u);
-                                const uint32_t wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(fad ? f.resMask : 0u);
-                                const bool anyFad = __any(fad);
-                                auto stretch = [&](auto usual) __attribute__((always_inline)) {
-                                    const uint32_t w = decltype(usual)::value ? decltype(usual)::value : wResR;
-#pragma nounroll
-                                    for (int j = i; j < i + n; ++j) {
-                                        if (!f.done) {
-                                            f.cnt++;
-                                            if (anyFad) {
-                                                if (fad) {
-                                                    stage_fade<D, MODE, true>(f, ps, X.A, RF, RB, lerpR, wResR);
-                                                    if constexpr (D::TRACK) {
-                                                        if (w != 0u) track_next<D>(f, w);
-                                                    }
-                                                }
-                                            }
-                                            if (D::PITCH) { if (!fad) { ps->cur0 += ps->oldInc; ps->old0 = ps->cur0; } }
-                                            // no event in the stretch: what forceGeneral() ruled out at its start (vibrato) stays out
-                                            body(c, j, false, 0.0);
-                                        }
-                                    }
-                                };
-                                // (compiled for the usual moving set like the fade chunks, or loading through all the stage's pointers without tests:
-                                //  both measured slower -- 208 / 200 bytes of scratch, profiles/r2_ab_track_variants.txt)
-                                stretch(std::integral_constant<uint32_t, 0u>());
-                                if (!f.done) fadeDone(n);
-                                i += n;
-                                STAMP_SUB_END(0, n);
-                                continue;
-                            }
-                        }
-                        STAMP_SUB_END(2, 1);
-                    }
-                    {
-                    STAMP_SUB_BEGIN();
                     if (K::DELAY) {
                         // a lane that has not started yet (pipeline skew) sits this step out
                         const bool hold = delay > 0u;
@@ -841,8 +651,6 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                     } else {
                         const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
                         gen(c, i, emit);
-                    }
-                    STAMP_SUB_END(1, 1);
                     }
                     ++i;
                 }
@@ -1066,18 +874,15 @@ __device__ __forceinline__ void flat_loop(int depth, int nIter, int nChunks, int
 // handle whose queue runs dry stops earlier), and every stage saves its slice again.  Live handles always take the
 // noisy instantiation: the noise generators' memories and counters advance with every sample whatever the gains
 // (reference src/speechWaveGenerator.cpp:39-42), and a handle that is quiet now may be given noisy frames later.
-// TRACK (noisy batch launches only): the utterances of the launch have coefficient tracks (klatt_tracks.h; host: UTT_TRACKED).
-// S1, S2 and S3 then track no (f, bw) parameters -- 1, 4 and 6 parameters instead of 11, 14 and 14 -- and pick their
-// resonators' coefficients up from the track on fade samples instead of evaluating exp and cos.
-// FLAT (tracked launches): S1, S2 and S3 are flat stages (above); S0 is the tracked launch's S0.
-template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false, bool TRACK = false, bool FLAT = false>
+// FLAT (noisy batch launches only): the utterances of the launch have tracks (klatt_tracks.h; host: UTT_TRACKED) and all four
+// stages are flat stages (above): no exp / cos, no interpolation, no frame state machine in the sample loop.
+template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false, bool FLAT = false>
 __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const KernelArgs A)
 {
-    static_assert(!FLAT || TRACK, "flat stages read tracks");
     static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
     static_assert(NOISE || !STREAM, "live handles take the noisy instantiation");
-    static_assert(!TRACK || (NOISE && !STREAM), "coefficient tracks: noisy batch launches");
-    using L = SysLds<NOISE, CH, TRACK, FLAT>;
+    static_assert(!FLAT || (NOISE && !STREAM), "tracks: noisy batch launches");
+    using L = SysLds<NOISE, CH, FLAT>;
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     double* const pipeX = reinterpret_cast<double*>(lds);                           // S0 -> S1
@@ -1098,7 +903,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     UttDesc d;
     d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
-    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart, TRACK ? A.trackRef + d.frameStart : nullptr};
+    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart, FLAT ? A.trackRef + d.frameStart : nullptr};
     const uint32_t nkey = noise_key(d.seed);
     constexpr int FINAL = NOISE ? 2 : 3;
     // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out
@@ -1139,8 +944,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // pipe slot of sample i of chunk c
 #define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
     // the chunk loop's knobs: quiet launches preload a steady chunk's inputs and run uniform stretches inside event chunks
-    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, TRACK && KLATT_MIXED_RUNS>;      // stages without a pipe input
-    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, TRACK && KLATT_MIXED_RUNS>;       // stages that read a pipe
+    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;      // stages without a pipe input
+    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;       // stages that read a pipe
     uint32_t noDelay = 0;
     auto never = [&]() __attribute__((always_inline)) { return false; };
     auto noBegin = [&](int) __attribute__((always_inline)) { return false; };
@@ -1150,9 +955,6 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     auto nothing = [&](int) __attribute__((always_inline)) {};
     auto noChunk = [&]() __attribute__((always_inline)) {};
 
-#ifndef KLATT_ONLY_STAGE
-#define KLATT_ONLY_STAGE -1
-#endif
     if (FLAT && KLATT_FLAT_SOURCE && stage == 0) {
         // ================= flat S0: the source stage without the chunk machinery of stage_loop =================
         // Its seven parameters come from the tracks (entry kinds 20..23); what stays here is the pitch, which glides with the sample
@@ -1315,7 +1117,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 A.result[u] = res;
             }
         }
-    } else if (stage == 0 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 0)) {
+    } else if (stage == 0) {
         // ================= S0: frame + glottal source (+ aspiration noise) =================
         // tracked: 1 vibratoPitchOffset, 2 vibratoSpeed, 3 turbulence, 4 openQuotient, 5 voiceAmplitude,
         //          6 aspirationAmplitude, 44 preFormantGain (quiet launches never read 3, 4, 6)
@@ -1331,7 +1133,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         int32_t lastIndex = -1;
         bool vibFrames = false;
         constexpr int GR0[1] = {0};
-        if constexpr (STREAM) if (live) {
+        if (STREAM && live) {
             if (streamState[239] != 0.0) {
                 pitchPhase = streamState[208]; vibPhase = streamState[209]; aspNoise = streamState[210];
                 lastIndex = (int32_t)streamState[220]; noiseIdx = (uint32_t)streamState[221];
@@ -1442,7 +1244,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             res.produced = f.produced; res.framesTaken = f.nextFrame; res.lastIndex = lastIndex; res.drained = STREAM ? (f.done ? 1u : 0u) : 1u;
             A.result[u] = res;
         }
-        if constexpr (STREAM) if (live) {
+        if (STREAM && live) {
             stage_state_save<D>(f, &ps, streamState, P, GR0);
             streamState[208] = pitchPhase; streamState[209] = vibPhase; streamState[210] = aspNoise;
             streamState[220] = (double)lastIndex; streamState[221] = (double)noiseIdx;
@@ -1575,20 +1377,19 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 nothing, nothing, noChunk);
         };
         if (s1) run(1); else run(2);
-    } else if (stage == 1 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 1)) {
+    } else if (stage == 1) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
         constexpr int NR = NOISE ? 5 : 3;
-        constexpr int NPAR = TRACK ? 1 : 2 * NR + 1;
-        using D = StageDesc<NPAR, NR, -1, false, true, NOISE && !TRACK, TRACK, 0x03u>;    // usually N0 and NP, when anything
-        // parameter list: (f, bw) of N0, NP, r6 [, r5, r4], then caNP; tracked: caNP alone, RF = the resonators' track numbers
-        constexpr int P[11] = {TRACK ? 23 : 13, 21, 14, 22, 12, 20, NOISE ? 11 : 23, 19, 10, 18, 23};
-        constexpr int RF[5] = {0, TRACK ? 1 : 2, TRACK ? 2 : 4, TRACK ? 3 : 6, TRACK ? 4 : 8};
+        using D = StageDesc<2 * NR + 1, NR, -1, false, true, NOISE>;
+        // parameter list: (f, bw) of N0, NP, r6 [, r5, r4], then caNP
+        constexpr int P[11] = {13, 21, 14, 22, 12, 20, NOISE ? 11 : 23, 19, 10, 18, 23};
+        constexpr int RF[5] = {0, 2, 4, 6, 8};
         constexpr int RB[5] = {1, 3, 5, 7, 9};
-        constexpr int CANP = NPAR - 1;
-        StageFrame<NPAR, NR> f;
+        constexpr int CANP = 2 * NR;
+        StageFrame<2 * NR + 1, NR> f;
         stage_frame_init(f, live, lds + L::kFrames1, lane);
         constexpr int GR1[5] = {0, 1, 2, 3, 4};
-        if constexpr (STREAM) if (live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR1, streamPurge);
+        if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR1, streamPurge);
         auto dsp = [&](double x) __attribute__((always_inline)) -> double {
             const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
             f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
@@ -1604,35 +1405,32 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             noFadeAlt,
             [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pipeO, c, i) = dsp(PIPE(pipeX, c, i)); },
             nothing, nothing, noChunk);
-        if constexpr (STREAM) if (live) stage_state_save<D>(f, nullptr, streamState, P, GR1);
-    } else if (NOISE && stage == 3 && (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 3)) {
+        if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GR1);
+    } else if (NOISE && stage == 3) {
         // ================= noisy S3: frication noise, parallel r1..r4 partial sum =================
         // tracked: (pf, pb) of parallel 1..4, then 24 fricationAmplitude, 44 preFormantGain, pa1..4 (37..40)
-        // tracked: the six gains alone, RF = the track numbers of parallel 1..4
-        constexpr int NPAR = TRACK ? 6 : 14;
-        constexpr int G0 = NPAR - 6;      // where 24 fricationAmplitude sits in P
-        using D = StageDesc<NPAR, 4, G0 + 1, false, false, !TRACK, TRACK, 0x07u>;       // usually parallel 1..3
-        constexpr int P[14] = {TRACK ? 24 : 25, TRACK ? 44 : 31, TRACK ? 37 : 26, TRACK ? 38 : 32, TRACK ? 39 : 27, TRACK ? 40 : 33, 28, 34, 24, 44, 37, 38, 39, 40};
-        constexpr int RF[4] = {TRACK ? 8 : 0, TRACK ? 9 : 2, TRACK ? 10 : 4, TRACK ? 11 : 6}, RB[4] = {1, 3, 5, 7};
-        StageFrame<NPAR, 4> f;
+        using D = StageDesc<14, 4, 9, false, false, true>;
+        constexpr int P[14] = {25, 31, 26, 32, 27, 33, 28, 34, 24, 44, 37, 38, 39, 40};
+        constexpr int RF[4] = {0, 2, 4, 6}, RB[4] = {1, 3, 5, 7};
+        StageFrame<14, 4> f;
         stage_frame_init(f, live, lds + L::kFrames3, lane);
         double fricNoise = 0.0;
         uint32_t noiseIdx = 1;
         constexpr int GR3[4] = {8, 9, 10, 11};
-        if constexpr (STREAM) if (live) {
+        if (STREAM && live) {
             if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseIdx = (uint32_t)streamState[221] + 1u; }
             stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR3, streamPurge);
         }
         auto dsp = [&](int c, int i) __attribute__((always_inline)) {
             fricNoise = noise_uniform(nkey, noiseIdx) + 0.75 * fricNoise;
             noiseIdx += 2u;
-            const double fric = fricNoise * 0.3 * f.cur[G0];
-            const double y = (fric * f.cur[G0 + 1]) * 0.5;
+            const double fric = fricNoise * 0.3 * f.cur[8];
+            const double y = (fric * f.cur[9]) * 0.5;
             double par = 0.0;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
-                par += (w - y) * f.cur[G0 + 2 + r];
+                par += (w - y) * f.cur[10 + r];
             }
             PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
         };
@@ -1642,7 +1440,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             noFadeAlt,
             [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) dsp(c, i); },
             nothing, nothing, noChunk);
-        if constexpr (STREAM) if (live) { stage_state_save<D>(f, nullptr, streamState, P, GR3); streamState[211] = fricNoise; }
+        if (STREAM && live) { stage_state_save<D>(f, nullptr, streamState, P, GR3); streamState[211] = fricNoise; }
     } else if (!NOISE && stage == 2) {
         // ================= quiet S2: r5, r4, r3 =================
         using D = StageDesc<6, 3, -1, false, false>;
@@ -1661,25 +1459,23 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             noFadeAlt,
             [&](int c, int i, bool emit) __attribute__((always_inline)) { if (emit) PIPE(pipeA, c, i) = dsp(PIPE(pipeO, c, i)); },
             nothing, nothing, noChunk);
-    } else if (KLATT_ONLY_STAGE < 0 || KLATT_ONLY_STAGE == 2) {
+    } else {
         // ================= final stage: rest of the cascade, (parallel r5, r6 + bypass), gain, clip, PCM ===
         // noisy (stage 2): r3, r2, r1 | parallel 5, 6 | pa5, pa6, parallelBypass, outputGain
         // quiet (stage 3): r2, r1 | outputGain          quiet, nasal-free (stage 3): outputGain only
         constexpr int NC = NOISE ? 3 : (NASAL ? 2 : 0);   // cascade resonators here
         constexpr int NR = NOISE ? 5 : NC;
-        // tracked (noisy): pa5, pa6, parallelBypass, outputGain alone, RF = the track numbers of c3, c2, c1, p5, p6
-        constexpr int NPAR = NOISE ? (TRACK ? 4 : 14) : (NASAL ? 5 : 1);
-        using D = StageDesc<NPAR, NR, -1, false, false, NOISE && !TRACK, TRACK, 0x07u>;  // usually c3, c2, c1
-        constexpr int P[14] = {TRACK ? 41 : (NOISE ? 9 : (NASAL ? 8 : 45)), TRACK ? 42 : (NOISE ? 17 : 16), TRACK ? 43 : (NOISE ? 8 : 7),
-                               TRACK ? 45 : (NOISE ? 16 : 15), NOISE ? 7 : 45, 15, 29, 35, 30, 36, 41, 42, 43, 45};
-        constexpr int RF[5] = {TRACK ? 5 : 0, TRACK ? 6 : 2, TRACK ? 7 : (NOISE ? 4 : 0), TRACK ? 12 : 6, TRACK ? 13 : 8};
+        constexpr int NPAR = NOISE ? 14 : (NASAL ? 5 : 1);
+        using D = StageDesc<NPAR, NR, -1, false, false, NOISE>;
+        constexpr int P[14] = {NOISE ? 9 : (NASAL ? 8 : 45), NOISE ? 17 : 16, NOISE ? 8 : 7, NOISE ? 16 : 15, NOISE ? 7 : 45, 15,
+                               29, 35, 30, 36, 41, 42, 43, 45};
+        constexpr int RF[5] = {0, 2, NOISE ? 4 : 0, 6, 8};
         constexpr int RB[5] = {1, 3, NOISE ? 5 : 0, 7, 9};
-        constexpr int OUTGAIN = NOISE ? NPAR - 1 : (NASAL ? 4 : 0);
-        constexpr int PA5 = NOISE ? NPAR - 4 : 0;
+        constexpr int OUTGAIN = NOISE ? 13 : (NASAL ? 4 : 0);
         StageFrame<NPAR, NR> f;
         stage_frame_init(f, live, lds + (NOISE ? L::kFrames2 : L::kFrames3), lane);
         constexpr int GRF[5] = {5, 6, 7, 12, 13};
-        if constexpr (STREAM) if (live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GRF, streamPurge);
+        if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GRF, streamPurge);
         int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
 
         auto finish = [&](double o, double y, double part) __attribute__((always_inline)) -> uint32_t {
@@ -1691,9 +1487,9 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
 #pragma unroll
                 for (int r = 3; r < 5; ++r) {
                     const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
-                    par += (w - y) * f.cur[PA5 + (r - 3)];
+                    par += (w - y) * f.cur[10 + (r - 3)];
                 }
-                par = fade_value(par, y, f.cur[PA5 + 2]);
+                par = fade_value(par, y, f.cur[12]);
                 mix = o + par;
             }
             const double v = (mix * f.cur[OUTGAIN]) * 4000.0;
@@ -1748,7 +1544,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             [&](int n) __attribute__((always_inline)) { f.produced += n; },
             [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
         if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
-        if constexpr (STREAM) if (live) stage_state_save<D>(f, nullptr, streamState, P, GRF);
+        if (STREAM && live) stage_state_save<D>(f, nullptr, streamState, P, GRF);
     }
 #undef PIPE
 }

@@ -296,7 +296,7 @@ class BatchPlayer(object):
                     stage_parallel_chunk=int(info[6]), noisy_group=bool(info[7]),
                     lane_pipelined=bool(info[8]), lane_pipelined_utterances=int(info[9]),
                     nasal_free=bool(info[10]), nasal_free_utterances=int(info[11]),
-                    tracked_utterances=int(info[12]), tracks=int(info[13]), track_mbytes=int(info[14]), tracked=bool(info[15]), flat=int(info[15]) == 2)
+                    tracked_utterances=int(info[12]), tracks=int(info[13]), track_mbytes=int(info[14]), tracked=bool(info[15]))
 
     def devicePcm(self):
         return self._dll.speechPlayer_batch_devicePcm(self._h)

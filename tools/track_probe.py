@@ -17,7 +17,6 @@ def run(b, tracks, sort=1, mode=0, launches=4, flat=0):
     bp = BatchPlayer(b["sr"], mode=mode)
     bp.setOption("sort", sort)
     bp.setOption("tracks", tracks)
-    bp.setOption("flat", flat)
     t0 = time.time()
     bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
     host = time.time() - t0
@@ -46,7 +45,6 @@ if __name__ == "__main__":
     for name, b, sort in cases:
         off = run(b, 0, sort)
         on = run(b, 1, sort)
-        fl = run(b, 1, sort, flat=1)
-        same = "same PCM" if off[1] == on[1] == fl[1] else "PCM DIFFERS (%016x vs %016x vs flat %016x)" % (off[1], on[1], fl[1])
-        print("%-9s %6d utt  untracked %7.2f ms  tracked %7.2f ms  (%.2fx)  flat %7.2f ms  %s  setUtterances %.2f -> %.2f s  tracked %d utt, %d tracks, %d MB" % (
-            name, b.n_utt, off[0], on[0], off[0] / on[0], fl[0], same, off[2], on[2], on[3].get("tracked_utterances"), on[3].get("tracks"), on[3].get("track_mbytes")), flush=True)
+        same = "same PCM" if off[1] == on[1] else "PCM DIFFERS (%016x vs %016x)" % (off[1], on[1])
+        print("%-9s %6d utt  untracked %7.2f ms  tracked %7.2f ms  (%.2fx)  %s  setUtterances %.2f -> %.2f s  tracked %d utt, %d tracks, %d MB" % (
+            name, b.n_utt, off[0], on[0], off[0] / on[0], same, off[2], on[2], on[3].get("tracked_utterances"), on[3].get("tracks"), on[3].get("track_mbytes")), flush=True)

@@ -538,7 +538,8 @@ int batch_launch(Batch* b)
         a.trackRef = b->dTrackRef.ptr; a.track = b->dTrack.ptr;
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
-        if (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true>(a, b->mode, g, st)
+        // flat stages keep nothing but the pipes and the PCM tile in LDS: 16-sample hand-overs fit two workgroups per CU (70 KB each)
+        if (pl.chunk == 8 ? launch_systolic<true, 16, KLATT_FLAT_WPS, true, false, true>(a, b->mode, g, st)
                           : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
         a.trackRef = nullptr; a.track = nullptr;
     }
@@ -1650,9 +1651,10 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         wavesPerGroup = kStages;
         groups = g;
     } else if (tracked) {
-        if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_NOISY_CH, KLATT_FLAT_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_NOISY_CH, true>::kBytes; }
-        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>; ldsBytes = SysLds<true, 16, true>::kBytes; }
-        chunk = pl.chunk;
+        if (pl.chunk == 8) fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, KLATT_FLAT_WPS, true, false, true>;
+        else fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>;
+        ldsBytes = SysLds<true, 16, true>::kBytes;
+        chunk = 16;
         wavesPerGroup = kStages;
     } else if (pl.systolic) {
         if (noisy && pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 8, 2> : (const void*)klatt_systolic<MODE_EXACT, true, 8, 2>; ldsBytes = SysLds<true, 8>::kBytes; }

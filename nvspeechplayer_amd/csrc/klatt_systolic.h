@@ -74,8 +74,8 @@ struct SysLds {
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
     static constexpr int kFrames = kMaxLen + 16;
     // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
-    // flat launches (FLAT): the filter stages take everything from the tracks and keep no fade end points: 7, 0, 0, 0
-    static constexpr int kParams0 = 7, kParams1 = FLAT ? 0 : (NOISE ? 11 : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
+    // flat launches (FLAT): the stages take everything from the tracks and keep no fade end points: 0, 0, 0, 0
+    static constexpr int kParams0 = (FLAT && KLATT_FLAT_SOURCE) ? 0 : 7, kParams1 = FLAT ? 0 : (NOISE ? 11 : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
     static constexpr int kFrames1 = kFrames + 1 * kParams0 * kLanes * 8;    // S0 keeps its target values in registers
     static constexpr int kFrames2 = kFrames1 + 2 * kParams1 * kLanes * 8;
     static constexpr int kFrames3 = kFrames2 + 2 * kParams2 * kLanes * 8;

@@ -360,6 +360,9 @@ long long lanepipe_count(const Batch* b)
 
 // How many of the noisy utterances (the head of the noisy part of `order`) take their coefficients from tracks: those the
 // host planned tracks for, under the stage-parallel layouts.
+#ifndef KLATT_FLAT_CH
+#define KLATT_FLAT_CH 16
+#endif
 #ifndef KLATT_FLAT_WPS
 #define KLATT_FLAT_WPS 2
 #endif
@@ -539,7 +542,7 @@ int batch_launch(Batch* b)
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
         // flat stages keep nothing but the pipes and the PCM tile in LDS: 16-sample hand-overs fit two workgroups per CU (70 KB each)
-        if (pl.chunk == 8 ? launch_systolic<true, 16, KLATT_FLAT_WPS, true, false, true>(a, b->mode, g, st)
+        if (pl.chunk == 8 ? launch_systolic<true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true>(a, b->mode, g, st)
                           : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
         a.trackRef = nullptr; a.track = nullptr;
     }
@@ -1651,10 +1654,8 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         wavesPerGroup = kStages;
         groups = g;
     } else if (tracked) {
-        if (pl.chunk == 8) fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, KLATT_FLAT_WPS, true, false, true>;
-        else fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>;
-        ldsBytes = SysLds<true, 16, true>::kBytes;
-        chunk = 16;
+        if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_FLAT_CH, true>::kBytes; chunk = KLATT_FLAT_CH; }
+        else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>; ldsBytes = SysLds<true, 16, true>::kBytes; chunk = 16; }
         wavesPerGroup = kStages;
     } else if (pl.systolic) {
         if (noisy && pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 8, 2> : (const void*)klatt_systolic<MODE_EXACT, true, 8, 2>; ldsBytes = SysLds<true, 8>::kBytes; }

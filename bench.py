@@ -312,7 +312,7 @@ def main():
                 out["mode_fast"] = {"value": samples / (fast_ms * 1e-3), "unit": "samples/s", "kernel_ms": fast_ms,
                                     "roofline_frac": alg_bytes / (fast_ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
             if world == 1 and args.mode == 0 and not args.no_extras and info.get("tracked"):
-                # the same batch without coefficient tracks (every stage evaluates exp/cos itself, as in round 1), and with every
+                # the same batch without tracks (every stage interpolates and evaluates exp/cos itself, as in round 1), and with every
                 # utterance's frame list rotated by a random amount -- same lengths, ~24 different timings per sentence in random
                 # order: the lane packing puts equally timed utterances side by side again
                 def timed(b, tracks):

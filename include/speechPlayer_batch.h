@@ -35,11 +35,11 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
  * "layout" (-1: chosen per batch, default; 2: lane-pipelined workgroups for the quiet, nasal-free utterances
  * whatever the batch size; 1: stage-parallel workgroups, four wavefronts per 64 utterances; 0: one wavefront
  * per 64 utterances);
- * "tracks" (1, default: noisy utterances whose parameters are all finite take their resonator coefficients from
- * coefficient tracks -- every fade's coefficients evaluated densely by a kernel of its own before the synthesis kernel,
- * one track per distinct fade of the batch -- instead of evaluating exp/cos inside the sample recurrence; 0: never) and
- * "track_budget_mb" (device memory the tracks of a batch may take, default 16384; a batch whose tracks do not fit runs
- * without them): both are read by speechPlayer_batch_setUtterances, set them before it.  No option changes the PCM. */
+ * "tracks" (1, default: noisy utterances whose parameters are all finite take what they need on fade samples -- resonator
+ * coefficients, interpolated gains -- from tracks: evaluated densely by a kernel of its own before the synthesis kernel, one
+ * track per distinct fade of the batch, instead of exp/cos, interpolation and a frame state machine inside the sample
+ * recurrence; 0: never) and "track_budget_mb" (device memory the tracks of a batch may take, default 16384; a batch whose
+ * tracks do not fit runs without them): both are read by speechPlayer_batch_setUtterances, set them before it.  No option changes the PCM. */
 int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value);
 
 /*
@@ -97,10 +97,10 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
 /* info[12..15] (nInfo >= 16): utterances that take their coefficients from tracks, distinct tracks of the batch, their size in
  * MB, 1 if the reported kernel is the tracked (flat-stage) instantiation. */
 
-/* Host-only view of the coefficient-track planning of speechPlayer_batch_setUtterances (tests, tools; touches no device):
+/* Host-only view of the track planning of speechPlayer_batch_setUtterances (tests, tools; touches no device):
  * the plan for these utterances under a budget of budgetMB.  eligible[u] != 0: utterance u may be tracked (NULL: all; the
- * engine itself tracks the noisy utterances whose parameters are all finite).  Per frame: first entry and resonator mask
- * (bit r of N0, NP, c6..c1, p1..p6) of its fade's track; per utterance: tracked or not (nothing is, once a tenth of the
+ * engine itself tracks the noisy utterances whose parameters are all finite).  Per frame: first entry and mask of the entry
+ * kinds that move (bits 0..13: N0, NP, c6..c1, p1..p6; 14..23: pairs of gains) of its fade's track; per utterance: tracked or not (nothing is, once a tenth of the
  * eligible utterances did not fit).  Returns the number of distinct tracks, *nEntries their 16-byte entries; -1 on bad
  * arguments.  A fade's end points follow reference src/frame.cpp:55-72; equal fades share a track. */
 long long speechPlayer_planTracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,

@@ -49,7 +49,7 @@ constexpr int MODE_FAST = 1;
 
 constexpr uint32_t FRAME_NULL = 1u;       // FrameMeta.flags
 constexpr uint32_t UTT_NEEDS_NOISE = 1u;  // UttDesc.flags
-constexpr uint32_t UTT_TRACKED = 4u;      // UttDesc.flags: noisy, every parameter finite, coefficient tracks planned (2u: UTT_NO_NASAL, klatt_lanepipe.h)
+constexpr uint32_t UTT_TRACKED = 4u;      // UttDesc.flags: noisy, every parameter finite, tracks planned (2u: UTT_NO_NASAL, klatt_lanepipe.h)
 
 struct FrameMeta {           // 16 B per frame; with the 376-B parameter vector: 392 B/frame read
     uint32_t minSamples;
@@ -126,7 +126,7 @@ constexpr int track_first_slot(int e) { return e + (e > 0 ? 1 : 0); }
 
 struct KernelArgs {
     const TrackRef* trackRef;    // [nFrames] tracked launches only
-    const double2* track;        // the launch's coefficient tracks
+    const double2* track;        // the launch's tracks
     const double* frames;        // [nFrames][47]
     const FrameMeta* meta;       // [nFrames]
     const UttDesc* utt;          // [nUtt]

@@ -313,13 +313,13 @@ struct Batch {
     int layout = -1;                       // -1: choose per group (plan_group); 2: lane-pipelined where eligible; 1: stage-parallel workgroups; 0: one wave per 64 utterances
     int cus = 256;
     hipStream_t stream = nullptr;
-    int tracks = 1;                        // 1: noisy utterances with finite parameters take their coefficients from tracks (klatt_tracks.h)
+    int tracks = 1;                        // 1: noisy utterances with finite parameters run on flat stages fed by tracks (klatt_tracks.h)
     long long trackBudgetMB = 16384;       // the tracks of a batch may take this much device memory; utterances beyond it run untracked
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
     hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     long long nUtt = 0, nFrames = 0, nSlots = 0;
     long long nQuiet = 0;                  // order[0..nQuiet) = utterances without noise, the rest with
-    long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with coefficient tracks (slots: utterances + padding)
+    long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with tracks (slots: utterances + padding)
     long long nTrackedUtt = 0;             // the utterances among them
     long long nJobs = 0, trackEntries = 0; // distinct tracks of the batch, their entries (16 B each)
     long long nNoNasal = 0;                // order[0..nNoNasal) = quiet utterances that never couple the nasal pair (UTT_NO_NASAL)
@@ -534,7 +534,7 @@ int batch_launch(Batch* b)
         t.jobs = b->dJobs.ptr; t.nJobs = b->nJobs; t.shapes = b->dShapes.ptr; t.track = b->dTrack.ptr;
         t.negPiOverSr = a.negPiOverSr; t.twoPiOverSr = a.twoPiOverSr;
         const long long tg = b->nJobs;     // one workgroup per track
-        if (tg > 0x7FFFFFFF) { set_error("too many coefficient tracks: %lld", b->nJobs); return -1; }
+        if (tg > 0x7FFFFFFF) { set_error("too many tracks: %lld", b->nJobs); return -1; }
         hipLaunchKernelGGL(klatt_tracks, dim3((unsigned)tg), dim3(kLanes * kTrackWaves), 0, st, t);
         HIP_TRY(hipGetLastError());
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nTr;
@@ -1016,7 +1016,7 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     }
     if (!strcmp(name, "sort")) { b->sortByLength = value ? 1 : 0; return 0; }
     if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value > 2 ? 1 : value); return 0; }
-    // coefficient tracks: planned by setUtterances (set the option before it), used by the stage-parallel layouts
+    // tracks: planned by setUtterances (set the option before it), used by the stage-parallel layouts
     if (!strcmp(name, "tracks")) { b->tracks = value ? 1 : 0; return 0; }
     if (!strcmp(name, "track_budget_mb")) { b->trackBudgetMB = value < 0 ? 0 : value; return 0; }
     set_error("unknown option %s", name);
@@ -1109,7 +1109,7 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         pool += ((long long)len + kTile - 1) / kTile * kTile;
     }
     outStart[nUtterances] = pool;
-    // ---- coefficient tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite: plan_tracks -----
+    // ---- tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite: plan_tracks -----
     TrackPlan plan;
     if (b->tracks && nF > 0) {
         std::vector<unsigned char> eligible((size_t)nUtterances, 0);

@@ -1,20 +1,20 @@
-// klatt_tracks.h -- coefficient tracks: the resonator coefficients of every fade sample, evaluated densely.
+// klatt_tracks.h -- tracks: what the synthesis needs on every fade sample, evaluated densely beforehand.
 //
 // The reference recomputes a resonator's coefficients whenever its frequency or bandwidth changed (reference
-// src/speechWaveGenerator.cpp:112-127), i.e. on every sample of a fade for every resonator the fade moves (reference
-// src/frame.cpp:48-53): one exp and one cos per resonator and fade sample, inside the sample recurrence.  Inside the synthesis
-// kernels that evaluation runs with lanes = utterances, so a wavefront pays for it on every sample in which ANY of its 64
-// utterances is fading -- always, once the utterances of a wavefront are not copies of one sentence -- and the polynomial
-// constants and temporaries of exp/cos share the register budget of the filter stages.
+// src/speechWaveGenerator.cpp:112-127), i.e. on every sample of a fade for every resonator the fade moves, and interpolates every
+// parameter on every sample of a fade (reference src/frame.cpp:48-53): inside the sample recurrence.  Inside the synthesis kernels
+// that work runs with lanes = utterances, so a wavefront pays for it on every sample in which ANY of its 64 utterances is
+// fading -- always, once the utterances of a wavefront are not copies of one sentence -- and its code (exp, cos, their polynomial
+// constants, the interpolation, the frame state machine) shares the register budget of the filter stages.
 //
-// But the values do not depend on the signal: (f, bw) on fade sample n are
+// But the values do not depend on the signal: a parameter on fade sample n is
 //     from + ((to - from) * (n / fadeSamples))                       (reference src/utils.h:20-23)
-// of the fade's two end frames.  This kernel evaluates them with lanes = ENTRIES of a track (a fade's samples x its moving
-// resonators; layout in klatt_device.h), every lane busy whatever the utterances' alignment, with the very functions the
+// of the fade's two end points.  This kernel evaluates them with lanes = ENTRIES of a track (a fade's samples x the entry kinds
+// it moves; layout in klatt_device.h), every lane busy whatever the utterances' alignment, with the very functions the
 // untracked stages call (fade_value, resonator_coefficients_inline: same operations, operands and rounding, so the tracked
-// kernels produce the same PCM bit for bit).  The host gives equal fades ONE track (setUtterances: a voice has a few dozen
-// formant targets, so the fades of a batch are few distinct transitions, whatever the text), which makes the tracks a small,
-// cache-resident table and this launch a fraction of a millisecond.
+// kernel produces the same PCM bit for bit).  The host gives equal fades ONE track (plan_tracks: a voice has a few dozen
+// phoneme targets, so the fades of a batch are few distinct transitions, whatever the text), which makes the tracks a small,
+// cache-resident table and this launch a few microseconds.  The flat stages of klatt_systolic.h pick the entries up.
 #pragma once
 
 #include "klatt_device.h"

@@ -1009,8 +1009,8 @@ def test_wild_batch_repeated_in_fresh_batches():
 @pytest.mark.gpu
 @pytest.mark.parametrize("seed,wild", [(11, False), (12, True)])
 def test_coefficient_tracks_change_nothing(seed, wild):
-    """Coefficient tracks (klatt_tracks.h: the resonator coefficients of every fade sample evaluated densely, one track per
-    distinct fade, picked up by the tracked stages) against the same batch without them: the PCM must be the same bytes, in
+    """Tracks and flat stages (klatt_tracks.h: the resonator coefficients and interpolated gains of every fade sample evaluated
+    densely, one track per distinct fade, picked up by stages without a frame state machine) against the same batch without them: the PCM must be the same bytes, in
     both arithmetic modes, sorted and unsorted, with a track budget too small for the batch (then nothing is tracked), and with utterances
     repeated (shared tracks).  Random ragged timing: NULL frames anywhere (also first, also in a row), fades longer than
     their frame, 1-sample fades; wild: NaN "hold" parameters, whose utterances must stay untracked."""

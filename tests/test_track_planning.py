@@ -1,4 +1,4 @@
-"""Host logic of the coefficient tracks (speechPlayer_planTracks: what speechPlayer_batch_setUtterances plans; no GPU needed):
+"""Host logic of the tracks (speechPlayer_planTracks: what speechPlayer_batch_setUtterances plans; no GPU needed):
 which resonators a fade moves, which fades share a track, where the tracks lie, and the all-or-nothing budget rule -- against a
 plain Python walk of the reference's frame rules (src/frame.cpp:55-72: silence keeps the last spoken shape, the first frame
 after silence starts from its own shape, any other frame fades from the last spoken frame's values)."""

@@ -45,7 +45,7 @@ jitter = workloads.jittered
 
 def distinct(b, seed=1):
     """Every frame's formant frequencies scaled by its own random factor (1 +- 0.5 %): no two fades of the batch are alike,
-    so nothing shares a coefficient track (klatt_tracks.h) -- the worst case for the tracked kernels' memory."""
+    so nothing shares a track (klatt_tracks.h) -- the worst case for the tracked kernels' memory."""
     rng = np.random.default_rng(seed)
     fr = b["frames"].copy()
     k = rng.uniform(0.995, 1.005, size=(len(fr), 1))

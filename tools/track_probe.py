@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Coefficient tracks on / off: kernel time and PCM digest of cfg2 as benchmarked, with rotated frame lists, with jittered
+"""Tracks (and the flat stages they feed) on / off: kernel time and PCM digest of cfg2 as benchmarked, with rotated frame lists, with jittered
 durations and without the sort by length (tools/mixed_probe.py), plus cfg3 / cfg4 on request.  The digests of a row must agree.
 
     python tools/track_probe.py [utterances] [+cfg3] [+cfg4] [+unsorted]

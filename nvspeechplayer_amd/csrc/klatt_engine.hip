@@ -5,7 +5,9 @@
 //     -- each handle is a GPU-resident stream: queueFrame keeps the producer-side queue on the
 //        host (as reference src/frame.cpp:90-115 does), synthesize runs the kernel for that one
 //        stream from its saved state and copies the PCM back;
-//   the additive batch entry points    (N independent streams per launch).
+//   the additive batch entry points    (N independent streams per launch): setUtterances classifies the utterances, packs them
+//     into wavefronts by length and timing and plans the tracks (plan_tracks); a synthesis call launches up to five groups side by
+//     side (batch_launch) -- for speech: klatt_tracks, then the stage-parallel kernel with flat stages.
 // There is no CPU synthesis path in this library: without a HIP device every entry point fails.
 #include "klatt_device.h"
 #include "klatt_systolic.h"
@@ -400,7 +402,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     struct Fade { uint32_t from, to, len; bool operator==(const Fade& o) const { return from == o.from && to == o.to && len == o.len; } };
     struct FadeHash { size_t operator()(const Fade& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
     std::unordered_map<Shape, uint32_t, ShapeHash> shapes;          // values -> id (row of out.shapes)
-    std::unordered_map<Fade, unsigned long long, FadeHash> fades;   // (from, to, length) -> first entry
+    std::unordered_map<Fade, TrackRef, FadeHash> fades;             // (from, to, length) -> the fade's track
     auto shape_id = [&](const Shape& sh) -> uint32_t {
         auto it = shapes.find(sh);
         if (it != shapes.end()) return it->second;
@@ -422,39 +424,45 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
         const unsigned long long before = out.entries;
         const size_t jobsBefore = out.jobs.size();
         bool fits = true, prevNull = true;
-        Shape prev = zero;         // the previous request's values (a fresh handle: all zero)
+        uint32_t prevId = 0;       // the previous request's values (a fresh handle: all zero = shape 0)
         for (long long k = frameStart[u]; k < frameStart[u + 1] && fits; ++k) {
-            Shape from = prev, to = prev;
+            uint32_t fromId = prevId, toId;
+            Shape to;
             if (meta[k].flags & FRAME_NULL) {
+                memcpy(to.v, &out.shapes[(size_t)prevId * kShapeStride], sizeof to.v);
                 to.v[kShapePreGain] = 0.0;                     // silence: the old values, the gain gated off (:59-63)
+                toId = shape_id(to);
                 prevNull = true;
             } else {
                 const double* p = reinterpret_cast<const double*>(frames + k);
                 for (int i = 0; i < kShapeValues; ++i) to.v[i] = p[shape_param(i)];
-                if (prevNull) { from = to; from.v[kShapePreGain] = 0.0; }   // out of silence: the new values, from gain 0 (:64-67)
+                toId = shape_id(to);
+                if (prevNull) { to.v[kShapePreGain] = 0.0; fromId = shape_id(to); }   // out of silence: the new values, from gain 0 (:64-67)
                 prevNull = false;
             }
-            prev = to;
-            uint32_t mask = 0;
-            for (int r = 0; r < kNumRes; ++r)
-                if (!(to.v[2 * r] == from.v[2 * r]) || !(to.v[2 * r + 1] == from.v[2 * r + 1])) mask |= 1u << r;
-            for (int e = kNumRes; e < kTrackEntries; ++e) {
-                const int a = entry_value(e, 0), c = entry_value(e, 1);
-                if (!(to.v[a] == from.v[a]) || (c >= 0 && !(to.v[c] == from.v[c]))) mask |= 1u << e;
-            }
-            const uint32_t nSlots = track_slots(mask);
-            const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
-            if (n >= (1ull << 27)) { fits = false; break; }
-            const Fade key{shape_id(from), shape_id(to), meta[k].fadeSamples};
+            prevId = toId;
+            const Fade key{fromId, toId, meta[k].fadeSamples};
             auto f = fades.find(key);
             if (f == fades.end()) {
-                if (out.entries + n > budget) { fits = false; break; }
-                f = fades.emplace(key, out.entries).first;
+                // a new fade: what moves in it (the comparisons stage_event makes on the device), its size, its place
+                const double* a = &out.shapes[(size_t)fromId * kShapeStride];
+                const double* c = &out.shapes[(size_t)toId * kShapeStride];
+                uint32_t mask = 0;
+                for (int r = 0; r < kNumRes; ++r)
+                    if (!(c[2 * r] == a[2 * r]) || !(c[2 * r + 1] == a[2 * r + 1])) mask |= 1u << r;
+                for (int e = kNumRes; e < kTrackEntries; ++e) {
+                    const int x = entry_value(e, 0), y = entry_value(e, 1);
+                    if (!(c[x] == a[x]) || (y >= 0 && !(c[y] == a[y]))) mask |= 1u << e;
+                }
+                const uint32_t nSlots = track_slots(mask);
+                const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
+                if (n >= (1ull << 27) || out.entries + n > budget) { fits = false; break; }
+                f = fades.emplace(key, TrackRef{out.entries, mask, nSlots}).first;
                 added.push_back(key);
                 out.jobs.push_back(TrackJob{out.entries, key.from, key.to, meta[k].fadeSamples, mask});
                 out.entries += n;
             }
-            out.ref[k] = TrackRef{f->second, mask, nSlots};
+            out.ref[k] = f->second;
         }
         if (fits) out.tracked[u] = 1;
         else {

@@ -680,7 +680,8 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
 //     a lane inside a fade:     loads through its pointers (an entry kind that does not move re-reads its first-row value)
 //     every lane that still has samples: the filters
 // with no dequeue / fade-end events, no interpolation, no end points in LDS.  A chunk in which no lane of the wave starts, runs
-// or ends anything is the straight-line steady chunk of the other kernels.  (S0, which glides the pitch, keeps its state machine.)
+// or ends anything is the straight-line steady chunk of the other kernels.  (The source stage is flat too -- its code is in the
+// kernel below: what it keeps is the pitch, which glides with the utterance's own sample count.)
 // USUAL: the entry kinds of the stage (bit e of its list) that usually move in speech -- a chunk in which every lane fades and
 // nothing outside this set moves loads through these pointers only (compiled in: no tests)
 // (USUAL: with the stage's gains; USUAL2: the resonators alone, when no gain moves either)

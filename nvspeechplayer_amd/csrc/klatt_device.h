@@ -201,6 +201,26 @@ __device__ __forceinline__ double dot3(double a, double x, double b, double y, d
     return a * x + b * y + c * z;
 }
 
+// The type of the signal in the flat filter stages (klatt_systolic.h): resonator memories and coefficients, gains, the pipes
+// between the stages.  double in every shipped build; -DKLATT_SIGNAL_F32 builds the float experiment of DESIGN.md section 6
+// (tools/f32_probe.py: how fast, how far from the double PCM).  Frames, tracks, the source stage (pitch, phases) and the
+// coefficient evaluation are double in both.
+#ifdef KLATT_SIGNAL_F32
+typedef float sig_t;
+#else
+typedef double sig_t;
+#endif
+template <int MODE>
+__device__ __forceinline__ float dot3(float a, float x, float b, float y, float c, float z)
+{
+    return __builtin_fmaf(c, z, __builtin_fmaf(b, y, a * x));
+}
+__device__ __forceinline__ float fade_value(float from, float to, float ratio)
+{
+    float v = from + ((to - from) * ratio);
+    return (to != to) ? from : v;
+}
+
 // reference src/speechWaveGenerator.cpp:112-127
 struct Coef { double a, b, c; };
 // `cls` (wave-uniform): what the caller already knows about the arguments of every active lane -- COEF_UNREDUCED: no

@@ -22,6 +22,7 @@
 #include <cstring>
 #include <chrono>
 #include <mutex>
+#include <atomic>
 #include <thread>
 #include <numeric>
 #include <string>
@@ -387,11 +388,18 @@ struct TrackPlan {
     std::vector<double> shapes;             // [nShapes][kShapeStride]
     std::vector<unsigned char> tracked;     // [nUtterances]
     unsigned long long entries = 0;
+    long long eligible = 0, missedSize = 0, missedBudget = 0;   // utterances that may be tracked; that a fade of 2^27 entries or the budget kept out
 };
-void plan_tracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameMeta* meta,
-                 const unsigned char* eligible, long long budgetMB, TrackPlan& out)
+// One pass over utterances [0, nUtterances) of the arrays given (frameStart may start anywhere: ref is indexed from frameStart[0]).
+// `whole`: this is the whole batch -- apply the all-or-nothing rule; a part of it (plan_tracks below) leaves that to the merge,
+// and gives up (missedBudget != 0) as soon as the parts' tracks together (`sum`) pass a quarter of the budget: that batch is
+// planned in one pass (its fades are shared by few utterances, if at all: the parts would each make most of the tracks again, or
+// fill the budget with 400 MB of shapes and map nodes only for the one pass to find that nothing fits -- 0.4 s for 65 536
+// utterances with nothing in common, which is what such a batch costs without the parts).
+void plan_tracks_pass(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameMeta* meta,
+                      const unsigned char* eligible, long long budgetMB, bool whole, std::atomic<unsigned long long>* sum, TrackPlan& out)
 {
-    const long long nF = frameStart[nUtterances];
+    const long long frame0 = frameStart[0], nF = frameStart[nUtterances] - frame0;
     out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
     out.jobs.clear();
     out.shapes.clear();
@@ -417,9 +425,12 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     const unsigned long long budget = (unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2);
     std::vector<Fade> added;
     long long nEligible = 0, nMissed = 0;
+    out.missedSize = 0; out.missedBudget = 0;
     for (long long u = 0; u < nUtterances; ++u) nEligible += eligible[u] ? 1 : 0;
-    for (long long u = 0; u < nUtterances && nMissed * 10 <= nEligible; ++u) {
+    out.eligible = nEligible;
+    for (long long u = 0; u < nUtterances && (!whole || nMissed * 10 <= nEligible); ++u) {
         if (!eligible[u]) continue;
+        if (sum && sum->load(std::memory_order_relaxed) > budget / 4) { ++out.missedBudget; return; }
         added.clear();
         const unsigned long long before = out.entries;
         const size_t jobsBefore = out.jobs.size();
@@ -456,13 +467,15 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
                 }
                 const uint32_t nSlots = track_slots(mask);
                 const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
-                if (n >= (1ull << 27) || out.entries + n > budget) { fits = false; break; }
+                if (n >= (1ull << 27)) { fits = false; ++out.missedSize; break; }
+                if (out.entries + n > budget) { fits = false; ++out.missedBudget; break; }
+                if (sum && sum->fetch_add(n, std::memory_order_relaxed) + n > budget / 4) { ++out.missedBudget; return; }
                 f = fades.emplace(key, TrackRef{out.entries, mask, nSlots}).first;
                 added.push_back(key);
                 out.jobs.push_back(TrackJob{out.entries, key.from, key.to, meta[k].fadeSamples, mask});
                 out.entries += n;
             }
-            out.ref[k] = f->second;
+            out.ref[k - frame0] = f->second;
         }
         if (fits) out.tracked[u] = 1;
         else {
@@ -472,10 +485,113 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
             ++nMissed;
         }
     }
-    if (nMissed * 10 > nEligible) {
+    if (whole && nMissed * 10 > nEligible) {
         out.tracked.assign((size_t)nUtterances, 0);
         out.jobs.clear();
         out.entries = 0;
+    }
+}
+
+// The plan of a batch.  Large batches are planned in parts, one host thread each (the walk is a hash of 45 values and two map
+// look-ups per frame: 0.2 s for BASELINE configs[2] on one thread), and the parts' shapes and fades merged: equal fades of
+// different parts end up with one track.  If the merged tracks fit the budget that is the plan; if not -- or if the parts gave
+// up (plan_tracks_pass) -- the batch is planned again in one pass, whose order decides which utterances stay in.
+void plan_tracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameMeta* meta,
+                 const unsigned char* eligible, long long budgetMB, TrackPlan& out)
+{
+    const long long nF = frameStart[nUtterances];
+    unsigned nThreads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("SPEECHPLAYER_PLAN_THREADS")) nThreads = (unsigned)std::max(1, atoi(e));
+    if (nThreads < 2 || nF < 200000 || nUtterances < (long long)nThreads * 64) {
+        plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
+        return;
+    }
+    // parts of about equal frame counts
+    std::vector<long long> cut(nThreads + 1, nUtterances);
+    cut[0] = 0;
+    for (unsigned t = 1; t < nThreads; ++t)
+        cut[t] = std::lower_bound(frameStart, frameStart + nUtterances, nF * (long long)t / nThreads) - frameStart;
+    std::vector<TrackPlan> part(nThreads);
+    std::atomic<unsigned long long> sum{0};
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nThreads; ++t)
+            pool.emplace_back([&, t] {
+                plan_tracks_pass(cut[t + 1] - cut[t], frameStart + cut[t], frames, meta, eligible + cut[t], budgetMB, false, &sum, part[t]);
+            });
+        for (auto& th : pool) th.join();
+    }
+    // merge: shapes by value, fades by (from, to, length)
+    struct ShapeKey { const double* v; bool operator==(const ShapeKey& o) const { return !memcmp(v, o.v, kShapeValues * sizeof(double)); } };
+    struct ShapeKeyHash { size_t operator()(const ShapeKey& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (int i = 0; i < kShapeValues; ++i) { unsigned long long w; memcpy(&w, &k.v[i], 8); h ^= w; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
+    struct FadeKey { uint32_t from, to, len; bool operator==(const FadeKey& o) const { return from == o.from && to == o.to && len == o.len; } };
+    struct FadeKeyHash { size_t operator()(const FadeKey& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
+    long long eligibleAll = 0, missedSize = 0, missedBudget = 0;
+    size_t nShapesUpper = 0;
+    for (const TrackPlan& p : part) { eligibleAll += p.eligible; missedSize += p.missedSize; missedBudget += p.missedBudget; nShapesUpper += p.shapes.size() / kShapeStride; }
+    if (missedBudget > 0) {
+        part.clear();
+        plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
+        return;
+    }
+    out.shapes.clear();
+    out.shapes.reserve(nShapesUpper * kShapeStride);     // no reallocation below: the keys point into it
+    out.jobs.clear();
+    out.entries = 0;
+    std::unordered_map<ShapeKey, uint32_t, ShapeKeyHash> shapes;
+    std::unordered_map<FadeKey, unsigned long long, FadeKeyHash> fades;
+    std::vector<std::vector<unsigned long long>> newOff(nThreads);      // part, its track's first entry -> the merged track's
+    std::vector<std::unordered_map<unsigned long long, unsigned long long>> offOf(nThreads);
+    for (unsigned t = 0; t < nThreads; ++t) {
+        const TrackPlan& p = part[t];
+        std::vector<uint32_t> gid(p.shapes.size() / kShapeStride);
+        for (size_t i = 0; i < gid.size(); ++i) {
+            const ShapeKey key{&p.shapes[i * kShapeStride]};
+            auto it = shapes.find(key);
+            if (it == shapes.end()) {
+                const uint32_t id = (uint32_t)(out.shapes.size() / kShapeStride);
+                out.shapes.insert(out.shapes.end(), key.v, key.v + kShapeStride);
+                it = shapes.emplace(ShapeKey{&out.shapes[(size_t)id * kShapeStride]}, id).first;
+            }
+            gid[i] = it->second;
+        }
+        for (const TrackJob& j : p.jobs) {
+            const FadeKey key{gid[j.fromShape], gid[j.toShape], j.fadeSamples};
+            auto it = fades.find(key);
+            if (it == fades.end()) {
+                it = fades.emplace(key, out.entries).first;
+                out.jobs.push_back(TrackJob{out.entries, key.from, key.to, j.fadeSamples, j.mask});
+                out.entries += (unsigned long long)kTrackFirst + (unsigned long long)(j.fadeSamples - 1u) * track_slots(j.mask);
+            }
+            offOf[t].emplace(j.off, it->second);
+        }
+    }
+    const unsigned long long budget = (unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2);
+    if (out.entries > budget) {
+        plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
+        return;
+    }
+    out.eligible = eligibleAll; out.missedSize = missedSize; out.missedBudget = 0;
+    out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
+    out.tracked.assign((size_t)nUtterances, 0);
+    if (missedSize * 10 > eligibleAll) { out.jobs.clear(); out.entries = 0; return; }   // all or nothing
+    {
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nThreads; ++t)
+            pool.emplace_back([&, t] {
+                const TrackPlan& p = part[t];
+                const long long f0 = frameStart[cut[t]];
+                for (long long u = cut[t]; u < cut[t + 1]; ++u) {
+                    if (!p.tracked[u - cut[t]]) continue;
+                    out.tracked[u] = 1;
+                    for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+                        TrackRef r = p.ref[k - f0];
+                        r.off = offOf[t].find(r.off)->second;
+                        out.ref[k] = r;
+                    }
+                }
+            });
+        for (auto& th : pool) th.join();
     }
 }
 

@@ -32,6 +32,8 @@
 // The PCM tile belongs to the final stage's wave alone (wave-level ordering, no barrier).
 #pragma once
 
+#include <type_traits>
+
 #include "klatt_device.h"
 
 namespace klatt {
@@ -66,7 +68,7 @@ constexpr int kStages = 4;
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
 template <bool NOISE, int CH, bool FLAT = false>
 struct SysLds {
-    static constexpr int kPipeBytes = 2 * CH * kLanes * 8;
+    static constexpr int kPipeBytes = 2 * CH * kLanes * (FLAT ? (int)sizeof(sig_t) : 8);
     static constexpr int kNumPipes = NOISE ? 4 : 3;
     static constexpr int kTileOff = kNumPipes * kPipeBytes;
     static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
@@ -391,10 +393,10 @@ __device__ __forceinline__ void stage_state_save(const SF& f, const PitchState* 
     }
 }
 
-template <int MODE>
-__device__ __forceinline__ double resonate(double& z1, double& z2, double a, double b, double c, double in)
+template <int MODE, class R>
+__device__ __forceinline__ R resonate(R& z1, R& z2, R a, R b, R c, R in)
 {
-    const double y = dot3<MODE>(a, in, b, z1, c, z2);
+    const R y = dot3<MODE>(a, in, b, z1, c, z2);
     z2 = z1; z1 = y;
     return y;
 }
@@ -685,8 +687,10 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
 // USUAL: the entry kinds of the stage (bit e of its list) that usually move in speech -- a chunk in which every lane fades and
 // nothing outside this set moves loads through these pointers only (compiled in: no tests)
 // (USUAL: with the stage's gains; USUAL2: the resonators alone, when no gain moves either)
-template <int NRES_, int NGAIN_, bool ANTI0_, uint32_t USUAL_ = 0, uint32_t USUAL2_ = 0>
+// R: the type the stage keeps its coefficients, memories and gains in (sig_t for the filter stages, double for the source stage)
+template <int NRES_, int NGAIN_, bool ANTI0_, uint32_t USUAL_ = 0, uint32_t USUAL2_ = 0, class R_ = sig_t>
 struct FlatDesc {
+    using R = R_;
     static constexpr int NRES = NRES_, NGAIN = NGAIN_, NE = NRES_ + NGAIN_;
     static constexpr bool ANTI0 = ANTI0_;
     static constexpr uint32_t USUAL = USUAL_, USUAL2 = USUAL2_;
@@ -694,8 +698,9 @@ struct FlatDesc {
 template <class FD>
 struct FlatState {
     static constexpr int NR = FD::NRES > 0 ? FD::NRES : 1;
-    double ra[NR], rb[NR], rc[NR], z1[NR], z2[NR];
-    double cur[2 * FD::NGAIN];
+    using R = typename FD::R;
+    R ra[NR], rb[NR], rc[NR], z1[NR], z2[NR];
+    R cur[2 * FD::NGAIN];
     const double2* tp[FD::NE];
     uint32_t ts[FD::NE];
     uint32_t startAt, left, next, nFrames, length, produced;
@@ -705,9 +710,9 @@ template <class FD>
 __device__ __forceinline__ void flat_init(FlatState<FD>& f, bool live, const UttDesc& d)
 {
 #pragma unroll
-    for (int r = 0; r < FD::NRES; ++r) { f.ra[r] = 0.0; f.rb[r] = 2.0; f.rc[r] = -1.0; f.z1[r] = 0.0; f.z2[r] = 0.0; }
+    for (int r = 0; r < FD::NRES; ++r) { f.ra[r] = 0; f.rb[r] = 2; f.rc[r] = -1; f.z1[r] = 0; f.z2[r] = 0; }
 #pragma unroll
-    for (int k = 0; k < 2 * FD::NGAIN; ++k) f.cur[k] = 0.0;
+    for (int k = 0; k < 2 * FD::NGAIN; ++k) f.cur[k] = 0;
 #pragma unroll
     for (int e = 0; e < FD::NE; ++e) { f.tp[e] = nullptr; f.ts[e] = 0; }
     f.live = live && d.length > 0u;
@@ -717,11 +722,12 @@ __device__ __forceinline__ void flat_init(FlatState<FD>& f, bool live, const Utt
 template <class FD>
 __device__ __forceinline__ void flat_take(FlatState<FD>& f, int e, const double2 v, double a0)
 {
+    using R = typename FD::R;
     if (e < FD::NRES) {
-        f.ra[e] = (FD::ANTI0 && e == 0) ? a0 : (1.0 - v.x - v.y);
-        f.rb[e] = v.x; f.rc[e] = v.y;
+        f.ra[e] = (R)((FD::ANTI0 && e == 0) ? a0 : (1.0 - v.x - v.y));     // (float: a from the ROUNDED b and c instead -- gain 1 at 0 Hz to float precision -- is further from the double PCM)
+        f.rb[e] = (R)v.x; f.rc[e] = (R)v.y;
     } else {
-        f.cur[2 * (e - FD::NRES)] = v.x; f.cur[2 * (e - FD::NRES) + 1] = v.y;
+        f.cur[2 * (e - FD::NRES)] = (R)v.x; f.cur[2 * (e - FD::NRES) + 1] = (R)v.y;
     }
 }
 // a fade starts on this sample: its first row (every entry kind), then the pointers for the rows that follow
@@ -889,10 +895,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     using L = SysLds<NOISE, CH, FLAT>;
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    double* const pipeX = reinterpret_cast<double*>(lds);                           // S0 -> S1
-    double* const pipeO = reinterpret_cast<double*>(lds + L::kPipeBytes);           // S1 -> S2
-    double* const pipeA = reinterpret_cast<double*>(lds + 2 * L::kPipeBytes);       // noisy: y      | quiet: S2 -> S3
-    double* const pipeB = reinterpret_cast<double*>(lds + (NOISE ? 3 : 2) * L::kPipeBytes);   // noisy: partial sum
+    using PipeT = typename std::conditional<FLAT, sig_t, double>::type;                // what the stages hand over
+    PipeT* const pipeX = reinterpret_cast<PipeT*>(lds);                             // S0 -> S1
+    PipeT* const pipeO = reinterpret_cast<PipeT*>(lds + L::kPipeBytes);             // S1 -> S2
+    PipeT* const pipeA = reinterpret_cast<PipeT*>(lds + 2 * L::kPipeBytes);         // noisy: y      | quiet: S2 -> S3
+    PipeT* const pipeB = reinterpret_cast<PipeT*>(lds + (NOISE ? 3 : 2) * L::kPipeBytes);     // noisy: partial sum
     unsigned char* const tile = lds + L::kTileOff;
     long long* const rowBase = reinterpret_cast<long long*>(lds + L::kRowBase);
     uint32_t* const rowCount = reinterpret_cast<uint32_t*>(lds + L::kRowCount);
@@ -966,7 +973,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // dequeue, of the running fade's end, the fade rows left.  Per sample a lane is dequeuing (sets up the pitch fade; the sample
         // is emitted unchanged), fading (pitch interpolated, a row taken), ending its fade (bookkeeping), or steady (glide).
         if constexpr (FLAT) {
-            using FD = FlatDesc<0, 4, false>;
+            using FD = FlatDesc<0, 4, false, 0, 0, double>;
             constexpr int GE[4] = {20, 21, 22, 23};     // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain
             FlatState<FD> f;
             flat_init<FD>(f, live, d);
@@ -1262,11 +1269,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             flat_init<FD>(f, live, d);
             flat_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i) __attribute__((always_inline)) {
-                    const double x = PIPE(pipeX, c, i);
-                    const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
+                    const sig_t x = PIPE(pipeX, c, i);
+                    const sig_t n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
                     f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
-                    const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
-                    double o = fade_value(x, np, f.cur[0]);
+                    const sig_t np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
+                    sig_t o = fade_value(x, np, f.cur[0]);
 #pragma unroll
                     for (int r = 2; r < 5; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
                     PIPE(pipeO, c, i) = o;
@@ -1280,18 +1287,18 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // cur: fricationAmplitude, preFormantGain, pa1..pa4
             FlatState<FD> f;
             flat_init<FD>(f, live, d);
-            double fricNoise = 0.0;
+            sig_t fricNoise = 0;
             uint32_t noiseIdx = 1;
             flat_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i) __attribute__((always_inline)) {
-                    fricNoise = noise_uniform(nkey, noiseIdx) + 0.75 * fricNoise;
+                    fricNoise = (sig_t)noise_uniform(nkey, noiseIdx) + (sig_t)0.75 * fricNoise;
                     noiseIdx += 2u;
-                    const double fric = fricNoise * 0.3 * f.cur[0];
-                    const double y = (fric * f.cur[1]) * 0.5;
-                    double par = 0.0;
+                    const sig_t fric = fricNoise * (sig_t)0.3 * f.cur[0];
+                    const sig_t y = (fric * f.cur[1]) * (sig_t)0.5;
+                    sig_t par = 0;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
+                        const sig_t w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
                         par += (w - y) * f.cur[2 + r];
                     }
                     PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
@@ -1337,21 +1344,21 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             };
             flat_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i) __attribute__((always_inline)) {
-                    double o = PIPE(pipeO, c, i);
-                    const double y = PIPE(pipeA, c, i);
+                    sig_t o = PIPE(pipeO, c, i);
+                    const sig_t y = PIPE(pipeA, c, i);
 #pragma unroll
                     for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
-                    double par = PIPE(pipeB, c, i);
+                    sig_t par = PIPE(pipeB, c, i);
 #pragma unroll
                     for (int r = 3; r < 5; ++r) {
-                        const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
+                        const sig_t w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
                         par += (w - y) * f.cur[r - 3];
                     }
                     par = fade_value(par, y, f.cur[2]);
-                    const double mix = o + par;
-                    const double v = (mix * f.cur[3]) * 4000.0;
-                    const double lo = (v < 32000.0) ? v : 32000.0;       // windows.h min(): NaN -> 32000
-                    const double cl = (lo > -32000.0) ? lo : -32000.0;
+                    const sig_t mix = o + par;
+                    const sig_t v = (mix * f.cur[3]) * (sig_t)4000.0;
+                    const sig_t lo = (v < (sig_t)32000.0) ? v : (sig_t)32000.0;       // windows.h min(): NaN -> 32000
+                    const sig_t cl = (lo > (sig_t)-32000.0) ? lo : (sig_t)-32000.0;
                     myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (:208)
                 },
                 [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
@@ -1365,8 +1372,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         constexpr int RF[3] = {0, 2, 4}, RB[3] = {1, 3, 5};
         StageFrame<6, 3> f;
         stage_frame_init(f, live, lds + (s1 ? L::kFrames1 : L::kFrames2), lane);
-        double* const pin = s1 ? pipeX : pipeO;
-        double* const pout = s1 ? pipeO : pipeA;
+        PipeT* const pin = s1 ? pipeX : pipeO;
+        PipeT* const pout = s1 ? pipeO : pipeA;
         auto dsp = [&](double o) __attribute__((always_inline)) -> double {
 #pragma unroll
             for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);

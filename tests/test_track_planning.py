@@ -123,3 +123,23 @@ def test_eligibility_and_budget():
         frames2[k + 1] = rng.uniform(100, 5000, 47); nul2 = nul.copy(); nul2[k] = 0; nul2[k + 1] = 0; fade2[k + 1] = 50_000_000
         n2, e2, off2, mask2, tracked2 = plan(fs, frames2, fade2, nul2, budget_mb=64)
         assert not tracked2[7] and tracked2.sum() == 199
+
+
+def test_planning_in_parts_gives_the_plan_of_one_pass(monkeypatch):
+    """Large batches are planned by several host threads and merged (plan_tracks): same tracks, same places, as one pass --
+    with the budget met, with it met by the merged tracks only, with it missed (the one pass decides) and with untrackable
+    utterances among them (the tracks of this batch take 2.5 MB)."""
+    rng = np.random.default_rng(11)
+    start, frames, fade, nul = random_frames(rng, 70000)          # > 200 000 frames: the parts are used
+    assert len(fade) > 200000
+    el = (rng.random(len(start) - 1) < 0.9).astype(np.uint8)
+    for budget, eligible in ((16384, None), (16384, el), (20, None), (3, el), (2, None), (0, None)):
+        monkeypatch.setenv("SPEECHPLAYER_PLAN_THREADS", "1")
+        one = plan(start, frames, fade, nul, eligible, budget)
+        for threads in ("2", "5", "8"):
+            monkeypatch.setenv("SPEECHPLAYER_PLAN_THREADS", threads)
+            many = plan(start, frames, fade, nul, eligible, budget)
+            assert many[:2] == one[:2]
+            for a, b in zip(many[2:], one[2:]):
+                assert np.array_equal(a, b)
+    assert one[0] == 0 and not one[4].any()                       # no budget: nothing tracked

@@ -2,7 +2,7 @@
 """Tracks (and the flat stages they feed) on / off: kernel time and PCM digest of cfg2 as benchmarked, with rotated frame lists, with jittered
 durations and without the sort by length (tools/mixed_probe.py), plus cfg3 / cfg4 on request.  The digests of a row must agree.
 
-    python tools/track_probe.py [utterances] [+cfg3] [+cfg4] [+unsorted]
+    python tools/track_probe.py [utterances] [+cfg3] [+cfg4] [+unsorted] [+distinct] [only=NAME]
 """
 import os
 import sys
@@ -29,7 +29,7 @@ def run(b, tracks, sort=1, mode=0, launches=4, flat=0):
 
 
 if __name__ == "__main__":
-    n = int(sys.argv[1]) if len(sys.argv) > 1 and not sys.argv[1].startswith("+") else 65536
+    n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 65536
     extra = [a[1:] for a in sys.argv[1:] if a.startswith("+")]
     base = workloads.make("cfg2", n)
     cases = [("cfg2", base, 1), ("rotated", rotate(base), 1), ("jittered", jitter(base), 1)]
@@ -42,7 +42,10 @@ if __name__ == "__main__":
         cases.append(("cfg3", workloads.make("cfg3", 125000), 1))
     if "cfg4" in extra:
         cases.append(("cfg4", workloads.make("cfg4", 32768), 1))
+    only = [a[5:] for a in sys.argv[1:] if a.startswith("only=")]
     for name, b, sort in cases:
+        if only and name not in only:
+            continue
         off = run(b, 0, sort)
         on = run(b, 1, sort)
         same = "same PCM" if off[1] == on[1] else "PCM DIFFERS (%016x vs %016x)" % (off[1], on[1])

@@ -23,6 +23,7 @@
 #include <chrono>
 #include <mutex>
 #include <atomic>
+#include <system_error>
 #include <thread>
 #include <numeric>
 #include <string>
@@ -492,6 +493,17 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
     }
 }
 
+// fn(0) .. fn(n - 1), each on a thread of its own; the last one -- and any a thread could not be started for -- on the caller's.
+template <class F>
+void run_parts(unsigned n, F fn)
+{
+    std::vector<std::thread> pool;
+    unsigned started = 0;
+    try { for (; started + 1 < n; ++started) pool.emplace_back(fn, started); } catch (const std::system_error&) {}
+    for (unsigned t = started; t < n; ++t) fn(t);
+    for (auto& th : pool) th.join();
+}
+
 // The plan of a batch.  Large batches are planned in parts, one host thread each (the walk is a hash of 45 values and two map
 // look-ups per frame: 0.2 s for BASELINE configs[2] on one thread), and the parts' shapes and fades merged: equal fades of
 // different parts end up with one track.  If the merged tracks fit the budget that is the plan; if not -- or if the parts gave
@@ -513,14 +525,9 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
         cut[t] = std::lower_bound(frameStart, frameStart + nUtterances, nF * (long long)t / nThreads) - frameStart;
     std::vector<TrackPlan> part(nThreads);
     std::atomic<unsigned long long> sum{0};
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nThreads; ++t)
-            pool.emplace_back([&, t] {
-                plan_tracks_pass(cut[t + 1] - cut[t], frameStart + cut[t], frames, meta, eligible + cut[t], budgetMB, false, &sum, part[t]);
-            });
-        for (auto& th : pool) th.join();
-    }
+    run_parts(nThreads, [&](unsigned t) {
+        plan_tracks_pass(cut[t + 1] - cut[t], frameStart + cut[t], frames, meta, eligible + cut[t], budgetMB, false, &sum, part[t]);
+    });
     // merge: shapes by value, fades by (from, to, length)
     struct ShapeKey { const double* v; bool operator==(const ShapeKey& o) const { return !memcmp(v, o.v, kShapeValues * sizeof(double)); } };
     struct ShapeKeyHash { size_t operator()(const ShapeKey& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (int i = 0; i < kShapeValues; ++i) { unsigned long long w; memcpy(&w, &k.v[i], 8); h ^= w; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
@@ -540,8 +547,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     out.entries = 0;
     std::unordered_map<ShapeKey, uint32_t, ShapeKeyHash> shapes;
     std::unordered_map<FadeKey, unsigned long long, FadeKeyHash> fades;
-    std::vector<std::vector<unsigned long long>> newOff(nThreads);      // part, its track's first entry -> the merged track's
-    std::vector<std::unordered_map<unsigned long long, unsigned long long>> offOf(nThreads);
+    std::vector<std::unordered_map<unsigned long long, unsigned long long>> offOf(nThreads);   // part, its track's first entry -> the merged track's
     for (unsigned t = 0; t < nThreads; ++t) {
         const TrackPlan& p = part[t];
         std::vector<uint32_t> gid(p.shapes.size() / kShapeStride);
@@ -575,24 +581,19 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
     out.tracked.assign((size_t)nUtterances, 0);
     if (missedSize * 10 > eligibleAll) { out.jobs.clear(); out.entries = 0; return; }   // all or nothing
-    {
-        std::vector<std::thread> pool;
-        for (unsigned t = 0; t < nThreads; ++t)
-            pool.emplace_back([&, t] {
-                const TrackPlan& p = part[t];
-                const long long f0 = frameStart[cut[t]];
-                for (long long u = cut[t]; u < cut[t + 1]; ++u) {
-                    if (!p.tracked[u - cut[t]]) continue;
-                    out.tracked[u] = 1;
-                    for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
-                        TrackRef r = p.ref[k - f0];
-                        r.off = offOf[t].find(r.off)->second;
-                        out.ref[k] = r;
-                    }
-                }
-            });
-        for (auto& th : pool) th.join();
-    }
+    run_parts(nThreads, [&](unsigned t) {
+        const TrackPlan& p = part[t];
+        const long long f0 = frameStart[cut[t]];
+        for (long long u = cut[t]; u < cut[t + 1]; ++u) {
+            if (!p.tracked[u - cut[t]]) continue;
+            out.tracked[u] = 1;
+            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+                TrackRef r = p.ref[k - f0];
+                r.off = offOf[t].find(r.off)->second;
+                out.ref[k] = r;
+            }
+        }
+    });
 }
 
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }

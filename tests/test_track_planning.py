@@ -143,3 +143,18 @@ def test_planning_in_parts_gives_the_plan_of_one_pass(monkeypatch):
             for a, b in zip(many[2:], one[2:]):
                 assert np.array_equal(a, b)
     assert one[0] == 0 and not one[4].any()                       # no budget: nothing tracked
+    # a fade too long for a track (2^27 entries) keeps its utterance out, in a part as in one pass; more than a tenth of them, everything
+    two = np.diff(start) >= 2
+    for share in (0.05, 0.9):
+        fade2 = fade.copy()
+        hit = two & (rng.random(len(start) - 1) < share)
+        fade2[start[:-1][hit] + 1] = 1 << 23                      # on the second frame (the first only moves the gain: from silence)
+        monkeypatch.setenv("SPEECHPLAYER_PLAN_THREADS", "1")
+        one = plan(start, frames, fade2, nul)
+        monkeypatch.setenv("SPEECHPLAYER_PLAN_THREADS", "8")
+        many = plan(start, frames, fade2, nul)
+        assert many[:2] == one[:2] and all(np.array_equal(a, b) for a, b in zip(many[2:], one[2:]))
+        if share < 0.1:
+            assert one[4][~hit].all() and not one[4][hit].all()  # (a hit utterance stays in when its long fade moves few kinds)
+        else:
+            assert not one[4].any()

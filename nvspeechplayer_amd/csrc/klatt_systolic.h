@@ -59,6 +59,11 @@ namespace klatt {
 #define KLATT_STR2(x) #x
 #define KLATT_STR(x) KLATT_STR2(x)
 
+#ifndef KLATT_FLAT_EXHAUSTIVE
+#define KLATT_FLAT_EXHAUSTIVE 1 // flat launches: the final stage is the chain's unconditional last branch, so that the compiler sees that a flat launch
+                                // runs none of the untracked stages (it cannot tell that a stage number is 0..3): the kernel is half the code, 245
+                                // VGPRs instead of 256 and NO scratch instead of 128 bytes per lane (0: the test `stage == 2`, as before)
+#endif
 constexpr int kStages = 4;
 #ifndef KLATT_FLAT_SOURCE
 #define KLATT_FLAT_SOURCE 1     // flat launches: S0 is a flat stage too (0: the source stage of the noisy launches, with its frame state machine)
@@ -1305,7 +1310,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 },
                 noChunk);
         }
-    } else if (FLAT && stage == 2) {
+    } else if (FLAT && (KLATT_FLAT_EXHAUSTIVE || stage == 2)) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
         if constexpr (FLAT) {
             using FD = FlatDesc<5, 2, false, 0x67u, 0x07u>;         // usually c3, c2, c1 and the gains

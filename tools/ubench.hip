@@ -32,6 +32,10 @@ __global__ void probe(unsigned long long* out, int iters, int activeLanes, doubl
             } else if (KIND == 2) {  // v_mul_lo_u32
                 u0 *= 0x7FEB352Du; u1 *= 0x7FEB352Du; u2 *= 0x7FEB352Du; u3 *= 0x7FEB352Du;
                 u4 *= 0x7FEB352Du; u5 *= 0x7FEB352Du; u6 *= 0x7FEB352Du; u7 *= 0x7FEB352Du;
+            } else if (KIND == 11) { // v_mul_lo_u32 by a value the compiler cannot fold (KIND 2 folds its eight constant multiplies into one)
+                u0 *= u1 | 1u; u1 *= u2 | 1u; u2 *= u3 | 1u; u3 *= u0 | 1u; u4 *= u5 | 1u; u5 *= u6 | 1u; u6 *= u7 | 1u; u7 *= u4 | 1u;
+            } else if (KIND == 12) { // the v_or_b32 of KIND 11 alone with an add in the multiply's place: what to subtract
+                u0 += u1 | 1u; u1 += u2 | 1u; u2 += u3 | 1u; u3 += u0 | 1u; u4 += u5 | 1u; u5 += u6 | 1u; u6 += u7 | 1u; u7 += u4 | 1u;
             } else if (KIND == 3) {  // v_mul_f64 + v_add_f64 (unfused)
                 a0 = a0 * m; a1 = a1 * m; a2 = a2 * m; a3 = a3 * m; a0 = a0 + c; a1 = a1 + c; a2 = a2 + c; a3 = a3 + c;
             } else if (KIND == 4) {  // dependent v_fma_f64 chain (latency)
@@ -117,6 +121,8 @@ int main()
         run<1>("v_fma_f32", w, 16, dOut);
         run<6>("v_pk_fma_f32", w, 64, dOut);
         run<2>("v_mul_lo_u32", w, 64, dOut);
+        run<11>("v_or + v_mul_lo_u32", w, 64, dOut);
+        run<12>("v_or + v_add_u32", w, 64, dOut);
         run<4>("v_fma_f64 dependent", w, 64, dOut);
         run<5>("v_fma_f32 dependent", w, 64, dOut);
     }

@@ -297,7 +297,7 @@ def main():
                                         "peak_spec": SIMDS * CLOCK_HZ / F64_CYCLES_SPEC,
                                         "insts_per_64_samples": insts * 64.0 / samples,
                                         "source": "profiles/r2_pmc.json SQ_INSTS_VALU; peak = 1024 SIMDs x 2.4 GHz / 4.8 cycles per f64 wave instruction "
-                                                  "(measured; 4 by the datasheet = peak_spec); instructions that are not f64 issue faster, so frac is a lower bound on issue-slot use"}
+                                                  "(measured; 4 by the datasheet = peak_spec); instructions that are not f64 (a quarter to a third of them) issue in about half that, so frac is an upper bound on issue-slot use"}
                     else:
                         roof["traffic_source"] = "profiles/r2_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
             except Exception:

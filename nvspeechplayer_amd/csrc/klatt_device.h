@@ -180,16 +180,28 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
     x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
     return x;
 }
-// the engine's noise definition (restated by oracle/klatt_oracle.c klatt_noise31)
+// The engine's noise definition (restated by oracle/klatt_oracle.c).  The reference draws (double)rand()/RAND_MAX twice per
+// sample from the process-global rand() (src/speechWaveGenerator.cpp:40, called at :75 and :205): not reproducible across
+// handles.  Here every utterance has a stream of its own: a 32-bit linear congruential generator (Numerical Recipes'
+// multiplier and increment) started from a hash of the utterance's seed,
+//     s_0 = noise_key(seed),   s_(n+1) = 1664525 s_n + 1013904223  (mod 2^32),   value k = s_(k+1) >> 1     (0 .. 2^31-1, glibc's range)
+// and sample n takes value 2n for the aspiration and value 2n+1 for the frication, the order of the reference's two calls.
+// One multiply per value: the counter hash of rounds 1-2 (two multiplies and four xor-shifts per value) was 35 of the ~200-250 issue
+// cycles of the source and frication stages per sample; this is 11 (cfg2 9.48 -> 8.96 ms).  The stages step their own
+// sub-sequence two values at a time (noise_step2).  A live handle keeps the state of its next aspiration value (stream slot 221).
 __device__ __forceinline__ uint32_t noise_key(uint32_t seed) { return mix32(seed ^ 0x9E3779B9u); }
-__device__ __forceinline__ uint32_t noise31(uint32_t key, uint32_t k) { return mix32((k * 0x9E3779B1u) ^ key) >> 1; }
-// (double)rand()/RAND_MAX with RAND_MAX = 2^31-1 (reference src/speechWaveGenerator.cpp:40).  For the integers
-// r < 2^31 the correctly rounded quotient is fma(r, yh, r * yl) with 1/(2^31-1) = yh + yl to double-double
+constexpr uint32_t kNoiseA = 1664525u, kNoiseC = 1013904223u;
+constexpr uint32_t kNoiseA2 = kNoiseA * kNoiseA, kNoiseC2 = (kNoiseA + 1u) * kNoiseC;       // two steps in one (mod 2^32)
+__device__ __forceinline__ uint32_t noise_step(uint32_t s) { return s * kNoiseA + kNoiseC; }
+__device__ __forceinline__ uint32_t noise_step2(uint32_t s) { return s * kNoiseA2 + kNoiseC2; }
+__device__ __forceinline__ uint32_t noise_first(uint32_t key) { return noise_step(key); }     // the state of value 0
+// (double)rand()/RAND_MAX with RAND_MAX = 2^31-1 (reference src/speechWaveGenerator.cpp:40) of the value in state s.  For the
+// integers r < 2^31 the correctly rounded quotient is fma(r, yh, r * yl) with 1/(2^31-1) = yh + yl to double-double
 // (yh = 0x1.00000002p-31, yl = 2^-93; r * yl is exact): two operations instead of div_by's three.
 // tests/native/check_math.cpp compares it with '/' for ALL 2^31 values.
-__device__ __forceinline__ double noise_uniform(uint32_t key, uint32_t k)
+__device__ __forceinline__ double noise_uniform(uint32_t s)
 {
-    const double r = (double)noise31(key, k);
+    const double r = (double)(s >> 1);
     return __builtin_fma(r, 0x1.00000002p-31, r * 0x1p-93);
 }
 
@@ -320,7 +332,7 @@ struct Lane {
     double ra[kNumRes], rb[kNumRes], rc[kNumRes], z1[kNumRes], z2[kNumRes];
     double pitchPhase, vibPhase, aspNoise, fricNoise;
     uint32_t cnt, oldMin, newMin, newFade;
-    uint32_t resMask, nextFrame, noiseIdx, produced;
+    uint32_t resMask, nextFrame, noiseState, produced;   // noiseState: the noise stream's state of the next aspiration value
     int32_t lastIndex;
     bool hasNew, oldNull, newNull, done, drained;
     bool vibFrames;            // the old or new frame has a non-zero (or NaN) vibrato depth/speed
@@ -343,7 +355,7 @@ __device__ __forceinline__ uint32_t dsp_sample(Lane& s, const KernelArgs& A, uin
     double voice = (s.pitchPhase * 2.0) - 1.0;
     double src;
     if (NOISE) {
-        s.aspNoise = noise_uniform(nkey, s.noiseIdx) + 0.75 * s.aspNoise;     // :40
+        s.aspNoise = noise_uniform(s.noiseState) + 0.75 * s.aspNoise;     // :40
         double asp = s.aspNoise * 0.2;
         double turb = asp * s.cur[3];
         turb = (s.pitchPhase >= s.cur[4]) ? turb : turb * 0.01;               // glottis closed
@@ -376,8 +388,8 @@ __device__ __forceinline__ uint32_t dsp_sample(Lane& s, const KernelArgs& A, uin
     double mix = o;
     if (NOISE) {
         // frication + parallel bank (:205-206, :170-180)
-        s.fricNoise = noise_uniform(nkey, s.noiseIdx + 1u) + 0.75 * s.fricNoise;
-        s.noiseIdx += 2u;
+        s.fricNoise = noise_uniform(noise_step(s.noiseState)) + 0.75 * s.fricNoise;
+        s.noiseState = noise_step2(s.noiseState);
         const double fric = s.fricNoise * 0.3 * s.cur[24];
         const double y = (fric * s.cur[44]) * 0.5;
         double par = 0.0;
@@ -542,7 +554,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
     s.old0 = 0.0; s.new0 = 0.0; s.oldInc = 0.0; s.newInc = 0.0; s.invFade = 1.0;
     s.cnt = 0; s.oldMin = 0; s.newMin = 0; s.newFade = 1;
     s.hasNew = false; s.oldNull = true; s.newNull = false;
-    s.lastIndex = -1; s.resMask = 0; s.nextFrame = 0; s.noiseIdx = 0; s.produced = 0;
+    s.lastIndex = -1; s.resMask = 0; s.nextFrame = 0; s.noiseState = noise_first(nkey); s.produced = 0;
     s.done = !live; s.drained = false; s.vibFrames = false;
 #pragma unroll
     for (int r = 0; r < kNumRes; ++r) { s.ra[r] = 0.0; s.rb[r] = 2.0; s.rc[r] = -1.0; s.z1[r] = 0.0; s.z2[r] = 0.0; }
@@ -575,7 +587,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
             s.cnt = (uint32_t)S[215]; s.oldMin = (uint32_t)S[216]; s.newMin = (uint32_t)S[217]; s.newFade = (uint32_t)S[218];
             const uint32_t fl = (uint32_t)S[219];
             s.hasNew = fl & 1; s.oldNull = fl & 2; s.newNull = fl & 4;
-            s.lastIndex = (int32_t)S[220]; s.noiseIdx = (uint32_t)S[221];
+            s.lastIndex = (int32_t)S[220]; s.noiseState = (uint32_t)S[221];
             // which resonators move in the running fade follows from the fade's end points (as event_step derived it); the
             // state may have been saved by the stage-parallel stream kernel, whose stages keep their own masks
             uint32_t mk = 0;
@@ -723,7 +735,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
         S[212] = s.oldInc; S[213] = s.newInc; S[214] = s.invFade;
         S[215] = (double)s.cnt; S[216] = (double)s.oldMin; S[217] = (double)s.newMin; S[218] = (double)s.newFade;
         S[219] = (double)((s.hasNew ? 1u : 0u) | (s.oldNull ? 2u : 0u) | (s.newNull ? 4u : 0u));
-        S[220] = (double)s.lastIndex; S[221] = (double)s.noiseIdx;
+        S[220] = (double)s.lastIndex; S[221] = (double)s.noiseState;
         S[239] = 1.0;
     }
 }

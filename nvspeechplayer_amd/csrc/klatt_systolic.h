@@ -985,7 +985,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             PitchState ps;
             ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
             double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, invFade = 1.0, nfD = 1.0;
-            uint32_t noiseIdx = 0, cntF = 0, fmask = 0, fslots = 0;
+            uint32_t noiseSt = noise_first(nkey), cntF = 0, fmask = 0, fslots = 0;    // the state of this stage's next noise value (aspiration: values 0, 2, 4, ...)
             uint32_t deqAt = (live && d.nFrames > 0u) ? 0u : 0xFFFFFFFFu, fadeEndAt = 0xFFFFFFFFu;
             const double2* tBase = nullptr;
             int32_t lastIndex = -1;
@@ -1000,8 +1000,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 }
                 pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
                 double voice = (pitchPhase * 2.0) - 1.0;
-                aspNoise = noise_uniform(nkey, noiseIdx) + 0.75 * aspNoise;
-                noiseIdx += 2u;
+                aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
+                noiseSt = noise_step2(noiseSt);
                 double asp = aspNoise * 0.2;
                 double turb = asp * f.cur[2];
                 turb = (pitchPhase >= f.cur[3]) ? turb : turb * 0.01;
@@ -1145,14 +1145,14 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         stage_frame_init(f, live, lds + L::kFrames, lane);
         ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
         double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0;
-        uint32_t noiseIdx = 0;
+        uint32_t noiseSt = noise_first(nkey);     // the state of this stage's next noise value (aspiration: values 0, 2, 4, ...)
         int32_t lastIndex = -1;
         bool vibFrames = false;
         constexpr int GR0[1] = {0};
         if (STREAM && live) {
             if (streamState[239] != 0.0) {
                 pitchPhase = streamState[208]; vibPhase = streamState[209]; aspNoise = streamState[210];
-                lastIndex = (int32_t)streamState[220]; noiseIdx = (uint32_t)streamState[221];
+                lastIndex = (int32_t)streamState[220]; noiseSt = (uint32_t)streamState[221];
             }
             stage_state_load<D>(f, &ps, streamState, P, RF, RB, GR0, streamPurge);
             vibFrames = f.oldL[0] != 0.0 || f.oldL[kLanes] != 0.0 || f.getNew(0) != 0.0 || f.getNew(1) != 0.0;
@@ -1170,8 +1170,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             double voice = (pitchPhase * 2.0) - 1.0;
             double src;
             if (NOISE) {
-                aspNoise = noise_uniform(nkey, noiseIdx) + 0.75 * aspNoise;
-                noiseIdx += 2u;
+                aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
+                noiseSt = noise_step2(noiseSt);
                 double asp = aspNoise * 0.2;
                 double turb = asp * f.cur[2];
                 turb = (pitchPhase >= f.cur[3]) ? turb : turb * 0.01;
@@ -1263,7 +1263,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         if (STREAM && live) {
             stage_state_save<D>(f, &ps, streamState, P, GR0);
             streamState[208] = pitchPhase; streamState[209] = vibPhase; streamState[210] = aspNoise;
-            streamState[220] = (double)lastIndex; streamState[221] = (double)noiseIdx;
+            streamState[220] = (double)lastIndex; streamState[221] = (double)noiseSt;
         }
     } else if (FLAT && stage == 1) {
         // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 =================
@@ -1293,11 +1293,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             FlatState<FD> f;
             flat_init<FD>(f, live, d);
             sig_t fricNoise = 0;
-            uint32_t noiseIdx = 1;
+            uint32_t noiseSt = noise_step(noise_first(nkey));     // frication: values 1, 3, 5, ...
             flat_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i) __attribute__((always_inline)) {
-                    fricNoise = (sig_t)noise_uniform(nkey, noiseIdx) + (sig_t)0.75 * fricNoise;
-                    noiseIdx += 2u;
+                    fricNoise = (sig_t)noise_uniform(noiseSt) + (sig_t)0.75 * fricNoise;
+                    noiseSt = noise_step2(noiseSt);
                     const sig_t fric = fricNoise * (sig_t)0.3 * f.cur[0];
                     const sig_t y = (fric * f.cur[1]) * (sig_t)0.5;
                     sig_t par = 0;
@@ -1431,15 +1431,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         StageFrame<14, 4> f;
         stage_frame_init(f, live, lds + L::kFrames3, lane);
         double fricNoise = 0.0;
-        uint32_t noiseIdx = 1;
+        uint32_t noiseSt = noise_step(noise_first(nkey));     // frication: values 1, 3, 5, ...
         constexpr int GR3[4] = {8, 9, 10, 11};
         if (STREAM && live) {
-            if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseIdx = (uint32_t)streamState[221] + 1u; }
+            if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseSt = noise_step((uint32_t)streamState[221]); }   // slot 221: the state of the next aspiration value
             stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR3, streamPurge);
         }
         auto dsp = [&](int c, int i) __attribute__((always_inline)) {
-            fricNoise = noise_uniform(nkey, noiseIdx) + 0.75 * fricNoise;
-            noiseIdx += 2u;
+            fricNoise = noise_uniform(noiseSt) + 0.75 * fricNoise;
+            noiseSt = noise_step2(noiseSt);
             const double fric = fricNoise * 0.3 * f.cur[8];
             const double y = (fric * f.cur[9]) * 0.5;
             double par = 0.0;

@@ -29,9 +29,11 @@
  *
  * Noise: the reference draws from libc rand().  ORACLE_NOISE_LIBC reproduces that
  * (used only for the pin above).  ORACLE_NOISE_COUNTER is the engine's defined
- * per-utterance stream: value k of stream `seed` is klatt_noise31(seed, k), and a
- * produced sample n consumes k = 2n (aspiration) then k = 2n+1 (frication),
- * exactly the order of the two rand() calls at speechWaveGenerator.cpp:75,205.
+ * per-utterance stream, a 32-bit linear congruential generator started from a hash
+ * of the seed: s_0 = key(seed), s_(n+1) = 1664525 s_n + 1013904223 (mod 2^32), value
+ * k = s_(k+1) >> 1 = klatt_noise31(seed, k); a produced sample n consumes k = 2n
+ * (aspiration) then k = 2n+1 (frication), exactly the order of the two rand() calls
+ * at speechWaveGenerator.cpp:75,205.
  *
  * Build with contraction off so that every multiply and add rounds separately,
  * as the reference binary (x86 without FMA) does.
@@ -98,18 +100,30 @@ typedef struct oracle_player {
     /* noise source selection */
     int noiseMode;
     uint32_t noiseSeed;
-    uint32_t noiseIndex;
+    uint32_t noiseState;   /* the stream's state of the next value */
 } oracle_player;
 
-/* ---- counter-based noise (the engine's definition; the HIP kernel restates it) ---- */
-uint32_t klatt_noise31(uint32_t seed, uint32_t k)
+/* ---- the engine's noise stream (the HIP kernels restate it: klatt_device.h) ---- */
+#define NOISE_A 1664525u
+#define NOISE_C 1013904223u
+static uint32_t noise_key(uint32_t seed)
 {
-    /* key: one avalanche of the seed; stream: multiply-xorshift hash of the index */
+    /* one avalanche of the seed */
     uint32_t key = seed ^ 0x9E3779B9u;
     key ^= key >> 16; key *= 0x7FEB352Du; key ^= key >> 15; key *= 0x846CA68Bu; key ^= key >> 16;
-    uint32_t x = (k * 0x9E3779B1u) ^ key;
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x >> 1; /* 0 .. 2^31-1, the range of glibc rand() */
+    return key;
+}
+/* value k of stream `seed`, by random access: k + 1 steps from the key in O(log k) (the players below step one at a time) */
+uint32_t klatt_noise31(uint32_t seed, uint32_t k)
+{
+    uint32_t a = NOISE_A, c = NOISE_C, accA = 1u, accC = 0u;
+    uint64_t n = (uint64_t)k + 1u;
+    while (n) {
+        if (n & 1u) { accA *= a; accC = accC * a + c; }
+        c = (a + 1u) * c; a *= a;
+        n >>= 1;
+    }
+    return (accA * noise_key(seed) + accC) >> 1; /* 0 .. 2^31-1, the range of glibc rand() */
 }
 
 static double next_uniform(oracle_player *s)
@@ -119,7 +133,10 @@ static double next_uniform(oracle_player *s)
     if (s->noiseMode == ORACLE_NOISE_LIBC)
         r = (double)rand();
     else
-        r = (double)klatt_noise31(s->noiseSeed, s->noiseIndex++);
+    {
+        r = (double)(s->noiseState >> 1);
+        s->noiseState = s->noiseState * NOISE_A + NOISE_C;
+    }
     return r / 2147483647.0;
 }
 
@@ -284,7 +301,7 @@ void oracle_setNoise(oracle_player *s, int mode, uint32_t seed)
 {
     s->noiseMode = mode;
     s->noiseSeed = seed;
-    s->noiseIndex = 0;
+    s->noiseState = noise_key(seed) * NOISE_A + NOISE_C;
 }
 
 /* speechPlayer.cpp:34-37 + frame.cpp:90-115 */

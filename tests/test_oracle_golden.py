@@ -60,11 +60,24 @@ def test_chunking_invariance(ref):
 
 
 def test_noise_function_reference_values():
-    """The counter noise definition is part of the engine's contract; lock a few values."""
+    """The noise definition is part of the engine's contract (klatt_device.h): a 32-bit LCG per stream, started from a hash of
+    the seed; value k = state k + 1 >> 1.  Restated here in plain integers, against the oracle's random access and its players."""
     L = oracle.lib()
     vals = [L.klatt_noise31(s, k) for s, k in ((0, 0), (0, 1), (1, 0), (12345, 678), (0xFFFFFFFF, 0xFFFFFFFF))]
     assert all(0 <= v < 2 ** 31 for v in vals)
     assert len(set(vals)) == len(vals)
+
+    def key(seed):
+        x = (seed ^ 0x9E3779B9) & 0xFFFFFFFF
+        x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF; x ^= x >> 16
+        return x
+    for seed in (0, 7, 0xFFFFFFFF):
+        st, seq = key(seed), []
+        for _ in range(3000):
+            st = (st * 1664525 + 1013904223) & 0xFFFFFFFF
+            seq.append(st >> 1)
+        assert seq == [L.klatt_noise31(seed, k) for k in range(3000)]
+    assert L.klatt_noise31(7, 0xFFFFFFFF) == L.klatt_noise31(7, 0xFFFFFFFF) < 2 ** 31     # k + 1 = 2^32 steps: no overflow
     # uniformity smoke: mean of 1e5 draws within 1% of 0.5
     xs = np.array([L.klatt_noise31(7, k) for k in range(100000)], dtype=np.float64) / 2147483647.0
     assert abs(xs.mean() - 0.5) < 0.005

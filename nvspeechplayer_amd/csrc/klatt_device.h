@@ -214,7 +214,7 @@ __device__ __forceinline__ double dot3(double a, double x, double b, double y, d
 }
 
 // The type of the signal in the flat filter stages (klatt_systolic.h): resonator memories and coefficients, gains, the pipes
-// between the stages.  double in every shipped build; -DKLATT_SIGNAL_F32 builds the float experiment of DESIGN.md section 6
+// between the stages.  double in every shipped build; -DKLATT_SIGNAL_F32 builds the float experiment of DESIGN.md section 4 ("A float signal path")
 // (tools/f32_probe.py: how fast, how far from the double PCM).  Frames, tracks, the source stage (pitch, phases) and the
 // coefficient evaluation are double in both.
 #ifdef KLATT_SIGNAL_F32

@@ -1079,3 +1079,23 @@ def test_coefficient_tracks_change_nothing(seed, wild):
     d = pcm.astype(np.int32) - exp.astype(np.int32)
     assert np.array_equal(start, exp_start) and np.abs(d).max() <= 1
     assert int(np.count_nonzero(d)) <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
+
+
+@pytest.mark.gpu
+def test_planning_threads_change_nothing(monkeypatch):
+    """A large batch's tracks are planned in parts by several host threads (plan_tracks): the engine must make the same tracks and
+    the same PCM as with one pass (SPEECHPLAYER_PLAN_THREADS=1).  16 384 sampleIpa utterances: 395 000 frames, above the threshold."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    b = workloads.make("cfg2", 16384)
+    assert len(b["fade"]) > 200000
+    got = {}
+    for threads in ("1", "8"):
+        monkeypatch.setenv("SPEECHPLAYER_PLAN_THREADS", threads)
+        bp = eng.BatchPlayer(b["sr"])
+        bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+        bp.synthesize()
+        info = bp.kernelInfo()
+        got[threads] = (bp.digest(), info["tracked_utterances"], info["tracks"], info["track_mbytes"])
+        bp.close()
+    assert got["1"] == got["8"] and got["1"][1] > 0

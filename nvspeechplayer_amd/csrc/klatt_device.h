@@ -50,6 +50,8 @@ constexpr int MODE_FAST = 1;
 constexpr uint32_t FRAME_NULL = 1u;       // FrameMeta.flags
 constexpr uint32_t UTT_NEEDS_NOISE = 1u;  // UttDesc.flags
 constexpr uint32_t UTT_TRACKED = 4u;      // UttDesc.flags: noisy, every parameter finite, tracks planned (2u: UTT_NO_NASAL, klatt_lanepipe.h)
+constexpr int kUttKindShift = 8;          // UttDesc.flags bits 8..31 of a tracked utterance: the entry kinds (klatt_tracks) whose values change after the first sample
+                                          // of its first fade -- a kind outside the mask of every lane of a wavefront is loaded once and never again (flat stages)
 
 struct FrameMeta {           // 16 B per frame; with the 376-B parameter vector: 392 B/frame read
     uint32_t minSamples;
@@ -86,9 +88,13 @@ struct UttResult {           // written by the kernel
 //           (fricationAmplitude, preFormantGain) (pa1, pa2) (pa3, pa4)          -- S1 | final stage | parallel stage
 //   20..23  the source stage's parameters: (vibratoPitchOffset, vibratoSpeed) (voiceTurbulenceAmplitude, glottalOpenQuotient)
 //           (voiceAmplitude, aspirationAmplitude) (preFormantGain, -)           -- S0 (the pitch itself glides: not in a track)
-// Fade sample 1 (everything is re-evaluated there, see fade_update below): all of them, kTrackFirst entries in the order above.
-// Fade samples 2..F: one entry per kind that MOVES in the fade (mask, ascending; N0 takes two), nSlots entries per sample.
-// Fades with bitwise equal end values of all 39 parameters involved and the same length share one track (host, plan_tracks).
+// On fade sample 1 everything is re-evaluated (see fade_update below): every kind has an entry for it, kTrackFirst entries (N0
+// takes two).  Fade samples 2..F change only the kinds that MOVE in the fade (mask).  Layout of a fade's track:
+//   header   the kinds that do NOT move, ascending: their value of fade sample 1 (which is their value on every later sample)
+//   matrix   F rows of nSlots entries: the kinds that move, ascending (N0 takes two); row j holds fade sample j + 1
+// so a moving kind's entries are one stride (nSlots) apart from the first fade sample on, and a kind that does not move has ONE
+// entry: a stage points at it with stride 0.  kTrackFirst + (F - 1) * nSlots entries in all.
+// Fades with bitwise equal end values of all the parameters involved and the same length share one track (host, plan_tracks).
 constexpr int kTrackEntries = 24;
 constexpr int kTrackFirst = kTrackEntries + 1;   // entries of a fade's first sample (N0 takes two)
 constexpr int kShapeValues = 45;                 // a SHAPE: the parameter values a track depends on at one end of the fade
@@ -113,6 +119,19 @@ struct TrackRef {            // 16 B per frame, read by the tracked stages at a 
     uint32_t mask;           // entry kinds that move in the fade (bit e)
     uint32_t nSlots;         // entries per fade sample after the first: popcount(mask) + (mask & 1)
 };
+struct FlatRef {             // 16 B per frame: what a flat stage needs when the frame's fade starts, in one load (host: setUtterances)
+    uint32_t off;            // first entry of the fade's track (tracks hold fewer than 2^32 entries: 64 GB)
+    uint32_t mask;           // entry kinds that move in the fade
+    uint32_t fadeSamples;
+    uint32_t span;           // samples from this frame's dequeue to the next frame's: max(minSamples, fadeSamples + 1) + 1
+};
+struct SourceRef {           // 32 B per frame: what the flat source stage needs when the frame is dequeued, in two loads (host: setUtterances)
+    double pitch;            // voicePitch (parameter 0)
+    double pitchInc;         // (endVoicePitch - voicePitch) / minSamples     (reference src/frame.cpp:98; the host's division is the device's: IEEE)
+    double invFade;          // 1 / fadeSamples
+    int32_t userIndex;
+    uint32_t flags;          // FRAME_NULL
+};
 struct TrackJob {            // one distinct track, read by klatt_tracks
     unsigned long long off;
     uint32_t fromShape, toShape;    // the fade's end points (index into TrackArgs.shapes)
@@ -122,10 +141,21 @@ struct TrackJob {            // one distinct track, read by klatt_tracks
 __host__ __device__ inline uint32_t track_slots(uint32_t mask) { return (uint32_t)__builtin_popcount(mask) + (mask & 1u); }
 // slot of entry kind e among the entries of a later fade sample / of the first one
 __host__ __device__ inline uint32_t track_slot(uint32_t mask, int e) { return (uint32_t)__builtin_popcount(mask & ((1u << e) - 1u)) + ((e > 0) ? (mask & 1u) : 0u); }
-constexpr int track_first_slot(int e) { return e + (e > 0 ? 1 : 0); }
+constexpr int track_first_slot(int e) { return e + (e > 0 ? 1 : 0); }      // entries of the kinds below e (moving or not)
+// entries of a track's header: the kinds that do not move
+__host__ __device__ inline uint32_t track_header(uint32_t mask) { return (uint32_t)kTrackFirst - track_slots(mask); }
+// where kind e's entry of fade sample 1 sits in the track: in row 0 of the matrix if it moves, in the header if not
+__host__ __device__ inline uint32_t track_entry0(uint32_t mask, int e)
+{
+    const uint32_t s = track_slot(mask, e);
+    return ((mask >> e) & 1u) ? track_header(mask) + s : (uint32_t)track_first_slot(e) - s;
+}
 
 struct KernelArgs {
     const TrackRef* trackRef;    // [nFrames] tracked launches only
+    const FlatRef* flatRef;      // [nFrames] tracked launches only
+    const SourceRef* sourceRef;  // [nFrames] tracked launches only
+    uint32_t trackBytes;         // size of `track` (below 4 GB: the flat stages address it through a buffer descriptor with 32-bit offsets)
     const double2* track;        // the launch's tracks
     const double* frames;        // [nFrames][47]
     const FrameMeta* meta;       // [nFrames]

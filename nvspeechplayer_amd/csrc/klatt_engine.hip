@@ -339,6 +339,8 @@ struct Batch {
     DeviceBuffer<int16_t> dPcm;
     DeviceBuffer<UttResult> dResult;
     DeviceBuffer<TrackRef> dTrackRef;          // [nFrames]
+    DeviceBuffer<FlatRef> dFlatRef;            // [nFrames] the same for the flat filter stages: one 16-byte load per fade start
+    DeviceBuffer<SourceRef> dSourceRef;        // [nFrames] what the flat source stage reads at a dequeue
     DeviceBuffer<TrackJob> dJobs;
     DeviceBuffer<double> dShapes;              // [nShapes][kShapeStride]
     DeviceBuffer<double2> dTrack;
@@ -388,6 +390,7 @@ struct TrackPlan {
     std::vector<TrackJob> jobs;             // one per distinct track
     std::vector<double> shapes;             // [nShapes][kShapeStride]
     std::vector<unsigned char> tracked;     // [nUtterances]
+    std::vector<uint32_t> kinds;            // [nUtterances] the entry kinds whose values change after the first sample of the utterance's first fade (UttDesc.flags)
     unsigned long long entries = 0;
     long long eligible = 0, missedSize = 0, missedBudget = 0;   // utterances that may be tracked; that a fade of 2^27 entries or the budget kept out
 };
@@ -405,7 +408,19 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
     out.jobs.clear();
     out.shapes.clear();
     out.tracked.assign((size_t)nUtterances, 0);
+    out.kinds.assign((size_t)nUtterances, 0);
     out.entries = 0;
+    // the entry kinds whose values differ between two shapes (the comparisons stage_event makes on the device)
+    auto diff_kinds = [](const double* a, const double* c) -> uint32_t {
+        uint32_t mask = 0;
+        for (int r = 0; r < kNumRes; ++r)
+            if (!(c[2 * r] == a[2 * r]) || !(c[2 * r + 1] == a[2 * r + 1])) mask |= 1u << r;
+        for (int e = kNumRes; e < kTrackEntries; ++e) {
+            const int x = entry_value(e, 0), y = entry_value(e, 1);
+            if (!(c[x] == a[x]) || (y >= 0 && !(c[y] == a[y]))) mask |= 1u << e;
+        }
+        return mask;
+    };
     struct Shape { double v[kShapeValues]; bool operator==(const Shape& o) const { return !memcmp(v, o.v, sizeof v); } };
     struct ShapeHash { size_t operator()(const Shape& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (double d : k.v) { unsigned long long w; memcpy(&w, &d, 8); h ^= w; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
     struct Fade { uint32_t from, to, len; bool operator==(const Fade& o) const { return from == o.from && to == o.to && len == o.len; } };
@@ -423,7 +438,8 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
     };
     Shape zero; memset(&zero, 0, sizeof zero);
     shape_id(zero);
-    const unsigned long long budget = (unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2);
+    // (the flat stages address the tracks with 32-bit byte offsets: below 4 GB, 2^28 entries)
+    const unsigned long long budget = std::min((unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2), (1ull << 28) - (1ull << 21) - kTrackPad);
     std::vector<Fade> added;
     long long nEligible = 0, nMissed = 0;
     out.missedSize = 0; out.missedBudget = 0;
@@ -437,8 +453,10 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
         const size_t jobsBefore = out.jobs.size();
         bool fits = true, prevNull = true;
         uint32_t prevId = 0;       // the previous request's values (a fresh handle: all zero = shape 0)
+        uint32_t kinds = 0;
         for (long long k = frameStart[u]; k < frameStart[u + 1] && fits; ++k) {
             uint32_t fromId = prevId, toId;
+            const uint32_t lastTo = prevId;
             Shape to;
             if (meta[k].flags & FRAME_NULL) {
                 memcpy(to.v, &out.shapes[(size_t)prevId * kShapeStride], sizeof to.v);
@@ -457,15 +475,7 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
             auto f = fades.find(key);
             if (f == fades.end()) {
                 // a new fade: what moves in it (the comparisons stage_event makes on the device), its size, its place
-                const double* a = &out.shapes[(size_t)fromId * kShapeStride];
-                const double* c = &out.shapes[(size_t)toId * kShapeStride];
-                uint32_t mask = 0;
-                for (int r = 0; r < kNumRes; ++r)
-                    if (!(c[2 * r] == a[2 * r]) || !(c[2 * r + 1] == a[2 * r + 1])) mask |= 1u << r;
-                for (int e = kNumRes; e < kTrackEntries; ++e) {
-                    const int x = entry_value(e, 0), y = entry_value(e, 1);
-                    if (!(c[x] == a[x]) || (y >= 0 && !(c[y] == a[y]))) mask |= 1u << e;
-                }
+                const uint32_t mask = diff_kinds(&out.shapes[(size_t)fromId * kShapeStride], &out.shapes[(size_t)toId * kShapeStride]);
                 const uint32_t nSlots = track_slots(mask);
                 const unsigned long long n = (unsigned long long)kTrackFirst + (unsigned long long)(meta[k].fadeSamples - 1u) * nSlots;
                 if (n >= (1ull << 27)) { fits = false; ++out.missedSize; break; }
@@ -477,7 +487,13 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
                 out.entries += n;
             }
             out.ref[k - frame0] = f->second;
+            // what changes after the utterance's first fade sample: what a fade moves, and what a later fade's first sample re-sets
+            // to other values than the previous fade ended on (the frame after a silence starts from ITS values, gain gated off)
+            kinds |= f->second.mask;
+            if (k > frameStart[u] && fromId != lastTo)
+                kinds |= diff_kinds(&out.shapes[(size_t)lastTo * kShapeStride], &out.shapes[(size_t)fromId * kShapeStride]);
         }
+        out.kinds[u] = kinds;
         if (fits) out.tracked[u] = 1;
         else {
             for (const Fade& key : added) fades.erase(key);
@@ -572,7 +588,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
             offOf[t].emplace(j.off, it->second);
         }
     }
-    const unsigned long long budget = (unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2);
+    const unsigned long long budget = std::min((unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2), (1ull << 28) - (1ull << 21) - kTrackPad);
     if (out.entries > budget) {
         plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
         return;
@@ -580,6 +596,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     out.eligible = eligibleAll; out.missedSize = missedSize; out.missedBudget = 0;
     out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
     out.tracked.assign((size_t)nUtterances, 0);
+    out.kinds.assign((size_t)nUtterances, 0);
     if (missedSize * 10 > eligibleAll) { out.jobs.clear(); out.entries = 0; return; }   // all or nothing
     run_parts(nThreads, [&](unsigned t) {
         const TrackPlan& p = part[t];
@@ -587,6 +604,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
         for (long long u = cut[t]; u < cut[t + 1]; ++u) {
             if (!p.tracked[u - cut[t]]) continue;
             out.tracked[u] = 1;
+            out.kinds[u] = p.kinds[u - cut[t]];
             for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
                 TrackRef r = p.ref[k - f0];
                 r.off = offOf[t].find(r.off)->second;
@@ -663,13 +681,14 @@ int batch_launch(Batch* b)
         hipLaunchKernelGGL(klatt_tracks, dim3((unsigned)tg), dim3(kLanes * kTrackWaves), 0, st, t);
         HIP_TRY(hipGetLastError());
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nTr;
-        a.trackRef = b->dTrackRef.ptr; a.track = b->dTrack.ptr;
+        a.trackRef = b->dTrackRef.ptr; a.flatRef = b->dFlatRef.ptr; a.sourceRef = b->dSourceRef.ptr; a.track = b->dTrack.ptr;
+        a.trackBytes = (uint32_t)std::min<unsigned long long>(((unsigned long long)b->trackEntries + kTrackPad) * sizeof(double2), 0xFFFFFFFFull);
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
         // flat stages keep nothing but the pipes and the PCM tile in LDS: 16-sample hand-overs fit two workgroups per CU (70 KB each)
         if (pl.chunk == 8 ? launch_systolic<true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true>(a, b->mode, g, st)
                           : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
-        a.trackRef = nullptr; a.track = nullptr;
+        a.trackRef = nullptr; a.flatRef = nullptr; a.sourceRef = nullptr; a.track = nullptr;
     }
     if (nNoisy > 0) {
         a.order = b->dOrder.ptr + b->nQuiet + nTr; a.nSlots = nNoisy;
@@ -1125,7 +1144,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
-    b->dTrackRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
+    b->dTrackRef.release(); b->dFlatRef.release(); b->dSourceRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
     delete b;
 }
 
@@ -1234,6 +1253,33 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         pool += ((long long)len + kTile - 1) / kTile * kTile;
     }
     outStart[nUtterances] = pool;
+    // An utterance's TIMING: a hash of its sequence of frame durations, fades and silences -- the same text at the same speed, whatever
+    // the pitch, the voice or the noise seed.  Lanes with one timing dequeue and fade on the same samples (lane packing, below).
+    std::vector<unsigned long long> timing((size_t)nUtterances);
+    for (long long u = 0; u < nUtterances; ++u) {
+        unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(frameStart[u + 1] - frameStart[u]);
+        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+            h ^= ((unsigned long long)meta[k].minSamples << 32) ^ meta[k].fadeSamples ^ ((unsigned long long)(meta[k].flags & FRAME_NULL) << 63);
+            h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29;
+        }
+        timing[u] = h;
+    }
+    // A quiet utterance whose timing too few others share cannot fill a wavefront of the quiet kernels with lanes that fade together:
+    // its wavefront would run every chunk sample by sample, evaluating exp / cos for whichever lane is fading (a few workgroups that
+    // take longer than the whole flat launch: 24 ms for the 8192 quiet utterances of a batch with 65 536 different timings).  Such an
+    // utterance goes with the noisy ones instead -- same PCM (its noise gains are zero: the sources add exactly 0), flat stages.
+    constexpr long long kQuietRunMin = 32;
+    std::vector<std::pair<long long, uint32_t>> rerouted;      // (utterance, its flags as a quiet one): back to the quiet kernels if it gets no tracks
+    if (b->tracks && nF > 0 && b->layout == -1) {      // (an explicit layout is taken at its word)
+        std::unordered_map<unsigned long long, long long> runOf;
+        for (long long u = 0; u < nUtterances; ++u)
+            if (!(utt[u].flags & UTT_NEEDS_NOISE)) ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)];
+        for (long long u = 0; u < nUtterances; ++u)
+            if (!(utt[u].flags & UTT_NEEDS_NOISE) && runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)] < kQuietRunMin) {
+                rerouted.emplace_back(u, utt[u].flags);
+                utt[u].flags = (utt[u].flags | UTT_NEEDS_NOISE) & ~UTT_NO_NASAL;
+            }
+    }
     // ---- tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite: plan_tracks -----
     TrackPlan plan;
     if (b->tracks && nF > 0) {
@@ -1250,9 +1296,31 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         }
         plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible.data(), b->trackBudgetMB, plan);
         for (long long u = 0; u < nUtterances; ++u)
-            if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED;
+            if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED | (plan.kinds[u] << kUttKindShift);
+    }
+    for (const auto& r : rerouted)
+        if (!(utt[r.first].flags & UTT_TRACKED)) utt[r.first].flags = r.second;
+    if (const char* e = getenv("SPEECHPLAYER_EXP_NEAR")) {      // timing experiment (wrong PCM): every fade reads its rows from the first entries of the track buffer
+        const unsigned long long n = strtoull(e, nullptr, 10);
+        if (n) for (auto& r : plan.ref) r.off %= n;
     }
     std::vector<TrackRef>& trackRef = plan.ref;
+    std::vector<FlatRef> flatRef;
+    std::vector<SourceRef> sourceRef;
+    if (!plan.jobs.empty()) {
+        flatRef.resize((size_t)nF);
+        sourceRef.resize((size_t)nF);
+        for (long long k = 0; k < nF; ++k) {
+            const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
+            flatRef[k] = FlatRef{(uint32_t)plan.ref[k].off, plan.ref[k].mask, meta[k].fadeSamples, (uint32_t)std::min<unsigned long long>(std::max(m, f + 1) + 1, 0xFFFFFFFFull)};
+            const bool isNullFrame = (meta[k].flags & FRAME_NULL) != 0;
+            const double* p = reinterpret_cast<const double*>(frames + k);
+            const double g0 = isNullFrame ? 0.0 : p[0], g46 = isNullFrame ? 0.0 : p[46];
+            // (volatile: the divisions are IEEE double divisions at run time, like the kernels' -- nothing folded, nothing reassociated)
+            volatile double num = g46 - g0, den = (double)meta[k].minSamples, one = 1.0, fd = (double)meta[k].fadeSamples;
+            sourceRef[k] = SourceRef{g0, isNullFrame ? 0.0 : num / den, one / fd, meta[k].userIndex, meta[k].flags & FRAME_NULL};
+        }
+    }
     std::vector<TrackJob>& jobs = plan.jobs;
     const unsigned long long trackEntries = plan.entries;
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
@@ -1270,15 +1338,6 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
         // Within a group: longest first, and utterances with the same TIMING (the same sequence of frame durations, fades and
         // silences: the same text at the same speed, whatever the pitch, the voice or the noise seed) side by side.  Lanes
         // with one timing dequeue and fade on the same samples, so their wavefront runs whole chunks on the uniform paths.
-        std::vector<unsigned long long> timing((size_t)nUtterances);
-        for (long long u = 0; u < nUtterances; ++u) {
-            unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(frameStart[u + 1] - frameStart[u]);
-            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
-                h ^= ((unsigned long long)meta[k].minSamples << 32) ^ meta[k].fadeSamples ^ ((unsigned long long)(meta[k].flags & FRAME_NULL) << 63);
-                h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29;
-            }
-            timing[u] = h;
-        }
         auto before = [&](uint32_t x, uint32_t y) { return lens[x] != lens[y] ? lens[x] > lens[y] : timing[x] < timing[y]; };
         std::stable_sort(order.begin(), noNasalEnd, before);
         std::stable_sort(noNasalEnd, quietEnd, before);
@@ -1320,10 +1379,12 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
             b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
         if (nTrackedUtt > 0) {
-            if (b->dTrackRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
+            if (b->dTrackRef.reserve((size_t)nF) || b->dFlatRef.reserve((size_t)nF) || b->dSourceRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
                 b->dTrack.reserve((size_t)trackEntries + kTrackPad)) return -1;
             HIP_TRY(hipMemcpyAsync(b->dShapes.ptr, plan.shapes.data(), plan.shapes.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dTrackRef.ptr, trackRef.data(), (size_t)nF * sizeof(TrackRef), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dFlatRef.ptr, flatRef.data(), (size_t)nF * sizeof(FlatRef), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dSourceRef.ptr, sourceRef.data(), (size_t)nF * sizeof(SourceRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dJobs.ptr, jobs.data(), jobs.size() * sizeof(TrackJob), hipMemcpyHostToDevice, b->stream));
         }
         if (nF) {

@@ -59,6 +59,9 @@ namespace klatt {
 #define KLATT_STR2(x) #x
 #define KLATT_STR(x) KLATT_STR2(x)
 
+#ifndef KLATT_EXP
+#define KLATT_EXP 0             // timing experiments of the flat stages (wrong PCM): 1 rows without loads, 4 no fade ever starts; (same PCM) 8 every chunk a mixed one
+#endif
 #ifndef KLATT_FLAT_EXHAUSTIVE
 #define KLATT_FLAT_EXHAUSTIVE 1 // flat launches: the final stage is the chain's unconditional last branch, so that the compiler sees that a flat launch
                                 // runs none of the untracked stages (it cannot tell that a stage number is 0..3): the kernel is half the code, 245
@@ -139,6 +142,8 @@ struct StageCtx {          // what every stage needs from the launch
     const double* myFrames;
     const FrameMeta* myMeta;
     const TrackRef* myTrack;   // flat launches: the utterance's per-frame track references
+    const FlatRef* myFlat;     // flat launches: the same in the form the filter stages load ahead (klatt_device.h)
+    const SourceRef* mySrc;    // flat launches: what the source stage loads ahead
 };
 
 // OR over the wavefront of the low NBITS bits of a per-lane mask, as a wave-uniform (scalar) value.
@@ -744,14 +749,20 @@ __device__ __forceinline__ void flat_begin(FlatState<FD>& f, const StageCtx& X, 
     const double2* const base = X.A.track + tr.off;
     double2 v[FD::NE];
     double a0 = 0.0;
+#if KLATT_EXP & 2      // timing experiment (wrong PCM): a fade's first row costs no memory access
 #pragma unroll
-    for (int e = 0; e < FD::NE; ++e) v[e] = base[track_first_slot(GE[e])];
-    if (FD::ANTI0) a0 = base[track_first_slot(GE[0]) + 1].x;
+    for (int e = 0; e < FD::NE; ++e) v[e] = e < FD::NRES ? make_double2((double)f.rb[e], (double)f.rc[e]) : make_double2((double)f.cur[2 * (e - FD::NRES)], (double)f.cur[2 * (e - FD::NRES) + 1]);
+    if (FD::ANTI0) a0 = (double)f.ra[0];
+#else
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) v[e] = base[track_entry0(tr.mask, GE[e])];
+    if (FD::ANTI0) a0 = base[track_entry0(tr.mask, GE[0]) + 1].x;
+#endif
 #pragma unroll
     for (int e = 0; e < FD::NE; ++e) {
         flat_take<FD>(f, e, v[e], a0);
         const bool moves = (tr.mask >> GE[e]) & 1u;
-        f.tp[e] = base + (moves ? (uint32_t)kTrackFirst + track_slot(tr.mask, GE[e]) : (uint32_t)track_first_slot(GE[e]));
+        f.tp[e] = base + (track_entry0(tr.mask, GE[e]) + (moves ? tr.nSlots : 0u));      // a kind that moves: its entry in the matrix's next row
         f.ts[e] = moves ? tr.nSlots : 0u;
     }
     uint32_t mine = 0;
@@ -771,9 +782,19 @@ __device__ __forceinline__ void flat_next(FlatState<FD>& f)
 {
     double2 v[FD::NE];
     double a0 = 0.0;
+#if KLATT_EXP & 1      // timing experiment (wrong PCM): a later row costs no memory access
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e)
+        if (SET & (1u << e)) {
+            v[e] = e < FD::NRES ? make_double2((double)f.rb[e], (double)f.rc[e]) : make_double2((double)f.cur[2 * (e - FD::NRES)], (double)f.cur[2 * (e - FD::NRES) + 1]);
+            if (FD::ANTI0 && e == 0) a0 = (double)f.ra[0];
+            f.tp[e] += f.ts[e];
+        }
+#else
 #pragma unroll
     for (int e = 0; e < FD::NE; ++e)
         if (SET & (1u << e)) { v[e] = f.tp[e][0]; if (FD::ANTI0 && e == 0) a0 = f.tp[e][1].x; f.tp[e] += f.ts[e]; }
+#endif
 #pragma unroll
     for (int e = 0; e < FD::NE; ++e)
         if (SET & (1u << e)) flat_take<FD>(f, e, v[e], a0);
@@ -878,6 +899,275 @@ __device__ __forceinline__ void flat_loop(int depth, int nIter, int nChunks, int
     (void)stampSlot;
 }
 
+
+// ---- flat filter stages, second form (round 3): rows loaded one sample ahead, straight into the coefficients ---------------------
+// The sample-by-sample path above pays, on every sample in which ANY lane fades: two ballots and two divergent blocks, the row's
+// loads, their full latency (a wait right behind them, ~900 cycles with the tracks beyond the L2) and then the filters, in a
+// rolled loop that keeps every sample's operations apart.  Measured with the loads taken out (wrong PCM, -DKLATT_EXP=3): the
+// all-different batch 32.6 -> 24.7 ms against 9.2 for the aligned one -- the structure costs more than the latency.  This form
+// has ONE kind of chunk besides the steady one:
+//   * a lane's fade state is a row counter (`left`) and an entry index + stride per kind; with the track layout of klatt_device.h
+//     (header + matrix) the first fade sample is a row like any other, so a fade start is one switch of the indices;
+//   * on sample t the rows of sample t + 1 are loaded: for each kind right after its LAST use in sample t, under the mask of the
+//     lanes that have a row, straight into the registers the filters read (no staging registers, no copies): the loads have a whole
+//     sample's arithmetic (and the SIMD's other wave) to arrive;
+//   * a = 1 - b - c is derived where it is used (two operations; for a lane without a new row it reproduces the value it had), so
+//     nothing has to wait for a row at the top of a sample; steady chunks keep `a` in registers as before (re-derived once after
+//     a mixed stretch);
+//   * the filters run unmasked for every lane (a lane past its end computes into its own pipe slots and tile row, which nobody
+//     reads: rowCount / produced bound what is flushed), so a sample is straight-line code between the masked loads;
+//   * what a fade start needs (track, mask, length, distance to the next start) is ONE 16-byte FlatRef, loaded when the PREVIOUS
+//     fade starts.
+#ifndef KLATT_FLAT_V2
+#define KLATT_FLAT_V2 1
+#endif
+#ifndef KLATT_MIX_UNROLL
+#define KLATT_MIX_UNROLL 4
+#endif
+template <int E> using KindTag = std::integral_constant<int, E>;
+typedef unsigned int flat_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned int flat_u2 __attribute__((ext_vector_type(2)));
+typedef double flat_d2 __attribute__((ext_vector_type(2)));
+template <class FD>
+struct FlatState2 {
+    static constexpr int NR = FD::NRES > 0 ? FD::NRES : 1;
+    using R = typename FD::R;
+    R ra[NR], rb[NR], rc[NR], z1[NR], z2[NR];
+    R cur[2 * FD::NGAIN > 0 ? 2 * FD::NGAIN : 1];
+    uint32_t idx[FD::NE], stride[FD::NE];      // per kind: byte offset of its next entry in the launch's tracks, bytes per row (0: the kind does not move)
+    uint32_t startAt, left, next, nFrames, length, produced;      // startAt: the sample the next fade's first row applies to; left: rows of the running fade not yet loaded
+    FlatRef nextRef;                            // frame `next`'s fade, loaded ahead
+    uint32_t wmask;                             // wave-uniform: bit e -- kind GE[e] changes, in some lane of the wavefront, after the first sample of the first fade
+    bool live;
+};
+template <class R> struct ResPre { R a, p1, p2; };      // a resonator's first half (res_pre below)
+template <class T> __device__ __forceinline__ void flat_pin(T v) { asm volatile("" :: "v"(v) : "memory"); }
+template <class R> __device__ __forceinline__ void flat_pin(const ResPre<R>& q) { asm volatile("" :: "v"(q.a), "v"(q.p1), "v"(q.p2) : "memory"); }
+// OR over the wavefront of the utterances' kind masks (UttDesc.flags), restricted to a stage's kinds: bit e <- kind GE[e]
+template <int NE>
+__device__ __forceinline__ uint32_t flat2_wave_kinds(uint32_t flags, bool live, const int* GE)
+{
+    const uint32_t mine = live ? (flags >> kUttKindShift) : 0u;
+    uint32_t w = 0;
+#pragma unroll
+    for (int e = 0; e < NE; ++e) w |= __any((mine >> GE[e]) & 1u) ? (1u << e) : 0u;
+    return w;
+}
+template <class FD>
+__device__ __forceinline__ void flat2_init(FlatState2<FD>& f, bool live, const UttDesc& d, const StageCtx& X, const int* GE)
+{
+#pragma unroll
+    for (int r = 0; r < FD::NRES; ++r) { f.ra[r] = 0; f.rb[r] = 2; f.rc[r] = -1; f.z1[r] = 0; f.z2[r] = 0; }
+#pragma unroll
+    for (int k = 0; k < 2 * FD::NGAIN; ++k) f.cur[k] = 0;
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) { f.idx[e] = 0; f.stride[e] = 0; }
+    f.live = live && d.length > 0u;
+    f.nFrames = d.nFrames; f.length = d.length; f.next = 0; f.left = 0; f.produced = 0;
+    const bool any = live && d.nFrames > 0u;
+    f.startAt = any ? 1u : 0xFFFFFFFFu;      // frame 0 is dequeued on sample 0, its fade's first row applies to sample 1
+    f.nextRef = FlatRef{0u, 0u, 1u, 0u};
+    if (any) f.nextRef = X.myFlat[0];
+    f.wmask = (uint32_t)__builtin_amdgcn_readfirstlane((int)flat2_wave_kinds<FD::NE>(d.flags, live, GE));
+}
+// the fade of frame `next` starts with the coming sample: point every kind at its entries, load the following frame's reference
+template <class FD>
+__device__ __forceinline__ void flat2_switch(FlatState2<FD>& f, const StageCtx& X, const int* GE)
+{
+    const FlatRef p = f.nextRef;
+    const uint32_t nSlots = track_slots(p.mask), hdr = (uint32_t)kTrackFirst - nSlots;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) {
+        const bool moves = (p.mask >> GE[e]) & 1u;
+        const uint32_t s = track_slot(p.mask, GE[e]);
+        f.idx[e] = (p.off + (moves ? hdr + s : (uint32_t)track_first_slot(GE[e]) - s)) * 16u;
+        f.stride[e] = moves ? nSlots * 16u : 0u;
+        mine |= moves ? 1u : 0u;
+    }
+    f.left = mine ? p.fadeSamples : 1u;        // a fade that moves nothing of this stage: its first row only
+    f.next++;
+    const bool more = f.next < f.nFrames;
+    f.startAt = more ? f.startAt + p.span : 0xFFFFFFFFu;
+    // The following frame's reference, loaded now and read when ITS fade starts.  Everything that reads the current one is pinned
+    // before the load (an asm statement with those values as inputs, clobbering memory): its registers are then dead and the load
+    // lands in them -- hoisted above, it would land in temporaries and be moved home behind a wait at the end of this block.
+#pragma unroll
+    for (int e = 0; e < FD::NE; ++e) { flat_pin(f.idx[e]); flat_pin(f.stride[e]); }
+    flat_pin(f.left); flat_pin(f.startAt);
+    f.nextRef = X.myFlat[more ? f.next : f.nFrames - 1u];      // (past the last frame: any valid frame; never read)
+}
+// Called by a stage's sample BETWEEN its two halves: the first half has read every coefficient and gain (a = 1 - b - c, the
+// products b * z1 and c * z2 -- which depend on the previous samples only --, copies of the gains); here the lanes with a row for the
+// NEXT sample load it, all kinds in one masked block, straight into the registers the first half reads; the second half (the
+// chains through the sample's input) runs while the loads are in flight.  `firstHalf`: the values of the first half -- empty asm
+// statements (inputs: those values; clobber: memory) keep the compiler from hoisting the loads above the first half (it would
+// have to copy the old values aside) and from sinking the first half below them.  SET (compile time): the kinds loaded -- a
+// chunk runs the instantiation for the stage's USUAL kinds when no lane of the wavefront ever changes another one, else the
+// one for all kinds (a wave-uniform test per kind and sample cost more in branches than the loads it saved).
+template <class FD, uint32_t SET>
+struct FlatMid {
+    FlatState2<FD>& f;
+    __amdgpu_buffer_rsrc_t rsrc;
+    bool has;
+    template <class... T>
+    __device__ __forceinline__ void operator()(T... firstHalf) const
+    {
+        using R = typename FD::R;
+        (flat_pin(firstHalf), ...);
+#if KLATT_EXP & 1      // timing experiment (wrong PCM): rows cost no memory access
+        if (has) {
+#pragma unroll
+            for (int e = 0; e < FD::NE; ++e) if (SET & (1u << e)) f.idx[e] += f.stride[e];
+        }
+        return;
+#endif
+        if (has) {
+#pragma unroll
+            for (int e = 0; e < FD::NE; ++e) {
+                if (!(SET & (1u << e))) continue;
+                const uint32_t off = f.idx[e];
+                const flat_d2 v = __builtin_bit_cast(flat_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+                if (e < FD::NRES) {
+                    f.rb[e < FD::NRES ? e : 0] = (R)v.x; f.rc[e < FD::NRES ? e : 0] = (R)v.y;
+                    if (FD::ANTI0 && e == 0) f.ra[0] = (R)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0));
+                } else {
+                    const int g = e < FD::NRES ? 0 : e - FD::NRES;
+                    f.cur[2 * g] = (R)v.x; f.cur[2 * g + 1] = (R)v.y;
+                }
+                f.idx[e] = off + f.stride[e];
+            }
+        }
+    }
+};
+struct NoMid { template <class... T> __device__ __forceinline__ void operator()(T...) const {} };
+// A resonator's sample in two halves.  First half (before the rows of the next sample are loaded over b and c): a -- DERIVEd from
+// b and c in a chunk that loads the resonator's kind, else the register -- and the two products that do not depend on the
+// sample's input.  Second half: ((a * in) + (b * z1)) + (c * z2), the reference's order
+// (src/speechWaveGenerator.cpp:131); MODE_FAST fuses, so its first half only sets b and c aside.
+template <int MODE, bool DERIVE, class R>
+__device__ __forceinline__ ResPre<R> res_pre(R ra, R rb, R rc, R z1, R z2)
+{
+    ResPre<R> p;
+    p.a = DERIVE ? (R)((R)1 - rb - rc) : ra;
+    if (MODE == MODE_FAST || !std::is_same<R, double>::value) { p.p1 = rb; p.p2 = rc; }
+    else { p.p1 = rb * z1; p.p2 = rc * z2; }
+    return p;
+}
+template <int MODE, class R>
+__device__ __forceinline__ R res_post(const ResPre<R>& p, R in, R& z1, R& z2)
+{
+    R y;
+    if (MODE == MODE_FAST || !std::is_same<R, double>::value) y = dot3<MODE>(p.a, in, p.p1, z1, p.p2, z2);
+    else y = p.a * in + p.p1 + p.p2;
+    z2 = z1; z1 = y;
+    return y;
+}
+
+// body(c, i, std::bool_constant<MIXED>, gate, mid): one sample of the stage; same barrier discipline as flat_loop
+template <class FD, int CH, class FBody, class FChunk>
+__device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, int stampSlot, FlatState2<FD>& f, const StageCtx& X, const int* GE, FBody body, FChunk perChunk)
+{
+#ifdef KLATT_STAMPS
+    Stamps st;
+#endif
+    using R = typename FD::R;
+    uint32_t staleG = 0;       // wave-uniform: the kinds whose `a` in registers predates the last rows (mixed chunks derive it on the fly)
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(X.A.track), 0, (int)X.A.trackBytes, 0x00020000);
+    for (int iter = 0; iter < nIter; ++iter) {
+        STAMP_BEGIN();
+        STAMP_IDLE();
+        const int c = iter - depth;
+        if (c >= 0 && c < nChunks) {
+            const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
+            if (f.length <= t0) f.live = false;                               // this lane has emitted its last sample
+            // a chunk is steady when no lane loads a row in it: none pending, no fade whose first row applies to t0 + 1 .. t1
+            const bool busy = (KLATT_EXP & 8) || f.left > 0u || f.startAt <= t1;      // (timing experiment 8: every chunk a mixed one)
+            if (!__any(busy)) {
+                if (staleG) {
+#pragma unroll
+                    for (int r = (FD::ANTI0 ? 1 : 0); r < FD::NRES; ++r)
+                        if (staleG & (1u << r)) f.ra[r] = (R)((R)1 - f.rb[r] - f.rc[r]);
+                    staleG = 0;
+                }
+                // decided once: the chunks until some live lane's next fade comes into reach run in a tight loop
+                uint32_t run = f.live ? (f.startAt - t0 - 1u) / (uint32_t)CH : 0xFFFFFFFFu;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
+                run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                const uint32_t room = (uint32_t)(nChunks - c);
+                run = run < room ? run : room;
+                run = run < 1u ? 1u : run;
+                int cc = c;
+                STAMP_KIND(0);
+                for (uint32_t q = 1; q < run; ++q) {
+                    if (f.live) {
+#pragma unroll
+                        for (int i = 0; i < CH; ++i) body(cc, i, std::integral_constant<uint32_t, 0u>{}, NoMid{});
+                    }
+                    { const uint32_t e1 = (uint32_t)(cc + 1) * (uint32_t)CH; f.produced = f.length < e1 ? f.length : e1; }
+                    perChunk();
+                    STAMP_WORKED();
+                    __syncthreads();
+                    STAMP_SYNCED();
+                    STAMP_BEGIN();
+                    ++iter; ++cc;
+                }
+                if (f.live) {
+#pragma unroll
+                    for (int i = 0; i < CH; ++i) body(cc, i, std::integral_constant<uint32_t, 0u>{}, NoMid{});
+                }
+                { const uint32_t e1 = (uint32_t)(cc + 1) * (uint32_t)CH; f.produced = f.length < e1 ? f.length : e1; }
+                perChunk();
+                STAMP_WORKED();
+                __syncthreads();
+                STAMP_SYNCED();
+                continue;
+            }
+            STAMP_KIND(-1);
+            // The kinds loaded in this chunk: every one in chunk 0 (the first fade's first row sets them all); afterwards the stage's
+            // usual ones when no lane of the wavefront ever changes another kind (f.wmask), else every one again.
+            auto mixedChunk = [&](auto setTag) __attribute__((always_inline)) {
+                constexpr uint32_t SET = decltype(setTag)::value;
+                const uint32_t fix = staleG & ~SET;      // kinds loaded in earlier chunks and not in this one: their `a` goes back to the register
+                if (fix) {
+#pragma unroll
+                    for (int r = (FD::ANTI0 ? 1 : 0); r < FD::NRES; ++r)
+                        if (fix & (1u << r)) f.ra[r] = (R)((R)1 - f.rb[r] - f.rc[r]);
+                    staleG &= SET;
+                }
+                staleG |= SET;
+#pragma unroll KLATT_MIX_UNROLL
+                for (int i = 0; i < CH; ++i) {
+                    const uint32_t tn = t0 + (uint32_t)i + 1u;            // the sample whose rows this one loads
+                    const bool starts = tn == f.startAt;
+#if !(KLATT_EXP & 4)      // (timing experiment 4, wrong PCM: no fade ever starts)
+                    if (__any(starts)) { if (starts) flat2_switch<FD>(f, X, GE); }
+#endif
+                    const bool has = f.left > 0u;
+                    body(c, i, setTag, FlatMid<FD, SET>{f, rsrc, has});
+                    if (has) f.left--;
+                }
+            };
+            constexpr uint32_t ALL = (1u << FD::NE) - 1u;
+            if (FD::USUAL != 0u && FD::USUAL != ALL && c != 0 && (f.wmask & ~FD::USUAL) == 0u) mixedChunk(std::integral_constant<uint32_t, FD::USUAL>{});
+            else mixedChunk(std::integral_constant<uint32_t, ALL>{});
+            f.produced = f.length < t1 ? f.length : t1;
+            perChunk();
+        }
+        STAMP_WORKED();
+        __syncthreads();
+        STAMP_SYNCED();
+    }
+#ifdef KLATT_STAMPS
+    if (X.A.debug && (threadIdx.x & (kLanes - 1)) == 0) {
+        unsigned long long* o = X.A.debug + (blockIdx.x * 4 + stampSlot) * 8;
+        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
+    }
+#endif
+    (void)stampSlot;
+}
+
 // ---- the kernel ---------------------------------------------------------------------------
 // NASAL = false (quiet launches only): every utterance of the launch is nasal-free (UTT_NO_NASAL, classified on the
 // host): caNP == 0 in every frame with bounded, stable N0/NP parameters.  The cascade input then passes the nasal pair
@@ -919,7 +1209,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     UttDesc d;
     d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
-    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart, FLAT ? A.trackRef + d.frameStart : nullptr};
+    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart, FLAT ? A.trackRef + d.frameStart : nullptr,
+                     FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr};
     const uint32_t nkey = noise_key(d.seed);
     constexpr int FINAL = NOISE ? 2 : 3;
     // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out
@@ -972,6 +1263,157 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     auto noChunk = [&]() __attribute__((always_inline)) {};
 
     if (FLAT && KLATT_FLAT_SOURCE && stage == 0) {
+#if KLATT_FLAT_V2
+        // ================= flat S0, second form: the source stage with its rows loaded one sample ahead (see flat2_loop) =================
+        // Its seven parameters come from the tracks (entry kinds 20..23); what stays here is the pitch, which glides with the sample
+        // count of THIS utterance (reference src/frame.cpp:76-79, :98, :71) and so cannot be shared.  Frame k is dequeued on sample
+        // T_k (the sample before its fade's first row: the stage's `startAt - 1`); per sample a lane is dequeuing (sets up the pitch
+        // fade and the rows; the sample itself is emitted unchanged), fading (pitch interpolated), ending its fade (bookkeeping) or
+        // steady (glide).  What a dequeue reads (durations, index mark, the frame's two pitch values, the FlatRef) was loaded when the
+        // previous frame was dequeued.
+        if constexpr (FLAT) {
+            using FD = FlatDesc<0, 4, false, 0, 0, double>;
+            constexpr int GE[4] = {20, 21, 22, 23};     // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain
+            FlatState2<FD> f;
+            flat2_init<FD>(f, live, d, X, GE);
+            PitchState ps;
+            ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
+            double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, invFade = 1.0, nfD = 1.0;
+            uint32_t noiseSt = noise_first(nkey), cntF = 0, nfU = 0;    // noiseSt: the state of this stage's next noise value (aspiration: values 0, 2, 4, ...); cntF of nfU pitch-fade samples done
+            uint32_t fadeEndAt = 0xFFFFFFFFu;
+            int32_t lastIndex = -1;
+            bool oldNull = true, newNull = false;
+            SourceRef nextSrc{0.0, 0.0, 1.0, -1, 0u};     // frame `f.next`, loaded ahead like f.nextRef
+            if (live && d.nFrames > 0u) nextSrc = X.mySrc[0];
+            auto source = [&](bool waveVib, const auto& mid) __attribute__((always_inline)) -> double {
+                double vib = 1.0;
+                if (waveVib) {
+                    const double vs = f.cur[1];
+                    const double adv = frac_toward_zero(div_by(vs, A.sampleRateF, A.invSampleRate) + vibPhase);
+                    vibPhase = (vs != 0.0) ? adv : vibPhase;
+                    vib = (sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[0]) + 1.0;
+                }
+                const double turbGain = f.cur[2], openQ = f.cur[3], voiceAmp = f.cur[4], aspAmp = f.cur[5], preGain = f.cur[6];
+                pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
+                double voice = (pitchPhase * 2.0) - 1.0;
+                aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
+                noiseSt = noise_step2(noiseSt);
+                double asp = aspNoise * 0.2;
+                double turb = asp * turbGain;
+                turb = (pitchPhase >= openQ) ? turb : turb * 0.01;
+                voice += turb;
+                voice *= voiceAmp;
+                asp *= aspAmp;
+                const double src = asp + voice;
+                const double out = (src * preGain) * 0.5;
+                mid(out);            // the next sample's rows (flat2_loop): every parameter has been read; they land while the next sample's pitch, phase and noise are computed
+                return out;
+            };
+            auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase; };
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(A.track), 0, (int)A.trackBytes, 0x00020000);
+#ifdef KLATT_STAMPS
+            Stamps st;
+#endif
+            for (int iter = 0; iter < nIter; ++iter) {
+                STAMP_BEGIN();
+                STAMP_IDLE();
+                const int c = iter;
+                if (c < nChunks) {
+                    const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
+                    if (f.length <= t0) f.live = false;
+                    const bool busy = (KLATT_EXP & 8) || f.left > 0u || f.startAt <= t1 || cntF < nfU || fadeEndAt < t1 || vib_live();
+                    STAMP_KIND(__any(busy) ? -1 : 0);
+                    if (!__any(busy)) {
+                        // steady stretch, decided once (as in flat2_loop): the pitch glides, nothing else changes
+                        uint32_t run = f.live ? (f.startAt - t0 - 1u) / (uint32_t)CH : 0xFFFFFFFFu;
+#pragma unroll
+                        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
+                        run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                        const uint32_t room = (uint32_t)(nChunks - c);
+                        run = run < room ? run : room;
+                        run = run < 1u ? 1u : run;
+                        int cc = c;
+                        for (uint32_t q = 0; q < run; ++q) {
+                            if (f.live) {
+#pragma unroll
+                                for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; PIPE(pipeX, cc, i) = source(false, NoMid{}); }
+                                ps.old0 = ps.cur0;
+                            }
+                            if (q + 1 < run) { STAMP_WORKED(); __syncthreads(); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; }
+                        }
+                    } else {
+                        // the kinds loaded in this chunk (as in flat2_loop): all in chunk 0, afterwards the usual two -- the amplitudes and
+                        // the gain -- when no lane of the wavefront ever changes vibrato, turbulence or the open quotient
+                        auto mixedChunk = [&](auto setTag) __attribute__((always_inline)) {
+                        constexpr uint32_t SET = decltype(setTag)::value;
+                        // vibrato can only come alive in this chunk through a row of its kind (the phase only turns NaN while it advances)
+                        const bool vibChunk = (SET & 1u) != 0u || __any(vib_live());
+#pragma unroll KLATT_MIX_UNROLL
+                        for (int i = 0; i < CH; ++i) {
+                            const uint32_t t = t0 + (uint32_t)i;
+                            const bool deq = t + 1u == f.startAt;
+                            if (!(KLATT_EXP & 4) && __any(deq)) {
+                                if (deq) {   // reference src/frame.cpp:55-72 (stage_event restates it); the sample itself is emitted as it is
+                                    const SourceRef m = nextSrc;
+                                    const uint32_t nf = f.nextRef.fadeSamples;
+                                    newNull = (m.flags & FRAME_NULL) != 0;
+                                    ps.new0 = newNull ? ps.cur0 : m.pitch;
+                                    ps.newInc = newNull ? 0.0 : m.pitchInc;                // reference src/frame.cpp:98 (the division: host)
+                                    if (!newNull && oldNull) ps.old0 = m.pitch;
+                                    oldNull = newNull;                                    // for the NEXT dequeue: this fade has ended by then (:44-47)
+                                    if (m.userIndex != -1) lastIndex = m.userIndex;       // (:69)
+                                    nfD = (double)nf; nfU = nf;
+                                    ps.new0 += ps.newInc * nfD;                           // (:71)
+                                    invFade = m.invFade;
+                                    cntF = 0;
+                                    fadeEndAt = t + nf + 1u;
+                                    flat_pin(ps.new0); flat_pin(ps.newInc); flat_pin(ps.old0); flat_pin(invFade); flat_pin(lastIndex); flat_pin(oldNull);
+                                    flat2_switch<FD>(f, X, GE);                           // the rows: the first one applies to sample t + 1
+                                    nextSrc = X.mySrc[f.next < f.nFrames ? f.next : f.nFrames - 1u];
+                                }
+                            }
+                            // the pitch of this sample, as selects (every lane computes both candidates: cheaper than three masked blocks):
+                            // fading -> interpolated; the sample after the fade -> the fade's target becomes the glide's start; steady -> glide
+                            // (reference src/frame.cpp:48-53, :44-47, :76-79); a dequeuing lane leaves it alone
+                            const bool fad = !deq && cntF < nfU;
+                            const bool ending = !deq && !fad && t == fadeEndAt;
+                            const bool glide = !deq && !fad && !ending;
+                            const uint32_t cn = cntF + 1u;
+                            const double ratio = div_by((double)cn, nfD, invFade);
+                            const double fv = fade_value(ps.old0, ps.new0, ratio);
+                            const double gv = ps.cur0 + ps.oldInc;
+                            ps.cur0 = fad ? fv : (glide ? gv : ps.cur0);
+                            ps.old0 = ending ? ps.new0 : (glide ? gv : ps.old0);
+                            ps.oldInc = ending ? ps.newInc : ps.oldInc;
+                            cntF = fad ? cn : cntF;
+                            fadeEndAt = ending ? 0xFFFFFFFFu : fadeEndAt;
+                            const bool waveVib = vibChunk && __any(vib_live());
+                            const bool has = f.left > 0u;
+                            PIPE(pipeX, c, i) = source(waveVib, FlatMid<FD, SET>{f, rsrc, has});
+                            if (has) f.left--;
+                        }
+                        };
+                        if (c != 0 && (f.wmask & ~0xCu) == 0u) mixedChunk(std::integral_constant<uint32_t, 0xCu>{});
+                        else mixedChunk(std::integral_constant<uint32_t, 0xFu>{});
+                    }
+                }
+                STAMP_WORKED();
+                __syncthreads();
+                STAMP_SYNCED();
+            }
+#ifdef KLATT_STAMPS
+            if (A.debug && lane == 0) {
+                unsigned long long* o = A.debug + (blockIdx.x * 4 + 0) * 8;
+                o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
+            }
+#endif
+            if (live) {
+                UttResult res;
+                res.produced = d.length; res.framesTaken = f.next; res.lastIndex = lastIndex; res.drained = 1u;
+                A.result[u] = res;
+            }
+        }
+#else
         // ================= flat S0: the source stage without the chunk machinery of stage_loop =================
         // Its seven parameters come from the tracks (entry kinds 20..23); what stays here is the pitch, which glides with the sample
         // count of THIS utterance (reference src/frame.cpp:76-79, :98, :71) and so cannot be shared: per lane the sample of the next
@@ -1081,7 +1523,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                                     cntF = 0;
                                     tBase = X.A.track + tr.off; fmask = tr.mask; fslots = tr.nSlots;
 #pragma unroll
-                                    for (int e = 0; e < FD::NE; ++e) { f.tp[e] = tBase + track_first_slot(GE[e]); f.ts[e] = 0u; }
+                                    for (int e = 0; e < FD::NE; ++e) { f.tp[e] = tBase + track_entry0(fmask, GE[e]); f.ts[e] = 0u; }
                                     f.left = m.fadeSamples; first = true; rows = true;
                                     fadeEndAt = t + m.fadeSamples + 1u;
                                     const uint32_t span = (m.minSamples > m.fadeSamples + 1u ? m.minSamples : m.fadeSamples + 1u) + 1u;
@@ -1103,7 +1545,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                                         for (int e = 0; e < FD::NE; ++e) {
                                             const bool moves = (fmask >> GE[e]) & 1u;
                                             mine |= moves ? 1u : 0u;
-                                            if (moves) { f.tp[e] = tBase + ((uint32_t)kTrackFirst + track_slot(fmask, GE[e])); f.ts[e] = fslots; }
+                                            if (moves) { f.tp[e] = tBase + (track_entry0(fmask, GE[e]) + fslots); f.ts[e] = fslots; }
                                         }
                                         rows = mine != 0u;
                                     }
@@ -1133,6 +1575,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 A.result[u] = res;
             }
         }
+#endif
     } else if (stage == 0) {
         // ================= S0: frame + glottal source (+ aspiration noise) =================
         // tracked: 1 vibratoPitchOffset, 2 vibratoSpeed, 3 turbulence, 4 openQuotient, 5 voiceAmplitude,
@@ -1267,6 +1710,36 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         }
     } else if (FLAT && stage == 1) {
         // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 =================
+#if KLATT_FLAT_V2
+        if constexpr (FLAT) {
+            using FD = FlatDesc<5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
+            constexpr int GE[6] = {0, 1, 2, 3, 4, 14};           // N0, NP, r6, r5, r4 | cur: caNP
+            FlatState2<FD> f;
+            flat2_init<FD>(f, live, d, X, GE);
+            flat2_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
+                [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
+                    constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
+                    const ResPre<sig_t> q0 = res_pre<MODE, false>(f.ra[0], f.rb[0], f.rc[0], f.z1[0], f.z2[0]);      // N0's a comes from the track
+                    const ResPre<sig_t> q1 = res_pre<MODE, ((SET >> 1) & 1u) != 0u>(f.ra[1], f.rb[1], f.rc[1], f.z1[1], f.z2[1]);
+                    const ResPre<sig_t> q2 = res_pre<MODE, ((SET >> 2) & 1u) != 0u>(f.ra[2], f.rb[2], f.rc[2], f.z1[2], f.z2[2]);
+                    const ResPre<sig_t> q3 = res_pre<MODE, ((SET >> 3) & 1u) != 0u>(f.ra[3], f.rb[3], f.rc[3], f.z1[3], f.z2[3]);
+                    const ResPre<sig_t> q4 = res_pre<MODE, ((SET >> 4) & 1u) != 0u>(f.ra[4], f.rb[4], f.rc[4], f.z1[4], f.z2[4]);
+                    const sig_t caNP = f.cur[0];
+                    mid(q0, q1, q2, q3, q4, caNP);
+                    const sig_t x = PIPE(pipeX, c, i);
+                    sig_t zin = f.z1[0];
+                    const sig_t n0 = res_post<MODE>(q0, x, zin, f.z2[0]);       // the anti-resonator remembers its INPUT (:133)
+                    f.z1[0] = x;
+                    const sig_t np = res_post<MODE>(q1, n0, f.z1[1], f.z2[1]);
+                    sig_t o = fade_value(x, np, caNP);
+                    o = res_post<MODE>(q2, o, f.z1[2], f.z2[2]);
+                    o = res_post<MODE>(q3, o, f.z1[3], f.z2[3]);
+                    o = res_post<MODE>(q4, o, f.z1[4], f.z2[4]);
+                    PIPE(pipeO, c, i) = o;
+                },
+                noChunk);
+        }
+#else
         if constexpr (FLAT) {
             using FD = FlatDesc<5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
             constexpr int GE[6] = {0, 1, 2, 3, 4, 14};
@@ -1285,8 +1758,44 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 },
                 noChunk);
         }
+#endif
     } else if (FLAT && stage == 3) {
         // ================= flat S3: frication noise, parallel r1..r4 partial sum =================
+#if KLATT_FLAT_V2
+        if constexpr (FLAT) {
+            using FD = FlatDesc<4, 3, false, 0x77u>;                // usually parallel 1..3 and the gains
+            constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // parallel 1..4 | cur: fricationAmplitude, preFormantGain, pa1..pa4
+            FlatState2<FD> f;
+            flat2_init<FD>(f, live, d, X, GE);
+            sig_t fricNoise = 0;
+            uint32_t noiseSt = noise_step(noise_first(nkey));     // frication: values 1, 3, 5, ...
+            flat2_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
+                [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
+                    constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
+                    const ResPre<sig_t> q0 = res_pre<MODE, ((SET >> 0) & 1u) != 0u>(f.ra[0], f.rb[0], f.rc[0], f.z1[0], f.z2[0]);
+                    const ResPre<sig_t> q1 = res_pre<MODE, ((SET >> 1) & 1u) != 0u>(f.ra[1], f.rb[1], f.rc[1], f.z1[1], f.z2[1]);
+                    const ResPre<sig_t> q2 = res_pre<MODE, ((SET >> 2) & 1u) != 0u>(f.ra[2], f.rb[2], f.rc[2], f.z1[2], f.z2[2]);
+                    const ResPre<sig_t> q3 = res_pre<MODE, ((SET >> 3) & 1u) != 0u>(f.ra[3], f.rb[3], f.rc[3], f.z1[3], f.z2[3]);
+                    fricNoise = (sig_t)noise_uniform(noiseSt) + (sig_t)0.75 * fricNoise;
+                    noiseSt = noise_step2(noiseSt);
+                    const sig_t fric = fricNoise * (sig_t)0.3 * f.cur[0];
+                    const sig_t y = (fric * f.cur[1]) * (sig_t)0.5;
+                    const sig_t pa1 = f.cur[2], pa2 = f.cur[3], pa3 = f.cur[4], pa4 = f.cur[5];
+                    mid(q0, q1, q2, q3, y, pa1, pa2, pa3, pa4);
+                    sig_t par = 0;
+                    sig_t w = res_post<MODE>(q0, y, f.z1[0], f.z2[0]);
+                    par += (w - y) * pa1;
+                    w = res_post<MODE>(q1, y, f.z1[1], f.z2[1]);
+                    par += (w - y) * pa2;
+                    w = res_post<MODE>(q2, y, f.z1[2], f.z2[2]);
+                    par += (w - y) * pa3;
+                    w = res_post<MODE>(q3, y, f.z1[3], f.z2[3]);
+                    par += (w - y) * pa4;
+                    PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
+                },
+                noChunk);
+        }
+#else
         if constexpr (FLAT) {
             using FD = FlatDesc<4, 3, false, 0x77u, 0x07u>;         // usually parallel 1..3 and the gains
             constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // cur: fricationAmplitude, preFormantGain, pa1..pa4
@@ -1310,13 +1819,20 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 },
                 noChunk);
         }
+#endif
     } else if (FLAT && (KLATT_FLAT_EXHAUSTIVE || stage == 2)) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
         if constexpr (FLAT) {
-            using FD = FlatDesc<5, 2, false, 0x67u, 0x07u>;         // usually c3, c2, c1 and the gains
             constexpr int GE[7] = {5, 6, 7, 12, 13, 15, 16};      // cur: pa5, pa6, parallelBypass, outputGain
+#if KLATT_FLAT_V2
+            using FD = FlatDesc<5, 2, false, 0x77u>;                // usually c3, c2, c1, parallel 6 and the gains
+            FlatState2<FD> f;
+            flat2_init<FD>(f, live, d, X, GE);
+#else
+            using FD = FlatDesc<5, 2, false, 0x67u, 0x07u>;         // usually c3, c2, c1 and the gains
             FlatState<FD> f;
             flat_init<FD>(f, live, d);
+#endif
             int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
             uint32_t it = 0;
             auto flush_tile = [&](uint32_t tileStart, uint32_t validTo) __attribute__((always_inline)) {
@@ -1347,6 +1863,36 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
+#if KLATT_FLAT_V2
+            flat2_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
+                [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
+                    constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
+                    const ResPre<sig_t> q0 = res_pre<MODE, ((SET >> 0) & 1u) != 0u>(f.ra[0], f.rb[0], f.rc[0], f.z1[0], f.z2[0]);
+                    const ResPre<sig_t> q1 = res_pre<MODE, ((SET >> 1) & 1u) != 0u>(f.ra[1], f.rb[1], f.rc[1], f.z1[1], f.z2[1]);
+                    const ResPre<sig_t> q2 = res_pre<MODE, ((SET >> 2) & 1u) != 0u>(f.ra[2], f.rb[2], f.rc[2], f.z1[2], f.z2[2]);
+                    const ResPre<sig_t> q3 = res_pre<MODE, ((SET >> 3) & 1u) != 0u>(f.ra[3], f.rb[3], f.rc[3], f.z1[3], f.z2[3]);
+                    const ResPre<sig_t> q4 = res_pre<MODE, ((SET >> 4) & 1u) != 0u>(f.ra[4], f.rb[4], f.rc[4], f.z1[4], f.z2[4]);
+                    const sig_t pa5 = f.cur[0], pa6 = f.cur[1], bypass = f.cur[2], outGain = f.cur[3];
+                    mid(q0, q1, q2, q3, q4, pa5, pa6, bypass, outGain);
+                    sig_t o = PIPE(pipeO, c, i);
+                    const sig_t y = PIPE(pipeA, c, i);
+                    o = res_post<MODE>(q0, o, f.z1[0], f.z2[0]);
+                    o = res_post<MODE>(q1, o, f.z1[1], f.z2[1]);
+                    o = res_post<MODE>(q2, o, f.z1[2], f.z2[2]);
+                    sig_t par = PIPE(pipeB, c, i);
+                    sig_t w = res_post<MODE>(q3, y, f.z1[3], f.z2[3]);
+                    par += (w - y) * pa5;
+                    w = res_post<MODE>(q4, y, f.z1[4], f.z2[4]);
+                    par += (w - y) * pa6;
+                    par = fade_value(par, y, bypass);
+                    const sig_t mix = o + par;
+                    const sig_t v = (mix * outGain) * (sig_t)4000.0;
+                    const sig_t lo = (v < (sig_t)32000.0) ? v : (sig_t)32000.0;       // windows.h min(): NaN -> 32000
+                    const sig_t cl = (lo > (sig_t)-32000.0) ? lo : (sig_t)-32000.0;
+                    myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (:208)
+                },
+                [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
+#else
             flat_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i) __attribute__((always_inline)) {
                     sig_t o = PIPE(pipeO, c, i);
@@ -1367,6 +1913,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (:208)
                 },
                 [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
+#endif
             if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
         }
     } else if (!NOISE && !NASAL && (stage == 1 || stage == 2)) {

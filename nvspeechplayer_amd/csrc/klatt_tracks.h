@@ -42,23 +42,25 @@ __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const Track
     const double* const fo = T.shapes + (size_t)job.fromShape * kShapeStride;
     const double* const fn = T.shapes + (size_t)job.toShape * kShapeStride;
     const uint32_t total = (uint32_t)kTrackFirst + (job.fadeSamples - 1u) * nSlots;   // host: below 2^27
+    const uint32_t header = track_header(mask);
     double2* const out = T.track + job.off;
     for (uint32_t e0 = (threadIdx.x >> 6) * kLanes; e0 < total; e0 += kLanes * kTrackWaves) {
         // every lane evaluates (the last pass repeats the track's last entry in its idle lanes): the wave-uniform short cuts of
         // resonator_coefficients_inline ballot over a full wavefront
         const uint32_t e = min(e0 + (uint32_t)lane, total - 1u);
-        uint32_t cnt, r;          // r: the entry's kind
-        bool second;              // N0's second entry: its a
-        if (e < (uint32_t)kTrackFirst) {
-            cnt = 1u; r = e <= 1u ? 0u : e - 1u; second = (e == 1u);
-        } else {
-            const uint32_t q = e - (uint32_t)kTrackFirst, n = q / div, s = q - n * div;
-            cnt = 2u + n; r = 0u; second = false;
-            uint32_t acc = 0;
+        uint32_t cnt, r = 0u;     // r: the entry's kind
+        bool second = false;      // N0's second entry: its a
+        {
+            // header (the kinds that do not move, fade sample 1), then the matrix (row n: fade sample n + 1 of the kinds that move)
+            const bool hdr = e < header;
+            const uint32_t q = hdr ? e : e - header, n = hdr ? 0u : q / div, s = hdr ? q : q - n * div;
+            cnt = 1u + n;
+            uint32_t accM = 0, accH = 0;
             for (int k = 0; k < kTrackEntries; ++k) {
-                if (!((mask >> k) & 1u)) continue;     // wave-uniform
+                const bool moves = (mask >> k) & 1u;     // wave-uniform
                 const uint32_t w = k == 0 ? 2u : 1u;
-                if (s >= acc && s < acc + w) { r = (uint32_t)k; second = (k == 0 && s == acc + 1u); }
+                uint32_t& acc = moves ? accM : accH;
+                if (moves != hdr && s >= acc && s < acc + w) { r = (uint32_t)k; second = (k == 0 && s == acc + 1u); }
                 acc += w;
             }
         }

@@ -1300,10 +1300,6 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
     }
     for (const auto& r : rerouted)
         if (!(utt[r.first].flags & UTT_TRACKED)) utt[r.first].flags = r.second;
-    if (const char* e = getenv("SPEECHPLAYER_EXP_NEAR")) {      // timing experiment (wrong PCM): every fade reads its rows from the first entries of the track buffer
-        const unsigned long long n = strtoull(e, nullptr, 10);
-        if (n) for (auto& r : plan.ref) r.off %= n;
-    }
     std::vector<TrackRef>& trackRef = plan.ref;
     std::vector<FlatRef> flatRef;
     std::vector<SourceRef> sourceRef;

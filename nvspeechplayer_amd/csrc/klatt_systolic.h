@@ -1005,24 +1005,24 @@ __device__ __forceinline__ void flat2_switch(FlatState2<FD>& f, const StageCtx& 
 // have to copy the old values aside) and from sinking the first half below them.  SET (compile time): the kinds loaded -- a
 // chunk runs the instantiation for the stage's USUAL kinds when no lane of the wavefront ever changes another one, else the
 // one for all kinds (a wave-uniform test per kind and sample cost more in branches than the loads it saved).
-template <class FD, uint32_t SET>
+template <class FD, uint32_t SET, bool ALLROWS = false>
 struct FlatMid {
     FlatState2<FD>& f;
     __amdgpu_buffer_rsrc_t rsrc;
-    bool has;
+    bool has;      // (ALLROWS: every lane has a row -- no mask)
     template <class... T>
     __device__ __forceinline__ void operator()(T... firstHalf) const
     {
         using R = typename FD::R;
         (flat_pin(firstHalf), ...);
 #if KLATT_EXP & 1      // timing experiment (wrong PCM): rows cost no memory access
-        if (has) {
+        if (ALLROWS || has) {
 #pragma unroll
             for (int e = 0; e < FD::NE; ++e) if (SET & (1u << e)) f.idx[e] += f.stride[e];
         }
         return;
 #endif
-        if (has) {
+        if (ALLROWS || has) {
 #pragma unroll
             for (int e = 0; e < FD::NE; ++e) {
                 if (!(SET & (1u << e))) continue;
@@ -1127,8 +1127,9 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
             STAMP_KIND(-1);
             // The kinds loaded in this chunk: every one in chunk 0 (the first fade's first row sets them all); afterwards the stage's
             // usual ones when no lane of the wavefront ever changes another kind (f.wmask), else every one again.
-            auto mixedChunk = [&](auto setTag) __attribute__((always_inline)) {
+            auto mixedChunk = [&](auto setTag, auto allRowsTag) __attribute__((always_inline)) {
                 constexpr uint32_t SET = decltype(setTag)::value;
+                constexpr bool ALLROWS = decltype(allRowsTag)::value;      // every live lane loads a row on every sample of the chunk, no fade starts: no masks, no look-out
                 const uint32_t fix = staleG & ~SET;      // kinds loaded in earlier chunks and not in this one: their `a` goes back to the register
                 if (fix) {
 #pragma unroll
@@ -1139,19 +1140,25 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
                 staleG |= SET;
 #pragma unroll KLATT_MIX_UNROLL
                 for (int i = 0; i < CH; ++i) {
-                    const uint32_t tn = t0 + (uint32_t)i + 1u;            // the sample whose rows this one loads
-                    const bool starts = tn == f.startAt;
 #if !(KLATT_EXP & 4)      // (timing experiment 4, wrong PCM: no fade ever starts)
-                    if (__any(starts)) { if (starts) flat2_switch<FD>(f, X, GE); }
+                    if (!ALLROWS) {
+                        const uint32_t tn = t0 + (uint32_t)i + 1u;            // the sample whose rows this one loads
+                        if (tn == f.startAt) flat2_switch<FD>(f, X, GE);
+                    }
 #endif
-                    const bool has = f.left > 0u;
-                    body(c, i, setTag, FlatMid<FD, SET>{f, rsrc, has});
-                    if (has) f.left--;
+                    const bool has = ALLROWS || f.left > 0u;
+                    body(c, i, setTag, FlatMid<FD, SET, ALLROWS>{f, rsrc, has});
+                    if (!ALLROWS && has) f.left--;
                 }
+                if (ALLROWS) f.left = f.left > (uint32_t)CH ? f.left - (uint32_t)CH : 0u;      // (a lane past its end had none)
             };
             constexpr uint32_t ALL = (1u << FD::NE) - 1u;
-            if (FD::USUAL != 0u && FD::USUAL != ALL && c != 0 && (f.wmask & ~FD::USUAL) == 0u) mixedChunk(std::integral_constant<uint32_t, FD::USUAL>{});
-            else mixedChunk(std::integral_constant<uint32_t, ALL>{});
+            const bool usual = FD::USUAL != 0u && FD::USUAL != ALL && c != 0 && (f.wmask & ~FD::USUAL) == 0u;
+            // every live lane inside a fade that moves something of this stage for the whole chunk (time-aligned batches: always, when any)
+            const bool allRows = usual && __all(!f.live || (f.left >= (uint32_t)CH && f.startAt > t1));
+            if (allRows) mixedChunk(std::integral_constant<uint32_t, FD::USUAL>{}, std::true_type{});
+            else if (usual) mixedChunk(std::integral_constant<uint32_t, FD::USUAL>{}, std::false_type{});
+            else mixedChunk(std::integral_constant<uint32_t, ALL>{}, std::false_type{});
             f.produced = f.length < t1 ? f.length : t1;
             perChunk();
         }
@@ -1344,15 +1351,16 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     } else {
                         // the kinds loaded in this chunk (as in flat2_loop): all in chunk 0, afterwards the usual two -- the amplitudes and
                         // the gain -- when no lane of the wavefront ever changes vibrato, turbulence or the open quotient
-                        auto mixedChunk = [&](auto setTag) __attribute__((always_inline)) {
+                        auto mixedChunk = [&](auto setTag, auto allFadeTag) __attribute__((always_inline)) {
                         constexpr uint32_t SET = decltype(setTag)::value;
+                        constexpr bool ALLFADE = decltype(allFadeTag)::value;      // every live lane's pitch fades through the whole chunk, nobody dequeues: no selects, no look-out
                         // vibrato can only come alive in this chunk through a row of its kind (the phase only turns NaN while it advances)
                         const bool vibChunk = (SET & 1u) != 0u || __any(vib_live());
 #pragma unroll KLATT_MIX_UNROLL
                         for (int i = 0; i < CH; ++i) {
                             const uint32_t t = t0 + (uint32_t)i;
-                            const bool deq = t + 1u == f.startAt;
-                            if (!(KLATT_EXP & 4) && __any(deq)) {
+                            const bool deq = !ALLFADE && t + 1u == f.startAt;
+                            if (!ALLFADE && !(KLATT_EXP & 4) && __any(deq)) {
                                 if (deq) {   // reference src/frame.cpp:55-72 (stage_event restates it); the sample itself is emitted as it is
                                     const SourceRef m = nextSrc;
                                     const uint32_t nf = f.nextRef.fadeSamples;
@@ -1375,6 +1383,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                             // the pitch of this sample, as selects (every lane computes both candidates: cheaper than three masked blocks):
                             // fading -> interpolated; the sample after the fade -> the fade's target becomes the glide's start; steady -> glide
                             // (reference src/frame.cpp:48-53, :44-47, :76-79); a dequeuing lane leaves it alone
+                            if (ALLFADE) {
+                                cntF++;
+                                ps.cur0 = fade_value(ps.old0, ps.new0, div_by((double)cntF, nfD, invFade));
+                            } else {
                             const bool fad = !deq && cntF < nfU;
                             const bool ending = !deq && !fad && t == fadeEndAt;
                             const bool glide = !deq && !fad && !ending;
@@ -1387,14 +1399,19 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                             ps.oldInc = ending ? ps.newInc : ps.oldInc;
                             cntF = fad ? cn : cntF;
                             fadeEndAt = ending ? 0xFFFFFFFFu : fadeEndAt;
+                            }
                             const bool waveVib = vibChunk && __any(vib_live());
                             const bool has = f.left > 0u;
                             PIPE(pipeX, c, i) = source(waveVib, FlatMid<FD, SET>{f, rsrc, has});
                             if (has) f.left--;
                         }
                         };
-                        if (c != 0 && (f.wmask & ~0xCu) == 0u) mixedChunk(std::integral_constant<uint32_t, 0xCu>{});
-                        else mixedChunk(std::integral_constant<uint32_t, 0xFu>{});
+                        const bool usual = c != 0 && (f.wmask & ~0xCu) == 0u;
+                        // (a lane past its end: cntF == nfU; its pitch is nobody's business)
+                        const bool allFade = usual && !__any(vib_live()) && __all(!f.live || (cntF + (uint32_t)CH <= nfU && f.startAt > t1));
+                        if (allFade) mixedChunk(std::integral_constant<uint32_t, 0xCu>{}, std::true_type{});
+                        else if (usual) mixedChunk(std::integral_constant<uint32_t, 0xCu>{}, std::false_type{});
+                        else mixedChunk(std::integral_constant<uint32_t, 0xFu>{}, std::false_type{});
                     }
                 }
                 STAMP_WORKED();

@@ -89,11 +89,15 @@ struct UttResult {           // written by the kernel
 //   20..23  the source stage's parameters: (vibratoPitchOffset, vibratoSpeed) (voiceTurbulenceAmplitude, glottalOpenQuotient)
 //           (voiceAmplitude, aspirationAmplitude) (preFormantGain, -)           -- S0 (the pitch itself glides: not in a track)
 // On fade sample 1 everything is re-evaluated (see fade_update below): every kind has an entry for it, kTrackFirst entries (N0
-// takes two).  Fade samples 2..F change only the kinds that MOVE in the fade (mask).  Layout of a fade's track:
-//   header   the kinds that do NOT move, ascending: their value of fade sample 1 (which is their value on every later sample)
-//   matrix   F rows of nSlots entries: the kinds that move, ascending (N0 takes two); row j holds fade sample j + 1
-// so a moving kind's entries are one stride (nSlots) apart from the first fade sample on, and a kind that does not move has ONE
-// entry: a stage points at it with stride 0.  kTrackFirst + (F - 1) * nSlots entries in all.
+// takes two).  Fade samples 2..F change only the kinds that MOVE in the fade (mask).  A fade's track is four PARTS, one per flat
+// stage (S0: kinds 20..23 | S1: 0..4, 14 | final stage: 5..7, 12, 13, 15, 16 | parallel stage: 8..11, 17..19), so that what a
+// stage streams through is contiguous and no cache line is shared by two stages -- which work 16 to 32 samples apart: with the
+// kinds of all stages interleaved in one row a line was fetched once per stage, 34 GB from HBM per launch of a batch with 445 MB
+// of tracks, for 22 GB of rows.  Layout of a part:
+//   header   the stage's kinds that do NOT move, ascending: their value of fade sample 1 (which is their value on every later sample)
+//   matrix   F rows of the stage's kinds that move, ascending (N0 takes two); row j holds fade sample j + 1
+// so a moving kind's entries are one stride (the part's moving entries) apart from the first fade sample on, and a kind that
+// does not move has ONE entry: a stage points at it with stride 0.  kTrackFirst + (F - 1) * nSlots entries in all.
 // Fades with bitwise equal end values of all the parameters involved and the same length share one track (host, plan_tracks).
 constexpr int kTrackEntries = 24;
 constexpr int kTrackFirst = kTrackEntries + 1;   // entries of a fade's first sample (N0 takes two)
@@ -114,7 +118,7 @@ __host__ __device__ constexpr int entry_value(int e, int half)
     constexpr int kV[10][2] = {{28, -1}, {29, 30}, {31, 32}, {33, 34}, {35, 36}, {37, 38}, {39, 40}, {41, 42}, {43, 44}, {34, -1}};
     return kV[e - 14][half];
 }
-struct TrackRef {            // 16 B per frame, read by the tracked stages at a dequeue
+struct TrackRef {            // per frame on the host (plan_tracks); the stages read it as a FlatRef
     unsigned long long off;  // first entry of the fade's track
     uint32_t mask;           // entry kinds that move in the fade (bit e)
     uint32_t nSlots;         // entries per fade sample after the first: popcount(mask) + (mask & 1)
@@ -139,20 +143,21 @@ struct TrackJob {            // one distinct track, read by klatt_tracks
     uint32_t mask;
 };
 __host__ __device__ inline uint32_t track_slots(uint32_t mask) { return (uint32_t)__builtin_popcount(mask) + (mask & 1u); }
-// slot of entry kind e among the entries of a later fade sample / of the first one
-__host__ __device__ inline uint32_t track_slot(uint32_t mask, int e) { return (uint32_t)__builtin_popcount(mask & ((1u << e) - 1u)) + ((e > 0) ? (mask & 1u) : 0u); }
-constexpr int track_first_slot(int e) { return e + (e > 0 ? 1 : 0); }      // entries of the kinds below e (moving or not)
-// entries of a track's header: the kinds that do not move
-__host__ __device__ inline uint32_t track_header(uint32_t mask) { return (uint32_t)kTrackFirst - track_slots(mask); }
-// where kind e's entry of fade sample 1 sits in the track: in row 0 of the matrix if it moves, in the header if not
-__host__ __device__ inline uint32_t track_entry0(uint32_t mask, int e)
+constexpr int kTrackStages = 4;
+// the kinds of a stage's part, and their entries (N0 takes two)
+__host__ __device__ constexpr uint32_t track_stage_kinds(int s) { return s == 0 ? 0xF00000u : s == 1 ? 0x00401Fu : s == 2 ? 0x01B0E0u : 0x0E0F00u; }
+__host__ __device__ constexpr uint32_t track_stage_entries(int s) { return s == 0 ? 4u : 7u; }
+// entries of stage s's part that move: per row of its matrix
+__host__ __device__ inline uint32_t track_stage_slots(uint32_t mask, int s) { return (uint32_t)__builtin_popcount(mask & track_stage_kinds(s)) + (s == 1 ? (mask & 1u) : 0u); }
+// first entry of stage s's part in a track of a fade of F samples
+__host__ __device__ inline uint32_t track_part(uint32_t mask, uint32_t F, int s)
 {
-    const uint32_t s = track_slot(mask, e);
-    return ((mask >> e) & 1u) ? track_header(mask) + s : (uint32_t)track_first_slot(e) - s;
+    uint32_t at = 0;
+    for (int k = 0; k < s; ++k) at += track_stage_entries(k) + (F - 1u) * track_stage_slots(mask, k);
+    return at;
 }
 
 struct KernelArgs {
-    const TrackRef* trackRef;    // [nFrames] tracked launches only
     const FlatRef* flatRef;      // [nFrames] tracked launches only
     const SourceRef* sourceRef;  // [nFrames] tracked launches only
     uint32_t trackBytes;         // size of `track` (below 4 GB: the flat stages address it through a buffer descriptor with 32-bit offsets)

@@ -338,7 +338,6 @@ struct Batch {
     DeviceBuffer<uint32_t> dOrder;
     DeviceBuffer<int16_t> dPcm;
     DeviceBuffer<UttResult> dResult;
-    DeviceBuffer<TrackRef> dTrackRef;          // [nFrames]
     DeviceBuffer<FlatRef> dFlatRef;            // [nFrames] the same for the flat filter stages: one 16-byte load per fade start
     DeviceBuffer<SourceRef> dSourceRef;        // [nFrames] what the flat source stage reads at a dequeue
     DeviceBuffer<TrackJob> dJobs;
@@ -681,14 +680,14 @@ int batch_launch(Batch* b)
         hipLaunchKernelGGL(klatt_tracks, dim3((unsigned)tg), dim3(kLanes * kTrackWaves), 0, st, t);
         HIP_TRY(hipGetLastError());
         a.order = b->dOrder.ptr + b->nQuiet; a.nSlots = nTr;
-        a.trackRef = b->dTrackRef.ptr; a.flatRef = b->dFlatRef.ptr; a.sourceRef = b->dSourceRef.ptr; a.track = b->dTrack.ptr;
+        a.flatRef = b->dFlatRef.ptr; a.sourceRef = b->dSourceRef.ptr; a.track = b->dTrack.ptr;
         a.trackBytes = (uint32_t)std::min<unsigned long long>(((unsigned long long)b->trackEntries + kTrackPad) * sizeof(double2), 0xFFFFFFFFull);
         const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
         const long long g = (nTr + kLanes - 1) / kLanes;
         // flat stages keep nothing but the pipes and the PCM tile in LDS: 16-sample hand-overs fit two workgroups per CU (70 KB each)
         if (pl.chunk == 8 ? launch_systolic<true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true>(a, b->mode, g, st)
                           : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
-        a.trackRef = nullptr; a.flatRef = nullptr; a.sourceRef = nullptr; a.track = nullptr;
+        a.flatRef = nullptr; a.sourceRef = nullptr; a.track = nullptr;
     }
     if (nNoisy > 0) {
         a.order = b->dOrder.ptr + b->nQuiet + nTr; a.nSlots = nNoisy;
@@ -1144,7 +1143,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
-    b->dTrackRef.release(); b->dFlatRef.release(); b->dSourceRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
+    b->dFlatRef.release(); b->dSourceRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
     delete b;
 }
 
@@ -1375,10 +1374,9 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
             b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
         if (nTrackedUtt > 0) {
-            if (b->dTrackRef.reserve((size_t)nF) || b->dFlatRef.reserve((size_t)nF) || b->dSourceRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
+            if (b->dFlatRef.reserve((size_t)nF) || b->dSourceRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
                 b->dTrack.reserve((size_t)trackEntries + kTrackPad)) return -1;
             HIP_TRY(hipMemcpyAsync(b->dShapes.ptr, plan.shapes.data(), plan.shapes.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->dTrackRef.ptr, trackRef.data(), (size_t)nF * sizeof(TrackRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dFlatRef.ptr, flatRef.data(), (size_t)nF * sizeof(FlatRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dSourceRef.ptr, sourceRef.data(), (size_t)nF * sizeof(SourceRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dJobs.ptr, jobs.data(), jobs.size() * sizeof(TrackJob), hipMemcpyHostToDevice, b->stream));

@@ -141,8 +141,7 @@ struct StageCtx {          // what every stage needs from the launch
     const UttDesc& d;
     const double* myFrames;
     const FrameMeta* myMeta;
-    const TrackRef* myTrack;   // flat launches: the utterance's per-frame track references
-    const FlatRef* myFlat;     // flat launches: the same in the form the filter stages load ahead (klatt_device.h)
+    const FlatRef* myFlat;     // flat launches: the utterance's per-frame track references, loaded ahead by the stages (klatt_device.h)
     const SourceRef* mySrc;    // flat launches: what the source stage loads ahead
 };
 
@@ -682,223 +681,24 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
     (void)stampSlot;
 }
 
-// ---- flat filter stages (FLAT launches) ---------------------------------------------------------------------------
+// ---- flat stages (FLAT launches) ------------------------------------------------------------------------------------
 // With the gains in the tracks as well (entry kinds 14..19, klatt_device.h) a filter stage needs no frame state machine: what
 // changes its state is a list of fades at sample positions that follow from the frame durations alone.  Frame k of an
 // utterance is dequeued on sample T_k (T_0 = 0, T_k+1 = T_k + max(min_k, fade_k + 1) + 1; reference src/frame.cpp:41-80) and its
-// fade's rows apply to samples T_k + 1 .. T_k + fade_k.  So a flat stage keeps per lane: the sample on which its next fade starts,
-// the rows left of the running one, one pointer and stride per entry kind it uses -- and per sample does
-//     a lane whose fade starts: reads the frame's TrackRef and durations, takes the first row, points at the later rows
-//     a lane inside a fade:     loads through its pointers (an entry kind that does not move re-reads its first-row value)
-//     every lane that still has samples: the filters
-// with no dequeue / fade-end events, no interpolation, no end points in LDS.  A chunk in which no lane of the wave starts, runs
-// or ends anything is the straight-line steady chunk of the other kernels.  (The source stage is flat too -- its code is in the
-// kernel below: what it keeps is the pitch, which glides with the utterance's own sample count.)
-// USUAL: the entry kinds of the stage (bit e of its list) that usually move in speech -- a chunk in which every lane fades and
-// nothing outside this set moves loads through these pointers only (compiled in: no tests)
-// (USUAL: with the stage's gains; USUAL2: the resonators alone, when no gain moves either)
-// R: the type the stage keeps its coefficients, memories and gains in (sig_t for the filter stages, double for the source stage)
-template <int NRES_, int NGAIN_, bool ANTI0_, uint32_t USUAL_ = 0, uint32_t USUAL2_ = 0, class R_ = sig_t>
+// fade's rows apply to samples T_k + 1 .. T_k + fade_k.  So a flat stage keeps per lane the sample on which its next fade starts,
+// the rows left of the running one, one offset and stride per entry kind it uses -- no dequeue / fade-end events, no
+// interpolation, no end points in LDS.  (The source stage is flat too: what it keeps is the pitch, which glides with the
+// utterance's own sample count.)
+// USUAL: the entry kinds of the stage (bit e of its list) that usually change in speech -- the mixed chunks are compiled for this
+// set and for all kinds.  R: the type the stage keeps its coefficients, memories and gains in.
+template <int STAGE_, int NRES_, int NGAIN_, bool ANTI0_, uint32_t USUAL_ = 0, uint32_t USUAL2_ = 0, class R_ = sig_t>
 struct FlatDesc {
     using R = R_;
+    static constexpr int STAGE = STAGE_;      // which part of a track the stage reads (klatt_device.h)
     static constexpr int NRES = NRES_, NGAIN = NGAIN_, NE = NRES_ + NGAIN_;
     static constexpr bool ANTI0 = ANTI0_;
     static constexpr uint32_t USUAL = USUAL_, USUAL2 = USUAL2_;
 };
-template <class FD>
-struct FlatState {
-    static constexpr int NR = FD::NRES > 0 ? FD::NRES : 1;
-    using R = typename FD::R;
-    R ra[NR], rb[NR], rc[NR], z1[NR], z2[NR];
-    R cur[2 * FD::NGAIN];
-    const double2* tp[FD::NE];
-    uint32_t ts[FD::NE];
-    uint32_t startAt, left, next, nFrames, length, produced;
-    bool live;
-};
-template <class FD>
-__device__ __forceinline__ void flat_init(FlatState<FD>& f, bool live, const UttDesc& d)
-{
-#pragma unroll
-    for (int r = 0; r < FD::NRES; ++r) { f.ra[r] = 0; f.rb[r] = 2; f.rc[r] = -1; f.z1[r] = 0; f.z2[r] = 0; }
-#pragma unroll
-    for (int k = 0; k < 2 * FD::NGAIN; ++k) f.cur[k] = 0;
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e) { f.tp[e] = nullptr; f.ts[e] = 0; }
-    f.live = live && d.length > 0u;
-    f.nFrames = d.nFrames; f.length = d.length; f.next = 0; f.left = 0; f.produced = 0;
-    f.startAt = (live && d.nFrames > 0u) ? 1u : 0xFFFFFFFFu;      // frame 0 is dequeued on sample 0, its fade's first row applies to sample 1
-}
-template <class FD>
-__device__ __forceinline__ void flat_take(FlatState<FD>& f, int e, const double2 v, double a0)
-{
-    using R = typename FD::R;
-    if (e < FD::NRES) {
-        f.ra[e] = (R)((FD::ANTI0 && e == 0) ? a0 : (1.0 - v.x - v.y));     // (float: a from the ROUNDED b and c instead -- gain 1 at 0 Hz to float precision -- is further from the double PCM)
-        f.rb[e] = (R)v.x; f.rc[e] = (R)v.y;
-    } else {
-        f.cur[2 * (e - FD::NRES)] = (R)v.x; f.cur[2 * (e - FD::NRES) + 1] = (R)v.y;
-    }
-}
-// a fade starts on this sample: its first row (every entry kind), then the pointers for the rows that follow
-template <class FD>
-__device__ __forceinline__ void flat_begin(FlatState<FD>& f, const StageCtx& X, const int* GE)
-{
-    const FrameMeta m = X.myMeta[f.next];
-    const TrackRef tr = X.myTrack[f.next];
-    const double2* const base = X.A.track + tr.off;
-    double2 v[FD::NE];
-    double a0 = 0.0;
-#if KLATT_EXP & 2      // timing experiment (wrong PCM): a fade's first row costs no memory access
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e) v[e] = e < FD::NRES ? make_double2((double)f.rb[e], (double)f.rc[e]) : make_double2((double)f.cur[2 * (e - FD::NRES)], (double)f.cur[2 * (e - FD::NRES) + 1]);
-    if (FD::ANTI0) a0 = (double)f.ra[0];
-#else
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e) v[e] = base[track_entry0(tr.mask, GE[e])];
-    if (FD::ANTI0) a0 = base[track_entry0(tr.mask, GE[0]) + 1].x;
-#endif
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e) {
-        flat_take<FD>(f, e, v[e], a0);
-        const bool moves = (tr.mask >> GE[e]) & 1u;
-        f.tp[e] = base + (track_entry0(tr.mask, GE[e]) + (moves ? tr.nSlots : 0u));      // a kind that moves: its entry in the matrix's next row
-        f.ts[e] = moves ? tr.nSlots : 0u;
-    }
-    uint32_t mine = 0;
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e) mine |= (tr.mask >> GE[e]) & 1u;
-    f.left = mine ? m.fadeSamples - 1u : 0u;       // a fade that moves nothing of this stage has no further rows for it
-    const uint32_t span = (m.minSamples > m.fadeSamples + 1u ? m.minSamples : m.fadeSamples + 1u) + 1u;
-    f.next++;
-    f.startAt = f.next < f.nFrames ? f.startAt + span : 0xFFFFFFFFu;
-}
-// (On the sample-by-sample path, loading only the kinds that move in the lane's OWN fade -- a test per kind and lane, half the
-// memory requests -- measured slower: all-different batch 32.7 -> 36.3 ms.  Reading the next row ahead into LDS rows with
-// global_load_lds_dwordx4: 9.6 -> 11.4 ms on cfg2, 33.7 -> 35.9 on the all-different batch.  Fade stretches in a tight loop: no gain.)
-// one later row of the running fade; SET (compile time): the entry kinds to load (those outside it do not move in any lane)
-template <class FD, uint32_t SET = 0xFFFFFFFFu>
-__device__ __forceinline__ void flat_next(FlatState<FD>& f)
-{
-    double2 v[FD::NE];
-    double a0 = 0.0;
-#if KLATT_EXP & 1      // timing experiment (wrong PCM): a later row costs no memory access
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e)
-        if (SET & (1u << e)) {
-            v[e] = e < FD::NRES ? make_double2((double)f.rb[e], (double)f.rc[e]) : make_double2((double)f.cur[2 * (e - FD::NRES)], (double)f.cur[2 * (e - FD::NRES) + 1]);
-            if (FD::ANTI0 && e == 0) a0 = (double)f.ra[0];
-            f.tp[e] += f.ts[e];
-        }
-#else
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e)
-        if (SET & (1u << e)) { v[e] = f.tp[e][0]; if (FD::ANTI0 && e == 0) a0 = f.tp[e][1].x; f.tp[e] += f.ts[e]; }
-#endif
-#pragma unroll
-    for (int e = 0; e < FD::NE; ++e)
-        if (SET & (1u << e)) flat_take<FD>(f, e, v[e], a0);
-    f.left--;
-}
-// the chunk loop of a flat stage: same barrier discipline as stage_loop (nIter iterations, one barrier each, chunk iter - depth)
-template <class FD, int CH, class FBody, class FChunk>
-__device__ __forceinline__ void flat_loop(int depth, int nIter, int nChunks, int stampSlot, FlatState<FD>& f, const StageCtx& X, const int* GE, FBody body, FChunk perChunk)
-{
-#ifdef KLATT_STAMPS
-    Stamps st;
-#endif
-    for (int iter = 0; iter < nIter; ++iter) {
-        STAMP_BEGIN();
-        STAMP_IDLE();
-        const int c = iter - depth;
-        if (c >= 0 && c < nChunks) {
-            const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
-            if (f.length <= t0) f.live = false;                               // this lane has emitted its last sample
-            const bool busy = f.live && (f.left > 0u || f.startAt < t1 || f.length < t1);
-            if (!__any(busy)) {
-                // a steady stretch is decided once: the chunks until some live lane starts a fade or ends run in a tight loop
-                // (chunk, barrier, chunk, ...) with the barrier count of the outer loop
-                uint32_t run = 0xFFFFFFFFu;
-                if (f.live) { const uint32_t until = f.startAt < f.length ? f.startAt : f.length; run = (until - t0) / (uint32_t)CH; }
-#pragma unroll
-                for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
-                run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
-                const uint32_t room = (uint32_t)(nChunks - c);
-                run = run < room ? run : room;
-                int cc = c;
-                STAMP_KIND(0);
-                for (uint32_t q = 1; q < run; ++q) {
-                    if (f.live) {
-#pragma unroll
-                        for (int i = 0; i < CH; ++i) body(cc, i);
-                    }
-                    if (f.live) f.produced = (uint32_t)(cc + 1) * (uint32_t)CH;
-                    perChunk();
-                    STAMP_WORKED();
-                    __syncthreads();
-                    STAMP_SYNCED();
-                    STAMP_BEGIN();
-                    ++iter; ++cc;
-                }
-                if (f.live) {
-#pragma unroll
-                    for (int i = 0; i < CH; ++i) body(cc, i);
-                }
-                if (f.live) f.produced = (uint32_t)(cc + 1) * (uint32_t)CH;
-                perChunk();
-                STAMP_WORKED();
-                __syncthreads();
-                STAMP_SYNCED();
-                continue;
-            } else if (!__any(f.live && (f.left < (uint32_t)CH || f.startAt < t1 || f.length < t1))) {
-                // every live lane is inside a fade for the whole chunk: no tests per sample
-                STAMP_KIND(1);
-                uint32_t wMove = 0;     // entry kinds that move in some live lane
-                if (FD::USUAL != 0u) {
-#pragma unroll
-                    for (int e = 0; e < FD::NE; ++e) wMove |= __any(f.live && f.ts[e] != 0u) ? (1u << e) : 0u;
-                }
-                if (f.live) {
-                    if (FD::USUAL2 != 0u && (wMove & ~FD::USUAL2) == 0u) {
-#pragma unroll 2
-                        for (int i = 0; i < CH; ++i) { flat_next<FD, FD::USUAL2>(f); body(c, i); }
-                    } else if (FD::USUAL != 0u && (wMove & ~FD::USUAL) == 0u) {
-#pragma unroll 2
-                        for (int i = 0; i < CH; ++i) { flat_next<FD, FD::USUAL>(f); body(c, i); }
-                    } else {
-#pragma unroll 2
-                        for (int i = 0; i < CH; ++i) { flat_next<FD>(f); body(c, i); }
-                    }
-                }
-            } else {
-                STAMP_KIND(-1);
-#pragma nounroll
-                for (int i = 0; i < CH; ++i) {
-                    const uint32_t t = t0 + (uint32_t)i;
-                    const bool emit = f.live && t < f.length;
-                    const bool starting = emit && t == f.startAt;
-                    if (__any(starting)) { if (starting) flat_begin<FD>(f, X, GE); }
-                    const bool fading = emit && !starting && f.left > 0u;
-                    if (__any(fading)) { if (fading) flat_next<FD>(f); }
-                    if (emit) body(c, i);
-                }
-            }
-            f.produced = f.length < t1 ? f.length : t1;
-            perChunk();
-        }
-        STAMP_WORKED();
-        __syncthreads();
-        STAMP_SYNCED();
-    }
-#ifdef KLATT_STAMPS
-    if (X.A.debug && (threadIdx.x & (kLanes - 1)) == 0) {
-        unsigned long long* o = X.A.debug + (blockIdx.x * 4 + stampSlot) * 8;
-        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
-    }
-#endif
-    (void)stampSlot;
-}
-
 
 // ---- flat filter stages, second form (round 3): rows loaded one sample ahead, straight into the coefficients ---------------------
 // The sample-by-sample path above pays, on every sample in which ANY lane fades: two ballots and two divergent blocks, the row's
@@ -918,9 +718,6 @@ __device__ __forceinline__ void flat_loop(int depth, int nIter, int nChunks, int
 //     reads: rowCount / produced bound what is flushed), so a sample is straight-line code between the masked loads;
 //   * what a fade start needs (track, mask, length, distance to the next start) is ONE 16-byte FlatRef, loaded when the PREVIOUS
 //     fade starts.
-#ifndef KLATT_FLAT_V2
-#define KLATT_FLAT_V2 1
-#endif
 #ifndef KLATT_MIX_UNROLL
 #define KLATT_MIX_UNROLL 4
 #endif
@@ -975,17 +772,19 @@ template <class FD>
 __device__ __forceinline__ void flat2_switch(FlatState2<FD>& f, const StageCtx& X, const int* GE)
 {
     const FlatRef p = f.nextRef;
-    const uint32_t nSlots = track_slots(p.mask), hdr = (uint32_t)kTrackFirst - nSlots;
-    uint32_t mine = 0;
+    // the stage's part of the track (klatt_device.h): its header (the kinds that do not move), then F rows of those that do
+    const uint32_t part = p.off + track_part(p.mask, p.fadeSamples, FD::STAGE);
+    const uint32_t nMove = track_stage_slots(p.mask, FD::STAGE), hdr = track_stage_entries(FD::STAGE) - nMove;
+    uint32_t moving = 0, still = 0;            // entries of the stage's kinds before this one, among the moving / among the others
 #pragma unroll
     for (int e = 0; e < FD::NE; ++e) {
         const bool moves = (p.mask >> GE[e]) & 1u;
-        const uint32_t s = track_slot(p.mask, GE[e]);
-        f.idx[e] = (p.off + (moves ? hdr + s : (uint32_t)track_first_slot(GE[e]) - s)) * 16u;
-        f.stride[e] = moves ? nSlots * 16u : 0u;
-        mine |= moves ? 1u : 0u;
+        f.idx[e] = (part + (moves ? hdr + moving : still)) * 16u;
+        f.stride[e] = moves ? nMove * 16u : 0u;
+        const uint32_t w = GE[e] == 0 ? 2u : 1u;      // N0 takes two entries
+        moving += moves ? w : 0u; still += moves ? 0u : w;
     }
-    f.left = mine ? p.fadeSamples : 1u;        // a fade that moves nothing of this stage: its first row only
+    f.left = nMove ? p.fadeSamples : 1u;        // a fade that moves nothing of this stage: its first row only
     f.next++;
     const bool more = f.next < f.nFrames;
     f.startAt = more ? f.startAt + p.span : 0xFFFFFFFFu;
@@ -1216,7 +1015,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     UttDesc d;
     d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
-    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart, FLAT ? A.trackRef + d.frameStart : nullptr,
+    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart,
                      FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr};
     const uint32_t nkey = noise_key(d.seed);
     constexpr int FINAL = NOISE ? 2 : 3;
@@ -1270,7 +1069,6 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     auto noChunk = [&]() __attribute__((always_inline)) {};
 
     if (FLAT && KLATT_FLAT_SOURCE && stage == 0) {
-#if KLATT_FLAT_V2
         // ================= flat S0, second form: the source stage with its rows loaded one sample ahead (see flat2_loop) =================
         // Its seven parameters come from the tracks (entry kinds 20..23); what stays here is the pitch, which glides with the sample
         // count of THIS utterance (reference src/frame.cpp:76-79, :98, :71) and so cannot be shared.  Frame k is dequeued on sample
@@ -1279,7 +1077,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // steady (glide).  What a dequeue reads (durations, index mark, the frame's two pitch values, the FlatRef) was loaded when the
         // previous frame was dequeued.
         if constexpr (FLAT) {
-            using FD = FlatDesc<0, 4, false, 0, 0, double>;
+            using FD = FlatDesc<0, 0, 4, false, 0, 0, double>;
             constexpr int GE[4] = {20, 21, 22, 23};     // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
@@ -1430,169 +1228,6 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 A.result[u] = res;
             }
         }
-#else
-        // ================= flat S0: the source stage without the chunk machinery of stage_loop =================
-        // Its seven parameters come from the tracks (entry kinds 20..23); what stays here is the pitch, which glides with the sample
-        // count of THIS utterance (reference src/frame.cpp:76-79, :98, :71) and so cannot be shared: per lane the sample of the next
-        // dequeue, of the running fade's end, the fade rows left.  Per sample a lane is dequeuing (sets up the pitch fade; the sample
-        // is emitted unchanged), fading (pitch interpolated, a row taken), ending its fade (bookkeeping), or steady (glide).
-        if constexpr (FLAT) {
-            using FD = FlatDesc<0, 4, false, 0, 0, double>;
-            constexpr int GE[4] = {20, 21, 22, 23};     // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain
-            FlatState<FD> f;
-            flat_init<FD>(f, live, d);
-            PitchState ps;
-            ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
-            double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, invFade = 1.0, nfD = 1.0;
-            uint32_t noiseSt = noise_first(nkey), cntF = 0, fmask = 0, fslots = 0;    // the state of this stage's next noise value (aspiration: values 0, 2, 4, ...)
-            uint32_t deqAt = (live && d.nFrames > 0u) ? 0u : 0xFFFFFFFFu, fadeEndAt = 0xFFFFFFFFu;
-            const double2* tBase = nullptr;
-            int32_t lastIndex = -1;
-            bool oldNull = true, newNull = false, first = false, rows = false;   // rows: the running fade moves some parameter of this stage
-            auto source = [&](bool waveVib) __attribute__((always_inline)) -> double {
-                double vib = 1.0;
-                if (waveVib) {
-                    const double vs = f.cur[1];
-                    const double adv = frac_toward_zero(div_by(vs, A.sampleRateF, A.invSampleRate) + vibPhase);
-                    vibPhase = (vs != 0.0) ? adv : vibPhase;
-                    vib = (sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[0]) + 1.0;
-                }
-                pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
-                double voice = (pitchPhase * 2.0) - 1.0;
-                aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
-                noiseSt = noise_step2(noiseSt);
-                double asp = aspNoise * 0.2;
-                double turb = asp * f.cur[2];
-                turb = (pitchPhase >= f.cur[3]) ? turb : turb * 0.01;
-                voice += turb;
-                voice *= f.cur[4];
-                asp *= f.cur[5];
-                const double src = asp + voice;
-                return (src * f.cur[6]) * 0.5;
-            };
-            auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase; };
-#ifdef KLATT_STAMPS
-            Stamps st;
-#endif
-            for (int iter = 0; iter < nIter; ++iter) {
-                STAMP_BEGIN();
-                STAMP_IDLE();
-                const int c = iter;
-                if (c < nChunks) {
-                    const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
-                    if (f.length <= t0) f.live = false;
-                    const bool busy = f.live && (f.left > 0u || deqAt < t1 || fadeEndAt < t1 || f.length < t1 || vib_live());
-                    STAMP_KIND(__any(busy) ? -1 : 0);
-                    if (!__any(busy)) {
-                        // steady stretch, decided once (as in flat_loop): the pitch glides, nothing else changes
-                        uint32_t run = 0xFFFFFFFFu;
-                        if (f.live) { const uint32_t until = deqAt < f.length ? deqAt : f.length; run = (until - t0) / (uint32_t)CH; }
-#pragma unroll
-                        for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
-                        run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
-                        const uint32_t room = (uint32_t)(nChunks - c);
-                        run = run < room ? run : room;
-                        int cc = c;
-                        for (uint32_t q = 0; q < run; ++q) {
-                            if (f.live) {
-#pragma unroll
-                                for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; PIPE(pipeX, cc, i) = source(false); }
-                                ps.old0 = ps.cur0;
-                            }
-                            if (q + 1 < run) { STAMP_WORKED(); __syncthreads(); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; }
-                        }
-                    } else if (!__any(f.live && (f.left < (uint32_t)CH || first || deqAt < t1 || f.length < t1 || vib_live()))) {
-                        // every live lane is inside a fade (past its first row) for the whole chunk, no vibrato: no tests per sample
-                        const bool anyRows = __any(f.live && rows);
-                        if (f.live) {
-#pragma unroll 2
-                            for (int i = 0; i < CH; ++i) {
-                                cntF++;
-                                const double ratio = div_by((double)cntF, nfD, invFade);
-                                ps.cur0 = fade_value(ps.old0, ps.new0, ratio);
-                                if (anyRows) flat_next<FD>(f); else f.left--;
-                                PIPE(pipeX, c, i) = source(false);
-                            }
-                        }
-                    } else {
-#pragma nounroll
-                        for (int i = 0; i < CH; ++i) {
-                            const uint32_t t = t0 + (uint32_t)i;
-                            const bool emit = f.live && t < f.length;
-                            const bool deq = emit && t == deqAt;
-                            if (__any(deq)) {
-                                if (deq) {   // reference src/frame.cpp:55-72 (stage_event restates it); the sample itself is emitted as it is
-                                    const FrameMeta m = X.myMeta[f.next];
-                                    const TrackRef tr = X.myTrack[f.next];
-                                    const double* g = X.myFrames + (size_t)f.next * kNumParams;
-                                    newNull = (m.flags & FRAME_NULL) != 0;
-                                    if (newNull) { ps.new0 = ps.cur0; ps.newInc = 0.0; }
-                                    else {
-                                        const double g0 = g[0], g46 = g[46];
-                                        ps.new0 = g0;
-                                        ps.newInc = (g46 - g0) / (double)m.minSamples;   // reference src/frame.cpp:98
-                                        if (oldNull) ps.old0 = g0;
-                                    }
-                                    if (m.userIndex != -1) lastIndex = m.userIndex;       // (:69)
-                                    nfD = (double)m.fadeSamples;
-                                    ps.new0 += ps.newInc * nfD;                           // (:71)
-                                    invFade = 1.0 / nfD;
-                                    cntF = 0;
-                                    tBase = X.A.track + tr.off; fmask = tr.mask; fslots = tr.nSlots;
-#pragma unroll
-                                    for (int e = 0; e < FD::NE; ++e) { f.tp[e] = tBase + track_entry0(fmask, GE[e]); f.ts[e] = 0u; }
-                                    f.left = m.fadeSamples; first = true; rows = true;
-                                    fadeEndAt = t + m.fadeSamples + 1u;
-                                    const uint32_t span = (m.minSamples > m.fadeSamples + 1u ? m.minSamples : m.fadeSamples + 1u) + 1u;
-                                    f.next++;
-                                    deqAt = f.next < f.nFrames ? t + span : 0xFFFFFFFFu;
-                                }
-                            }
-                            const bool fad = emit && !deq && f.left > 0u;
-                            if (__any(fad)) {
-                                if (fad) {
-                                    cntF++;
-                                    const double ratio = div_by((double)cntF, nfD, invFade);
-                                    ps.cur0 = fade_value(ps.old0, ps.new0, ratio);
-                                    if (rows) flat_next<FD>(f); else f.left--;
-                                    if (first) {   // the first row read: from here on the rows that follow
-                                        first = false;
-                                        uint32_t mine = 0;
-#pragma unroll
-                                        for (int e = 0; e < FD::NE; ++e) {
-                                            const bool moves = (fmask >> GE[e]) & 1u;
-                                            mine |= moves ? 1u : 0u;
-                                            if (moves) { f.tp[e] = tBase + (track_entry0(fmask, GE[e]) + fslots); f.ts[e] = fslots; }
-                                        }
-                                        rows = mine != 0u;
-                                    }
-                                }
-                            }
-                            const bool ending = emit && !deq && !fad && t == fadeEndAt;
-                            if (__any(ending)) { if (ending) { ps.old0 = ps.new0; ps.oldInc = ps.newInc; oldNull = newNull; fadeEndAt = 0xFFFFFFFFu; } }
-                            if (emit && !deq && !fad && !ending) { ps.cur0 += ps.oldInc; ps.old0 = ps.cur0; }   // glide (reference src/frame.cpp:76-79)
-                            const bool waveVib = __any(emit && vib_live());
-                            if (emit) PIPE(pipeX, c, i) = source(waveVib);
-                        }
-                    }
-                }
-                STAMP_WORKED();
-                __syncthreads();
-                STAMP_SYNCED();
-            }
-#ifdef KLATT_STAMPS
-            if (A.debug && lane == 0) {
-                unsigned long long* o = A.debug + (blockIdx.x * 4 + 0) * 8;
-                o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
-            }
-#endif
-            if (live) {
-                UttResult res;
-                res.produced = d.length; res.framesTaken = f.next; res.lastIndex = lastIndex; res.drained = 1u;
-                A.result[u] = res;
-            }
-        }
-#endif
     } else if (stage == 0) {
         // ================= S0: frame + glottal source (+ aspiration noise) =================
         // tracked: 1 vibratoPitchOffset, 2 vibratoSpeed, 3 turbulence, 4 openQuotient, 5 voiceAmplitude,
@@ -1727,9 +1362,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         }
     } else if (FLAT && stage == 1) {
         // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 =================
-#if KLATT_FLAT_V2
         if constexpr (FLAT) {
-            using FD = FlatDesc<5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
+            using FD = FlatDesc<1, 5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
             constexpr int GE[6] = {0, 1, 2, 3, 4, 14};           // N0, NP, r6, r5, r4 | cur: caNP
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
@@ -1756,31 +1390,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 },
                 noChunk);
         }
-#else
-        if constexpr (FLAT) {
-            using FD = FlatDesc<5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
-            constexpr int GE[6] = {0, 1, 2, 3, 4, 14};
-            FlatState<FD> f;
-            flat_init<FD>(f, live, d);
-            flat_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
-                [&](int c, int i) __attribute__((always_inline)) {
-                    const sig_t x = PIPE(pipeX, c, i);
-                    const sig_t n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
-                    f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
-                    const sig_t np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
-                    sig_t o = fade_value(x, np, f.cur[0]);
-#pragma unroll
-                    for (int r = 2; r < 5; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
-                    PIPE(pipeO, c, i) = o;
-                },
-                noChunk);
-        }
-#endif
     } else if (FLAT && stage == 3) {
         // ================= flat S3: frication noise, parallel r1..r4 partial sum =================
-#if KLATT_FLAT_V2
         if constexpr (FLAT) {
-            using FD = FlatDesc<4, 3, false, 0x77u>;                // usually parallel 1..3 and the gains
+            using FD = FlatDesc<3, 4, 3, false, 0x77u>;                // usually parallel 1..3 and the gains
             constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // parallel 1..4 | cur: fricationAmplitude, preFormantGain, pa1..pa4
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
@@ -1812,44 +1425,13 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 },
                 noChunk);
         }
-#else
-        if constexpr (FLAT) {
-            using FD = FlatDesc<4, 3, false, 0x77u, 0x07u>;         // usually parallel 1..3 and the gains
-            constexpr int GE[7] = {8, 9, 10, 11, 17, 18, 19};     // cur: fricationAmplitude, preFormantGain, pa1..pa4
-            FlatState<FD> f;
-            flat_init<FD>(f, live, d);
-            sig_t fricNoise = 0;
-            uint32_t noiseSt = noise_step(noise_first(nkey));     // frication: values 1, 3, 5, ...
-            flat_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
-                [&](int c, int i) __attribute__((always_inline)) {
-                    fricNoise = (sig_t)noise_uniform(noiseSt) + (sig_t)0.75 * fricNoise;
-                    noiseSt = noise_step2(noiseSt);
-                    const sig_t fric = fricNoise * (sig_t)0.3 * f.cur[0];
-                    const sig_t y = (fric * f.cur[1]) * (sig_t)0.5;
-                    sig_t par = 0;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const sig_t w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
-                        par += (w - y) * f.cur[2 + r];
-                    }
-                    PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
-                },
-                noChunk);
-        }
-#endif
     } else if (FLAT && (KLATT_FLAT_EXHAUSTIVE || stage == 2)) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
         if constexpr (FLAT) {
             constexpr int GE[7] = {5, 6, 7, 12, 13, 15, 16};      // cur: pa5, pa6, parallelBypass, outputGain
-#if KLATT_FLAT_V2
-            using FD = FlatDesc<5, 2, false, 0x77u>;                // usually c3, c2, c1, parallel 6 and the gains
+            using FD = FlatDesc<2, 5, 2, false, 0x77u>;                // usually c3, c2, c1, parallel 6 and the gains
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
-#else
-            using FD = FlatDesc<5, 2, false, 0x67u, 0x07u>;         // usually c3, c2, c1 and the gains
-            FlatState<FD> f;
-            flat_init<FD>(f, live, d);
-#endif
             int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
             uint32_t it = 0;
             auto flush_tile = [&](uint32_t tileStart, uint32_t validTo) __attribute__((always_inline)) {
@@ -1880,7 +1462,6 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             };
-#if KLATT_FLAT_V2
             flat2_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
                     constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
@@ -1909,28 +1490,6 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (:208)
                 },
                 [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
-#else
-            flat_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
-                [&](int c, int i) __attribute__((always_inline)) {
-                    sig_t o = PIPE(pipeO, c, i);
-                    const sig_t y = PIPE(pipeA, c, i);
-#pragma unroll
-                    for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
-                    sig_t par = PIPE(pipeB, c, i);
-#pragma unroll
-                    for (int r = 3; r < 5; ++r) {
-                        const sig_t w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
-                        par += (w - y) * f.cur[r - 3];
-                    }
-                    par = fade_value(par, y, f.cur[2]);
-                    const sig_t mix = o + par;
-                    const sig_t v = (mix * f.cur[3]) * (sig_t)4000.0;
-                    const sig_t lo = (v < (sig_t)32000.0) ? v : (sig_t)32000.0;       // windows.h min(): NaN -> 32000
-                    const sig_t cl = (lo > (sig_t)-32000.0) ? lo : (sig_t)-32000.0;
-                    myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (:208)
-                },
-                [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
-#endif
             if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
         }
     } else if (!NOISE && !NASAL && (stage == 1 || stage == 2)) {

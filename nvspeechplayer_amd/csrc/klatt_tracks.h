@@ -37,15 +37,18 @@ __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const Track
     const int lane = threadIdx.x & (kLanes - 1);
     const long long j = blockIdx.x;
     const TrackJob job = T.jobs[j];
-    const uint32_t mask = job.mask, nSlots = track_slots(mask), div = nSlots ? nSlots : 1u;
+    const uint32_t mask = job.mask;
     const double nf = (double)job.fadeSamples, invFade = 1.0 / nf;
     const double* const fo = T.shapes + (size_t)job.fromShape * kShapeStride;
     const double* const fn = T.shapes + (size_t)job.toShape * kShapeStride;
-    const uint32_t total = (uint32_t)kTrackFirst + (job.fadeSamples - 1u) * nSlots;   // host: below 2^27
-    const uint32_t header = track_header(mask);
     double2* const out = T.track + job.off;
+    // part by part (klatt_device.h: S0 | S1 | final stage | parallel stage), each its header, then its matrix
+    uint32_t partAt = 0;
+    for (int st = 0; st < kTrackStages; ++st) {
+    const uint32_t kinds = track_stage_kinds(st), nS = track_stage_slots(mask, st), div = nS ? nS : 1u;
+    const uint32_t header = track_stage_entries(st) - nS, total = track_stage_entries(st) + (job.fadeSamples - 1u) * nS;
     for (uint32_t e0 = (threadIdx.x >> 6) * kLanes; e0 < total; e0 += kLanes * kTrackWaves) {
-        // every lane evaluates (the last pass repeats the track's last entry in its idle lanes): the wave-uniform short cuts of
+        // every lane evaluates (the last pass repeats the part's last entry in its idle lanes): the wave-uniform short cuts of
         // resonator_coefficients_inline ballot over a full wavefront
         const uint32_t e = min(e0 + (uint32_t)lane, total - 1u);
         uint32_t cnt, r = 0u;     // r: the entry's kind
@@ -57,6 +60,7 @@ __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const Track
             cnt = 1u + n;
             uint32_t accM = 0, accH = 0;
             for (int k = 0; k < kTrackEntries; ++k) {
+                if (!((kinds >> k) & 1u)) continue;      // wave-uniform
                 const bool moves = (mask >> k) & 1u;     // wave-uniform
                 const uint32_t w = k == 0 ? 2u : 1u;
                 uint32_t& acc = moves ? accM : accH;
@@ -80,7 +84,9 @@ __global__ void __launch_bounds__(kLanes * kTrackWaves) klatt_tracks(const Track
             v.x = fade_value(fo[ga], fn[ga], ratio);
             v.y = gb >= 0 ? fade_value(fo[gb], fn[gb], ratio) : 0.0;
         }
-        if (e0 + (uint32_t)lane < total) out[e] = v;
+        if (e0 + (uint32_t)lane < total) out[partAt + e] = v;
+    }
+    partAt += total;
     }
 }
 

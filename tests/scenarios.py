@@ -191,6 +191,17 @@ def build_scenarios(ref):
     i1 = ref.find_ipa(0)
     ops = [q(fr, m, f) for (fr, m, f) in ref.ipa_case(i1, sr=16000)] + [("drain",)]
     sc.append(Scenario("ipa_l0_16k", ops, sr=16000, seed=21, batchable=True))
+
+    # other sample rates the C-ABI accepts (reference src/speechPlayer.cpp:25-32 takes any): everything that depends on the rate --
+    # the resonator coefficients, the phase increments, ms -> samples, the tracks' evaluation -- at 44.1 kHz and at 8 kHz
+    # (at 8 kHz the upper formants lie beyond the Nyquist frequency: the coefficients simply follow the formulas)
+    for sr, line, seed in ((44100, 1, 23), (8000, 3, 25)):
+        ops = [q(fr, m, f) for (fr, m, f) in ref.ipa_case(ref.find_ipa(line), sr=sr)] + [("drain",)]
+        sc.append(Scenario("ipa_l%d_%dk" % (line, sr // 1000), ops, sr=sr, seed=seed, batchable=True))
+        fv = vowel_frame(ref, "ɑ", 110.0, 170.0); fv[VIBOFFSET] = 0.1; fv[VIBSPEED] = 5.5
+        ops = [q(fv, ms(180, sr), ms(40, sr)), q(vowel_frame(ref, "s", 120.0), ms(90, sr), ms(30, sr)),
+               q(vowel_frame(ref, "m", 100.0, 90.0), ms(120, sr), ms(50, sr)), q(None, ms(40, sr), ms(40, sr)), ("drain",)]
+        sc.append(Scenario("vowel_fric_nasal_%dk" % (sr // 1000), ops, sr=sr, seed=seed + 1, batchable=True))
     return sc
 
 
@@ -211,7 +222,7 @@ def play_oracle(scn):
 
 
 STORED_PCM = ("cfg0_a_1s", "stream_chunks", "purge_resume", "vowelchart_pairs", "hannah_vibrato", "nan_hold",
-              "duration_edges", "ipa_l0_16k")
+              "duration_edges", "ipa_l0_16k", "ipa_l1_44k", "ipa_l3_8k", "vowel_fric_nasal_44k", "vowel_fric_nasal_8k")
 
 
 def write_expected_pcm(ref_path, outdir):

@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # f64 VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz; a wave64 f64 instruction occupies a SIMD for 4 cycles by the datasheet
 # (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz) and for 4.8 measured (profiles/r1_ubench_issue_rates.txt)
 SIMDS, CLOCK_HZ, F64_CYCLES_SPEC, F64_CYCLES_MEASURED = 1024, 2.4e9, 4.0, 4.8
-PMC_FILE = os.path.join(ROOT, "profiles", "r2_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc.json")
 
 
 def parse(argv=None):
@@ -211,21 +211,32 @@ def main():
         torch.cuda.set_device(device)
     dist = None
     shared_device = dry or world > ndev   # self-tests on a 1-GPU box: ranks share a device, RCCL cannot
-    if world > 1:
+    # BENCH_FORCE_PG=1: the process group of the N > 1 run -- RCCL ("nccl") with device_id, the barrier, both reductions on
+    # device tensors -- at world size 1, so that the branch can be exercised on a one-GPU box (tests/test_gpu_parity.py)
+    force_pg = world == 1 and not dry and os.environ.get("BENCH_FORCE_PG") == "1"
+    if world > 1 or force_pg:
         import torch.distributed as dist
-        if shared_device:
+        if force_pg:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % free_port(), rank=0, world_size=1,
+                                    device_id=torch.device("cuda", device))
+        elif shared_device:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         assert dist.get_world_size() == world and dist.get_rank() == rank
 
+    t_build = time.perf_counter()
     batch, shard = build_shard(args, rank, world)
+    t_build = time.perf_counter() - t_build
     samples = int(batch.sample_counts().sum())
     bp = None
+    t_set = 0.0
     if not dry:
         bp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
+        t_set = time.perf_counter()
         bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
                          batch["isnull"], batch["seeds"])
+        t_set = time.perf_counter() - t_set       # classification, lane packing, track planning, uploads: outside the timed region
         assert bp.totalSamples == samples
 
     def barrier():
@@ -243,12 +254,54 @@ def main():
     kernel_ms = bp.time(args.steps) if not dry else np.zeros(args.steps)      # K launches, each between two HIP events on the launch stream
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, total_samples = reduce_throughput(elapsed, samples, dist, device="cpu" if shared_device else "cuda")   # max / sum over ranks
+    red_dev = "cpu" if (shared_device and not force_pg) else "cuda"
+    elapsed, total_samples = reduce_throughput(elapsed, samples, dist, device=red_dev)   # max / sum over ranks
+    info = bp.kernelInfo() if not dry else {}
+    alg_bytes = batch.algorithmic_bytes()
+
+    # N > 1: BASELINE's node-wide configurations at their node sizes, as extra keys: configs[3] (world x 125 000 utterances cut to
+    # 0.5 s: 10^6 at N = 8) and configs[4] (world x 32 voice variants x 16 384 utterances: 256 x 16 384 at N = 8).  Same deal (contiguous
+    # shards of near-equal sample count), same barriers and reductions, 5 launches each.  --dry-run: the deal alone (closed-form lengths).
+    node_extras = {}
+    if world > 1 and not args.utterances and not args.no_extras:
+        from nvspeechplayer_amd.sharding import shard_bounds
+        if bp is not None:
+            bp.close(); bp = None
+        head_name, head_sr, head_frames = batch["name"], batch["sr"], int(len(batch["min"]))
+        batch = None
+        for key, wl, launches in (("cfg3_node", "cfg3", 5), ("cfg4_node", "cfg4", 5)):
+            per_gpu = workloads.PER_GPU[wl]
+            counts = workloads.sample_counts(wl, per_gpu * world)
+            bounds = shard_bounds(counts, world)
+            first, n = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
+            mine = int(counts[first:first + n].sum())
+            x_ms, x_el, x_info = [0.0], 0.0, {}
+            if not dry:
+                xb = workloads.make(wl, n, first=first)
+                x = BatchPlayer(xb["sr"], device=device, mode=args.mode, layout=args.layout)
+                x.setUtterances(xb["frame_start"], xb["frames"], xb["min"], xb["fade"], xb["index"], xb["isnull"], xb["seeds"])
+                assert x.totalSamples == mine
+                xb = None
+                x.time(1)
+                barrier()
+                t0 = time.perf_counter()
+                x_ms = x.time(launches)
+                barrier()
+                x_el = time.perf_counter() - t0
+                x_info = x.kernelInfo()
+                x.close()
+            x_el, x_total = reduce_throughput(x_el, mine, dist, device=red_dev)
+            node_extras[key] = {"workload": "BASELINE configs[%s] at its node size for %d GPUs" % (wl[-1], world), "node_utterances": per_gpu * world,
+                                "node_samples": int(counts.sum()), "total_samples_all_ranks": x_total, "launches": launches,
+                                "value": None if dry else x_total * launches / x_el, "unit": "samples/s",
+                                "ms_per_launch": None if dry else x_el / launches * 1e3, "kernel_ms_rank0": None if dry else float(np.mean(x_ms)),
+                                "shard_bounds": [int(v) for v in bounds],
+                                "tracks_rank0": None if dry else {"tracked_utterances": x_info.get("tracked_utterances"), "tracks": x_info.get("tracks"), "mbytes": x_info.get("track_mbytes")}}
+    else:
+        head_name, head_sr, head_frames = batch["name"], batch["sr"], int(len(batch["min"]))
 
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        alg_bytes = batch.algorithmic_bytes()
-        info = bp.kernelInfo() if not dry else {}
         out = {
             "metric": "audio samples/sec (whole node) at 22.05 kHz Klatt synth, batch-N utterances",
             "value": None if dry else total_samples * args.steps / elapsed,
@@ -262,19 +315,25 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": batch["name"], "utterances_per_gpu": shard["utterances"], "samples_per_gpu": samples,
-                       "frames_per_gpu": int(len(batch["min"])), "sample_rate": batch["sr"], "mode": args.mode, "layout": args.layout,
+            "config": {"workload": head_name, "utterances_per_gpu": shard["utterances"], "samples_per_gpu": samples,
+                       "frames_per_gpu": head_frames, "sample_rate": head_sr, "mode": args.mode, "layout": args.layout,
                        "coefficient_tracks": None if dry else {"tracked_utterances": info["tracked_utterances"], "tracks": info["tracks"], "mbytes": info["track_mbytes"]},
                        "node_utterances": shard["node_utterances"], "node_samples": shard["node_samples"],
                        "shard_bounds": shard["bounds"], "process_group": None if dist is None else dist.get_backend(),
                        "world_size": 1 if dist is None else dist.get_world_size(),
+                       "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else None,
+                       "host": {"build_batch_s": round(t_build, 3), "set_utterances_s": round(t_set, 3),
+                                "note": "outside the timed region: the frame producer (build) and speechPlayer_batch_setUtterances (classification, "
+                                        "lane packing, track planning, uploads); a batch is set once and synthesised many times"},
                        "parallelism": "node batch cut into %d contiguous shards of near-equal sample count, one process per GPU, no collective on the data path" % world},
         }
+        out.update(node_extras)
         if dry:
             out["dry_run"] = True
             out["total_samples_all_ranks"] = total_samples
         else:
-            out["realtime_factor"] = total_samples * args.steps / elapsed / batch["sr"]
+            out["realtime_factor"] = total_samples * args.steps / elapsed / head_sr
+            out["config"]["host"]["first_launch_end_to_end_samples_per_s"] = samples / (t_set + k_ms * 1e-3)
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "kernel": kernel_name(info), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -289,17 +348,17 @@ def main():
                 if ent and not args.utterances and world == 1 and args.mode == 0 and args.layout == -1:
                     if pj.get("engine_sources_sha") == engine_source_digest():
                         roof["traffic"] = ent["hbm_bytes_per_launch"]
-                        roof["traffic_source"] = "profiles/r2_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
+                        roof["traffic_source"] = "profiles/r3_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
                         insts = ent["valu_insts_per_launch"]
                         peak = SIMDS * CLOCK_HZ / F64_CYCLES_MEASURED
                         roof["valu"] = {"insts_per_launch": insts, "achieved": insts / (k_ms * 1e-3), "peak": peak,
                                         "unit": "wave64 VALU instructions/s", "frac": insts / (k_ms * 1e-3) / peak,
                                         "peak_spec": SIMDS * CLOCK_HZ / F64_CYCLES_SPEC,
                                         "insts_per_64_samples": insts * 64.0 / samples,
-                                        "source": "profiles/r2_pmc.json SQ_INSTS_VALU; peak = 1024 SIMDs x 2.4 GHz / 4.8 cycles per f64 wave instruction "
+                                        "source": "profiles/r3_pmc.json SQ_INSTS_VALU; peak = 1024 SIMDs x 2.4 GHz / 4.8 cycles per f64 wave instruction "
                                                   "(measured; 4 by the datasheet = peak_spec); instructions that are not f64 (a quarter to a third of them) issue in about half that, so frac is an upper bound on issue-slot use"}
                     else:
-                        roof["traffic_source"] = "profiles/r2_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
+                        roof["traffic_source"] = "profiles/r3_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
             except Exception:
                 pass
             out["roofline"] = roof

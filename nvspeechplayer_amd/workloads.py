@@ -126,33 +126,35 @@ def cfg4_voice_variants(n_variants=256, utt_per_variant=16384, first_variant=0, 
     total = n_variants * utt_per_variant
     lo = first_utt
     hi = total if n_utt is None else min(total, first_utt + n_utt)
-    frames, mins, fades, nul, counts, seeds = [], [], [], [], [], []
     bfs = base["frame_start"]
+    # the pieces (variant, first utterance, end) of the flat list, then ONE allocation of the shard's arrays, filled piece by
+    # piece (a list of per-variant copies and a concatenate held the frames twice: 2 x 4.7 GB per rank at configs[4]'s per-GPU size)
+    pieces = []
     for k in range(lo // utt_per_variant, (max(hi, lo + 1) - 1) // utt_per_variant + 1):
-        v = first_variant + k
         a, b = max(lo, k * utt_per_variant) - k * utt_per_variant, min(hi, (k + 1) * utt_per_variant) - k * utt_per_variant
-        if b <= a:
-            continue
+        if b > a:
+            pieces.append((first_variant + k, a, b))
+    nU = sum(b - a for _, a, b in pieces)
+    nF = sum(int(bfs[b] - bfs[a]) for _, a, b in pieces)
+    frames = np.empty((nF, 47)); mins = np.empty(nF, np.uint32); fades = np.empty(nF, np.uint32); nul = np.empty(nF, np.uint8)
+    fs = np.zeros(nU + 1, np.int64); seeds = np.empty(nU, np.uint32)
+    atF = atU = 0
+    for v, a, b in pieces:
+        n = int(bfs[b] - bfs[a])
         rng = np.random.default_rng(1234 + v)
-        g = base["frames"][bfs[a]:bfs[b]].copy()
+        g = frames[atF:atF + n]
+        g[:] = base["frames"][bfs[a]:bfs[b]]
         g[:, 7:10] *= rng.uniform(0.75, 1.05, size=3)          # cf1..cf3
         g[:, 15] *= rng.uniform(1.0, 1.3)                      # cb1
         pm = rng.uniform(0.75, 1.5)
         g[:, 0] *= pm; g[:, 46] *= pm                          # voicePitch, endVoicePitch
         g[:, 24] *= rng.uniform(0.7, 1.0)                      # fricationAmplitude
         g[:, 42] *= rng.uniform(1.0, 1.3)                      # pa6
-        frames.append(g)
-        mins.append(base["min"][bfs[a]:bfs[b]]); fades.append(base["fade"][bfs[a]:bfs[b]]); nul.append(base["isnull"][bfs[a]:bfs[b]])
-        counts.append(np.diff(bfs[a:b + 1]))
-        seeds.append(base["seeds"][a:b].astype(np.uint64) + np.uint64(v) * np.uint64(utt_per_variant))
-    if not frames:
-        frames, mins, fades, nul, counts, seeds = ([np.zeros((0, 47))], [np.zeros(0, np.uint32)], [np.zeros(0, np.uint32)],
-                                                   [np.zeros(0, np.uint8)], [np.zeros(0, np.int64)], [np.zeros(0, np.uint64)])
-    fs = np.concatenate([[0], np.cumsum(np.concatenate(counts))]).astype(np.int64)
-    nF = int(fs[-1])
-    return Batch(frames=np.concatenate(frames), min=np.concatenate(mins), fade=np.concatenate(fades),
-                 index=np.full(nF, -1, np.int32), isnull=np.concatenate(nul),
-                 frame_start=fs, seeds=(np.concatenate(seeds) & np.uint64(0xFFFFFFFF)).astype(np.uint32),
+        mins[atF:atF + n] = base["min"][bfs[a]:bfs[b]]; fades[atF:atF + n] = base["fade"][bfs[a]:bfs[b]]; nul[atF:atF + n] = base["isnull"][bfs[a]:bfs[b]]
+        fs[atU + 1:atU + 1 + (b - a)] = atF + (bfs[a + 1:b + 1] - bfs[a])
+        seeds[atU:atU + (b - a)] = ((base["seeds"][a:b].astype(np.uint64) + np.uint64(v) * np.uint64(utt_per_variant)) & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+        atF += n; atU += b - a
+    return Batch(frames=frames, min=mins, fade=fades, index=np.full(nF, -1, np.int32), isnull=nul, frame_start=fs, seeds=seeds,
                  name="cfg4: %d voice variants x %d utterances" % (n_variants, utt_per_variant), sr=sr)
 
 

@@ -83,3 +83,17 @@ def test_bench_starts_its_own_ranks(tmp_path):
         halves = [int(counts[:b[1]].sum()), int(counts[b[1]:].sum())]
         assert abs(halves[0] - halves[1]) <= 2 * int(counts.max())                                # balanced by samples, not by count
         assert c["samples_per_gpu"] == halves[0]
+    # without --utterances the N > 1 run also carries BASELINE's node-wide configurations at their node sizes as extra keys
+    # (--dry-run: the deal alone, from the closed-form lengths)
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "0"],
+                                  env=env, cwd=str(tmp_path), timeout=280)
+    d = json.loads([l for l in out.decode().splitlines() if l.startswith("{")][0])
+    assert d["config"]["node_utterances"] == 2 * 65536 and d["config"]["rccl_ranks"] is None      # gloo here; RCCL reports its ranks
+    for key, per_gpu, wl in (("cfg3_node", 125000, "cfg3"), ("cfg4_node", 32 * 16384, "cfg4")):
+        e = d[key]
+        counts = workloads.sample_counts(wl, 2 * per_gpu)
+        assert e["node_utterances"] == 2 * per_gpu and e["node_samples"] == int(counts.sum()) == int(e["total_samples_all_ranks"])
+        b = e["shard_bounds"]
+        assert b[0] == 0 and b[2] == 2 * per_gpu
+        assert abs(int(counts[:b[1]].sum()) - int(counts[b[1]:].sum())) <= 2 * int(counts.max())
+        assert e["value"] is None and e["launches"] == 5

@@ -857,6 +857,27 @@ def test_bench_two_ranks_on_one_gpu(tmp_path):
     assert b[0] == 0 and b[2] == 8000 and abs(b[1] - 4000) < 200
 
 
+def test_bench_rccl_branch_at_world_size_one(tmp_path):
+    """The process group of the N > 1 run -- backend "nccl" (RCCL) initialised with device_id, the barrier around the timed region
+    and both all_reduces on device tensors -- on the one GPU of this box: BENCH_FORCE_PG=1 takes that branch at world size 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["BENCH_FORCE_PG"] = "1"
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    out = subprocess.check_output([sys.executable, os.path.join(root, "bench.py"), "--workload", "cfg3", "--utterances", "4000", "--steps", "4",
+                                   "--warmup", "1", "--no-extras", "--no-cpu-baseline"], env=env, cwd=str(tmp_path), timeout=600)
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert c["process_group"] == "nccl" and c["rccl_ranks"] == 1 and c["world_size"] == 1 and d["n_gpus"] == 1
+    assert d["value"] > 1e9 and d["steps"] == 4 and "roofline" in d
+    assert c["host"]["set_utterances_s"] > 0 and c["host"]["first_launch_end_to_end_samples_per_s"] > 0
+
+
 def test_error_codes_and_digest(ref):
     """speechPlayer_lastErrorCode: non-zero after a failed call, back to 0 after the next successful one; and the device-side
     digest against the same formula in numpy, per utterance, on a ragged batch (lengths 0, 1, 7, 8, 9, ... samples)."""

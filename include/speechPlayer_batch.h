@@ -38,7 +38,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
  * "tracks" (1, default: noisy utterances whose parameters are all finite take what they need on fade samples -- resonator
  * coefficients, interpolated gains -- from tracks: evaluated densely by a kernel of its own before the synthesis kernel, one
  * track per distinct fade of the batch, instead of exp/cos, interpolation and a frame state machine inside the sample
- * recurrence; 0: never) and "track_budget_mb" (device memory the tracks of a batch may take, default 16384; a batch whose
+ * recurrence; 0: never) and "track_budget_mb" (device memory the tracks of a batch may take, default 4096, which is also the most: the flat stages address the tracks with 32-bit byte offsets; a batch whose
  * tracks do not fit runs without them): both are read by speechPlayer_batch_setUtterances, set them before it.  No option changes the PCM. */
 int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value);
 
@@ -167,7 +167,8 @@ int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int s
  *                applied to every non-silence frame: absolute values first, then multipliers (applyVoiceToFrame)
  */
 /* One utterance.  Returns its number of frames n; fills the arrays (each may be NULL) when n <= capacity.  isNull[k] != 0
- * marks silence (the reference yields None); durations are in MILLISECONDS as the reference yields them.  -1: unknown voice. */
+ * marks silence (the reference yields None); durations are in MILLISECONDS as the reference yields them.  -1: unknown voice;
+ * -2: a clauseType the intonation table does not hold (the reference raises KeyError, ipa.py:281). */
 long long speechPlayer_ipa_frames(const char* ipaUtf8, double speed, double basePitch, double inflection, int clauseType,
 	const char* voiceName, speechPlayer_frame_t* frames, unsigned char* isNull, double* durationMs, double* fadeMs, long long capacity);
 /* Many utterances, packed as speechPlayer_batch_setUtterances takes them: durations converted to samples the way the
@@ -175,7 +176,7 @@ long long speechPlayer_ipa_frames(const char* ipaUtf8, double speed, double base
  * test_speakIpa.py:27 queues it (negative: none).  basePitch[nTexts] may be NULL (100 Hz), clauseTypes[nTexts] may be NULL
  * (none).  Returns the total number of frames; writes frameStart[nTexts+1] when given, and the frame arrays when all four
  * are given and frameCapacity suffices (call once with NULL arrays to size them).  Distinct (text, clause, pitch)
- * combinations are built once per call and instanced. */
+ * combinations are built once per call and instanced.  -1: bad arguments or unknown voice; -2: unknown clause type. */
 long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed, const double* basePitch,
 	double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
 	long long* frameStart, speechPlayer_frame_t* frames, unsigned int* minFrameDuration, unsigned int* fadeDuration,
@@ -184,6 +185,12 @@ long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* co
 int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
 	const double* basePitch, double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
 	const unsigned int* noiseSeed);
+/* The phoneme table the producer is driven by (the reference's data.py, as numbers): entry `index` of
+ * speechPlayer_ipa_phonemeCount() -- its IPA symbol (UTF-8, NUL-terminated, symbolCapacity bytes), its 47 parameter values in
+ * speechPlayer_frame_t order, which of them the entry sets (bit k of *fieldMask), and its class bits (1 _isVowel, 2 _isVoiced,
+ * 4 _isNasal, 8 _isStop, 16 _isLiquid, 32 _isSemivowel, 64 _isAfricate, 128 _copyAdjacent).  Any output may be NULL.  0, or -1. */
+int speechPlayer_ipa_phonemeCount(void);
+int speechPlayer_ipa_phoneme(int index, char* symbolUtf8, int symbolCapacity, double* values, unsigned long long* fieldMask, unsigned int* classBits);
 /* The voice presets of the NVDA driver (reference __init__.py:86-116), by index and by name. */
 int speechPlayer_voiceCount(void);
 const char* speechPlayer_voiceName(int index);

@@ -42,6 +42,7 @@ EXPORTS = [
     "speechPlayer_synthesizeManyDevice", "speechPlayer_lastLiveKernelMs",
     "speechPlayer_ipa_frames", "speechPlayer_ipa_pack", "speechPlayer_batch_setIpa",
     "speechPlayer_voiceCount", "speechPlayer_voiceName", "speechPlayer_applyVoiceToFrame",
+    "speechPlayer_ipa_phonemeCount", "speechPlayer_ipa_phoneme",
     "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
     "speechPlayer_node_setUtterances", "speechPlayer_node_synthesize", "speechPlayer_node_wait", "speechPlayer_node_totalSamples",
     "speechPlayer_node_read", "speechPlayer_node_getLastIndex", "speechPlayer_node_shardInfo", "speechPlayer_node_part",
@@ -88,6 +89,17 @@ def build(force=False, verbose=False, extra_hipcc_flags=(), lib_path=None):
         raise RuntimeError("hipcc not found; cannot build %s" % out)
     os.makedirs(os.path.dirname(out), exist_ok=True)
     os.makedirs(OBJ_DIR, exist_ok=True)
+    # one builder at a time (the rank processes of bench.py, pytest-xdist workers and tools may all import at once); whoever
+    # comes second finds the library current
+    import fcntl
+    with open(os.path.join(OBJ_DIR, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not variant and not _stale():
+            return out
+        return _build_locked(hipcc, out, variant, force, verbose, extra_hipcc_flags)
+
+
+def _build_locked(hipcc, out, variant, force, verbose, extra_hipcc_flags):
     objs = []
     for src in SOURCES:
         is_hip = src.endswith(".hip")
@@ -108,10 +120,12 @@ def build(force=False, verbose=False, extra_hipcc_flags=(), lib_path=None):
                 print(" ".join(cmd))
             subprocess.check_call(cmd)
         objs.append(o)
-    cmd = [hipcc] + LINK_FLAGS + ["-o", out] + objs
+    tmp = out + ".tmp.%d" % os.getpid()      # linked beside its place, then moved into it: nobody loads a half-written library
+    cmd = [hipcc] + LINK_FLAGS + ["-o", tmp] + objs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    os.replace(tmp, out)
     return out
 
 
@@ -230,6 +244,10 @@ def load():
     L.speechPlayer_voiceName.argtypes = [i32]
     L.speechPlayer_applyVoiceToFrame.restype = i32
     L.speechPlayer_applyVoiceToFrame.argtypes = [vp, ctypes.c_char_p]
+    L.speechPlayer_ipa_phonemeCount.restype = i32
+    L.speechPlayer_ipa_phonemeCount.argtypes = []
+    L.speechPlayer_ipa_phoneme.restype = i32
+    L.speechPlayer_ipa_phoneme.argtypes = [i32, vp, i32, vp, vp, vp]
     L.speechPlayer_planTracks.restype = i64
     L.speechPlayer_planTracks.argtypes = [i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
     _lib = L

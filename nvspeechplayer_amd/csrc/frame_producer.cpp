@@ -473,12 +473,46 @@ int speechPlayer_applyVoiceToFrame(speechPlayer_frame_t* frame, const char* voic
     return 0;
 }
 
+// the clause types the intonation table knows (reference ipa.py:207-276; the reference raises KeyError for any other), and 0: none
+static bool clause_known(int clause)
+{
+    if (clause == 0) return true;
+    for (const IntonationRow& r : kIntonationRows)
+        if (r.clause == clause) return true;
+    return false;
+}
+
+int speechPlayer_ipa_phonemeCount(void) { return kNumPhonemes; }
+
+int speechPlayer_ipa_phoneme(int index, char* symbolUtf8, int symbolCapacity, double* values, unsigned long long* fieldMask, unsigned int* classBits)
+{
+    if (index < 0 || index >= kNumPhonemes) return -1;
+    const PhonemeRow& r = kPhonemeRows[index];
+    if (symbolUtf8) {
+        std::string u;
+        for (int i = 0; i < r.nSymbol; ++i) {
+            const uint32_t c = r.symbol[i];
+            if (c < 0x80) u.push_back((char)c);
+            else if (c < 0x800) { u.push_back((char)(0xC0 | (c >> 6))); u.push_back((char)(0x80 | (c & 0x3F))); }
+            else if (c < 0x10000) { u.push_back((char)(0xE0 | (c >> 12))); u.push_back((char)(0x80 | ((c >> 6) & 0x3F))); u.push_back((char)(0x80 | (c & 0x3F))); }
+            else { u.push_back((char)(0xF0 | (c >> 18))); u.push_back((char)(0x80 | ((c >> 12) & 0x3F))); u.push_back((char)(0x80 | ((c >> 6) & 0x3F))); u.push_back((char)(0x80 | (c & 0x3F))); }
+        }
+        if ((int)u.size() + 1 > symbolCapacity) return -1;
+        memcpy(symbolUtf8, u.c_str(), u.size() + 1);
+    }
+    if (values) memcpy(values, r.value, sizeof r.value);
+    if (fieldMask) *fieldMask = r.mask;
+    if (classBits) *classBits = r.cls;
+    return 0;
+}
+
 long long speechPlayer_ipa_frames(const char* ipaUtf8, double speed, double basePitch, double inflection, int clauseType,
                                   const char* voiceName, speechPlayer_frame_t* frames, unsigned char* isNull,
                                   double* durationMs, double* fadeMs, long long capacity)
 {
     const VoiceRow* voice = find_voice(voiceName);
     if (voiceName && *voiceName && !voice) return -1;
+    if (!clause_known(clauseType)) return -2;
     Producer p(speed, inflection, voice);
     const Stream& s = p.stream(ipaUtf8, clauseType, basePitch);
     const long long n = (long long)s.size();
@@ -491,6 +525,11 @@ long long speechPlayer_ipa_frames(const char* ipaUtf8, double speed, double base
     return n;
 }
 
+// one pass over the texts with a producer (and its memo) the caller keeps: sizes when the arrays are absent, else fills them
+static long long pack_with(Producer& p, int sampleRate, long long nTexts, const char* const* ipaUtf8, const double* basePitch,
+                           const char* clauseTypes, double trailingSilenceMs, long long* frameStart, speechPlayer_frame_t* frames,
+                           unsigned int* minFrameDuration, unsigned int* fadeDuration, unsigned char* isNull, long long frameCapacity);
+
 long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed, const double* basePitch,
                                 double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
                                 long long* frameStart, speechPlayer_frame_t* frames, unsigned int* minFrameDuration,
@@ -499,7 +538,16 @@ long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* co
     if (nTexts < 0 || (nTexts > 0 && !ipaUtf8)) return -1;
     const VoiceRow* voice = find_voice(voiceName);
     if (voiceName && *voiceName && !voice) return -1;
+    for (long long i = 0; clauseTypes && i < nTexts; ++i)
+        if (!clause_known((int)(unsigned char)clauseTypes[i])) return -2;
     Producer p(speed, inflection, voice);
+    return pack_with(p, sampleRate, nTexts, ipaUtf8, basePitch, clauseTypes, trailingSilenceMs, frameStart, frames, minFrameDuration, fadeDuration, isNull, frameCapacity);
+}
+
+static long long pack_with(Producer& p, int sampleRate, long long nTexts, const char* const* ipaUtf8, const double* basePitch,
+                           const char* clauseTypes, double trailingSilenceMs, long long* frameStart, speechPlayer_frame_t* frames,
+                           unsigned int* minFrameDuration, unsigned int* fadeDuration, unsigned char* isNull, long long frameCapacity)
+{
     const bool tail = trailingSilenceMs >= 0.0;
     const bool store = frames && minFrameDuration && fadeDuration && isNull;
     long long pos = 0;
@@ -534,16 +582,20 @@ int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, cons
                               double trailingSilenceMs, const unsigned int* noiseSeed)
 {
     int rate = speechPlayer_batch_sampleRate(batch);
-    if (rate <= 0 || nTexts < 0) return -1;
+    if (rate <= 0 || nTexts < 0 || (nTexts > 0 && !ipaUtf8)) return -1;
+    const VoiceRow* voice = find_voice(voiceName);
+    if (voiceName && *voiceName && !voice) return -1;
+    for (long long i = 0; clauseTypes && i < nTexts; ++i)
+        if (!clause_known((int)(unsigned char)clauseTypes[i])) return -1;
+    // ONE producer for the sizing pass and the filling pass: the second finds every stream in the first's memo
+    Producer p(speed, inflection, voice);
     std::vector<long long> start((size_t)nTexts + 1, 0);
-    const long long total = speechPlayer_ipa_pack(rate, nTexts, ipaUtf8, speed, basePitch, inflection, clauseTypes, voiceName, trailingSilenceMs,
-                                                  start.data(), nullptr, nullptr, nullptr, nullptr, 0);
+    const long long total = pack_with(p, rate, nTexts, ipaUtf8, basePitch, clauseTypes, trailingSilenceMs, start.data(), nullptr, nullptr, nullptr, nullptr, 0);
     if (total < 0) return -1;
     std::vector<speechPlayer_frame_t> frames((size_t)total);
     std::vector<unsigned int> mins((size_t)total), fades((size_t)total);
     std::vector<unsigned char> nul((size_t)total);
-    if (speechPlayer_ipa_pack(rate, nTexts, ipaUtf8, speed, basePitch, inflection, clauseTypes, voiceName, trailingSilenceMs, start.data(),
-                              frames.data(), mins.data(), fades.data(), nul.data(), total) != total)
+    if (pack_with(p, rate, nTexts, ipaUtf8, basePitch, clauseTypes, trailingSilenceMs, start.data(), frames.data(), mins.data(), fades.data(), nul.data(), total) != total)
         return -1;
     return speechPlayer_batch_setUtterances(batch, nTexts, start.data(), frames.data(), mins.data(), fades.data(), nullptr, nul.data(), noiseSeed);
 }

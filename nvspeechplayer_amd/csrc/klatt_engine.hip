@@ -318,7 +318,7 @@ struct Batch {
     int cus = 256;
     hipStream_t stream = nullptr;
     int tracks = 1;                        // 1: noisy utterances with finite parameters run on flat stages fed by tracks (klatt_tracks.h)
-    long long trackBudgetMB = 16384;       // the tracks of a batch may take this much device memory; utterances beyond it run untracked
+    long long trackBudgetMB = 4096;        // the tracks of a batch may take this much device memory (at most 4 GB: the flat stages address them with 32-bit byte offsets); utterances beyond it run untracked
     hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
     hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
     long long nUtt = 0, nFrames = 0, nSlots = 0;
@@ -444,7 +444,23 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
     out.missedSize = 0; out.missedBudget = 0;
     for (long long u = 0; u < nUtterances; ++u) nEligible += eligible[u] ? 1 : 0;
     out.eligible = nEligible;
+    // Give up early on a batch whose fades are (nearly) all different: its tracks grow in proportion to the utterances walked and
+    // would pass the budget long before the end -- walking on until they do, hashing 45 values per frame and filling the maps,
+    // was 0.6 s for 65 536 such utterances (30 launches' worth) for nothing.  Two look-outs, after 1/32 and 1/16 of the
+    // utterances: tracks that doubled in between (no sharing yet: a batch that shares its fades saturates early) and that at this
+    // rate end beyond the budget.
+    const long long look1 = nUtterances / 32, look2 = nUtterances / 16;
+    unsigned long long entriesAt1 = 0;
     for (long long u = 0; u < nUtterances && (!whole || nMissed * 10 <= nEligible); ++u) {
+        if (whole && look1 >= 256) {
+            if (u == look1) entriesAt1 = out.entries;
+            if (u == look2 && out.entries - entriesAt1 >= entriesAt1 - entriesAt1 / 8 &&
+                (long double)out.entries * ((long double)nUtterances / (long double)look2) > (long double)budget) {
+                nMissed = nEligible + 1;      // the all-or-nothing rule below: nothing is tracked
+                out.missedBudget = nEligible;
+                break;
+            }
+        }
         if (!eligible[u]) continue;
         if (sum && sum->load(std::memory_order_relaxed) > budget / 4) { ++out.missedBudget; return; }
         added.clear();
@@ -527,12 +543,45 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
                  const unsigned char* eligible, long long budgetMB, TrackPlan& out)
 {
     const long long nF = frameStart[nUtterances];
+    static const bool trace = getenv("SPEECHPLAYER_PLAN_TRACE") != nullptr;      // where the planning's time goes, on stderr
+    const auto tStart = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (trace) fprintf(stderr, "[speechPlayer/plan] %s: %.1f ms since the start\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count());
+    };
     unsigned nThreads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
     if (const char* e = getenv("SPEECHPLAYER_PLAN_THREADS")) nThreads = (unsigned)std::max(1, atoi(e));
     if (nThreads < 2 || nF < 200000 || nUtterances < (long long)nThreads * 64) {
         plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
         return;
     }
+    // A look at the first 128th of the batch before the threads start (the look-outs of plan_tracks_pass, whole = true): a batch
+    // whose fades are all different is given up after a few milliseconds instead of after the parts have filled a quarter of the budget.
+    {
+        TrackPlan probe;
+        const long long nProbe = std::max<long long>(nUtterances / 128, 256);
+        std::vector<unsigned char> none;
+        plan_tracks_pass(nProbe, frameStart, frames, meta, eligible, budgetMB, false, nullptr, probe);
+        TrackPlan half;
+        plan_tracks_pass(nProbe / 2, frameStart, frames, meta, eligible, budgetMB, false, nullptr, half);
+        const unsigned long long cap = std::min((unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2), (1ull << 28) - (1ull << 21) - kTrackPad);
+        if (trace) fprintf(stderr, "[speechPlayer/plan] look: %llu entries after %lld utterances, %llu after %lld; budget %llu\n", half.entries, nProbe / 2, probe.entries, nProbe, cap);
+        const long double scale = (long double)nUtterances / (long double)nProbe;
+        // (tracks that double with the utterances and at that rate end more than a ninth beyond the budget: then more than a tenth of
+        // the utterances would not fit, and the rule is all or nothing)
+        if (half.entries > 0 && probe.missedBudget == 0 && probe.entries - half.entries >= half.entries - half.entries / 8 &&
+            (long double)probe.entries * scale * 0.9L > (long double)cap) {
+            out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
+            out.jobs.clear(); out.shapes.clear(); out.entries = 0;
+            out.tracked.assign((size_t)nUtterances, 0);
+            out.kinds.assign((size_t)nUtterances, 0);
+            out.eligible = 0; out.missedSize = 0; out.missedBudget = 0;
+            for (long long u = 0; u < nUtterances; ++u) out.eligible += eligible[u] ? 1 : 0;
+            out.missedBudget = out.eligible;
+            lap("given up after the look at the first utterances");
+            return;
+        }
+    }
+    lap("looked at the first utterances");
     // parts of about equal frame counts
     std::vector<long long> cut(nThreads + 1, nUtterances);
     cut[0] = 0;
@@ -543,6 +592,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     run_parts(nThreads, [&](unsigned t) {
         plan_tracks_pass(cut[t + 1] - cut[t], frameStart + cut[t], frames, meta, eligible + cut[t], budgetMB, false, &sum, part[t]);
     });
+    lap("parts planned");
     // merge: shapes by value, fades by (from, to, length)
     struct ShapeKey { const double* v; bool operator==(const ShapeKey& o) const { return !memcmp(v, o.v, kShapeValues * sizeof(double)); } };
     struct ShapeKeyHash { size_t operator()(const ShapeKey& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (int i = 0; i < kShapeValues; ++i) { unsigned long long w; memcpy(&w, &k.v[i], 8); h ^= w; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
@@ -611,6 +661,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
             }
         }
     });
+    lap("merged");
 }
 
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
@@ -1166,12 +1217,28 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     return -1;
 }
 
+static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
+                                const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
+                                const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
+                                const unsigned int* noiseSeed);
 int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
                                      const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
                                      const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
                                      const unsigned int* noiseSeed)
 {
     begin_call();
+    try {       // nothing may throw across the C ABI (host allocations of a large batch; the planning threads)
+        return batch_set_utterances(batch, nUtterances, frameStart, frames, minFrameDuration, fadeDuration, userIndex, isNull, noiseSeed);
+    } catch (const std::exception& e) {
+        set_error("setUtterances: %s", e.what());
+        return -1;
+    }
+}
+static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
+                                const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
+                                const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
+                                const unsigned int* noiseSeed)
+{
     Batch* b = static_cast<Batch*>(batch);
     if (!b || nUtterances < 0 || !frameStart) { set_error("setUtterances: bad arguments"); return -1; }
     if (nUtterances >= 0xFFFFFFFFll) { set_error("setUtterances: too many utterances"); return -1; }
@@ -1692,9 +1759,11 @@ int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtteran
     // one host thread per device: rebase the shard's index array, give every utterance its GLOBAL default seed, upload
     std::vector<int> rc((size_t)nd, 0), codes((size_t)nd, 0);
     std::vector<std::string> errors((size_t)nd);
-    std::vector<std::thread> workers;
-    for (int d = 0; d < nd; ++d) {
-        workers.emplace_back([&, d]() {
+    // (run_parts: a thread that cannot be started leaves its shard to the caller's thread; nothing may throw across the C ABI)
+    try {
+    run_parts((unsigned)nd, [&](unsigned ud) {
+        const int d = (int)ud;
+        try {
             const long long u0 = n->bounds[d], u1 = n->bounds[d + 1], f0 = frameStart[u0];
             std::vector<long long> fs((size_t)(u1 - u0) + 1);
             for (long long u = u0; u <= u1; ++u) fs[u - u0] = frameStart[u] - f0;
@@ -1704,9 +1773,14 @@ int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtteran
                                                      minFrameDuration ? minFrameDuration + f0 : nullptr, fadeDuration ? fadeDuration + f0 : nullptr,
                                                      userIndex ? userIndex + f0 : nullptr, isNull ? isNull + f0 : nullptr, seeds.data());
             if (rc[d]) { errors[d] = g_lastError; codes[d] = g_lastErrorCode; }
-        });
+        } catch (const std::exception& e) {
+            rc[d] = -1; errors[d] = e.what(); codes[d] = SPEECHPLAYER_ERR_ARGUMENT;
+        }
+    });
+    } catch (const std::exception& e) {
+        set_error("node_setUtterances: %s", e.what());
+        return -1;
     }
-    for (auto& w : workers) w.join();
     for (int d = 0; d < nd; ++d)
         if (rc[d]) { set_error_code(codes[d]); set_error("node_setUtterances: shard %d: %s", d, errors[d].c_str()); return -1; }
     return 0;

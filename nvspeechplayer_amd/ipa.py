@@ -35,12 +35,87 @@ def applyVoiceToFrame(frame, voiceName):
         raise KeyError(voiceName)
 
 
+_CLASS_FLAGS = ("_isVowel", "_isVoiced", "_isNasal", "_isStop", "_isLiquid", "_isSemivowel", "_isAfricate", "_copyAdjacent")
+
+
+def _load_table():
+    """The producer's phoneme table as the reference's `data` dict (reference ipa.py:22, data.py): symbol -> {field: value, '_is...': True}."""
+    L = _native.load()
+    names = [n for n, _ in Frame._fields_]
+    table = {}
+    for i in range(L.speechPlayer_ipa_phonemeCount()):
+        sym = ctypes.create_string_buffer(16)
+        vals = (ctypes.c_double * 47)()
+        mask = ctypes.c_ulonglong(0)
+        cls = ctypes.c_uint(0)
+        if L.speechPlayer_ipa_phoneme(i, sym, 16, vals, ctypes.byref(mask), ctypes.byref(cls)) != 0:
+            raise RuntimeError("phoneme table entry %d" % i)
+        entry = {names[k]: vals[k] for k in range(47) if (mask.value >> k) & 1}
+        for b, flag in enumerate(_CLASS_FLAGS):
+            if (cls.value >> b) & 1:
+                entry[flag] = True
+        table[sym.value.decode("utf8")] = entry
+    return table
+
+
+class _LazyTable(dict):
+    """`data` is filled from the library on first use (importing this module must not need the library)."""
+    _loaded = False
+
+    def _fill(self):
+        if not self._loaded:
+            self._loaded = True
+            self.update(_load_table())
+
+    def __getitem__(self, k):
+        self._fill(); return dict.__getitem__(self, k)
+
+    def __iter__(self):
+        self._fill(); return dict.__iter__(self)
+
+    def __len__(self):
+        self._fill(); return dict.__len__(self)
+
+    def __contains__(self, k):
+        self._fill(); return dict.__contains__(self, k)
+
+    def items(self):
+        self._fill(); return dict.items(self)
+
+    def keys(self):
+        self._fill(); return dict.keys(self)
+
+    def values(self):
+        self._fill(); return dict.values(self)
+
+    def get(self, k, d=None):
+        self._fill(); return dict.get(self, k, d)
+
+
+data = _LazyTable()
+
+
+def iterPhonemes(**kwargs):
+    """reference ipa.py:24-27: the symbols whose entry has the given values, e.g. iterPhonemes(_isVoiced=True)."""
+    for k, v in data.items():
+        if all(v.get(x) == y for x, y in kwargs.items()):
+            yield k
+
+
+def setFrame(frame, phoneme):
+    """reference ipa.py:29-32: overwrite the fields the phoneme's entry defines (the class flags become plain attributes)."""
+    for k, v in data[phoneme].items():
+        setattr(frame, k, v)
+
+
 def frame_arrays(ipaText, speed=1, basePitch=100, inflection=0.5, clauseType=None, voice=None):
     """One utterance as arrays: (frames[n, 47] f64, isnull[n] u8, duration_ms[n], fade_ms[n])."""
     L = _native.load()
     text = ipaText.encode("utf8")
     args = (text, float(speed), float(basePitch), float(inflection), _clause_code(clauseType), _voice_arg(voice))
     n = L.speechPlayer_ipa_frames(*args, None, None, None, None, 0)
+    if n == -2:
+        raise KeyError(clauseType)          # as the reference: intonationParamTable[clauseType]
     if n < 0:
         raise KeyError("unknown voice %r" % (voice,))
     frames = np.zeros((n, 47)); nul = np.zeros(n, np.uint8); dur = np.zeros(n); fade = np.zeros(n)
@@ -81,6 +156,8 @@ def frames_for_batch(texts, sampleRate=22050, speed=1, basePitch=100, inflection
     start = np.zeros(n + 1, np.int64)
     head = (int(sampleRate), n, ptrs, float(speed), pitch.ctypes.data, float(inflection), clauses + b"\0", _voice_arg(voice), tail)
     total = L.speechPlayer_ipa_pack(*head, start.ctypes.data, None, None, None, None, 0)
+    if total == -2:
+        raise KeyError("unknown clause type in %r" % (clauseType,))
     if total < 0:
         raise KeyError("unknown voice %r" % (voice,))
     frames = np.zeros((total, 47)); m = np.zeros(total, np.uint32); f = np.zeros(total, np.uint32); nul = np.zeros(total, np.uint8)

@@ -5,6 +5,7 @@ duration and fade must be identical, for the eight sampleIpa.txt lines x five cl
 inflection variants, ten extra lines with tie bars, length and stress marks and unknown symbols, and the four voice
 presets.  Host code: runs without a GPU."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -126,3 +127,26 @@ def test_producer_under_sanitizers(tmp_path):
                            os.path.join(root, "nvspeechplayer_amd", "csrc", "frame_producer.cpp"), "-o", exe])
     out = subprocess.check_output([exe], stderr=subprocess.STDOUT).decode()
     assert out.startswith("ok ") and "runtime error" not in out and "AddressSanitizer" not in out, out
+
+
+def test_phoneme_table_surface_of_the_reference():
+    """`data`, `setFrame`, `iterPhonemes` (reference ipa.py:22-32), served from the producer's own table: every entry equals the
+    captured reference table value for value and flag for flag; an unknown clause type raises KeyError as the reference does."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import ipa
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ref_frames.npz"))
+    names = [b.decode("utf8") for b in z["phoneme_names"]]
+    assert sorted(ipa.data) == sorted(names) and len(ipa.data) == 49
+    fields = [n for n, _ in eng.Frame._fields_]
+    for i, n in enumerate(names):
+        fr = eng.Frame()
+        ipa.setFrame(fr, n)
+        assert np.array_equal(np.array([getattr(fr, k) for k in fields]), z["phoneme_frames"][i]), n
+        assert sorted(k for k in ipa.data[n] if not k.startswith("_")) == sorted(f for f, m in zip(fields, z["phoneme_mask"][i]) if m), n
+        for fl in ("_isVowel", "_isVoiced", "_isNasal", "_isStop", "_isLiquid", "_isSemivowel", "_isAfricate", "_copyAdjacent"):
+            assert bool(ipa.data[n].get(fl)) == bool(z["phoneme" + fl][i]), (n, fl)
+    assert sorted(ipa.iterPhonemes(_isVoiced=True)) == sorted(names[i] for i in z["voiced_order"])
+    with pytest.raises(KeyError):
+        list(ipa.generateFramesAndTiming("hælou", clauseType=";"))
+    with pytest.raises(KeyError):
+        ipa.frames_for_batch(["hælou", "wɜːld"], clauseType=[".", ";"])

@@ -218,18 +218,23 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x)
 // The engine's noise definition (restated by oracle/klatt_oracle.c).  The reference draws (double)rand()/RAND_MAX twice per
 // sample from the process-global rand() (src/speechWaveGenerator.cpp:40, called at :75 and :205): not reproducible across
 // handles.  Here every utterance has a stream of its own: a 32-bit linear congruential generator (Numerical Recipes'
-// multiplier and increment) started from a hash of the utterance's seed,
-//     s_0 = noise_key(seed),   s_(n+1) = 1664525 s_n + 1013904223  (mod 2^32),   value k = s_(k+1) >> 1     (0 .. 2^31-1, glibc's range)
+// multiplier) whose start AND increment come from the utterance's seed,
+//     s_0 = noise_key(seed),  c = noise_inc(seed) (odd),   s_(n+1) = 1664525 s_n + c  (mod 2^32),   value k = s_(k+1) >> 1     (0 .. 2^31-1, glibc's range)
 // and sample n takes value 2n for the aspiration and value 2n+1 for the frication, the order of the reference's two calls.
-// One multiply per value: the counter hash of rounds 1-2 (two multiplies and four xor-shifts per value) was 35 of the ~200-250 issue
-// cycles of the source and frication stages per sample; this is 11 (cfg2 9.48 -> 8.96 ms).  The stages step their own
-// sub-sequence two values at a time (noise_step2).  A live handle keeps the state of its next aspiration value (stream slot 221).
+// Generators with different odd increments run through different full-period sequences, so two utterances do not replay each
+// other's noise at a lag (round 2's generator had ONE increment: every stream was a window of the same 2^32-cycle, and a launch of
+// BASELINE configs[2] draws 2.7e9 values, most of that cycle).  One multiply per value: the counter hash of round 1 (two multiplies
+// and four xor-shifts per value) was 35 of the ~200-250 issue cycles of the source and frication stages per sample; this is 11.
+// The stages step their own sub-sequence two values at a time (noise_step2).  A live handle keeps the state of its next
+// aspiration value (stream slot 221); the increment is recomputed from the handle's seed.
 __device__ __forceinline__ uint32_t noise_key(uint32_t seed) { return mix32(seed ^ 0x9E3779B9u); }
-constexpr uint32_t kNoiseA = 1664525u, kNoiseC = 1013904223u;
-constexpr uint32_t kNoiseA2 = kNoiseA * kNoiseA, kNoiseC2 = (kNoiseA + 1u) * kNoiseC;       // two steps in one (mod 2^32)
-__device__ __forceinline__ uint32_t noise_step(uint32_t s) { return s * kNoiseA + kNoiseC; }
-__device__ __forceinline__ uint32_t noise_step2(uint32_t s) { return s * kNoiseA2 + kNoiseC2; }
-__device__ __forceinline__ uint32_t noise_first(uint32_t key) { return noise_step(key); }     // the state of value 0
+__device__ __forceinline__ uint32_t noise_inc(uint32_t seed) { return (mix32(seed + 0x85EBCA6Bu) << 1) | 1u; }
+constexpr uint32_t kNoiseA = 1664525u;
+constexpr uint32_t kNoiseA2 = kNoiseA * kNoiseA;                                       // two steps in one (mod 2^32): s * A^2 + (A + 1) c
+__device__ __forceinline__ uint32_t noise_inc2(uint32_t inc) { return (kNoiseA + 1u) * inc; }
+__device__ __forceinline__ uint32_t noise_step(uint32_t s, uint32_t inc) { return s * kNoiseA + inc; }
+__device__ __forceinline__ uint32_t noise_step2(uint32_t s, uint32_t inc2) { return s * kNoiseA2 + inc2; }
+__device__ __forceinline__ uint32_t noise_first(uint32_t key, uint32_t inc) { return noise_step(key, inc); }     // the state of value 0
 // (double)rand()/RAND_MAX with RAND_MAX = 2^31-1 (reference src/speechWaveGenerator.cpp:40) of the value in state s.  For the
 // integers r < 2^31 the correctly rounded quotient is fma(r, yh, r * yl) with 1/(2^31-1) = yh + yl to double-double
 // (yh = 0x1.00000002p-31, yl = 2^-93; r * yl is exact): two operations instead of div_by's three.
@@ -376,7 +381,7 @@ struct Lane {
 // ---- one output sample from the lane's current parameters (reference :72-86, :147-180, :203-208)
 // NOISE: the wavefront holds an utterance with non-zero noise gains; waveVib: some lane may have vibrato.
 template <int MODE, bool NOISE>
-__device__ __forceinline__ uint32_t dsp_sample(Lane& s, const KernelArgs& A, uint32_t nkey, bool waveVib)
+__device__ __forceinline__ uint32_t dsp_sample(Lane& s, const KernelArgs& A, uint32_t ninc, bool waveVib)
 {
     double vib = 1.0;
     if (waveVib) {   // wave-uniform
@@ -423,8 +428,8 @@ __device__ __forceinline__ uint32_t dsp_sample(Lane& s, const KernelArgs& A, uin
     double mix = o;
     if (NOISE) {
         // frication + parallel bank (:205-206, :170-180)
-        s.fricNoise = noise_uniform(noise_step(s.noiseState)) + 0.75 * s.fricNoise;
-        s.noiseState = noise_step2(s.noiseState);
+        s.fricNoise = noise_uniform(noise_step(s.noiseState, ninc)) + 0.75 * s.fricNoise;
+        s.noiseState = noise_step2(s.noiseState, noise_inc2(ninc));
         const double fric = s.fricNoise * 0.3 * s.cur[24];
         const double y = (fric * s.cur[44]) * 0.5;
         double par = 0.0;
@@ -580,7 +585,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
     if (live) d = A.utt[u];
     const double* const myFrames = A.frames + d.frameStart * kNumParams;
     const FrameMeta* const myMeta = A.meta + d.frameStart;
-    const uint32_t nkey = noise_key(d.seed);
+    const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed);
 
     // ---- fresh-handle state (reference src/frame.cpp:85-88, src/speechWaveGenerator.cpp:37,52,108-109)
     Lane s;
@@ -589,7 +594,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
     s.old0 = 0.0; s.new0 = 0.0; s.oldInc = 0.0; s.newInc = 0.0; s.invFade = 1.0;
     s.cnt = 0; s.oldMin = 0; s.newMin = 0; s.newFade = 1;
     s.hasNew = false; s.oldNull = true; s.newNull = false;
-    s.lastIndex = -1; s.resMask = 0; s.nextFrame = 0; s.noiseState = noise_first(nkey); s.produced = 0;
+    s.lastIndex = -1; s.resMask = 0; s.nextFrame = 0; s.noiseState = noise_first(nkey, ninc); s.produced = 0;
     s.done = !live; s.drained = false; s.vibFrames = false;
 #pragma unroll
     for (int r = 0; r < kNumRes; ++r) { s.ra[r] = 0.0; s.rb[r] = 2.0; s.rc[r] = -1.0; s.z1[r] = 0.0; s.z2[r] = 0.0; }
@@ -701,7 +706,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
         }
         const bool waveVib = __any(emit && vib_live(s));
         if (emit) {
-            myRow[it % kTile] = (int16_t)dsp_sample<MODE, NOISE>(s, A, nkey, waveVib);
+            myRow[it % kTile] = (int16_t)dsp_sample<MODE, NOISE>(s, A, ninc, waveVib);
             s.produced++;
         }
         it++;
@@ -717,7 +722,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
                 s.cnt++;
                 if (KIND == 0) { s.cur[0] += s.oldInc; s.old0 = s.cur[0]; }
                 else fade_update<MODE, STREAM, (NOISE ? kNumRes : 8)>(s, A, oldP, newP, curFB, lane);
-                myRow[tpos + i] = (int16_t)dsp_sample<MODE, NOISE>(s, A, nkey, false);
+                myRow[tpos + i] = (int16_t)dsp_sample<MODE, NOISE>(s, A, ninc, false);
             }
             s.produced += kBlock;
         }

@@ -1017,7 +1017,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     if (live) d = A.utt[u];
     const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart,
                      FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr};
-    const uint32_t nkey = noise_key(d.seed);
+    const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed), ninc2 = noise_inc2(ninc);
     constexpr int FINAL = NOISE ? 2 : 3;
     // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out
     // together instead of one LDS latency per unrolled group); the noisy kernels have no registers to spare
@@ -1084,7 +1084,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             PitchState ps;
             ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
             double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, invFade = 1.0, nfD = 1.0;
-            uint32_t noiseSt = noise_first(nkey), cntF = 0, nfU = 0;    // noiseSt: the state of this stage's next noise value (aspiration: values 0, 2, 4, ...); cntF of nfU pitch-fade samples done
+            uint32_t noiseSt = noise_first(nkey, ninc), cntF = 0, nfU = 0;    // noiseSt: the state of this stage's next noise value (aspiration: values 0, 2, 4, ...); cntF of nfU pitch-fade samples done
             uint32_t fadeEndAt = 0xFFFFFFFFu;
             int32_t lastIndex = -1;
             bool oldNull = true, newNull = false;
@@ -1102,7 +1102,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
                 double voice = (pitchPhase * 2.0) - 1.0;
                 aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
-                noiseSt = noise_step2(noiseSt);
+                noiseSt = noise_step2(noiseSt, ninc2);
                 double asp = aspNoise * 0.2;
                 double turb = asp * turbGain;
                 turb = (pitchPhase >= openQ) ? turb : turb * 0.01;
@@ -1240,7 +1240,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         stage_frame_init(f, live, lds + L::kFrames, lane);
         ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
         double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0;
-        uint32_t noiseSt = noise_first(nkey);     // the state of this stage's next noise value (aspiration: values 0, 2, 4, ...)
+        uint32_t noiseSt = noise_first(nkey, ninc);     // the state of this stage's next noise value (aspiration: values 0, 2, 4, ...)
         int32_t lastIndex = -1;
         bool vibFrames = false;
         constexpr int GR0[1] = {0};
@@ -1266,7 +1266,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             double src;
             if (NOISE) {
                 aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
-                noiseSt = noise_step2(noiseSt);
+                noiseSt = noise_step2(noiseSt, ninc2);
                 double asp = aspNoise * 0.2;
                 double turb = asp * f.cur[2];
                 turb = (pitchPhase >= f.cur[3]) ? turb : turb * 0.01;
@@ -1398,7 +1398,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
             sig_t fricNoise = 0;
-            uint32_t noiseSt = noise_step(noise_first(nkey));     // frication: values 1, 3, 5, ...
+            uint32_t noiseSt = noise_step(noise_first(nkey, ninc), ninc);     // frication: values 1, 3, 5, ...
             flat2_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
                     constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
@@ -1407,7 +1407,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     const ResPre<sig_t> q2 = res_pre<MODE, ((SET >> 2) & 1u) != 0u>(f.ra[2], f.rb[2], f.rc[2], f.z1[2], f.z2[2]);
                     const ResPre<sig_t> q3 = res_pre<MODE, ((SET >> 3) & 1u) != 0u>(f.ra[3], f.rb[3], f.rc[3], f.z1[3], f.z2[3]);
                     fricNoise = (sig_t)noise_uniform(noiseSt) + (sig_t)0.75 * fricNoise;
-                    noiseSt = noise_step2(noiseSt);
+                    noiseSt = noise_step2(noiseSt, ninc2);
                     const sig_t fric = fricNoise * (sig_t)0.3 * f.cur[0];
                     const sig_t y = (fric * f.cur[1]) * (sig_t)0.5;
                     const sig_t pa1 = f.cur[2], pa2 = f.cur[3], pa3 = f.cur[4], pa4 = f.cur[5];
@@ -1554,15 +1554,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         StageFrame<14, 4> f;
         stage_frame_init(f, live, lds + L::kFrames3, lane);
         double fricNoise = 0.0;
-        uint32_t noiseSt = noise_step(noise_first(nkey));     // frication: values 1, 3, 5, ...
+        uint32_t noiseSt = noise_step(noise_first(nkey, ninc), ninc);     // frication: values 1, 3, 5, ...
         constexpr int GR3[4] = {8, 9, 10, 11};
         if (STREAM && live) {
-            if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseSt = noise_step((uint32_t)streamState[221]); }   // slot 221: the state of the next aspiration value
+            if (streamState[239] != 0.0) { fricNoise = streamState[211]; noiseSt = noise_step((uint32_t)streamState[221], ninc); }   // slot 221: the state of the next aspiration value
             stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR3, streamPurge);
         }
         auto dsp = [&](int c, int i) __attribute__((always_inline)) {
             fricNoise = noise_uniform(noiseSt) + 0.75 * fricNoise;
-            noiseSt = noise_step2(noiseSt);
+            noiseSt = noise_step2(noiseSt, ninc2);
             const double fric = fricNoise * 0.3 * f.cur[8];
             const double y = (fric * f.cur[9]) * 0.5;
             double par = 0.0;

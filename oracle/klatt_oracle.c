@@ -29,8 +29,9 @@
  *
  * Noise: the reference draws from libc rand().  ORACLE_NOISE_LIBC reproduces that
  * (used only for the pin above).  ORACLE_NOISE_COUNTER is the engine's defined
- * per-utterance stream, a 32-bit linear congruential generator started from a hash
- * of the seed: s_0 = key(seed), s_(n+1) = 1664525 s_n + 1013904223 (mod 2^32), value
+ * per-utterance stream, a 32-bit linear congruential generator whose start and odd
+ * increment are hashes of the seed: s_0 = key(seed), c = inc(seed),
+ * s_(n+1) = 1664525 s_n + c (mod 2^32), value
  * k = s_(k+1) >> 1 = klatt_noise31(seed, k); a produced sample n consumes k = 2n
  * (aspiration) then k = 2n+1 (frication), exactly the order of the two rand() calls
  * at speechWaveGenerator.cpp:75,205.
@@ -103,20 +104,20 @@ typedef struct oracle_player {
     uint32_t noiseState;   /* the stream's state of the next value */
 } oracle_player;
 
-/* ---- the engine's noise stream (the HIP kernels restate it: klatt_device.h) ---- */
+/* ---- the engine's noise stream (the HIP kernels restate it: klatt_device.h) ----
+ * a 32-bit linear congruential generator per stream; its start and its (odd) increment both come from the stream's seed */
 #define NOISE_A 1664525u
-#define NOISE_C 1013904223u
-static uint32_t noise_key(uint32_t seed)
+static uint32_t noise_mix(uint32_t x)
 {
-    /* one avalanche of the seed */
-    uint32_t key = seed ^ 0x9E3779B9u;
-    key ^= key >> 16; key *= 0x7FEB352Du; key ^= key >> 15; key *= 0x846CA68Bu; key ^= key >> 16;
-    return key;
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
 }
+static uint32_t noise_key(uint32_t seed) { return noise_mix(seed ^ 0x9E3779B9u); }
+static uint32_t noise_inc(uint32_t seed) { return (noise_mix(seed + 0x85EBCA6Bu) << 1) | 1u; }
 /* value k of stream `seed`, by random access: k + 1 steps from the key in O(log k) (the players below step one at a time) */
 uint32_t klatt_noise31(uint32_t seed, uint32_t k)
 {
-    uint32_t a = NOISE_A, c = NOISE_C, accA = 1u, accC = 0u;
+    uint32_t a = NOISE_A, c = noise_inc(seed), accA = 1u, accC = 0u;
     uint64_t n = (uint64_t)k + 1u;
     while (n) {
         if (n & 1u) { accA *= a; accC = accC * a + c; }
@@ -135,7 +136,7 @@ static double next_uniform(oracle_player *s)
     else
     {
         r = (double)(s->noiseState >> 1);
-        s->noiseState = s->noiseState * NOISE_A + NOISE_C;
+        s->noiseState = s->noiseState * NOISE_A + noise_inc(s->noiseSeed);
     }
     return r / 2147483647.0;
 }
@@ -301,7 +302,7 @@ void oracle_setNoise(oracle_player *s, int mode, uint32_t seed)
 {
     s->noiseMode = mode;
     s->noiseSeed = seed;
-    s->noiseState = noise_key(seed) * NOISE_A + NOISE_C;
+    s->noiseState = noise_key(seed) * NOISE_A + noise_inc(seed);
 }
 
 /* speechPlayer.cpp:34-37 + frame.cpp:90-115 */

@@ -60,24 +60,32 @@ def test_chunking_invariance(ref):
 
 
 def test_noise_function_reference_values():
-    """The noise definition is part of the engine's contract (klatt_device.h): a 32-bit LCG per stream, started from a hash of
-    the seed; value k = state k + 1 >> 1.  Restated here in plain integers, against the oracle's random access and its players."""
+    """The noise definition is part of the engine's contract (klatt_device.h): a 32-bit LCG per stream whose start and odd increment are
+    hashes of the seed; value k = state k + 1 >> 1.  Restated here in plain integers, against the oracle's random access and its players."""
     L = oracle.lib()
     vals = [L.klatt_noise31(s, k) for s, k in ((0, 0), (0, 1), (1, 0), (12345, 678), (0xFFFFFFFF, 0xFFFFFFFF))]
     assert all(0 <= v < 2 ** 31 for v in vals)
     assert len(set(vals)) == len(vals)
 
-    def key(seed):
-        x = (seed ^ 0x9E3779B9) & 0xFFFFFFFF
+    def mix(x):
+        x &= 0xFFFFFFFF
         x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF; x ^= x >> 16
         return x
+    incs = set()
     for seed in (0, 7, 0xFFFFFFFF):
-        st, seq = key(seed), []
+        st, inc, seq = mix(seed ^ 0x9E3779B9), ((mix(seed + 0x85EBCA6B) << 1) | 1) & 0xFFFFFFFF, []
+        incs.add(inc)
         for _ in range(3000):
-            st = (st * 1664525 + 1013904223) & 0xFFFFFFFF
+            st = (st * 1664525 + inc) & 0xFFFFFFFF
             seq.append(st >> 1)
         assert seq == [L.klatt_noise31(seed, k) for k in range(3000)]
+    assert len(incs) == 3                                                                 # a generator of its own per seed, not a window of one cycle
     assert L.klatt_noise31(7, 0xFFFFFFFF) == L.klatt_noise31(7, 0xFFFFFFFF) < 2 ** 31     # k + 1 = 2^32 steps: no overflow
+    # two streams do not replay each other at a lag (round 2's single increment made every stream a shifted copy of the others):
+    # no value of stream 8's first 2000 is followed by the same successor in stream 7
+    a = [L.klatt_noise31(7, k) for k in range(2001)]
+    b = [L.klatt_noise31(8, k) for k in range(2001)]
+    assert not (set(zip(a[:-1], a[1:])) & set(zip(b[:-1], b[1:])))
     # uniformity smoke: mean of 1e5 draws within 1% of 0.5
     xs = np.array([L.klatt_noise31(7, k) for k in range(100000)], dtype=np.float64) / 2147483647.0
     assert abs(xs.mean() - 0.5) < 0.005

@@ -144,14 +144,21 @@ int speechPlayer_node_time(speechPlayer_node_t node, int launches, float* msPerL
  * produced[i] receives each call's return value.  Handles must be distinct and share sample rate.
  * The reference's consumer loop is one thread per stream pulling 8192 samples
  * (nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:62-81); this is that loop for N streams.
+ * Host cost per call: one control block (44 bytes per handle) and the frames queued since the last call travel, nothing else --
+ * a handle's saved state and its queued frames live in a per-device arena (speechPlayer_queueFrame writes a frame once, into a
+ * pinned log; a scatter kernel places the log's entries in the handles' rings).  Listing the handles in ascending order of
+ * creation saves a sort.
  */
 int speechPlayer_synthesizeMany(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced);
 /* The same with the PCM left in HBM: handle i's samples start at *devicePcm + i * *rowStride (device memory, valid until the next
  * live call on that device).  For consumers on the GPU and for measuring the engine without the PCIe copy of the PCM. */
 int speechPlayer_synthesizeManyDevice(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, const sample** devicePcm,
 	long long* rowStride, int* produced);
-/* Duration in milliseconds of the last live-handle kernel launch on HIP device `device` (HIP events on its stream). */
+/* Kernel time in milliseconds of the last live call on HIP device `device` (HIP events on its stream). */
 float speechPlayer_lastLiveKernelMs(int device);
+/* Kernel launches that call took: 1, unless a handle had more frames queued than the 256 its device-side ring holds and the
+ * ring's frames ended before sampleCount samples -- such a call proceeds in pieces, with the same result. */
+int speechPlayer_lastLiveLaunches(int device);
 /* Process-wide options.  "live_layout": the kernel that advances live handles -- 1 (default): the stage-parallel kernel, four
  * wavefronts per 64 handles; 0: the lane kernel, one wavefront per 64 handles.  Same saved state, same PCM. */
 int speechPlayer_setGlobalOption(const char* name, int value);

@@ -39,7 +39,7 @@ EXPORTS = [
     "speechPlayer_batch_readAll", "speechPlayer_batch_readFloat", "speechPlayer_batch_digest", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
     "speechPlayer_batch_deviceOffset", "speechPlayer_batch_time", "speechPlayer_batch_kernelInfo",
     "speechPlayer_lastError", "speechPlayer_lastErrorCode", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany", "speechPlayer_setGlobalOption",
-    "speechPlayer_synthesizeManyDevice", "speechPlayer_lastLiveKernelMs",
+    "speechPlayer_synthesizeManyDevice", "speechPlayer_lastLiveKernelMs", "speechPlayer_lastLiveLaunches",
     "speechPlayer_ipa_frames", "speechPlayer_ipa_pack", "speechPlayer_batch_setIpa",
     "speechPlayer_voiceCount", "speechPlayer_voiceName", "speechPlayer_applyVoiceToFrame",
     "speechPlayer_ipa_phonemeCount", "speechPlayer_ipa_phoneme",
@@ -161,6 +161,8 @@ def load():
     L.speechPlayer_synthesizeManyDevice.argtypes = [vp, i32, u32, vp, vp, vp]
     L.speechPlayer_lastLiveKernelMs.restype = ctypes.c_float
     L.speechPlayer_lastLiveKernelMs.argtypes = [i32]
+    L.speechPlayer_lastLiveLaunches.restype = i32
+    L.speechPlayer_lastLiveLaunches.argtypes = [i32]
     L.speechPlayer_setGlobalOption.restype = i32
     L.speechPlayer_setGlobalOption.argtypes = [ctypes.c_char_p, i32]
     L.speechPlayer_lastError.restype = ctypes.c_char_p

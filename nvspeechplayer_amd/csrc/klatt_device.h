@@ -173,6 +173,8 @@ struct KernelArgs {
     const uint32_t* control;     // [nUtt] streaming only: bit0 = apply purge before synthesising
     long long nSlots;
     uint32_t maxSamples;         // per launch and utterance; 0xFFFFFFFF = until drained
+    uint32_t ringMask;           // 0: an utterance's frames are frameStart, frameStart + 1, ...; live handles: its frames sit in a ring of
+                                 // ringMask + 1 frames (a power of two, aligned to its size) and frameStart points at the oldest one
     int sampleRate;
     double sampleRateF;          // (double)sampleRate
     double invSampleRate;        // RN(1/sr)
@@ -493,9 +495,17 @@ __device__ __forceinline__ bool vib_live(const Lane& s)
     return s.vibFrames || s.cur[1] != 0.0 || s.cur[2] != 0.0 || s.vibPhase != s.vibPhase;
 }
 
+// Where an utterance's frames are: frame k of the queue is frames[base + ((off + k) & mask)] (KernelArgs.ringMask).
+struct FrameWindow { long long base; uint32_t off, mask; };
+__device__ __forceinline__ FrameWindow frame_window(const KernelArgs& A, const UttDesc& d)
+{
+    if (A.ringMask == 0) return FrameWindow{d.frameStart, 0u, 0xFFFFFFFFu};
+    return FrameWindow{d.frameStart & ~(long long)A.ringMask, (uint32_t)d.frameStart & A.ringMask, A.ringMask};
+}
+
 // ---- an event sample: fade end, dequeue, or end of queue (reference src/frame.cpp:44-47, :54-75)
 // Called with counter already incremented.  Returns true when a sample is emitted.
-__device__ __forceinline__ bool event_step(Lane& s, const UttDesc& d, const double* myFrames, const FrameMeta* myMeta,
+__device__ __forceinline__ bool event_step(Lane& s, const UttDesc& d, const double* myFrames, const FrameMeta* myMeta, uint32_t ringOff, uint32_t ringMask,
                                            double* oldP, double* newP, int lane)
 {
     if (s.hasNew) {
@@ -513,8 +523,9 @@ __device__ __forceinline__ bool event_step(Lane& s, const UttDesc& d, const doub
         return false;
     }
     // dequeue (:55-72)
-    const FrameMeta m = myMeta[s.nextFrame];
-    const double* g = myFrames + (size_t)s.nextFrame * kNumParams;
+    const uint32_t at = (ringOff + s.nextFrame) & ringMask;
+    const FrameMeta m = myMeta[at];
+    const double* g = myFrames + (size_t)at * kNumParams;
     s.nextFrame++;
     s.newMin = m.minSamples; s.newFade = m.fadeSamples; s.newNull = (m.flags & FRAME_NULL) != 0;
     if (s.newNull) {
@@ -583,8 +594,9 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
     UttDesc d;
     d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
-    const double* const myFrames = A.frames + d.frameStart * kNumParams;
-    const FrameMeta* const myMeta = A.meta + d.frameStart;
+    const FrameWindow w = frame_window(A, d);
+    const double* const myFrames = A.frames + w.base * kNumParams;
+    const FrameMeta* const myMeta = A.meta + w.base;
     const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed);
 
     // ---- fresh-handle state (reference src/frame.cpp:85-88, src/speechWaveGenerator.cpp:37,52,108-109)
@@ -701,7 +713,7 @@ __global__ void __launch_bounds__(kLanes) klatt_synthesize(const KernelArgs A)
                 s.old0 = s.cur[0];
                 emit = true;
             } else {
-                emit = event_step(s, d, myFrames, myMeta, oldP, newP, lane);
+                emit = event_step(s, d, myFrames, myMeta, w.off, w.mask, oldP, newP, lane);
             }
         }
         const bool waveVib = __any(emit && vib_live(s));

@@ -757,10 +757,45 @@ int batch_launch(Batch* b)
 // ------------------------------------------------------------------------------------------
 // Streams behind the reference's five entry points
 // ------------------------------------------------------------------------------------------
+// What a live handle owns lives in ONE arena per device, indexed by the handle's slot: its saved synthesiser state
+// (kStateDoubles doubles) and a ring of kRing frames.  A queued frame is written once, into a pinned log
+// (speechPlayer_queueFrame), the log travels in one copy and a scatter kernel drops its entries into the rings; a pull
+// uploads one control block (what to do for each handle of the call) and whatever part of the log has not travelled yet.
+// Nothing a handle queued is staged again on a later pull (reference contract: src/frame.cpp:90-115 queue, :54-75 dequeue).
+constexpr uint32_t kRing = 256;                  // frames of a handle on the device; further ones wait on the host (Stream::overflow)
+constexpr size_t kLogEntries = 40960;            // 16 MB of pinned log
+constexpr size_t kLogEager = 2560;               // queueFrame sends the log on its way once 1 MB waits (if no pull is running)
+constexpr uint32_t kNoTarget = 0xFFFFFFFFu;
+
+struct LogEntry {            // 400 B
+    double p[kNumParams];
+    FrameMeta meta;
+    uint32_t target;         // slot * kRing + ring position, or kNoTarget (purged / handle closed before the entry travelled)
+    uint32_t pad;
+};
+static_assert(sizeof(LogEntry) == 400, "LogEntry layout");
+
 struct PendingFrame {
     double p[kNumParams];
     FrameMeta meta;
 };
+
+__global__ void __launch_bounds__(256) live_scatter(const LogEntry* __restrict__ log, uint32_t n, double* __restrict__ ringFrames,
+                                                    FrameMeta* __restrict__ ringMeta)
+{
+    const uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6), j = threadIdx.x & 63u;     // one wavefront per entry
+    if (e >= n) return;
+    const uint32_t at = log[e].target;
+    if (at == kNoTarget) return;
+    if (j < (uint32_t)kNumParams) ringFrames[(size_t)at * kNumParams + j] = log[e].p[j];
+    else if (j == (uint32_t)kNumParams) ringMeta[at] = log[e].meta;
+}
+
+inline uint32_t frame_span(const FrameMeta& m)      // samples from this frame's dequeue to the next one's, the closed form of speechPlayer_batch_setUtterances
+{
+    const unsigned long long v = std::max<unsigned long long>(m.minSamples, (unsigned long long)m.fadeSamples + 1) + 1;
+    return (uint32_t)std::min<unsigned long long>(v, 0xFFFFFFFFull);
+}
 
 struct Stream {
     int sampleRate = 0;
@@ -769,50 +804,83 @@ struct Stream {
     uint32_t seed = 0;
     uintptr_t id = 0;
     std::mutex mu;                       // per call, not per sample (reference locks per sample: src/frame.cpp:122)
-    std::vector<PendingFrame> pending;   // queued, not yet taken by the kernel: pending[head ..]
-    size_t head = 0;                     // frames before it were taken (dropped in bulk, not one erase per pull)
+    struct LiveContext* context = nullptr;   // the device's live-handle context
+    uint32_t slot = 0;                   // its place in the device's arena
+    uint32_t ringHead = 0;               // ring position of the oldest frame the kernel has not taken
+    uint32_t ringCount = 0;              // frames in the ring from there on (travelled, or waiting in the log)
+    uint32_t span[kRing];                // frame_span of each ring position; read only while frames wait in `overflow`
+    std::vector<PendingFrame> overflow;  // queued beyond the ring: overflow[overHead ..], in order
+    size_t overHead = 0;
+    uint32_t logEpoch = 0;               // logIdx is valid for this upload epoch of the log only
+    std::vector<uint32_t> logIdx;        // this handle's entries in the part of the log that has not travelled
     bool purgePending = false;
     int lastIndex = -1;
-    DeviceBuffer<double> dState;         // the stream's saved synthesiser state (kStateDoubles), lives on the GPU
 };
 
 std::mutex g_tableMutex;
 std::vector<Stream*> g_streams;   // handle = index + 1
 
-Stream* lookup(speechPlayer_handle_t h)
+Stream* lookup_locked(speechPlayer_handle_t h)
 {
     uintptr_t id = reinterpret_cast<uintptr_t>(h);
     // a prototype-less 32-bit ctypes call hands the id back sign-/zero-extended; ids are small
     id &= 0xFFFFFFFFu;
-    std::lock_guard<std::mutex> g(g_tableMutex);
     if (id == 0 || id > g_streams.size()) return nullptr;
     return g_streams[id - 1];
 }
+Stream* lookup(speechPlayer_handle_t h)
+{
+    std::lock_guard<std::mutex> g(g_tableMutex);
+    return lookup_locked(h);
+}
 
-// Launch context shared by the live streams of one device: staging buffers for the frames the handles
-// have queued, the PCM of the call, results.  Calls on one device are serialised by `mu`.
+template <typename T>
+struct PinnedBuffer {
+    T* ptr = nullptr;
+    size_t cap = 0;
+    int reserve(size_t n)
+    {
+        if (n <= cap) return 0;
+        n = std::max(n, cap * 2);          // contents are not kept
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr; cap = 0;
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T), hipHostMallocDefault));
+        cap = n;
+        return 0;
+    }
+};
+
+// The live handles of one device: arena, log, launch buffers.  Lock order: Stream::mu, then LiveContext::mu, then logMu.
+// `mu` serialises everything that enqueues on `stream` or moves the arena; `logMu` only guards the log's indices, so that
+// queueFrame on one handle does not wait for a pull of other handles.
 struct LiveContext {
     std::mutex mu;
     hipStream_t stream = nullptr;
-    DeviceBuffer<double> dFrames;
-    DeviceBuffer<FrameMeta> dMeta;
-    DeviceBuffer<UttDesc> dUtt;
-    DeviceBuffer<uint32_t> dOrder;
-    DeviceBuffer<uint32_t> dControl;
-    DeviceBuffer<int16_t> dPcm;
+    // arena
+    uint32_t slots = 0, nextSlot = 0;
+    std::vector<uint32_t> freeSlots;
+    DeviceBuffer<double> dState;         // [slots][kStateDoubles]
+    DeviceBuffer<double> dRingFrames;    // [slots][kRing][kNumParams]
+    DeviceBuffer<FrameMeta> dRingMeta;   // [slots][kRing]
+    // log
+    std::mutex logMu;
+    PinnedBuffer<LogEntry> hLog;
+    DeviceBuffer<LogEntry> dLog;
+    size_t logTail = 0, logSent = 0;     // entries [logSent, logTail) have not travelled
+    uint32_t logEpoch = 1;
+    // one pull
+    PinnedBuffer<unsigned char> hCtl;    // UttDesc[n] | state pointer[n] | control[n], one copy
+    DeviceBuffer<unsigned char> dCtl;
+    PinnedBuffer<UttResult> hResult;
     DeviceBuffer<UttResult> dResult;
-    DeviceBuffer<double*> dStatePtrs;
-    std::vector<double> hFrames;
-    std::vector<FrameMeta> hMeta;
-    std::vector<UttDesc> hUtt;
-    std::vector<uint32_t> hOrder, hControl;
-    std::vector<double*> hStatePtrs;
-    std::vector<UttResult> hResult;
-    std::vector<size_t> hTake;
+    DeviceBuffer<uint32_t> dOrder;       // 0, 1, 2, ...: written once
+    size_t orderFilled = 0;
+    DeviceBuffer<int16_t> dPcm, dPcmJoin;
+    std::vector<uint32_t> done;
     PinnedPair bounce;
     hipEvent_t kernelStart = nullptr, kernelStop = nullptr;
-    float lastKernelMs = 0.0f;           // the last launch's duration (speechPlayer_lastLiveKernelMs)
-    size_t lastStride = 0;               // samples between the rows of the last launch's PCM in dPcm
+    float lastKernelMs = 0.0f;           // the last call's kernel time (speechPlayer_lastLiveKernelMs)
+    int lastLaunches = 0;
 };
 std::mutex g_liveMutex;
 std::vector<LiveContext*> g_live;   // per device
@@ -828,8 +896,9 @@ LiveContext* live_context(int device)
     if (!g_live[device]) {
         LiveContext* c = new LiveContext;
         if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreate(&c->kernelStart) != hipSuccess || hipEventCreate(&c->kernelStop) != hipSuccess) {
-            set_error("cannot create a stream on device %d", device);
+            hipEventCreate(&c->kernelStart) != hipSuccess || hipEventCreate(&c->kernelStop) != hipSuccess ||
+            c->hLog.reserve(kLogEntries) || c->dLog.reserve(kLogEntries)) {
+            set_error("cannot create the live-handle context of device %d", device);
             delete c;
             return nullptr;
         }
@@ -838,15 +907,103 @@ LiveContext* live_context(int device)
     return g_live[device];
 }
 
-int stream_init_device(Stream* s)
+// c->mu held.  Room for `want` slots: the arena doubles, what the handles saved moves along (device to device).
+int arena_reserve(LiveContext* c, uint32_t want)
 {
-    HIP_TRY(hipSetDevice(s->device));
-    if (s->dState.reserve(kStateDoubles)) return -1;
-    HIP_TRY(hipMemset(s->dState.ptr, 0, kStateDoubles * sizeof(double)));
+    if (want <= c->slots) return 0;
+    uint32_t cap = std::max<uint32_t>(64, c->slots);
+    while (cap < want) cap *= 2;
+    DeviceBuffer<double> st, fr;
+    DeviceBuffer<FrameMeta> me;
+    if (st.reserve((size_t)cap * kStateDoubles) || fr.reserve((size_t)cap * kRing * kNumParams) || me.reserve((size_t)cap * kRing)) {
+        st.release(); fr.release(); me.release();
+        return -1;
+    }
+    if (c->slots) {
+        HIP_TRY(hipMemcpyAsync(st.ptr, c->dState.ptr, (size_t)c->slots * kStateDoubles * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(fr.ptr, c->dRingFrames.ptr, (size_t)c->slots * kRing * kNumParams * sizeof(double), hipMemcpyDeviceToDevice, c->stream));
+        HIP_TRY(hipMemcpyAsync(me.ptr, c->dRingMeta.ptr, (size_t)c->slots * kRing * sizeof(FrameMeta), hipMemcpyDeviceToDevice, c->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->dState.release(); c->dRingFrames.release(); c->dRingMeta.release();
+    c->dState = st; c->dRingFrames = fr; c->dRingMeta = me;
+    c->slots = cap;
     return 0;
 }
 
-// Advance n live streams by up to `count` samples each in ONE launch (one stream per wavefront lane).
+int stream_init_device(Stream* s)
+{
+    LiveContext* c = live_context(s->device);
+    if (!c) return -1;
+    std::lock_guard<std::mutex> g(c->mu);
+    HIP_TRY(hipSetDevice(s->device));
+    uint32_t slot;
+    if (!c->freeSlots.empty()) { slot = c->freeSlots.back(); c->freeSlots.pop_back(); }
+    else {
+        if (arena_reserve(c, c->nextSlot + 1)) return -1;
+        slot = c->nextSlot++;
+    }
+    s->slot = slot; s->context = c;
+    HIP_TRY(hipMemsetAsync(c->dState.ptr + (size_t)slot * kStateDoubles, 0, kStateDoubles * sizeof(double), c->stream));   // ordered before the handle's first pull
+    return 0;
+}
+
+// c->mu and c->logMu held.  What waits in the log goes on its way: one copy, one scatter launch; not waited for.
+int log_send(LiveContext* c)
+{
+    if (c->logSent == c->logTail) return 0;
+    const size_t n = c->logTail - c->logSent;
+    HIP_TRY(hipMemcpyAsync(c->dLog.ptr + c->logSent, c->hLog.ptr + c->logSent, n * sizeof(LogEntry), hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(live_scatter, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, c->stream, c->dLog.ptr + c->logSent, (uint32_t)n,
+                       c->dRingFrames.ptr, c->dRingMeta.ptr);
+    HIP_TRY(hipGetLastError());
+    c->logSent = c->logTail;
+    c->logEpoch++;                       // every Stream::logIdx is stale from here on
+    return 0;
+}
+
+// s->mu held.  One frame into the handle's ring, by way of the log.  The caller has checked ringCount < kRing.
+int log_append(LiveContext* c, Stream* s, const double* p, const FrameMeta& meta, bool holdsContext)
+{
+    std::unique_lock<std::mutex> lg(c->logMu);
+    if (c->logTail == c->hLog.cap) {     // full: send it, wait until it has arrived, start over (lock order: mu before logMu)
+        std::unique_lock<std::mutex> g(c->mu, std::defer_lock);
+        if (!holdsContext) { lg.unlock(); g.lock(); lg.lock(); }
+        if (c->logTail == c->hLog.cap) {
+            HIP_TRY(hipSetDevice(s->device));
+            if (log_send(c)) return -1;
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            c->logTail = c->logSent = 0;
+        }
+    }
+    const uint32_t pos = (s->ringHead + s->ringCount) & (kRing - 1);
+    LogEntry& e = c->hLog.ptr[c->logTail];
+    if (p) memcpy(e.p, p, sizeof e.p); else memset(e.p, 0, sizeof e.p);
+    e.meta = meta;
+    e.target = s->slot * kRing + pos;
+    e.pad = 0;
+    if (s->logEpoch != c->logEpoch) { s->logIdx.clear(); s->logEpoch = c->logEpoch; }
+    s->logIdx.push_back((uint32_t)c->logTail);
+    c->logTail++;
+    s->span[pos] = frame_span(meta);
+    s->ringCount++;
+    return 0;
+}
+
+// s->mu held.  Forget what the handle has in the ring and in the log (purge, close).
+void ring_drop(LiveContext* c, Stream* s)
+{
+    std::lock_guard<std::mutex> lg(c->logMu);
+    if (s->logEpoch == c->logEpoch)
+        for (uint32_t i : s->logIdx) c->hLog.ptr[i].target = kNoTarget;
+    s->logIdx.clear();
+    s->ringHead = (s->ringHead + s->ringCount) & (kRing - 1);
+    s->ringCount = 0;
+}
+
+// Advance n live streams by up to `count` samples each (one stream per wavefront lane; one launch, unless some handle has
+// more frames queued than its ring holds AND the ring's frames end before `count` samples: then the call proceeds in pieces,
+// refilling the rings in between -- a pull is the same as several shorter pulls, reference src/speechPlayer.cpp:39-42).
 // The callers hold every stream's mutex.  produced[i] receives speechPlayer_synthesize's return value.
 // outs == nullptr: the PCM stays on the device (row i at devicePcm + i * stride), for consumers on the GPU.
 int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* const* outs, int* produced,
@@ -868,94 +1025,132 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     if (!c) return -1;
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(device));
-    // Only the frames this pull can reach travel: the shortest prefix of the queue whose spans (the closed form
-    // of speechPlayer_batch_setUtterances) cover `count` samples, plus one.  The rest stays queued on the host.
-    std::vector<size_t>& take = c->hTake;
-    take.resize(n);
-    size_t nf = 0;
-    for (int i = 0; i < n; ++i) {
-        unsigned long long span = 0;
-        size_t k = 0;
-        const size_t have = ss[i]->pending.size() - ss[i]->head;
-        while (k < have && span < count) {
-            const unsigned long long m = ss[i]->pending[ss[i]->head + k].meta.minSamples, f = ss[i]->pending[ss[i]->head + k].meta.fadeSamples;
-            span += std::max(m, f + 1) + 1;
-            ++k;
-        }
-        take[i] = std::min(have, k + 1);
-        nf += take[i];
-    }
     const size_t padded = ((size_t)count + kTile - 1) / kTile * kTile;
-    c->hFrames.resize(std::max<size_t>(nf, 1) * kNumParams);
-    c->hMeta.resize(std::max<size_t>(nf, 1));
-    c->hUtt.resize(n); c->hOrder.resize(n); c->hControl.resize(n); c->hStatePtrs.resize(n); c->hResult.resize(n);
-    size_t k = 0;
-    for (int i = 0; i < n; ++i) {
-        UttDesc& d = c->hUtt[i];
-        memset(&d, 0, sizeof d);
-        d.frameStart = (long long)k; d.outStart = (long long)(i * padded); d.nFrames = (uint32_t)take[i];
-        d.seed = ss[i]->seed; d.flags = UTT_NEEDS_NOISE;
-        d.length = count;                    // the stage-parallel kernel runs exactly `count` steps (klatt_systolic.h, STREAM)
-        for (size_t j = 0; j < take[i]; ++j) {
-            const PendingFrame& f = ss[i]->pending[ss[i]->head + j];
-            memcpy(&c->hFrames[k * kNumParams], f.p, sizeof(double) * kNumParams);
-            c->hMeta[k] = f.meta;
-            ++k;
-        }
-        c->hOrder[i] = (uint32_t)i;
-        c->hControl[i] = ss[i]->purgePending ? 1u : 0u;
-        c->hStatePtrs[i] = ss[i]->dState.ptr;
-    }
-    const auto t1 = now();
-    if (c->dFrames.reserve(std::max<size_t>(nf, 64) * kNumParams) || c->dMeta.reserve(std::max<size_t>(nf, 64)) ||
-        c->dUtt.reserve(n) || c->dOrder.reserve(n) || c->dControl.reserve(n) || c->dResult.reserve(n) ||
-        c->dStatePtrs.reserve(n) || c->dPcm.reserve(padded * n))
+    const size_t ctlBytes = (size_t)n * (sizeof(UttDesc) + sizeof(double*) + sizeof(uint32_t));
+    if (c->hCtl.reserve(ctlBytes) || c->dCtl.reserve(c->hCtl.cap) || c->hResult.reserve(n) || c->dResult.reserve(c->hResult.cap) ||
+        c->dPcm.reserve(padded * n))
         return -1;
-    if (nf) {
-        HIP_TRY(hipMemcpyAsync(c->dFrames.ptr, c->hFrames.data(), nf * kNumParams * sizeof(double), hipMemcpyHostToDevice, c->stream));
-        HIP_TRY(hipMemcpyAsync(c->dMeta.ptr, c->hMeta.data(), nf * sizeof(FrameMeta), hipMemcpyHostToDevice, c->stream));
+    if (c->orderFilled < (size_t)n) {
+        const size_t m = std::max<size_t>(n, 1024);
+        std::vector<uint32_t> iota(m);
+        std::iota(iota.begin(), iota.end(), 0u);
+        if (c->dOrder.reserve(m)) return -1;
+        HIP_TRY(hipMemcpy(c->dOrder.ptr, iota.data(), m * sizeof(uint32_t), hipMemcpyHostToDevice));
+        c->orderFilled = m;
     }
-    HIP_TRY(hipMemcpyAsync(c->dUtt.ptr, c->hUtt.data(), n * sizeof(UttDesc), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->dOrder.ptr, c->hOrder.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->dControl.ptr, c->hControl.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(hipMemcpyAsync(c->dStatePtrs.ptr, c->hStatePtrs.data(), n * sizeof(double*), hipMemcpyHostToDevice, c->stream));
+    UttDesc* const hUtt = reinterpret_cast<UttDesc*>(c->hCtl.ptr);
+    double** const hState = reinterpret_cast<double**>(c->hCtl.ptr + (size_t)n * sizeof(UttDesc));
+    uint32_t* const hControl = reinterpret_cast<uint32_t*>(c->hCtl.ptr + (size_t)n * (sizeof(UttDesc) + sizeof(double*)));
+    if (g_liveCus == 0) {
+        hipDeviceProp_t prop;
+        g_liveCus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    }
 
     KernelArgs a = base_args(rate);
-    a.frames = c->dFrames.ptr; a.meta = c->dMeta.ptr; a.utt = c->dUtt.ptr; a.order = c->dOrder.ptr;
-    a.pcm = c->dPcm.ptr; a.result = c->dResult.ptr; a.state = nullptr; a.statePtrs = c->dStatePtrs.ptr; a.control = c->dControl.ptr;
+    a.frames = c->dRingFrames.ptr; a.meta = c->dRingMeta.ptr; a.ringMask = kRing - 1;
+    a.utt = reinterpret_cast<const UttDesc*>(c->dCtl.ptr);
+    a.statePtrs = reinterpret_cast<double* const*>(c->dCtl.ptr + (size_t)n * sizeof(UttDesc));
+    a.control = reinterpret_cast<const uint32_t*>(c->dCtl.ptr + (size_t)n * (sizeof(UttDesc) + sizeof(double*)));
+    a.order = c->dOrder.ptr; a.pcm = c->dPcm.ptr; a.result = c->dResult.ptr; a.state = nullptr;
     a.nSlots = n;
-    a.maxSamples = count;
     const long long groups = (n + kLanes - 1) / kLanes;
-    HIP_TRY(hipEventRecord(c->kernelStart, c->stream));
-    if (g_liveLayout == 0) {
-        if (launch<true, true>(a, mode, groups, c->stream)) return -1;
-    } else {
-        if (g_liveCus == 0) {
-            hipDeviceProp_t prop;
-            g_liveCus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-        }
-        // one workgroup per CU while they all fit (16-sample hand-overs), else two per CU (8-sample hand-overs), as for batches
-        if (groups <= g_liveCus ? launch_systolic<true, 16, 1, true, true>(a, mode, groups, c->stream)
-                                : launch_systolic<true, KLATT_NOISY_CH, 2, true, true>(a, mode, groups, c->stream)) return -1;
-    }
-    HIP_TRY(hipEventRecord(c->kernelStop, c->stream));
 
-    HIP_TRY(hipMemcpyAsync(c->hResult.data(), c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->done.assign(n, 0u);
+    c->lastKernelMs = 0.0f; c->lastLaunches = 0;
+    double tFill = 0, tRun = 0;
+    unsigned int at = 0;                 // samples of the call behind us
+    bool joined = false;                 // the pieces of a call in pieces are put together in dPcmJoin
+    while (at < count) {
+        const auto ta = now();
+        // rings take what waited on the host; how far may this launch go without meeting a frame that is not in a ring?
+        unsigned int piece = count - at;
+        for (int i = 0; i < n; ++i) {
+            Stream* s = ss[i];
+            if (s->overHead < s->overflow.size()) {
+                while (s->ringCount < kRing && s->overHead < s->overflow.size()) {
+                    const PendingFrame& f = s->overflow[s->overHead];
+                    if (log_append(c, s, (f.meta.flags & FRAME_NULL) ? nullptr : f.p, f.meta, true)) return -1;
+                    s->overHead++;
+                }
+                if (s->overHead == s->overflow.size()) { s->overflow.clear(); s->overHead = 0; }
+                else {
+                    if (s->overHead >= 64 && s->overHead * 2 >= s->overflow.size()) { s->overflow.erase(s->overflow.begin(), s->overflow.begin() + s->overHead); s->overHead = 0; }
+                    // the ring's last frame may be dequeued only when its successor is there to follow it
+                    unsigned long long safe = 0;
+                    for (uint32_t k = 0; k + 1 < s->ringCount && safe < piece; ++k) safe += s->span[(s->ringHead + k) & (kRing - 1)];
+                    piece = (unsigned int)std::min<unsigned long long>(piece, safe);
+                }
+            }
+        }
+        for (int i = 0; i < n; ++i) {
+            const Stream* s = ss[i];
+            UttDesc& d = hUtt[i];
+            d.frameStart = (long long)s->slot * kRing + s->ringHead;
+            d.outStart = (long long)(i * padded);
+            d.nFrames = s->ringCount;
+            d.seed = s->seed; d.flags = UTT_NEEDS_NOISE;
+            d.length = piece;                // the stage-parallel kernel runs exactly `piece` steps (klatt_systolic.h, STREAM)
+            hState[i] = c->dState.ptr + (size_t)s->slot * kStateDoubles;
+            hControl[i] = s->purgePending ? 1u : 0u;
+        }
+        const auto tb = now();
+        tFill += ms(ta, tb);
+        {
+            std::lock_guard<std::mutex> lg(c->logMu);
+            if (log_send(c)) return -1;
+        }
+        HIP_TRY(hipMemcpyAsync(c->dCtl.ptr, c->hCtl.ptr, ctlBytes, hipMemcpyHostToDevice, c->stream));
+        a.maxSamples = piece;
+        HIP_TRY(hipEventRecord(c->kernelStart, c->stream));
+        if (g_liveLayout == 0) {
+            if (launch<true, true>(a, mode, groups, c->stream)) return -1;
+        } else {
+            // one workgroup per CU while they all fit (16-sample hand-overs), else two per CU (8-sample hand-overs), as for batches
+            if (groups <= g_liveCus ? launch_systolic<true, 16, 1, true, true>(a, mode, groups, c->stream)
+                                    : launch_systolic<true, KLATT_NOISY_CH, 2, true, true>(a, mode, groups, c->stream)) return -1;
+        }
+        HIP_TRY(hipEventRecord(c->kernelStop, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->hResult.ptr, c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
+        if (piece < count || joined) {       // a call in pieces: this piece's columns into the joined rows
+            if (c->dPcmJoin.reserve(padded * n)) return -1;
+            HIP_TRY(hipMemcpy2DAsync(c->dPcmJoin.ptr + at, padded * sizeof(int16_t), c->dPcm.ptr, padded * sizeof(int16_t), (size_t)piece * sizeof(int16_t), n,
+                                     hipMemcpyDeviceToDevice, c->stream));
+            joined = true;
+        }
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        {
+            std::lock_guard<std::mutex> lg(c->logMu);      // everything sent has arrived: an empty log starts over
+            if (c->logSent == c->logTail) c->logSent = c->logTail = 0;
+        }
+        float kms = 0.0f;
+        (void)hipEventElapsedTime(&kms, c->kernelStart, c->kernelStop);
+        c->lastKernelMs += kms; c->lastLaunches++;
+        for (int i = 0; i < n; ++i) {
+            Stream* s = ss[i];
+            const UttResult& r = c->hResult.ptr[i];
+            if (r.produced > piece || r.framesTaken > s->ringCount) { set_error("kernel produced %u > %u (took %u frames of %u)", r.produced, piece, r.framesTaken, s->ringCount); return -1; }
+            s->purgePending = false;
+            s->ringHead = (s->ringHead + r.framesTaken) & (kRing - 1);
+            s->ringCount -= r.framesTaken;
+            s->lastIndex = r.lastIndex;
+            c->done[i] += r.produced;
+        }
+        at += piece;
+        tRun += ms(tb, now());
+    }
     const auto t2 = now();
-    (void)hipEventElapsedTime(&c->lastKernelMs, c->kernelStart, c->kernelStop);
-    c->lastStride = padded;
-    if (devicePcm) *devicePcm = c->dPcm.ptr;
+    const int16_t* const pcm = joined ? c->dPcmJoin.ptr : c->dPcm.ptr;
+    if (devicePcm) *devicePcm = pcm;
     if (deviceStride) *deviceStride = (long long)padded;
     size_t lastWithData = 0;
     bool any = false;
     for (int i = 0; i < n; ++i) {
-        if (c->hResult[i].produced > count) { set_error("kernel produced %u > %u", c->hResult[i].produced, count); return -1; }
-        if (c->hResult[i].produced) { lastWithData = i; any = true; }
+        produced[i] = (int)c->done[i];
+        if (c->done[i]) { lastWithData = i; any = true; }
     }
     if (any && outs) {
         if (n == 1) {
-            HIP_TRY(hipMemcpy(outs[0], c->dPcm.ptr, (size_t)c->hResult[0].produced * sizeof(int16_t), hipMemcpyDeviceToHost));
+            HIP_TRY(hipMemcpy(outs[0], pcm, (size_t)c->done[0] * sizeof(int16_t), hipMemcpyDeviceToHost));
         } else {
             // whole rows in pieces of about 16 MB through two pinned buffers; piece k + 1 is in flight while the
             // rows of piece k are handed to their callers
@@ -964,7 +1159,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
             const size_t rows = lastWithData + 1, nPieces = (rows + rowsPerPiece - 1) / rowsPerPiece;
             auto issue = [&](size_t k) -> int {
                 const size_t r0 = k * rowsPerPiece, r1 = std::min(rows, r0 + rowsPerPiece);
-                HIP_TRY(hipMemcpyAsync(c->bounce.buf[k & 1], c->dPcm.ptr + r0 * padded, (r1 - r0) * padded * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
+                HIP_TRY(hipMemcpyAsync(c->bounce.buf[k & 1], pcm + r0 * padded, (r1 - r0) * padded * sizeof(int16_t), hipMemcpyDeviceToHost, c->stream));
                 HIP_TRY(hipEventRecord(c->bounce.ev[k & 1], c->stream));
                 return 0;
             };
@@ -974,25 +1169,32 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
                 HIP_TRY(hipEventSynchronize(c->bounce.ev[k & 1]));
                 const size_t r0 = k * rowsPerPiece, r1 = std::min(rows, r0 + rowsPerPiece);
                 const int16_t* src = static_cast<const int16_t*>(c->bounce.buf[k & 1]);
-                for (size_t i = r0; i < r1; ++i)
-                    if (c->hResult[i].produced) memcpy(outs[i], src + (i - r0) * padded, (size_t)c->hResult[i].produced * sizeof(int16_t));
+                auto rows_out = [&](size_t b0, size_t b1) {
+                    for (size_t i = b0; i < b1; ++i)
+                        if (c->done[i]) memcpy(outs[i], src + (i - r0) * padded, (size_t)c->done[i] * sizeof(int16_t));
+                };
+                // a piece of several megabytes is handed out by four threads: one thread's memcpy (about 20 GB/s) is slower than the copy over PCIe
+                constexpr int kHands = 4;
+                const size_t share = (r1 - r0 + kHands - 1) / kHands;
+                std::thread hands[kHands - 1];
+                int started = 0;
+                if ((r1 - r0) * padded * sizeof(int16_t) >= (4u << 20)) {
+                    try {
+                        for (; started < kHands - 1; ++started) {
+                            const size_t b0 = std::min(r1, r0 + (started + 1) * share), b1 = std::min(r1, b0 + share);
+                            hands[started] = std::thread(rows_out, b0, b1);
+                        }
+                    } catch (const std::system_error&) {}
+                }
+                rows_out(r0, started ? std::min(r1, r0 + share) : r1);
+                for (int t = 0; t < started; ++t) hands[t].join();
+                if (started && started < kHands - 1) rows_out(std::min(r1, r0 + (started + 1) * share), r1);     // what the threads that did not start would have done
             }
         }
     }
-    const auto t3 = now();
-    for (int i = 0; i < n; ++i) {
-        Stream* s = ss[i];
-        const UttResult& r = c->hResult[i];
-        s->purgePending = false;
-        s->head += std::min<size_t>(r.framesTaken, s->pending.size() - s->head);
-        if (s->head == s->pending.size()) { s->pending.clear(); s->head = 0; }
-        else if (s->head >= 64 && s->head * 2 >= s->pending.size()) { s->pending.erase(s->pending.begin(), s->pending.begin() + s->head); s->head = 0; }
-        s->lastIndex = r.lastIndex;
-        produced[i] = (int)r.produced;
-    }
     if (trace)
-        fprintf(stderr, "[speechPlayer/live] %d handles x %u: stage frames %.2f ms | upload + kernel (%.2f ms) + results %.2f ms | PCM to host %.2f ms | bookkeeping %.2f ms\n",
-                n, count, ms(t0, t1), c->lastKernelMs, ms(t1, t2), ms(t2, t3), ms(t3, now()));
+        fprintf(stderr, "[speechPlayer/live] %d handles x %u in %d launch(es): control block + ring refill %.2f ms | log + upload + kernel (%.2f ms) + results %.2f ms | PCM to host %.2f ms | before %.2f ms\n",
+                n, count, c->lastLaunches, tFill, c->lastKernelMs, tRun, ms(t2, now()), ms(t0, t2) - tFill - tRun);
     return 0;
 }
 
@@ -1029,20 +1231,36 @@ void speechPlayer_queueFrame(speechPlayer_handle_t playerHandle, speechPlayer_fr
     begin_call();
     Stream* s = lookup(playerHandle);
     if (!s) { set_error("speechPlayer_queueFrame: invalid handle"); return; }
-    PendingFrame f;
-    memset(&f, 0, sizeof f);
-    f.meta.minSamples = minFrameDuration;
-    f.meta.fadeSamples = std::max(fadeDuration, 1u);     // reference src/speechPlayer.cpp:36
-    f.meta.userIndex = userIndex;
-    f.meta.flags = framePtr ? 0u : FRAME_NULL;
-    if (framePtr) memcpy(f.p, framePtr, sizeof f.p);     // copied: caller may reuse it (reference src/frame.cpp:97)
+    FrameMeta meta;
+    meta.minSamples = minFrameDuration;
+    meta.fadeSamples = std::max(fadeDuration, 1u);       // reference src/speechPlayer.cpp:36
+    meta.userIndex = userIndex;
+    meta.flags = framePtr ? 0u : FRAME_NULL;
+    LiveContext* const c = s->context;
     std::lock_guard<std::mutex> g(s->mu);
     if (purgeQueue) {                                    // reference src/frame.cpp:103-112; the state half of
-        s->pending.clear();                              // the purge runs in the kernel before the next sample
-        s->head = 0;
+        ring_drop(c, s);                                 // the purge runs in the kernel before the next sample
+        s->overflow.clear(); s->overHead = 0;
         s->purgePending = true;
     }
-    s->pending.push_back(f);
+    // copied: the caller may reuse its frame (reference src/frame.cpp:97) -- into the pinned log while the handle's ring has
+    // room, else into the handle's host queue, from where the next pulls refill the ring
+    if (s->overHead == s->overflow.size() && s->ringCount < kRing) {
+        if (log_append(c, s, reinterpret_cast<const double*>(framePtr), meta, false)) return;
+        bool eager;
+        { std::lock_guard<std::mutex> lg(c->logMu); eager = c->logTail - c->logSent >= kLogEager; }
+        if (eager && c->mu.try_lock()) {                 // no pull is running: the log need not wait for the next one
+            std::lock_guard<std::mutex> lg(c->logMu);
+            if (hipSetDevice(s->device) == hipSuccess) (void)log_send(c);
+            c->mu.unlock();
+        }
+    } else {
+        PendingFrame f;
+        memset(&f, 0, sizeof f);
+        f.meta = meta;
+        if (framePtr) memcpy(f.p, framePtr, sizeof f.p);
+        s->overflow.push_back(f);
+    }
 }
 
 int speechPlayer_synthesize(speechPlayer_handle_t playerHandle, unsigned int sampleCount, sample* sampleBuf)
@@ -1076,9 +1294,12 @@ void speechPlayer_terminate(speechPlayer_handle_t playerHandle)
         g_streams[id - 1] = nullptr;
     }
     if (!s) return;
-    (void)hipSetDevice(s->device);
     { std::lock_guard<std::mutex> g(s->mu); }   // let a call in flight finish
-    s->dState.release();
+    if (LiveContext* c = s->context) {
+        std::lock_guard<std::mutex> g(c->mu);
+        ring_drop(c, s);                        // its entries in the log go nowhere
+        c->freeSlots.push_back(s->slot);        // state block and ring are the next handle's (zeroed at its initialize, in stream order)
+    }
     delete s;
 }
 
@@ -1135,18 +1356,30 @@ float speechPlayer_lastLiveKernelMs(int device)
     return (device >= 0 && device < (int)g_live.size() && g_live[device]) ? g_live[device]->lastKernelMs : -1.0f;
 }
 
+// Kernel launches the last live call on `device` took: 1, unless it went in pieces (a handle with more frames queued than its ring holds).
+int speechPlayer_lastLiveLaunches(int device)
+{
+    std::lock_guard<std::mutex> g(g_liveMutex);
+    return (device >= 0 && device < (int)g_live.size() && g_live[device]) ? g_live[device]->lastLaunches : -1;
+}
+
 static int synthesize_many(speechPlayer_handle_t* handles, int nHandles, unsigned int sampleCount, sample** sampleBufs, int* produced,
                            const int16_t** devicePcm, long long* deviceStride)
 {
     if (nHandles < 0 || (nHandles > 0 && (!handles || !produced))) { set_error("speechPlayer_synthesizeMany: bad arguments"); return -1; }
     std::vector<Stream*> ss((size_t)nHandles);
-    for (int i = 0; i < nHandles; ++i) {
-        ss[i] = lookup(handles[i]);
-        if (!ss[i]) { set_error("speechPlayer_synthesizeMany: invalid handle at %d", i); return -1; }
+    bool ascending = true;
+    {
+        std::lock_guard<std::mutex> g(g_tableMutex);
+        for (int i = 0; i < nHandles; ++i) {
+            ss[i] = lookup_locked(handles[i]);
+            if (!ss[i]) { set_error("speechPlayer_synthesizeMany: invalid handle at %d", i); return -1; }
+            if (i && ss[i]->id <= ss[i - 1]->id) ascending = false;
+        }
     }
     // lock in handle order (no deadlock between concurrent calls); duplicates are an error
     std::vector<Stream*> order(ss);
-    std::sort(order.begin(), order.end(), [](Stream* x, Stream* y) { return x->id < y->id; });
+    if (!ascending) std::sort(order.begin(), order.end(), [](Stream* x, Stream* y) { return x->id < y->id; });
     for (size_t i = 1; i < order.size(); ++i)
         if (order[i] == order[i - 1]) { set_error("speechPlayer_synthesizeMany: handle listed twice"); return -1; }
     for (Stream* s : order) s->mu.lock();

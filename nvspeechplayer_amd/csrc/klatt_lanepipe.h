@@ -91,7 +91,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
     UttDesc d;
     d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
-    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart};
+    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart, 0u, 0xFFFFFFFFu};
     const double srF = A.sampleRateF, invSr = A.invSampleRate;   // by value into the lambdas below
     int16_t* const pcmOut = A.pcm;
 

@@ -141,6 +141,7 @@ struct StageCtx {          // what every stage needs from the launch
     const UttDesc& d;
     const double* myFrames;
     const FrameMeta* myMeta;
+    uint32_t ringOff, ringMask;    // frame k of the queue is myFrames[(ringOff + k) & ringMask] (frame_window, klatt_device.h)
     const FlatRef* myFlat;     // flat launches: the utterance's per-frame track references, loaded ahead by the stages (klatt_device.h)
     const SourceRef* mySrc;    // flat launches: what the source stage loads ahead
 };
@@ -178,8 +179,9 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
         return true;
     }
     if (f.nextFrame >= X.d.nFrames) { f.done = true; return false; }   // queue empty (:74)
-    const FrameMeta m = X.myMeta[f.nextFrame];
-    const double* g = X.myFrames + (size_t)f.nextFrame * kNumParams;
+    const uint32_t at = (X.ringOff + f.nextFrame) & X.ringMask;
+    const FrameMeta m = X.myMeta[at];
+    const double* g = X.myFrames + (size_t)at * kNumParams;
     f.nextFrame++;
     f.newMin = m.minSamples; f.newFade = m.fadeSamples; f.newNull = (m.flags & FRAME_NULL) != 0;
     constexpr int GI = D::GAIN >= 0 ? D::GAIN : 0;
@@ -1015,7 +1017,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     UttDesc d;
     d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
     if (live) d = A.utt[u];
-    const StageCtx X{A, d, A.frames + d.frameStart * kNumParams, A.meta + d.frameStart,
+    const FrameWindow fw = frame_window(A, d);
+    const StageCtx X{A, d, A.frames + fw.base * kNumParams, A.meta + fw.base, fw.off, fw.mask,
                      FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr};
     const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed), ninc2 = noise_inc2(ninc);
     constexpr int FINAL = NOISE ? 2 : 3;

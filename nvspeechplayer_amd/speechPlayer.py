@@ -150,6 +150,49 @@ class SpeechPlayer(object):
             pass
 
 
+class LiveGroup(object):
+    """A fixed set of live players pulled together again and again: the handle array and the result arrays are built once
+    (SpeechPlayer.synthesizeMany builds them per call -- about a millisecond for 8192 players, as much as the engine's own host
+    work per pull)."""
+
+    def __init__(self, players):
+        self.players = list(players)
+        n = len(self.players)
+        if n == 0:
+            raise ValueError("no players")
+        self._dll = self.players[0]._dll
+        self._handles = (c_void_p * n)(*[p._speechHandle for p in self.players])
+        self._produced = (c_int * n)()
+        self.produced = np.frombuffer(self._produced, dtype=np.int32)      # a view: overwritten by the next pull
+        self._ptr = c_void_p()
+        self._stride = ctypes_longlong()
+        self._out = None
+        self._rows = None
+
+    def pullDevice(self, numSamples):
+        """-> (device pointer, row stride in samples, produced[n]); the PCM stays in HBM (speechPlayer_synthesizeManyDevice)."""
+        rc = self._dll.speechPlayer_synthesizeManyDevice(self._handles, len(self.players), numSamples, byref(self._ptr), byref(self._stride),
+                                                         self._produced)
+        if rc != 0:
+            raise RuntimeError("speechPlayer_synthesizeManyDevice failed: %s" % _native.last_error())
+        return self._ptr.value, self._stride.value, self.produced
+
+    def pull(self, numSamples, out):
+        """Samples into the rows of `out` (C-contiguous int16 [n, >= numSamples]); -> produced[n]."""
+        n = len(self.players)
+        if self._out is not out:
+            if out.dtype != np.int16 or out.ndim != 2 or out.shape[0] < n or not out.flags["C_CONTIGUOUS"]:
+                raise ValueError("out must be a C-contiguous int16 array [n, >= numSamples]")
+            self._rows = (out.ctypes.data + np.arange(n, dtype=np.uint64) * np.uint64(out.strides[0])).astype(np.uint64)
+            self._out = out
+        if out.shape[1] < numSamples:
+            raise ValueError("out has fewer than numSamples columns")
+        rc = self._dll.speechPlayer_synthesizeMany(self._handles, n, numSamples, self._rows.ctypes.data, self._produced)
+        if rc != 0:
+            raise RuntimeError("speechPlayer_synthesizeMany failed: %s" % _native.last_error())
+        return self.produced
+
+
 def pcm_digest(pcm):
     """speechPlayer_batch_digest's per-utterance value for a host int16 array (uint64 arithmetic wraps)."""
     v = np.asarray(pcm, dtype=np.int16).view(np.uint16).astype(np.uint64)

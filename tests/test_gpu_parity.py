@@ -636,6 +636,62 @@ def test_many_live_streams_one_launch(ref, all_scenarios):
     assert total == 0
 
 
+def test_live_handles_with_more_frames_than_their_rings(ref):
+    """A handle keeps 256 frames on the device (klatt_engine.hip kRing); what is queued beyond waits on the host.  70 handles,
+    each with 700-1500 short frames (4-40 samples, a few null, a few of length 0) queued at once, so that an 8192-sample pull
+    runs past the ring's last frame and proceeds in pieces; a purge while frames wait on both sides; a handle closed with frames
+    waiting and its arena slot taken over by a new handle.  PCM, call lengths and index marks against one oracle player each."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    rng = np.random.default_rng(77)
+    names = ["a", "i", "u", "s", "z", "m", "n", "f", "v", "h"]
+    shapes = [scenarios.vowel_frame(ref, nm, 110.0 + 7 * k, 100.0 + 5 * k) for k, nm in enumerate(names)]
+    n = 70
+    players = [eng.SpeechPlayer(22050, noiseSeed=900 + k) for k in range(n)]
+    oracles = [oracle.OraclePlayer(22050, seed=900 + k) for k in range(n)]
+
+    def queue_some(k, count, base):
+        for j in range(count):
+            r = rng.random()
+            fr = None if r < 0.03 else shapes[int(rng.integers(0, len(shapes)))]
+            m = 0 if r > 0.97 else int(rng.integers(4, 41))
+            f = int(rng.integers(1, 30))
+            players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, base + j)
+            oracles[k].queue(fr, m, f, base + j)
+
+    for k in range(n):
+        queue_some(k, int(rng.integers(700, 1500)), 0)
+    got = [[] for _ in range(n)]
+    exp = [[] for _ in range(n)]
+    L = _native.load()
+    launches = []
+    for step, cnt in enumerate((8192, 5000, 8192, 333, 8192, 8192, 8192)):
+        if step == 1:       # purge: ring and host queue both hold frames of handle 3
+            players[3].queueFrameSamples(eng.Frame.from_array(shapes[1]), 700, 200, 5000, True)
+            oracles[3].queue(shapes[1], 700, 200, 5000, True)
+            queue_some(3, 400, 6000)
+        if step == 2:       # handle 5 closes with frames waiting; a new handle takes its slot over
+            players[5].close()
+            players[5] = eng.SpeechPlayer(22050, noiseSeed=4242)
+            oracles[5] = oracle.OraclePlayer(22050, seed=4242)
+            got[5], exp[5] = [], []
+            queue_some(5, 300, 0)
+        bufs = eng.SpeechPlayer.synthesizeMany(players, cnt)
+        launches.append(L.speechPlayer_lastLiveLaunches(0))
+        for k, b in enumerate(bufs):
+            e = oracles[k].synthesize(cnt)
+            g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
+            assert len(g) == len(e), (step, k, len(g), len(e))
+            assert players[k].getLastIndex() == oracles[k].last_index(), (step, k)
+            got[k].append(g); exp[k].append(e)
+    assert max(launches) > 1, launches          # some pull did go in pieces
+    total = 0
+    for k in range(n):
+        total += compare(np.concatenate(got[k]), np.concatenate(exp[k]), "overflowing live stream %d" % k)
+        players[k].close()
+    assert total == 0
+
+
 def test_random_ragged_batch_large():
     """One big random batch (20 000 utterances, ~8e7 samples, both launch groups, two workgroups per CU):
     bit-for-bit against the oracle.  Bounds the rate of differing samples well below 1e-7."""

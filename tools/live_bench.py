@@ -28,26 +28,32 @@ def fresh():
     return players
 
 
+t0 = time.perf_counter()
 players = fresh()
-eng.SpeechPlayer.synthesizeManyDevice(players, 64)      # warm-up
+tq = time.perf_counter() - t0
+nq = 3 * len(frames) * n
+group = eng.LiveGroup(players)                           # handle array built once
+group.pullDevice(64)                                     # warm-up
 t0 = time.perf_counter()
 total, kms = 0, 0.0
 for _ in range(pulls):
-    _, _, produced = eng.SpeechPlayer.synthesizeManyDevice(players, chunk)
+    _, _, produced = group.pullDevice(chunk)
     total += int(produced.sum())
     kms += L.speechPlayer_lastLiveKernelMs(0)
 dt = time.perf_counter() - t0
+print("%d handles created, %d frames queued (through ctypes): %.2f s = %.2f us per frame" % (n, nq, tq, tq / nq * 1e6), flush=True)
 print("%d live handles, %d-sample pulls, layout %s: kernel %.2f ms per pull = %.3g samples/s; call with PCM left in HBM %.2f ms = %.3g samples/s" % (
     n, chunk, os.environ.get("SPEECHPLAYER_LIVE_LAYOUT", "1"), kms / pulls, total / (kms * 1e-3), dt / pulls * 1e3, total / dt), flush=True)
 for p in players:
     p.close()
 players = fresh()
-eng.SpeechPlayer.synthesizeMany(players, 64)
+group = eng.LiveGroup(players)
 out = np.zeros((n, chunk), dtype=np.int16)
+group.pull(64, out)
 t0 = time.perf_counter()
 total = 0
 for _ in range(pulls):
-    total += int(eng.SpeechPlayer.synthesizeMany(players, chunk, out=out).sum())
+    total += int(group.pull(chunk, out).sum())
 dt = time.perf_counter() - t0
 print("    PCM to per-handle host buffers: %.1f ms per pull = %.3g samples/s (%.0f x real time per stream)" % (dt / pulls * 1e3, total / dt, total / dt / n / 22050), flush=True)
 few = players[:8]

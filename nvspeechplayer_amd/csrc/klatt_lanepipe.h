@@ -7,13 +7,13 @@
 // (reference :149-156) is laid across the LANES of a wavefront instead: lane (g, k) runs resonator k of
 // utterance g, and hands its output to lane (g, k + 1) with one DPP rotate per step (no LDS, no barrier):
 //
-//   wave 0      S0   frame(0, 1-6, 44) + glottal source for the workgroup's 20 utterances      -> x   (LDS pipe)
-//   wave 1, 2   F    10 utterances x 6 lanes each: lane (g, k) = resonator r(6-k) of utterance g
-//                    step t: lane k filters sample t - k; in = (k == 0) ? x[t] : rotate(out of lane k - 1)
+//   wave 0      S0   frame(0, 1-6, 44) + glottal source for the workgroup's 16 utterances      -> x   (LDS pipe)
+//   wave 1, 2   F    8 utterances each, two to a 16-lane row: row position 2 k + j = resonator r(6-k) of the row's utterance j
+//                    step t: resonator k filters sample t - k; in = (k == 0) ? x[t] : out of resonator k - 1 (DPP row_shr:2)
 //   wave 3      FIN  outputGain, x 4000, clip, int16 -> PCM tile -> HBM
 //
 // A step costs one resonator (5 f64 operations in the reference's order) plus the hand-over, ~3x less than a
-// stage of the stage-parallel kernel, and a 4096-utterance batch becomes 205 workgroups.  Every lane runs its own
+// stage of the stage-parallel kernel, and a 4096-utterance batch becomes 256 workgroups.  Every lane runs its own
 // copy of the frame state machine (reference src/frame.cpp:41-80) for its two parameters (f, bw), started k steps
 // late; the arithmetic per sample is the lane kernel's, operation for operation, so the PCM is bit-identical.
 //
@@ -30,7 +30,8 @@ namespace klatt {
 constexpr uint32_t UTT_NO_NASAL = 2u;     // UttDesc.flags: caNP == 0 throughout, N0/NP finite and stable
 
 constexpr int kLpK = 6;                   // lanes (cascade resonators r6..r1) per utterance
-constexpr int kLpUPW = kLanes / kLpK;     // utterances per filter wave (10; lanes 60..63 idle)
+constexpr int kLpUPR = 2;                 // utterances per 16-lane row, interleaved: row position p = 2 k + (utterance & 1); positions 12..15 idle
+constexpr int kLpUPW = 4 * kLpUPR;        // utterances per filter wave (8)
 constexpr int kLpUPG = 2 * kLpUPW;        // utterances per workgroup (two filter waves)
 constexpr int kLpSkew = kLpK - 1;         // the last lane emits sample t - kLpSkew at step t
 
@@ -38,8 +39,7 @@ template <int CH>
 struct LpLds {
     static constexpr int kPipeX = 0;                                   // S0 -> F : [2 buffers][CH][kLpUPG] f64
     static constexpr int kPipeY = kPipeX + 2 * CH * kLpUPG * 8;        // F -> FIN: ring [4][CH][kLpUPG] f64
-    static constexpr int kDummy = kPipeY + 4 * CH * kLpUPG * 8;       // where the lanes that are not last in their group "store"
-    static constexpr int kTileOff = kDummy + (CH * kLpUPG + kLanes) * 8;
+    static constexpr int kTileOff = kPipeY + 4 * CH * kLpUPG * 8;
     static constexpr int kT = CH > kTile ? CH : kTile;                // samples per tile row: a whole chunk leaves at once
     static constexpr int kTStride = kT * 2 + 8;                        // bytes per row; the pad keeps ds_write_b16 conflict-free
     static constexpr int kRowBase = kTileOff + kLanes * kTStride;
@@ -51,12 +51,14 @@ struct LpLds {
     static constexpr int kBytes = kFramesFin + 2 * 1 * kLanes * 8;     // FIN: old + new of outputGain
 };
 
-// lane i receives the value of lane i - 1 (lane 0 that of lane 63): v_mov_b32_dpp wave_ror:1, twice
-__device__ __forceinline__ double wave_ror1(double v)
+// The hand-over of a step: row position p receives `out` of position p - 2 (the same utterance's previous resonator); positions 0 and 1,
+// which have no such neighbour, keep `x`, their utterance's cascade input -- v_mov_b32_dpp row_shr:2 with bound_ctrl off, twice for a
+// double, and no select (lanes laid out six to an utterance needed wave_ror:1 plus two v_cndmask for the first lanes: 11 VALU
+// instructions per step instead of 9).
+__device__ __forceinline__ double lp_hand_over(double out, double x)
 {
-    int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_mov_dpp(lo, 0x13C, 0xF, 0xF, false);
-    hi = __builtin_amdgcn_mov_dpp(hi, 0x13C, 0xF, 0xF, false);
+    int lo = __builtin_amdgcn_update_dpp(__double2loint(x), __double2loint(out), 0x112, 0xF, 0xF, false);
+    int hi = __builtin_amdgcn_update_dpp(__double2hiint(x), __double2hiint(out), 0x112, 0xF, 0xF, false);
     return __hiloint2double(hi, lo);
 }
 
@@ -80,10 +82,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const bool filter = (wave == 1 || wave == 2);
     // which utterance of the workgroup this lane works for, and (filter waves) which resonator
-    const int grp = lane / kLpK;
-    const int k = filter ? (lane - grp * kLpK) : 0;
-    const int uw = filter ? (wave - 1) * kLpUPW + grp : lane;
-    const bool seated = filter ? (lane < kLpUPW * kLpK) : (lane < kLpUPG);
+    const int rowPos = lane & 15;
+    const int k = filter ? (rowPos >> 1) : 0;
+    const int uw = filter ? (wave - 1) * kLpUPW + (lane >> 4) * kLpUPR + (rowPos & 1) : lane;
+    const bool seated = filter ? (k < kLpK) : (lane < kLpUPG);
     const long long slot = (long long)blockIdx.x * kLpUPG + uw;
     const uint32_t u = (seated && slot < A.nSlots) ? A.order[slot] : 0xFFFFFFFFu;
     const bool live = (u != 0xFFFFFFFFu);
@@ -224,35 +226,43 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
         constexpr int RF[1] = {0}, RB[1] = {1};
         StageFrame<2, 1> f;
         stage_frame_init(f, live, lds + L::kFramesF + (wave - 1) * (2 * 2 * kLanes * 8), lane);
-        const bool first = (k == 0), last = (k == kLpK - 1);
+        const bool last = (k == kLpK - 1);
         uint32_t delay = (uint32_t)k;
         double out = 0.0;            // this lane's latest output: what lane k + 1 reads next step
-        // steady chunks store unconditionally (no EXEC juggling inside the block): last lanes into the ring,
-        // the others into a scratch area of the same row pitch
-        double* const dummyY = reinterpret_cast<double*>(lds + L::kDummy) + lane;
+        // steady chunks keep the step outputs in registers and the last lanes store them all at the end of the chunk: one EXEC
+        // change per chunk (an s_and_saveexec / s_or pair per step costs a lone wave ~11 ns), and only the 10 lanes that have
+        // something to say write (every lane storing every step, 54 of them to a scratch area, was 17 % of a cfg1 launch:
+        // 1 KB of LDS writes per step and filter wave, profiles/r3_cfg1_notes.txt)
+        double keep[CH];
         using KF = LoopKnobs<true, true, true, false, false, CH>;
         stage_loop<D, MODE, CH, KF>(1, nIter, nChunks, nChunks, wave, f, nullptr, nullptr, delay, P, RF, RB, X,
             [&]() { return __any(!f.done && delay > 0u); },
             [&](int) -> bool { return true; },
             [&](int) {},
             [&](int c, int i, double pre) {
-                double in = wave_ror1(out);
-                in = first ? pre : in;
+                const double in = lp_hand_over(out, pre);
                 out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);
-                double* const yRow = last ? &LP_Y(c * CH) : dummyY;
-                yRow[i * kLpUPG] = out;
+                keep[i] = out;
+                if (i == CH - 1 && last && !(KLATT_LP_EXP & 2)) {
+                    if (KLATT_LP_EXP & 4) {      // timing only: 16-byte stores, half as many
+#pragma unroll
+                        for (int j = 0; j < CH; j += 2)
+                            *reinterpret_cast<double2*>(reinterpret_cast<uintptr_t>(&LP_Y(c * CH + j)) & ~(uintptr_t)15) = make_double2(keep[j], keep[j + 1]);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < CH; ++j) LP_Y(c * CH + j) = keep[j];
+                    }
+                }
             },
-            [&](int c, int i) { return LP_X(c, i); },
+            [&](int c, int i) { return (KLATT_LP_EXP & 8) ? 0.25 : LP_X(c, i); },      // & 8, timing only: no input loads
             [&](int c, int i, bool, double) {
-                double in = wave_ror1(out);
-                if (first) in = LP_X(c, i);
+                const double in = lp_hand_over(out, LP_X(c, i));
                 out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);
                 if (last) LP_Y(c * CH + i) = out;
             },
             [&](int, bool, bool) -> bool { return false; },
             [&](int c, int i, bool emit) {
-                double in = wave_ror1(out);            // every lane takes part in the rotate
-                if (first) in = LP_X(c, i);
+                const double in = lp_hand_over(out, LP_X(c, i));            // every lane takes part in the shift
                 if (emit) {
                     out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);
                     if (last) LP_Y(c * CH + i) = out;

@@ -494,6 +494,11 @@ struct Stamps {
 // the event steps need the state machine sample by sample; the run length comes from a bisection with ballots.  (Off for
 // the noisy kernels: the extra code costs them more than the runs save, cfg2 15.8 -> 16.8 ms.)  DELAY: lanes start `delay`
 // steps late (the lane-pipelined kernel's skew).  STREAM: the launch runs exactly A.maxSamples steps (live handles).
+// timing experiments (results are garbage): KLATT_LP_EXP & 1: the chunk loop without its barriers; & 2: the lane-pipelined filter waves store nothing
+#ifndef KLATT_LP_EXP
+#define KLATT_LP_EXP 0
+#endif
+#define STAGE_SYNC() do { if (!(KLATT_LP_EXP & 1)) __syncthreads(); } while (0)
 template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_>
 struct LoopKnobs {
     static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_;
@@ -566,7 +571,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                     steadyChunk(c, useAlt);
                     perChunk();
                     STAMP_WORKED();
-                    __syncthreads();
+                    STAGE_SYNC();
                     STAMP_SYNCED();
                     STAMP_BEGIN();
                     ++iter; ++c;
@@ -599,7 +604,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                     fadeChunk(c);
                     perChunk();
                     STAMP_WORKED();
-                    __syncthreads();
+                    STAGE_SYNC();
                     STAMP_SYNCED();
                     STAMP_BEGIN();
                     ++iter; ++c;
@@ -671,7 +676,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
             perChunk();
         }
         STAMP_WORKED();
-        __syncthreads();
+        STAGE_SYNC();
         STAMP_SYNCED();
     }
 #ifdef KLATT_STAMPS

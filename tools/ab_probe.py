@@ -40,7 +40,7 @@ def measure(workloads_wanted):
     out = {}
     base = workloads.make("cfg2", 65536)
     for key in workloads_wanted:
-        b = {"cfg2": lambda: base, "rot": lambda: rotate(base), "cfg2_16k": lambda: base.slice(0, 16384), "jit": lambda: jitter(base), "cfg1": lambda: workloads.make("cfg1", 4096), "vowels64k": lambda: workloads.make("cfg1", 65536),
+        b = {"cfg2": lambda: base, "rot": lambda: rotate(base), "cfg2_16k": lambda: base.slice(0, 16384), "jit": lambda: jitter(base), "cfg1": lambda: workloads.make("cfg1", 4096), "cfg1_1k": lambda: workloads.make("cfg1", 1024), "cfg1_256": lambda: workloads.make("cfg1", 256), "cfg1_16": lambda: workloads.make("cfg1", 16), "vowels64k": lambda: workloads.make("cfg1", 65536),
              "cfg2_2k": lambda: base.slice(0, 2048), "cfg2_4k": lambda: base.slice(0, 4096), "cfg2_8k": lambda: base.slice(0, 8192), "cfg2_14k": lambda: base.slice(0, 14000),
              "cfg4": lambda: workloads.make("cfg4", 32768), "cfg3": lambda: workloads.make("cfg3", 125000)}[key]()
         bp = BatchPlayer(b["sr"])

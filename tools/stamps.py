@@ -9,7 +9,7 @@ from nvspeechplayer_amd import BatchPlayer, _native, workloads
 
 wl, n, mode = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]) if len(sys.argv) > 3 else 0
 layout = int(sys.argv[4]) if len(sys.argv) > 4 else 1     # 2: lane-pipelined workgroups (20 utterances each)
-per = 20 if layout == 2 else 64
+per = 16 if layout == 2 else 64
 if wl == "staggered":          # cfg2 with per-utterance leading silence: lanes of a wave do not fade together
     from mixed_probe import stagger
     batch = stagger(workloads.make("cfg2", n))
@@ -24,14 +24,16 @@ else:
 bp = BatchPlayer(batch["sr"], mode=mode, layout=layout)
 bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
 if layout == -1 and bp.kernelInfo()["lane_pipelined_utterances"] == n:
-    per = 20                   # the engine chose the lane-pipelined kernel for the whole batch
+    per = 16                   # the engine chose the lane-pipelined kernel for the whole batch
 bp.synthesize(); bp.synthesize()
 L = _native.load()
 L.speechPlayer_batch_debugStamps.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
 buf = np.zeros((n // per + 2) * 32, dtype=np.uint64)
 got = L.speechPlayer_batch_debugStamps(bp._h, buf.ctypes.data, len(buf))
 st = buf[:(n // per) * 32].reshape(-1, 4, 8).astype(np.float64)
-print("%s n=%d mode=%d: per stage mean cycles  work / barrier-wait   (over %d workgroups)" % (wl, n, mode, st.shape[0]))
+ms = float(np.mean(bp.time(4)))
+print("%s n=%d mode=%d: per stage mean cycles  work / barrier-wait   (over %d workgroups); a launch of this build takes %.3f ms: %.2f ticks per ns" % (
+    wl, n, mode, st.shape[0], ms, (st[:, 0, 0] + st[:, 0, 1]).mean() / (ms * 1e6)))
 for s in range(4):
     m = st[:, s, :].mean(axis=0)
     print("  stage %d: work %.3e wait %.3e | chunks steady/fade/general %5.0f %5.0f %5.0f | cycles per chunk %7.0f %7.0f %7.0f" % (

@@ -23,23 +23,31 @@ __device__ __forceinline__ double bperm_move(double v, int src)
 
 // VARIANT: 0 no hand-over (in = out); 1 wave_ror:1; 2 row_shr:1; 3 ds_bpermute; 4 wave_ror + select; 5 wave_ror + select + LDS store
 //          6: two independent pipelines interleaved (variant 5 twice); 7: FMA form y = fma(a, in, s), s = fma(b, z1, c * z2) + select + store
-template <int VARIANT>
-__global__ void __launch_bounds__(64) k(double* out, const double* coef, int steps, int probe)
+// WORKMASK: which waves of the block work (the others leave at once); every working wave has its own LDS areas
+template <int VARIANT, int NWAVES = 1, int WORKMASK = 1>
+__global__ void __launch_bounds__(64 * NWAVES) k(double* out, const double* coef, int steps, int probe)
 {
-    __shared__ double xs[64 * 32];
-    __shared__ double ys[64 * 33];
-    const int lane = threadIdx.x;
+    __shared__ double xsAll[NWAVES][64 * 32];
+    __shared__ double ysAll[NWAVES][64 * 33];
+    if (!((WORKMASK >> (threadIdx.x >> 6)) & 1)) return;
+    double* const xs = xsAll[threadIdx.x >> 6];
+    double* const ys = ysAll[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
     const double a = coef[lane], b = coef[64 + lane], c = coef[128 + lane];
     double z1 = 0.0, z2 = 0.0, y = 1e-3 * lane;
     double z1b = 0.0, z2b = 0.0, yb = 2e-3 * lane;
     const bool first = (lane % 6) == 0;
     for (int i = 0; i < 32; ++i) xs[i * 64 + lane] = 1e-3 * (i + lane);
-    __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0xC07F);      // this wave's own LDS writes (no barrier: some waves have left)
     const int src = (lane + 63) & 63;
     for (int t = 0; t < steps; t += 32) {
         double pre[32];
+        // VARIANT 9 / 11: the real kernel's input rows (20 doubles apart, the 6 lanes of an utterance read one address);
+        // VARIANT 10 / 11: its output rows (20 doubles apart; last lanes into the ring, the others into a scratch row)
+        const bool lastL = (lane % 6) == 5;
+        double* const yrow = lastL ? (ys + lane / 6) : (ys + 32 * 20 + lane);
 #pragma unroll
-        for (int i = 0; i < 32; ++i) pre[i] = xs[i * 64 + lane];
+        for (int i = 0; i < 32; ++i) pre[i] = (VARIANT == 9 || VARIANT == 11) ? xs[i * 20 + lane / 6] : xs[i * 64 + lane];
 #pragma unroll
         for (int i = 0; i < 32; ++i) {
             double in;
@@ -56,7 +64,8 @@ __global__ void __launch_bounds__(64) k(double* out, const double* coef, int ste
                 const double w = a * in + b * z1 + c * z2;
                 z2 = z1; z1 = w; y = w;
             }
-            if (VARIANT >= 5) ys[i * 66 + lane] = y;
+            if (VARIANT == 10 || VARIANT == 11) yrow[i * 20] = y;
+            else if (VARIANT >= 5) ys[i * 66 + lane] = y;
             if (VARIANT == 6) {
                 double inb = dpp_move<0x13C>(yb);
                 inb = first ? pre[31 - i] : inb;
@@ -66,13 +75,14 @@ __global__ void __launch_bounds__(64) k(double* out, const double* coef, int ste
             }
         }
     }
-    out[blockIdx.x * 64 + lane] = y + yb + ys[(probe & 31) * 66 + lane];
+    out[blockIdx.x * 64 * NWAVES + threadIdx.x] = y + yb + ys[(probe & 31) * 66 + lane];
 }
 
 // The whole workgroup of klatt_lanepipe.h in miniature: wave 0 source-like (phase chain + 5 elementwise operations
 // + LDS store), waves 1-2 the filter step of variant 5 fed from LDS, wave 3 final-like (two multiplies, clamp,
 // convert, ds_write_b16), one barrier per 32-sample chunk, double-buffered pipes.  ROLES: bit w set = wave w works.
-template <int ROLES, bool SYNC = true>
+// CUT (timing only): 1 the filter waves load nothing, 2 store nothing, 4 no select of the first lane
+template <int ROLES, bool SYNC = true, int CUT = 0>
 __global__ void __launch_bounds__(256) wg(double* out, const double* coef, int steps)
 {
     __shared__ double px[2 * 32 * 20];
@@ -103,14 +113,14 @@ __global__ void __launch_bounds__(256) wg(double* out, const double* coef, int s
             double* yrow = last ? (py + (((it + 3) & 3) * 32) * 20 + uw) : (py + 4 * 32 * 20 + lane);
             double pre[32];
 #pragma unroll
-            for (int i = 0; i < 32; ++i) pre[i] = xin[i * 20];
+            for (int i = 0; i < 32; ++i) pre[i] = (CUT & 1) ? 0.001 * i : xin[i * 20];
 #pragma unroll
             for (int i = 0; i < 32; ++i) {
                 double in = dpp_move<0x13C>(y);
-                in = first ? pre[i] : in;
+                if (!(CUT & 4)) in = first ? pre[i] : in; else in += pre[i];
                 const double w = a * in + b * z1 + c * z2;
                 z2 = z1; z1 = w; y = w;
-                yrow[i * 20] = y;
+                if (!(CUT & 2)) yrow[i * 20] = y;
             }
         } else if (wave == 3 && (ROLES & 8)) {
             const double* yin = py + uw;
@@ -134,15 +144,15 @@ __global__ void __launch_bounds__(256) wg(double* out, const double* coef, int s
     out[blockIdx.x * 256 + threadIdx.x] = y + pp + acc;
 }
 
-template <int ROLES, bool SYNC = true>
+template <int ROLES, bool SYNC = true, int CUT = 0>
 void run_wg(const char* name, double* dOut, double* dCoef, int blocks)
 {
     const int steps = 32 * 1024;
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
-    hipLaunchKernelGGL((wg<ROLES, SYNC>), dim3(blocks), dim3(256), 0, 0, dOut, dCoef, steps);
+    hipLaunchKernelGGL((wg<ROLES, SYNC, CUT>), dim3(blocks), dim3(256), 0, 0, dOut, dCoef, steps);
     hipEventRecord(e0);
-    hipLaunchKernelGGL((wg<ROLES, SYNC>), dim3(blocks), dim3(256), 0, 0, dOut, dCoef, steps);
+    hipLaunchKernelGGL((wg<ROLES, SYNC, CUT>), dim3(blocks), dim3(256), 0, 0, dOut, dCoef, steps);
     hipEventRecord(e1);
     hipEventSynchronize(e1);
     float ms = 0;
@@ -256,6 +266,22 @@ void run_chain3(const char* name, double* dOut, double* dCoef, int blocks)
     printf("%-58s blocks=%5d : %7.2f ns per step\n", name, blocks, ms * 1e6 / steps);
 }
 
+template <int V, int NWAVES, int WORKMASK>
+void run_multi(const char* name, double* dOut, double* dCoef, int blocks)
+{
+    const int steps = 32 * 1024;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<V, NWAVES, WORKMASK>), dim3(blocks), dim3(64 * NWAVES), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e0);
+    hipLaunchKernelGGL((k<V, NWAVES, WORKMASK>), dim3(blocks), dim3(64 * NWAVES), 0, 0, dOut, dCoef, steps, 3);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    printf("%-58s blocks=%5d : %7.2f ns per step\n", name, blocks, ms * 1e6 / steps);
+}
+
 template <int V>
 void run(const char* name, double* dOut, double* dCoef, int blocks)
 {
@@ -306,6 +332,23 @@ int main()
         run_wg<15>("workgroup: all four waves", dOut, dCoef, blocks);
         run_wg<2, false>("workgroup: one filter wave only, NO barrier (timing only)", dOut, dCoef, blocks);
         run_wg<15, false>("workgroup: all four waves, NO barrier (timing only)", dOut, dCoef, blocks);
+        run_wg<2, false, 1>("one filter wave, no barrier, no loads", dOut, dCoef, blocks);
+        run_wg<2, false, 2>("one filter wave, no barrier, no stores", dOut, dCoef, blocks);
+        run_wg<2, false, 3>("one filter wave, no barrier, no loads, no stores", dOut, dCoef, blocks);
+        run_wg<2, false, 7>("one filter wave, no barrier, no loads, stores, select", dOut, dCoef, blocks);
+    }
+    for (int blocks : {16, 205}) {
+        // the filter step (variant 5) by how many waves of a 256-thread block run it, and which
+        run_multi<5, 1, 1>("filter step, block of 1 wave", dOut, dCoef, blocks);
+        run_multi<9, 1, 1>("filter step, input rows as in the kernel", dOut, dCoef, blocks);
+        run_multi<10, 1, 1>("filter step, output rows as in the kernel", dOut, dCoef, blocks);
+        run_multi<11, 1, 1>("filter step, both as in the kernel", dOut, dCoef, blocks);
+        run_multi<5, 4, 1>("filter step, block of 4 waves, wave 0 works", dOut, dCoef, blocks);
+        run_multi<5, 4, 2>("filter step, block of 4 waves, wave 1 works", dOut, dCoef, blocks);
+        run_multi<5, 4, 3>("filter step, block of 4 waves, waves 0 and 1 work", dOut, dCoef, blocks);
+        run_multi<5, 4, 15>("filter step, block of 4 waves, all four work", dOut, dCoef, blocks);
+        run_multi<0, 4, 15>("resonator only, block of 4 waves, all four work", dOut, dCoef, blocks);
+        run_multi<0, 1, 1>("resonator only, block of 1 wave", dOut, dCoef, blocks);
     }
     for (int blocks : {256, 2048}) {
         run<0>("resonator only (in = own output)", dOut, dCoef, blocks);

@@ -374,9 +374,10 @@ def main():
                 # the same batch without tracks (every stage interpolates and evaluates exp/cos itself, as in round 1), and with every
                 # utterance's frame list rotated by a random amount -- same lengths, ~24 different timings per sentence in random
                 # order: the lane packing puts equally timed utterances side by side again
-                def timed(b, tracks):
+                def timed(b, tracks, sort=1):
                     x = BatchPlayer(b["sr"], device=device, mode=args.mode, layout=args.layout)
                     x.setOption("tracks", tracks)
+                    x.setOption("sort", sort)
                     x.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
                     x.time(1)
                     ms = float(np.mean(x.time(10)))
@@ -389,6 +390,8 @@ def main():
                 # no wavefront can be packed with equally timed utterances -- a batch of unrelated sentences
                 jit = workloads.jittered(batch)
                 out["jittered_durations"] = dict(timed(jit, 1), tracks_off=timed(jit, 0))
+                # and the benchmarked batch itself without the engine's sort by length and timing: wavefronts of 64 arbitrary neighbours
+                out["unsorted"] = dict(timed(batch, 1, 0), tracks_off=timed(batch, 0, 0))
             if world == 1 and not args.utterances and not args.no_extras:
                 # the other single-GPU configuration (BASELINE configs[1], 4096 steady vowels) and its recipe at 65 536 utterances
                 bp.close()

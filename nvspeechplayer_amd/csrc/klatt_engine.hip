@@ -356,9 +356,9 @@ long long lanepipe_count(const Batch* b)
 {
     if (b->layout == 2) return b->nNoNasal;
     if (b->layout != -1 || b->nNoNasal == 0) return 0;
-    // Its workgroups hold 20 utterances against 64, at 37 ns per sample against 46 for the stage-parallel kernel's
+    // Its workgroups hold 16 utterances against 64, at ~30 ns per sample against 46 for the stage-parallel kernel's
     // slowest stage (MI355X, tools/len_probe.py): it wins while every workgroup of the launch has a CU of its own --
-    // 1.03 against 1.22 ms at 4096 vowels -- and loses beyond (8192 vowels: 1.73 against 1.30 ms).
+    // 0.75 against 1.2 ms at 4096 vowels -- and loses beyond (8192 vowels: two workgroups per CU).
     const long long groups = (b->nNoNasal + kLpUPG - 1) / kLpUPG + (b->nSlots - b->nNoNasal + kLanes - 1) / kLanes;
     return groups <= b->cus ? b->nNoNasal : 0;
 }
@@ -1591,7 +1591,10 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
                 const double* p = reinterpret_cast<const double*>(frames + k);
                 for (int i = 0; i < kNumParams && finite; ++i) finite = std::isfinite(p[i]);
             }
-            eligible[u] = finite ? 1 : 0;     // "hold" targets and overflowing coefficients stay with the untracked kernel
+            // A NaN anywhere ("hold" targets, reference src/utils.h:21) or an infinite parameter keeps an utterance with the untracked kernel.
+            // Finite parameters whose COEFFICIENTS overflow (a huge bandwidth or frequency) are tracked all the same: klatt_tracks evaluates
+            // the same expressions as the kernels' own coefficient code, so the track holds the same inf / NaN the kernel would have computed.
+            eligible[u] = finite ? 1 : 0;
         }
         plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible.data(), b->trackBudgetMB, plan);
         for (long long u = 0; u < nUtterances; ++u)

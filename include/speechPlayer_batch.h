@@ -192,6 +192,28 @@ long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* co
 int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
 	const double* basePitch, double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
 	const unsigned int* noiseSeed);
+/*
+ * Optional text front-end: what the NVDA driver does before the frame producer (reference
+ * nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:189-234), with eSpeak NG loaded at run time (dlopen of libespeak-ng.so.1, or of
+ * $SPEECHPLAYER_ESPEAK_LIB) -- the library links against nothing of it.  PARITY UNPINNED: eSpeak NG is absent from the reference tree
+ * and from this image; only the clause splitting, the replacements and the error path are tested.  Without the library every
+ * function that needs it returns -3 (speechPlayer_text_available: 0) and speechPlayer_lastError() says what to install;
+ * IPA input (speechPlayer_batch_setIpa) never needs it.
+ *   speechPlayer_text_clauses   split text where white space follows one of . ? ! , : ; (:84, :189); per clause its byte range
+ *                               [begin, end) in textUtf8, its type ('.', '!', '?', ',' or 0) and the pause after it in ms (:195-205);
+ *                               returns the number of clauses (fills up to `capacity` of them; any array may be NULL)
+ *   speechPlayer_text_fixups    the four replacements of :214-217 and the strip of :218; returns the bytes needed with the NUL
+ *   speechPlayer_text_toIpa     one clause through espeak_TextToPhonemes (UTF-8 in, mode word 0x36100 + 0x82 as :210) + the fix-ups
+ *   speechPlayer_batch_setText  one utterance per text: its clauses' frame streams one after the other (clause type per clause),
+ *                               then silence of the last clause's pause / speed with a fade of max(10, 10 / speed) ms (:234);
+ *                               espeakVoice NULL = "en"; basePitch[nTexts] may be NULL (100 Hz); -1 bad arguments, -3 no eSpeak
+ */
+int speechPlayer_text_available(void);
+long long speechPlayer_text_clauses(const char* textUtf8, long long* begin, long long* end, char* clauseType, double* endPauseMs, long long capacity);
+long long speechPlayer_text_fixups(const char* ipaUtf8, char* out, long long capacity);
+long long speechPlayer_text_toIpa(const char* textUtf8, const char* espeakVoice, char* out, long long capacity);
+int speechPlayer_batch_setText(speechPlayer_batch_t batch, long long nTexts, const char* const* textUtf8, const char* espeakVoice, double speed,
+	const double* basePitch, double inflection, const char* voiceName, const unsigned int* noiseSeed);
 /* The phoneme table the producer is driven by (the reference's data.py, as numbers): entry `index` of
  * speechPlayer_ipa_phonemeCount() -- its IPA symbol (UTF-8, NUL-terminated, symbolCapacity bytes), its 47 parameter values in
  * speechPlayer_frame_t order, which of them the entry sets (bit k of *fieldMask), and its class bits (1 _isVowel, 2 _isVoiced,
@@ -213,6 +235,7 @@ const char* speechPlayer_lastError(void);
 #define SPEECHPLAYER_ERR_ARGUMENT 1   /* invalid handle, NULL pointer, inconsistent arrays, limit exceeded */
 #define SPEECHPLAYER_ERR_NO_DEVICE 2  /* no HIP device: the engine has no CPU path */
 #define SPEECHPLAYER_ERR_HIP 3        /* a HIP runtime call failed (allocation, copy, launch) */
+#define SPEECHPLAYER_ERR_TEXT_FRONTEND 4   /* the optional text front-end: eSpeak NG is not installed, or one of its calls failed */
 int speechPlayer_lastErrorCode(void);
 
 #ifdef __cplusplus

@@ -41,6 +41,7 @@ EXPORTS = [
     "speechPlayer_lastError", "speechPlayer_lastErrorCode", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany", "speechPlayer_setGlobalOption",
     "speechPlayer_synthesizeManyDevice", "speechPlayer_lastLiveKernelMs", "speechPlayer_lastLiveLaunches",
     "speechPlayer_ipa_frames", "speechPlayer_ipa_pack", "speechPlayer_batch_setIpa",
+    "speechPlayer_text_available", "speechPlayer_text_clauses", "speechPlayer_text_fixups", "speechPlayer_text_toIpa", "speechPlayer_batch_setText",
     "speechPlayer_voiceCount", "speechPlayer_voiceName", "speechPlayer_applyVoiceToFrame",
     "speechPlayer_ipa_phonemeCount", "speechPlayer_ipa_phoneme",
     "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
@@ -212,6 +213,16 @@ def load():
     L.speechPlayer_ipa_frames.argtypes = [ctypes.c_char_p, f64, f64, f64, i32, ctypes.c_char_p, vp, vp, vp, vp, i64]
     L.speechPlayer_ipa_pack.restype = i64
     L.speechPlayer_ipa_pack.argtypes = [i32, i64, vp, f64, vp, f64, ctypes.c_char_p, ctypes.c_char_p, f64, vp, vp, vp, vp, vp, i64]
+    L.speechPlayer_text_available.restype = i32
+    L.speechPlayer_text_available.argtypes = []
+    L.speechPlayer_text_clauses.restype = i64
+    L.speechPlayer_text_clauses.argtypes = [ctypes.c_char_p, vp, vp, vp, vp, i64]
+    L.speechPlayer_text_fixups.restype = i64
+    L.speechPlayer_text_fixups.argtypes = [ctypes.c_char_p, vp, i64]
+    L.speechPlayer_text_toIpa.restype = i64
+    L.speechPlayer_text_toIpa.argtypes = [ctypes.c_char_p, ctypes.c_char_p, vp, i64]
+    L.speechPlayer_batch_setText.restype = i32
+    L.speechPlayer_batch_setText.argtypes = [vp, i64, vp, ctypes.c_char_p, f64, vp, f64, ctypes.c_char_p, vp]
     L.speechPlayer_batch_setIpa.restype = i32
     L.speechPlayer_batch_setIpa.argtypes = [vp, i64, vp, f64, vp, f64, ctypes.c_char_p, ctypes.c_char_p, f64, vp]
     L.speechPlayer_node_create.restype = vp

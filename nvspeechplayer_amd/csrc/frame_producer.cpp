@@ -21,10 +21,15 @@
 // Plain host C++: no HIP here.  Everything is exported through the C-ABI of include/speechPlayer_batch.h.
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
+
+#include <dlfcn.h>
 
 #include "../../include/speechPlayer_batch.h"
 
@@ -597,6 +602,274 @@ int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, cons
     std::vector<unsigned char> nul((size_t)total);
     if (pack_with(p, rate, nTexts, ipaUtf8, basePitch, clauseTypes, trailingSilenceMs, start.data(), frames.data(), mins.data(), fades.data(), nul.data(), total) != total)
         return -1;
+    return speechPlayer_batch_setUtterances(batch, nTexts, start.data(), frames.data(), mins.data(), fades.data(), nullptr, nul.data(), noiseSeed);
+}
+
+}  // extern "C"
+
+// ==========================================================================================
+// Optional text front-end: text -> IPA through eSpeak NG, when that library is installed
+// ==========================================================================================
+// What the NVDA driver does before it reaches the frame producer (reference nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py):
+// split the text into clauses at white space that follows one of . ? ! , : ; (:84, :189), take the clause type and the pause
+// after the last clause from each clause's last character (:195-205), send the clause through espeak_TextToPhonemes with the
+// mode word 0x36100 + 0x82 (:210: IPA in UTF-8, U+0361 as the tie), apply four replacements to what comes back (:214-217) and
+// hand the IPA to ipa.generateFramesAndTiming (:222); after the last clause, silence of that pause (:234).
+// PARITY UNPINNED: eSpeak NG is a third-party library that neither the reference tree nor this image contains; nothing here
+// has been run against it.  The tests cover the splitting (against the reference's regular expression), the replacements and
+// the error when the library is absent -- not the phonemes.
+namespace {
+
+void set_text_error(const char* msg);
+
+bool is_space_at(const unsigned char* p, int* len)
+{
+    // Python's \s on str: ASCII white space and the Unicode spaces
+    const unsigned char c = p[0];
+    if (c == ' ' || (c >= 9 && c <= 13) || (c >= 0x1c && c <= 0x1f)) { *len = 1; return true; }
+    if (c == 0xC2 && (p[1] == 0x85 || p[1] == 0xA0)) { *len = 2; return true; }
+    if (c == 0xE1 && p[1] == 0x9A && p[2] == 0x80) { *len = 3; return true; }
+    if (c == 0xE2 && p[1] == 0x80 && ((p[2] >= 0x80 && p[2] <= 0x8A) || p[2] == 0xA8 || p[2] == 0xA9 || p[2] == 0xAF)) { *len = 3; return true; }
+    if (c == 0xE2 && p[1] == 0x81 && p[2] == 0x9F) { *len = 3; return true; }
+    if (c == 0xE3 && p[1] == 0x80 && p[2] == 0x80) { *len = 3; return true; }
+    return false;
+}
+
+struct Clause { size_t begin, end; char type; double endPauseMs; };
+
+// reference __init__.py:84 (re_textPause = (?<=[.?!,:;])\s), :189-205
+void split_clauses(const char* text, std::vector<Clause>& out)
+{
+    out.clear();
+    const unsigned char* t = reinterpret_cast<const unsigned char*>(text);
+    const size_t n = strlen(text);
+    size_t start = 0;
+    auto close = [&](size_t from, size_t to) {
+        int l;
+        while (from < to && is_space_at(t + from, &l)) from += l;      // chunk.strip()
+        for (;;) {
+            size_t k = to;
+            while (k > from && (t[k - 1] & 0xC0) == 0x80) --k;         // the start of the last code point
+            if (k > from && is_space_at(t + k - 1, &l) && k - 1 + l == to) to = k - 1; else break;
+        }
+        if (from >= to) return;
+        Clause c; c.begin = from; c.end = to;
+        const char last = (char)t[to - 1];
+        if (last == '.' || last == '!' || last == '?') { c.type = last; c.endPauseMs = 150.0; }
+        else if (last == ',') { c.type = ','; c.endPauseMs = 120.0; }
+        else { c.type = 0; c.endPauseMs = 100.0; }
+        out.push_back(c);
+    };
+    size_t i = 0;
+    while (i < n) {
+        int l;
+        if (i > 0 && is_space_at(t + i, &l) && strchr(".?!,:;", (char)t[i - 1]) && t[i - 1] < 0x80) {
+            close(start, i);
+            start = i + l;
+            i += l;
+        } else ++i;
+    }
+    close(start, n);
+}
+
+// reference __init__.py:214-218
+std::string ipa_fixups(const std::string& in)
+{
+    static const char* const pairs[4][2] = {
+        {"\xC9\x99\xCD\xA1l", "\xCA\x8A\xCD\xA1l"},                     // ə͡l -> ʊ͡l
+        {"a\xCD\xA1\xC9\xAA", "\xC9\x91\xCD\xA1\xC9\xAA"},           // a͡ɪ -> ɑ͡ɪ
+        {"e\xCD\xA1\xC9\xAA", "e\xCD\xA1i"},                             // e͡ɪ -> e͡i
+        {"\xC9\x99\xCD\xA1\xCA\x8A", "o\xCD\xA1u"},                    // ə͡ʊ -> o͡u
+    };
+    std::string s = in;
+    for (const auto& p : pairs) {
+        const std::string from = p[0], to = p[1];
+        for (size_t at = 0; (at = s.find(from, at)) != std::string::npos; at += to.size()) s.replace(at, from.size(), to);
+    }
+    size_t a = 0, b = s.size();
+    int l;
+    while (a < b && is_space_at(reinterpret_cast<const unsigned char*>(s.c_str()) + a, &l)) a += l;
+    while (b > a && (s[b - 1] == ' ' || (s[b - 1] >= 9 && s[b - 1] <= 13))) --b;
+    return s.substr(a, b - a);
+}
+
+// eSpeak NG's C interface (speak_lib.h, as published): only what TextToPhonemes needs
+struct Espeak {
+    void* lib = nullptr;
+    int (*Initialize)(int output, int buflength, const char* path, int options) = nullptr;
+    int (*SetVoiceByName)(const char* name) = nullptr;
+    const char* (*TextToPhonemes)(const void** textptr, int textmode, int phonememode) = nullptr;
+    std::string voice;
+    std::string why;            // why it is not available
+    bool tried = false;
+};
+std::mutex g_espeakMutex;       // eSpeak keeps global state: one caller at a time
+Espeak g_espeak;
+
+bool espeak_ready()             // g_espeakMutex held
+{
+    Espeak& e = g_espeak;
+    if (e.tried) return e.lib != nullptr;
+    e.tried = true;
+    const char* named = getenv("SPEECHPLAYER_ESPEAK_LIB");
+    const char* names[] = {named, "libespeak-ng.so.1", "libespeak-ng.so", "libespeak.so.1"};
+    std::string tried;
+    for (const char* nm : names) {
+        if (!nm || !*nm) continue;
+        e.lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (e.lib) break;
+        tried += tried.empty() ? "" : ", "; tried += nm;
+    }
+    if (!e.lib) {
+        e.why = "the text front-end needs eSpeak NG, and none of " + tried + " could be loaded (install libespeak-ng1, or point SPEECHPLAYER_ESPEAK_LIB at the library); "
+                "IPA input (speechPlayer_batch_setIpa) needs no such library";
+        return false;
+    }
+    e.Initialize = reinterpret_cast<int (*)(int, int, const char*, int)>(dlsym(e.lib, "espeak_Initialize"));
+    e.SetVoiceByName = reinterpret_cast<int (*)(const char*)>(dlsym(e.lib, "espeak_SetVoiceByName"));
+    e.TextToPhonemes = reinterpret_cast<const char* (*)(const void**, int, int)>(dlsym(e.lib, "espeak_TextToPhonemes"));
+    if (!e.Initialize || !e.SetVoiceByName || !e.TextToPhonemes) {
+        e.why = "the eSpeak library that was loaded lacks espeak_Initialize / espeak_SetVoiceByName / espeak_TextToPhonemes";
+        dlclose(e.lib); e.lib = nullptr;
+        return false;
+    }
+    // AUDIO_OUTPUT_RETRIEVAL (1): no audio device is opened; espeakINITIALIZE_DONT_EXIT (0x8000): report, do not exit()
+    if (e.Initialize(1, 0, nullptr, 0x8000) < 0) {
+        e.why = "espeak_Initialize failed (is espeak-ng-data installed?)";
+        dlclose(e.lib); e.lib = nullptr;
+        return false;
+    }
+    return true;
+}
+
+// one clause of text -> IPA (reference __init__.py:206-218); false with the reason in g_espeak.why
+bool clause_to_ipa(const char* text, size_t len, const char* voice, std::string& ipa)
+{
+    Espeak& e = g_espeak;
+    if (!espeak_ready()) return false;
+    const std::string v = (voice && *voice) ? voice : "en";
+    if (v != e.voice) {
+        if (e.SetVoiceByName(v.c_str()) != 0) { e.why = "espeak_SetVoiceByName(" + v + ") failed"; set_text_error(e.why.c_str()); return false; }
+        e.voice = v;
+    }
+    const std::string chunk(text, len);
+    const void* ptr = chunk.c_str();
+    std::string got;
+    while (ptr) {
+        const char* ph = e.TextToPhonemes(&ptr, 1 /* espeakCHARS_UTF8 */, 0x36100 + 0x82);
+        if (!ph) continue;
+        got += ph;
+    }
+    ipa = ipa_fixups(got);
+    return true;
+}
+
+}  // namespace
+
+extern "C" {
+
+void speechPlayer_internal_setError(int code, const char* message);      // klatt_engine.hip
+
+}
+
+namespace {
+void set_text_error(const char* msg) { speechPlayer_internal_setError(SPEECHPLAYER_ERR_TEXT_FRONTEND, msg); }
+}
+
+extern "C" {
+
+int speechPlayer_text_available(void)
+{
+    std::lock_guard<std::mutex> g(g_espeakMutex);
+    if (espeak_ready()) return 1;
+    set_text_error(g_espeak.why.c_str());
+    return 0;
+}
+
+long long speechPlayer_text_fixups(const char* ipaUtf8, char* out, long long capacity)
+{
+    if (!ipaUtf8) return -1;
+    const std::string s = ipa_fixups(ipaUtf8);
+    if (out && capacity > (long long)s.size()) memcpy(out, s.c_str(), s.size() + 1);
+    return (long long)s.size() + 1;
+}
+
+long long speechPlayer_text_clauses(const char* textUtf8, long long* begin, long long* end, char* clauseType, double* endPauseMs, long long capacity)
+{
+    if (!textUtf8) return -1;
+    std::vector<Clause> cl;
+    split_clauses(textUtf8, cl);
+    for (size_t i = 0; i < cl.size() && (long long)i < capacity; ++i) {
+        if (begin) begin[i] = (long long)cl[i].begin;
+        if (end) end[i] = (long long)cl[i].end;
+        if (clauseType) clauseType[i] = cl[i].type;
+        if (endPauseMs) endPauseMs[i] = cl[i].endPauseMs;
+    }
+    return (long long)cl.size();
+}
+
+long long speechPlayer_text_toIpa(const char* textUtf8, const char* espeakVoice, char* out, long long capacity)
+{
+    if (!textUtf8) return -1;
+    std::lock_guard<std::mutex> g(g_espeakMutex);
+    std::string ipa;
+    if (!clause_to_ipa(textUtf8, strlen(textUtf8), espeakVoice, ipa)) { set_text_error(g_espeak.why.c_str()); return -3; }
+    if (out && capacity > (long long)ipa.size()) memcpy(out, ipa.c_str(), ipa.size() + 1);
+    return (long long)ipa.size() + 1;
+}
+
+int speechPlayer_batch_setText(speechPlayer_batch_t batch, long long nTexts, const char* const* textUtf8, const char* espeakVoice, double speed,
+                               const double* basePitch, double inflection, const char* voiceName, const unsigned int* noiseSeed)
+{
+    const int rate = speechPlayer_batch_sampleRate(batch);
+    if (rate <= 0 || nTexts < 0 || (nTexts > 0 && !textUtf8) || !(speed > 0.0)) return -1;
+    const VoiceRow* voice = find_voice(voiceName);
+    if (voiceName && *voiceName && !voice) return -1;
+    Producer p(speed, inflection, voice);
+    std::vector<long long> start((size_t)nTexts + 1, 0);
+    std::vector<speechPlayer_frame_t> frames;
+    std::vector<unsigned int> mins, fades;
+    std::vector<unsigned char> nul;
+    std::vector<Clause> cl;
+    std::unordered_map<std::string, std::string> ipaOf;       // clause text -> IPA: a batch repeats its sentences
+    {
+        std::lock_guard<std::mutex> g(g_espeakMutex);
+        for (long long i = 0; i < nTexts; ++i) {
+            start[(size_t)i] = (long long)nul.size();
+            if (!textUtf8[i]) return -1;
+            split_clauses(textUtf8[i], cl);
+            double endPause = 20.0;                           // reference __init__.py:182
+            for (const Clause& c : cl) {
+                endPause = c.endPauseMs;
+                const std::string key(textUtf8[i] + c.begin, c.end - c.begin);
+                auto it = ipaOf.find(key);
+                if (it == ipaOf.end()) {
+                    std::string ipa;
+                    if (!clause_to_ipa(key.c_str(), key.size(), espeakVoice, ipa)) { set_text_error(g_espeak.why.c_str()); return -3; }
+                    it = ipaOf.emplace(key, ipa).first;
+                }
+                if (it->second.empty()) continue;             // :219
+                const Stream& s = p.stream(it->second.c_str(), (int)(unsigned char)c.type, basePitch ? basePitch[i] : 100.0);
+                const size_t n = s.size(), at = nul.size();
+                frames.resize(at + n); mins.resize(at + n); fades.resize(at + n); nul.resize(at + n);
+                if (n) {
+                    memcpy(&frames[at], s.frames.data(), n * sizeof(speechPlayer_frame_t));
+                    memcpy(&nul[at], s.isNull.data(), n);
+                }
+                for (size_t k = 0; k < n; ++k) {
+                    mins[at + k] = ms_to_samples(s.durationMs[k], rate);
+                    fades[at + k] = ms_to_samples(s.fadeMs[k], rate);
+                }
+            }
+            // silence after the last clause (:234): queueFrame(None, endPause / rate, max(10, 10 / rate))
+            speechPlayer_frame_t zero;
+            memset(&zero, 0, sizeof zero);
+            frames.push_back(zero); nul.push_back(1);
+            mins.push_back(ms_to_samples(endPause / speed, rate));
+            fades.push_back(ms_to_samples(std::max(10.0, 10.0 / speed), rate));
+        }
+        start[(size_t)nTexts] = (long long)nul.size();
+    }
     return speechPlayer_batch_setUtterances(batch, nTexts, start.data(), frames.data(), mins.data(), fades.data(), nullptr, nul.data(), noiseSeed);
 }
 

@@ -1206,6 +1206,13 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
 extern "C" {
 
 const char* speechPlayer_lastError(void) { return g_lastError.c_str(); }
+// for the library's other translation units (frame_producer.cpp); not in the public headers
+void speechPlayer_internal_setError(int code, const char* message)
+{
+    g_lastErrorCode = 0;
+    set_error_code(code);
+    set_error("%s", message ? message : "");
+}
 int speechPlayer_lastErrorCode(void) { return g_lastErrorCode; }
 
 speechPlayer_handle_t speechPlayer_initialize(int sampleRate)

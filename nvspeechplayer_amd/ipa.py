@@ -164,3 +164,50 @@ def frames_for_batch(texts, sampleRate=22050, speed=1, basePitch=100, inflection
     got = L.speechPlayer_ipa_pack(*head, start.ctypes.data, frames.ctypes.data, m.ctypes.data, f.ctypes.data, nul.ctypes.data, total)
     assert got == total
     return dict(frame_start=start, frames=frames, min=m, fade=f, isnull=nul)
+
+
+# ---- the optional text front-end (include/speechPlayer_batch.h: speechPlayer_text_*; eSpeak NG loaded at run time) ----
+def textAvailable():
+    """True when eSpeak NG could be loaded; otherwise False, and _native.last_error() says what is missing."""
+    return bool(_native.load().speechPlayer_text_available())
+
+
+def splitClauses(text):
+    """The NVDA driver's split of a text into clauses (reference __init__.py:84, :189-205):
+    -> [(clause text, clause type or None, pause after it in ms)]."""
+    import ctypes
+    L = _native.load()
+    b = text.encode("utf8")
+    n = L.speechPlayer_text_clauses(b, None, None, None, None, 0)
+    if n < 0:
+        raise ValueError("bad text")
+    beg = (ctypes.c_longlong * max(n, 1))(); end = (ctypes.c_longlong * max(n, 1))()
+    typ = (ctypes.c_char * max(n, 1))(); pause = (ctypes.c_double * max(n, 1))()
+    L.speechPlayer_text_clauses(b, beg, end, typ, pause, n)
+    return [(b[beg[i]:end[i]].decode("utf8"), (typ[i].decode("latin1") if typ[i] != b"\0" else None), pause[i]) for i in range(n)]
+
+
+def fixups(ipaText):
+    """The four replacements and the strip the driver applies to eSpeak's IPA (reference __init__.py:214-218)."""
+    import ctypes
+    L = _native.load()
+    b = ipaText.encode("utf8")
+    need = L.speechPlayer_text_fixups(b, None, 0)
+    buf = ctypes.create_string_buffer(int(need))
+    L.speechPlayer_text_fixups(b, buf, need)
+    return buf.value.decode("utf8")
+
+
+def textToIpa(text, espeakVoice="en"):
+    """One clause of text -> IPA through eSpeak NG (mode word 0x36100 + 0x82, reference __init__.py:210) + fixups.
+    RuntimeError when the library is not installed."""
+    import ctypes
+    L = _native.load()
+    b = text.encode("utf8")
+    v = espeakVoice.encode("utf8") if espeakVoice else None
+    need = L.speechPlayer_text_toIpa(b, v, None, 0)
+    if need < 0:
+        raise RuntimeError("speechPlayer_text_toIpa failed: %s" % _native.last_error())
+    buf = ctypes.create_string_buffer(int(need))
+    L.speechPlayer_text_toIpa(b, v, buf, need)
+    return buf.value.decode("utf8")

@@ -260,6 +260,21 @@ class BatchPlayer(object):
                                                         None if sd is None else sd.ctypes.data))
         self.nUtterances = n
 
+    def setText(self, texts, speed=1, basePitch=100, inflection=0.5, noiseSeed=None, voice=None, espeakVoice="en"):
+        """Plain text in (speechPlayer_batch_setText): each text becomes one utterance the way the NVDA driver speaks it -- clauses
+        through eSpeak NG's text-to-IPA, the frame producer per clause, the pause after the last clause.  Needs libespeak-ng at
+        run time (nvspeechplayer_amd.ipa.textAvailable()); raises RuntimeError with the reason when it is not there."""
+        import ctypes
+        n = len(texts)
+        enc = [t.encode("utf8") for t in texts]
+        ptrs = (ctypes.c_char_p * max(n, 1))(*enc)
+        pitch = np.ascontiguousarray(np.broadcast_to(np.asarray(basePitch, dtype=np.float64), (n,)))
+        sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
+        self._check(self._dll.speechPlayer_batch_setText(self._h, n, ptrs, None if not espeakVoice else espeakVoice.encode("utf8"), float(speed),
+                                                         pitch.ctypes.data, float(inflection), None if not voice else voice.encode("utf8"),
+                                                         None if sd is None else sd.ctypes.data))
+        self.nUtterances = n
+
     @property
     def totalSamples(self):
         return self._dll.speechPlayer_batch_totalSamples(self._h)

@@ -1223,3 +1223,20 @@ def test_planning_threads_change_nothing(monkeypatch):
         got[threads] = (bp.digest(), info["tracked_utterances"], info["tracks"], info["track_mbytes"])
         bp.close()
     assert got["1"] == got["8"] and got["1"][1] > 0
+
+
+def test_text_input_without_espeak_fails_loudly():
+    """speechPlayer_batch_setText needs eSpeak NG at run time; where it is absent the call fails with code 4 and a message that
+    names the library, and the batch stays usable through the IPA path."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native, ipa
+    if ipa.textAvailable():
+        pytest.skip("eSpeak NG is installed here")
+    bp = eng.BatchPlayer(22050)
+    with pytest.raises(RuntimeError) as e:
+        bp.setText(["Hello, world."])
+    assert "libespeak-ng" in str(e.value) and _native.last_error_code() == 4
+    bp.setIpa(["həlˈoʊ"], clauseType=".")
+    bp.synthesize()
+    assert bp.totalSamples > 0
+    bp.close()

@@ -10,6 +10,7 @@
 #include <random>
 #include "speechPlayer_batch.h"
 extern "C" int speechPlayer_batch_sampleRate(speechPlayer_batch_t) { return 22050; }
+extern "C" void speechPlayer_internal_setError(int, const char*) {}
 extern "C" int speechPlayer_batch_setUtterances(speechPlayer_batch_t, long long, const long long*, const speechPlayer_frame_t*, const unsigned int*, const unsigned int*, const int*, const unsigned char*, const unsigned int*) { return 0; }
 int main() {
     std::mt19937 rng(1);
@@ -30,6 +31,20 @@ int main() {
             if (m != n && !(v && !strcmp(v, "x"))) { printf("mismatch\n"); return 1; }
             total += n;
         }
+    }
+    // the text front-end's own string handling (no eSpeak here): clause splitting and the replacements on random bytes
+    for (int iter = 0; iter < 20000; ++iter) {
+        const char* bits[] = {"a", " ", ".", ",", "?", "!", ":", ";", "\t", "\n", "\xc2\xa0", "\xe2\x80\x89", "\xe3\x80\x80", "\xc9\x99", "\xcd\xa1", "l", "\xc9\xaa", "e", "\xca\x8a", "\xff", "\xe2", "\xc2"};
+        std::string s;
+        int len = rng() % 40;
+        for (int i = 0; i < len; ++i) s += bits[rng() % (sizeof bits / sizeof *bits)];
+        long long b[64], e[64]; char ty[64]; double pa[64];
+        long long nc = speechPlayer_text_clauses(s.c_str(), b, e, ty, pa, 64);
+        for (long long i = 0; i < nc && i < 64; ++i)
+            if (b[i] < 0 || e[i] > (long long)s.size() || b[i] >= e[i]) { printf("bad clause range\n"); return 1; }
+        std::vector<char> out(3 * s.size() + 8);
+        long long need = speechPlayer_text_fixups(s.c_str(), out.data(), (long long)out.size());
+        if (need < 1 || need > (long long)out.size()) { printf("bad fixups size\n"); return 1; }
     }
     // batch packer with duplicates and empties
     std::vector<const char*> texts;

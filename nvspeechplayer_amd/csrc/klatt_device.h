@@ -145,8 +145,14 @@ struct TrackJob {            // one distinct track, read by klatt_tracks
 __host__ __device__ inline uint32_t track_slots(uint32_t mask) { return (uint32_t)__builtin_popcount(mask) + (mask & 1u); }
 constexpr int kTrackStages = 4;
 // the kinds of a stage's part, and their entries (N0 takes two)
-__host__ __device__ constexpr uint32_t track_stage_kinds(int s) { return s == 0 ? 0xF00000u : s == 1 ? 0x00401Fu : s == 2 ? 0x01B0E0u : 0x0E0F00u; }
-__host__ __device__ constexpr uint32_t track_stage_entries(int s) { return s == 0 ? 4u : 7u; }
+#ifndef KLATT_R3_IN_S1
+#define KLATT_R3_IN_S1 1      // the cascade's r3 runs in the second stage (with N0, NP, r6..r4), not in the final one: the final stage was the slowest by 20 %
+#endif
+__host__ __device__ constexpr uint32_t track_stage_kinds(int s)
+{
+    return s == 0 ? 0xF00000u : s == 1 ? (KLATT_R3_IN_S1 ? 0x00403Fu : 0x00401Fu) : s == 2 ? (KLATT_R3_IN_S1 ? 0x01B0C0u : 0x01B0E0u) : 0x0E0F00u;
+}
+__host__ __device__ constexpr uint32_t track_stage_entries(int s) { return s == 0 ? 4u : s == 1 ? (KLATT_R3_IN_S1 ? 8u : 7u) : s == 2 ? (KLATT_R3_IN_S1 ? 6u : 7u) : 7u; }
 // entries of stage s's part that move: per row of its matrix
 __host__ __device__ inline uint32_t track_stage_slots(uint32_t mask, int s) { return (uint32_t)__builtin_popcount(mask & track_stage_kinds(s)) + (s == 1 ? (mask & 1u) : 0u); }
 // first entry of stage s's part in a track of a fade of F samples

@@ -1369,10 +1369,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             streamState[220] = (double)lastIndex; streamState[221] = (double)noiseSt;
         }
     } else if (FLAT && stage == 1) {
-        // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 =================
+        // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 (and r3: KLATT_R3_IN_S1) =================
         if constexpr (FLAT) {
+#if KLATT_R3_IN_S1
+            using FD = FlatDesc<1, 6, 1, true, 0x63u>;                 // usually N0, NP, r3 and caNP, when anything
+            constexpr int GE[7] = {0, 1, 2, 3, 4, 5, 14};        // N0, NP, r6, r5, r4, r3 | cur: caNP
+#else
             using FD = FlatDesc<1, 5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
             constexpr int GE[6] = {0, 1, 2, 3, 4, 14};           // N0, NP, r6, r5, r4 | cur: caNP
+#endif
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
             flat2_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
@@ -1384,7 +1389,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     const ResPre<sig_t> q3 = res_pre<MODE, ((SET >> 3) & 1u) != 0u>(f.ra[3], f.rb[3], f.rc[3], f.z1[3], f.z2[3]);
                     const ResPre<sig_t> q4 = res_pre<MODE, ((SET >> 4) & 1u) != 0u>(f.ra[4], f.rb[4], f.rc[4], f.z1[4], f.z2[4]);
                     const sig_t caNP = f.cur[0];
+#if KLATT_R3_IN_S1
+                    const ResPre<sig_t> q5 = res_pre<MODE, ((SET >> 5) & 1u) != 0u>(f.ra[5], f.rb[5], f.rc[5], f.z1[5], f.z2[5]);
+                    mid(q0, q1, q2, q3, q4, q5, caNP);
+#else
                     mid(q0, q1, q2, q3, q4, caNP);
+#endif
                     const sig_t x = PIPE(pipeX, c, i);
                     sig_t zin = f.z1[0];
                     const sig_t n0 = res_post<MODE>(q0, x, zin, f.z2[0]);       // the anti-resonator remembers its INPUT (:133)
@@ -1394,6 +1404,9 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     o = res_post<MODE>(q2, o, f.z1[2], f.z2[2]);
                     o = res_post<MODE>(q3, o, f.z1[3], f.z2[3]);
                     o = res_post<MODE>(q4, o, f.z1[4], f.z2[4]);
+#if KLATT_R3_IN_S1
+                    o = res_post<MODE>(q5, o, f.z1[5], f.z2[5]);
+#endif
                     PIPE(pipeO, c, i) = o;
                 },
                 noChunk);
@@ -1436,8 +1449,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (FLAT && (KLATT_FLAT_EXHAUSTIVE || stage == 2)) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
         if constexpr (FLAT) {
+#if KLATT_R3_IN_S1
+            constexpr int GE[6] = {6, 7, 12, 13, 15, 16};         // r2, r1, parallel 5, 6 | cur: pa5, pa6, parallelBypass, outputGain
+            using FD = FlatDesc<2, 4, 2, false, 0x3Bu>;                // usually c2, c1, parallel 6 and the gains
+            constexpr int RS = 0;                                      // the cascade's r3 ran in the stage before
+#else
             constexpr int GE[7] = {5, 6, 7, 12, 13, 15, 16};      // cur: pa5, pa6, parallelBypass, outputGain
             using FD = FlatDesc<2, 5, 2, false, 0x77u>;                // usually c3, c2, c1, parallel 6 and the gains
+            constexpr int RS = 1;
+#endif
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
             int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
@@ -1473,22 +1493,23 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             flat2_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
                     constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
-                    const ResPre<sig_t> q0 = res_pre<MODE, ((SET >> 0) & 1u) != 0u>(f.ra[0], f.rb[0], f.rc[0], f.z1[0], f.z2[0]);
-                    const ResPre<sig_t> q1 = res_pre<MODE, ((SET >> 1) & 1u) != 0u>(f.ra[1], f.rb[1], f.rc[1], f.z1[1], f.z2[1]);
-                    const ResPre<sig_t> q2 = res_pre<MODE, ((SET >> 2) & 1u) != 0u>(f.ra[2], f.rb[2], f.rc[2], f.z1[2], f.z2[2]);
-                    const ResPre<sig_t> q3 = res_pre<MODE, ((SET >> 3) & 1u) != 0u>(f.ra[3], f.rb[3], f.rc[3], f.z1[3], f.z2[3]);
-                    const ResPre<sig_t> q4 = res_pre<MODE, ((SET >> 4) & 1u) != 0u>(f.ra[4], f.rb[4], f.rc[4], f.z1[4], f.z2[4]);
+                    // resonators of the stage: [r3 when RS] r2, r1, parallel 5, parallel 6
+                    constexpr int NR = 4 + RS;
+                    ResPre<sig_t> q[5];
+#pragma unroll
+                    for (int r = 0; r < NR; ++r) q[r] = ((SET >> r) & 1u) ? res_pre<MODE, true>(f.ra[r], f.rb[r], f.rc[r], f.z1[r], f.z2[r])
+                                                                          : res_pre<MODE, false>(f.ra[r], f.rb[r], f.rc[r], f.z1[r], f.z2[r]);
                     const sig_t pa5 = f.cur[0], pa6 = f.cur[1], bypass = f.cur[2], outGain = f.cur[3];
-                    mid(q0, q1, q2, q3, q4, pa5, pa6, bypass, outGain);
+                    if constexpr (RS) mid(q[0], q[1], q[2], q[3], q[4], pa5, pa6, bypass, outGain);
+                    else mid(q[0], q[1], q[2], q[3], pa5, pa6, bypass, outGain);
                     sig_t o = PIPE(pipeO, c, i);
                     const sig_t y = PIPE(pipeA, c, i);
-                    o = res_post<MODE>(q0, o, f.z1[0], f.z2[0]);
-                    o = res_post<MODE>(q1, o, f.z1[1], f.z2[1]);
-                    o = res_post<MODE>(q2, o, f.z1[2], f.z2[2]);
+#pragma unroll
+                    for (int r = 0; r < 2 + RS; ++r) o = res_post<MODE>(q[r], o, f.z1[r], f.z2[r]);
                     sig_t par = PIPE(pipeB, c, i);
-                    sig_t w = res_post<MODE>(q3, y, f.z1[3], f.z2[3]);
+                    sig_t w = res_post<MODE>(q[2 + RS], y, f.z1[2 + RS], f.z2[2 + RS]);
                     par += (w - y) * pa5;
-                    w = res_post<MODE>(q4, y, f.z1[4], f.z2[4]);
+                    w = res_post<MODE>(q[3 + RS], y, f.z1[3 + RS], f.z2[3 + RS]);
                     par += (w - y) * pa6;
                     par = fade_value(par, y, bypass);
                     const sig_t mix = o + par;

@@ -145,16 +145,25 @@ struct TrackJob {            // one distinct track, read by klatt_tracks
 __host__ __device__ inline uint32_t track_slots(uint32_t mask) { return (uint32_t)__builtin_popcount(mask) + (mask & 1u); }
 constexpr int kTrackStages = 4;
 // the kinds of a stage's part, and their entries (N0 takes two)
-#ifndef KLATT_R3_IN_S1
-#define KLATT_R3_IN_S1 1      // the cascade's r3 runs in the second stage (with N0, NP, r6..r4), not in the final one: the final stage was the slowest by 20 %
+// Which stage runs what (the flat stages of klatt_systolic.h; a stage's part of a track holds its kinds):
+//   1: S0 source | S1 N0, NP, r6..r3 | final r2, r1, parallel 5, 6, mix, PCM | S3 frication, parallel 1..4
+//   2: S0 source, N0, NP | S1 r6..r1 | final parallel 5, 6, mix, PCM | S3 as before    (the final stage's mix / clip / PCM tail is as
+//      long as four resonators, the source stage was the lightest by a third: profiles/r3_stage_balance.txt)
+#ifndef KLATT_FLAT_LAYOUT
+#define KLATT_FLAT_LAYOUT 2
 #endif
 __host__ __device__ constexpr uint32_t track_stage_kinds(int s)
 {
-    return s == 0 ? 0xF00000u : s == 1 ? (KLATT_R3_IN_S1 ? 0x00403Fu : 0x00401Fu) : s == 2 ? (KLATT_R3_IN_S1 ? 0x01B0C0u : 0x01B0E0u) : 0x0E0F00u;
+    return KLATT_FLAT_LAYOUT == 2 ? (s == 0 ? 0xF04003u : s == 1 ? 0x0000FCu : s == 2 ? 0x01B000u : 0x0E0F00u)
+                                  : (s == 0 ? 0xF00000u : s == 1 ? 0x00403Fu : s == 2 ? 0x01B0C0u : 0x0E0F00u);
 }
-__host__ __device__ constexpr uint32_t track_stage_entries(int s) { return s == 0 ? 4u : s == 1 ? (KLATT_R3_IN_S1 ? 8u : 7u) : s == 2 ? (KLATT_R3_IN_S1 ? 6u : 7u) : 7u; }
+__host__ __device__ constexpr uint32_t track_stage_entries(int s)
+{
+    return KLATT_FLAT_LAYOUT == 2 ? (s == 0 ? 8u : s == 1 ? 6u : s == 2 ? 4u : 7u) : (s == 0 ? 4u : s == 1 ? 8u : s == 2 ? 6u : 7u);
+}
+constexpr int kTrackAntiStage = KLATT_FLAT_LAYOUT == 2 ? 0 : 1;      // the stage of N0, whose kind takes two entries
 // entries of stage s's part that move: per row of its matrix
-__host__ __device__ inline uint32_t track_stage_slots(uint32_t mask, int s) { return (uint32_t)__builtin_popcount(mask & track_stage_kinds(s)) + (s == 1 ? (mask & 1u) : 0u); }
+__host__ __device__ inline uint32_t track_stage_slots(uint32_t mask, int s) { return (uint32_t)__builtin_popcount(mask & track_stage_kinds(s)) + (s == kTrackAntiStage ? (mask & 1u) : 0u); }
 // first entry of stage s's part in a track of a fade of F samples
 __host__ __device__ inline uint32_t track_part(uint32_t mask, uint32_t F, int s)
 {

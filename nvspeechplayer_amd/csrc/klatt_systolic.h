@@ -1085,8 +1085,21 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // steady (glide).  What a dequeue reads (durations, index mark, the frame's two pitch values, the FlatRef) was loaded when the
         // previous frame was dequeued.
         if constexpr (FLAT) {
+#if KLATT_FLAT_LAYOUT == 2
+            // the source AND the head of the cascade: N0 (anti), NP mixed in by caNP (reference src/speechWaveGenerator.cpp:149-152)
+            using FD = FlatDesc<0, 2, 5, true, 0, 0, double>;
+            constexpr int GE[7] = {0, 1, 14, 20, 21, 22, 23};     // N0, NP | cur: caNP, - | vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain
+            constexpr int CB = 2;                                 // f.cur[CB + k]: the source's parameters
+            constexpr uint32_t kUsualS0 = 0x67u, kAllS0 = 0x7Fu, kVibBit = 8u;      // usually: N0, NP, caNP, the amplitudes and the gain
+            constexpr bool kHead = true;
+#else
             using FD = FlatDesc<0, 0, 4, false, 0, 0, double>;
             constexpr int GE[4] = {20, 21, 22, 23};     // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain
+            constexpr int CB = 0;
+            constexpr uint32_t kUsualS0 = 0xCu, kAllS0 = 0xFu, kVibBit = 1u;
+            constexpr bool kHead = false;
+#endif
+            bool staleNP = false;       // NP's `a` in its register predates the last rows (mixed chunks derive it on the fly)
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
             PitchState ps;
@@ -1098,15 +1111,16 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             bool oldNull = true, newNull = false;
             SourceRef nextSrc{0.0, 0.0, 1.0, -1, 0u};     // frame `f.next`, loaded ahead like f.nextRef
             if (live && d.nFrames > 0u) nextSrc = X.mySrc[0];
-            auto source = [&](bool waveVib, const auto& mid) __attribute__((always_inline)) -> double {
+            auto source = [&](bool waveVib, auto setTag, const auto& mid) __attribute__((always_inline)) -> double {
+                constexpr uint32_t SET = decltype(setTag)::value;
                 double vib = 1.0;
                 if (waveVib) {
-                    const double vs = f.cur[1];
+                    const double vs = f.cur[CB + 1];
                     const double adv = frac_toward_zero(div_by(vs, A.sampleRateF, A.invSampleRate) + vibPhase);
                     vibPhase = (vs != 0.0) ? adv : vibPhase;
-                    vib = (sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[0]) + 1.0;
+                    vib = (sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[CB + 0]) + 1.0;
                 }
-                const double turbGain = f.cur[2], openQ = f.cur[3], voiceAmp = f.cur[4], aspAmp = f.cur[5], preGain = f.cur[6];
+                const double turbGain = f.cur[CB + 2], openQ = f.cur[CB + 3], voiceAmp = f.cur[CB + 4], aspAmp = f.cur[CB + 5], preGain = f.cur[CB + 6];
                 pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
                 double voice = (pitchPhase * 2.0) - 1.0;
                 aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
@@ -1119,10 +1133,22 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 asp *= aspAmp;
                 const double src = asp + voice;
                 const double out = (src * preGain) * 0.5;
-                mid(out);            // the next sample's rows (flat2_loop): every parameter has been read; they land while the next sample's pitch, phase and noise are computed
-                return out;
+                if constexpr (kHead) {
+                    const ResPre<double> q0 = res_pre<MODE, false>(f.ra[0], f.rb[0], f.rc[0], f.z1[0], f.z2[0]);      // N0's a comes from the track
+                    const ResPre<double> q1 = res_pre<MODE, ((SET >> 1) & 1u) != 0u>(f.ra[1], f.rb[1], f.rc[1], f.z1[1], f.z2[1]);
+                    const double caNP = f.cur[0];
+                    mid(out, q0, q1, caNP);      // the next sample's rows (flat2_loop): every parameter has been read
+                    double zin = f.z1[0];
+                    const double n0 = res_post<MODE>(q0, out, zin, f.z2[0]);       // the anti-resonator remembers its INPUT (:133)
+                    f.z1[0] = out;
+                    const double np = res_post<MODE>(q1, n0, f.z1[1], f.z2[1]);
+                    return fade_value(out, np, caNP);
+                } else {
+                    mid(out);            // the next sample's rows (flat2_loop): every parameter has been read; they land while the next sample's pitch, phase and noise are computed
+                    return out;
+                }
             };
-            auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase; };
+            auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[CB + 0] != 0.0 || f.cur[CB + 1] != 0.0 || vibPhase != vibPhase; };
             const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double2*>(A.track), 0, (int)A.trackBytes, 0x00020000);
 #ifdef KLATT_STAMPS
             Stamps st;
@@ -1146,10 +1172,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                         run = run < room ? run : room;
                         run = run < 1u ? 1u : run;
                         int cc = c;
+                        if (kHead && staleNP) { f.ra[1] = 1.0 - f.rb[1] - f.rc[1]; staleNP = false; }
                         for (uint32_t q = 0; q < run; ++q) {
                             if (f.live) {
 #pragma unroll
-                                for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; PIPE(pipeX, cc, i) = source(false, NoMid{}); }
+                                for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; PIPE(pipeX, cc, i) = source(false, std::integral_constant<uint32_t, 0u>{}, NoMid{}); }
                                 ps.old0 = ps.cur0;
                             }
                             if (q + 1 < run) { STAMP_WORKED(); __syncthreads(); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; }
@@ -1161,7 +1188,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                         constexpr uint32_t SET = decltype(setTag)::value;
                         constexpr bool ALLFADE = decltype(allFadeTag)::value;      // every live lane's pitch fades through the whole chunk, nobody dequeues: no selects, no look-out
                         // vibrato can only come alive in this chunk through a row of its kind (the phase only turns NaN while it advances)
-                        const bool vibChunk = (SET & 1u) != 0u || __any(vib_live());
+                        const bool vibChunk = (SET & kVibBit) != 0u || __any(vib_live());
+                        staleNP = true;
 #pragma unroll KLATT_MIX_UNROLL
                         for (int i = 0; i < CH; ++i) {
                             const uint32_t t = t0 + (uint32_t)i;
@@ -1208,16 +1236,16 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                             }
                             const bool waveVib = vibChunk && __any(vib_live());
                             const bool has = f.left > 0u;
-                            PIPE(pipeX, c, i) = source(waveVib, FlatMid<FD, SET>{f, rsrc, has});
+                            PIPE(pipeX, c, i) = source(waveVib, setTag, FlatMid<FD, SET>{f, rsrc, has});
                             if (has) f.left--;
                         }
                         };
-                        const bool usual = c != 0 && (f.wmask & ~0xCu) == 0u;
+                        const bool usual = c != 0 && (f.wmask & ~kUsualS0) == 0u;
                         // (a lane past its end: cntF == nfU; its pitch is nobody's business)
                         const bool allFade = usual && !__any(vib_live()) && __all(!f.live || (cntF + (uint32_t)CH <= nfU && f.startAt > t1));
-                        if (allFade) mixedChunk(std::integral_constant<uint32_t, 0xCu>{}, std::true_type{});
-                        else if (usual) mixedChunk(std::integral_constant<uint32_t, 0xCu>{}, std::false_type{});
-                        else mixedChunk(std::integral_constant<uint32_t, 0xFu>{}, std::false_type{});
+                        if (allFade) mixedChunk(std::integral_constant<uint32_t, kUsualS0>{}, std::true_type{});
+                        else if (usual) mixedChunk(std::integral_constant<uint32_t, kUsualS0>{}, std::false_type{});
+                        else mixedChunk(std::integral_constant<uint32_t, kAllS0>{}, std::false_type{});
                     }
                 }
                 STAMP_WORKED();
@@ -1369,15 +1397,30 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             streamState[220] = (double)lastIndex; streamState[221] = (double)noiseSt;
         }
     } else if (FLAT && stage == 1) {
-        // ================= flat S1: N0 (anti), NP mixed by caNP, r6, r5, r4 (and r3: KLATT_R3_IN_S1) =================
+        // ================= flat S1: layout 2: the cascade r6 .. r1; layout 1: N0 (anti), NP mixed by caNP, r6 .. r3 =================
         if constexpr (FLAT) {
-#if KLATT_R3_IN_S1
+#if KLATT_FLAT_LAYOUT == 2
+            using FD = FlatDesc<1, 6, 0, false, 0x38u>;                // usually r3, r2, r1, when anything
+            constexpr int GE[6] = {2, 3, 4, 5, 6, 7};            // r6, r5, r4, r3, r2, r1
+            FlatState2<FD> f;
+            flat2_init<FD>(f, live, d, X, GE);
+            flat2_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
+                [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
+                    constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
+                    ResPre<sig_t> q[6];
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) q[r] = ((SET >> r) & 1u) ? res_pre<MODE, true>(f.ra[r], f.rb[r], f.rc[r], f.z1[r], f.z2[r])
+                                                                         : res_pre<MODE, false>(f.ra[r], f.rb[r], f.rc[r], f.z1[r], f.z2[r]);
+                    mid(q[0], q[1], q[2], q[3], q[4], q[5]);
+                    sig_t o = PIPE(pipeX, c, i);
+#pragma unroll
+                    for (int r = 0; r < 6; ++r) o = res_post<MODE>(q[r], o, f.z1[r], f.z2[r]);
+                    PIPE(pipeO, c, i) = o;
+                },
+                noChunk);
+#else
             using FD = FlatDesc<1, 6, 1, true, 0x63u>;                 // usually N0, NP, r3 and caNP, when anything
             constexpr int GE[7] = {0, 1, 2, 3, 4, 5, 14};        // N0, NP, r6, r5, r4, r3 | cur: caNP
-#else
-            using FD = FlatDesc<1, 5, 1, true, 0x23u>;                 // usually N0, NP and caNP, when anything
-            constexpr int GE[6] = {0, 1, 2, 3, 4, 14};           // N0, NP, r6, r5, r4 | cur: caNP
-#endif
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
             flat2_loop<FD, CH>(1, nIter, nChunks, stage, f, X, GE,
@@ -1388,13 +1431,9 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     const ResPre<sig_t> q2 = res_pre<MODE, ((SET >> 2) & 1u) != 0u>(f.ra[2], f.rb[2], f.rc[2], f.z1[2], f.z2[2]);
                     const ResPre<sig_t> q3 = res_pre<MODE, ((SET >> 3) & 1u) != 0u>(f.ra[3], f.rb[3], f.rc[3], f.z1[3], f.z2[3]);
                     const ResPre<sig_t> q4 = res_pre<MODE, ((SET >> 4) & 1u) != 0u>(f.ra[4], f.rb[4], f.rc[4], f.z1[4], f.z2[4]);
-                    const sig_t caNP = f.cur[0];
-#if KLATT_R3_IN_S1
                     const ResPre<sig_t> q5 = res_pre<MODE, ((SET >> 5) & 1u) != 0u>(f.ra[5], f.rb[5], f.rc[5], f.z1[5], f.z2[5]);
+                    const sig_t caNP = f.cur[0];
                     mid(q0, q1, q2, q3, q4, q5, caNP);
-#else
-                    mid(q0, q1, q2, q3, q4, caNP);
-#endif
                     const sig_t x = PIPE(pipeX, c, i);
                     sig_t zin = f.z1[0];
                     const sig_t n0 = res_post<MODE>(q0, x, zin, f.z2[0]);       // the anti-resonator remembers its INPUT (:133)
@@ -1404,12 +1443,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     o = res_post<MODE>(q2, o, f.z1[2], f.z2[2]);
                     o = res_post<MODE>(q3, o, f.z1[3], f.z2[3]);
                     o = res_post<MODE>(q4, o, f.z1[4], f.z2[4]);
-#if KLATT_R3_IN_S1
                     o = res_post<MODE>(q5, o, f.z1[5], f.z2[5]);
-#endif
                     PIPE(pipeO, c, i) = o;
                 },
                 noChunk);
+#endif
         }
     } else if (FLAT && stage == 3) {
         // ================= flat S3: frication noise, parallel r1..r4 partial sum =================
@@ -1449,14 +1487,14 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     } else if (FLAT && (KLATT_FLAT_EXHAUSTIVE || stage == 2)) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
         if constexpr (FLAT) {
-#if KLATT_R3_IN_S1
+#if KLATT_FLAT_LAYOUT == 2
+            constexpr int GE[4] = {12, 13, 15, 16};               // parallel 5, 6 | cur: pa5, pa6, parallelBypass, outputGain
+            using FD = FlatDesc<2, 2, 2, false, 0xEu>;                 // usually parallel 6 and the gains
+            constexpr int RS = 0;                                      // cascade resonators in this stage
+#else
             constexpr int GE[6] = {6, 7, 12, 13, 15, 16};         // r2, r1, parallel 5, 6 | cur: pa5, pa6, parallelBypass, outputGain
             using FD = FlatDesc<2, 4, 2, false, 0x3Bu>;                // usually c2, c1, parallel 6 and the gains
-            constexpr int RS = 0;                                      // the cascade's r3 ran in the stage before
-#else
-            constexpr int GE[7] = {5, 6, 7, 12, 13, 15, 16};      // cur: pa5, pa6, parallelBypass, outputGain
-            using FD = FlatDesc<2, 5, 2, false, 0x77u>;                // usually c3, c2, c1, parallel 6 and the gains
-            constexpr int RS = 1;
+            constexpr int RS = 2;
 #endif
             FlatState2<FD> f;
             flat2_init<FD>(f, live, d, X, GE);
@@ -1493,23 +1531,23 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             flat2_loop<FD, CH>(2, nIter, nChunks, stage, f, X, GE,
                 [&](int c, int i, auto setTag, const auto& mid) __attribute__((always_inline)) {
                     constexpr uint32_t SET = decltype(setTag)::value;      // the kinds this chunk loads (0: a steady chunk)
-                    // resonators of the stage: [r3 when RS] r2, r1, parallel 5, parallel 6
-                    constexpr int NR = 4 + RS;
-                    ResPre<sig_t> q[5];
+                    // resonators of the stage: RS of the cascade's last ones, then parallel 5 and 6
+                    constexpr int NR = 2 + RS;
+                    ResPre<sig_t> q[4];
 #pragma unroll
                     for (int r = 0; r < NR; ++r) q[r] = ((SET >> r) & 1u) ? res_pre<MODE, true>(f.ra[r], f.rb[r], f.rc[r], f.z1[r], f.z2[r])
                                                                           : res_pre<MODE, false>(f.ra[r], f.rb[r], f.rc[r], f.z1[r], f.z2[r]);
                     const sig_t pa5 = f.cur[0], pa6 = f.cur[1], bypass = f.cur[2], outGain = f.cur[3];
-                    if constexpr (RS) mid(q[0], q[1], q[2], q[3], q[4], pa5, pa6, bypass, outGain);
-                    else mid(q[0], q[1], q[2], q[3], pa5, pa6, bypass, outGain);
+                    if constexpr (RS == 2) mid(q[0], q[1], q[2], q[3], pa5, pa6, bypass, outGain);
+                    else mid(q[0], q[1], pa5, pa6, bypass, outGain);
                     sig_t o = PIPE(pipeO, c, i);
                     const sig_t y = PIPE(pipeA, c, i);
 #pragma unroll
-                    for (int r = 0; r < 2 + RS; ++r) o = res_post<MODE>(q[r], o, f.z1[r], f.z2[r]);
+                    for (int r = 0; r < RS; ++r) o = res_post<MODE>(q[r], o, f.z1[r], f.z2[r]);
                     sig_t par = PIPE(pipeB, c, i);
-                    sig_t w = res_post<MODE>(q[2 + RS], y, f.z1[2 + RS], f.z2[2 + RS]);
+                    sig_t w = res_post<MODE>(q[RS], y, f.z1[RS], f.z2[RS]);
                     par += (w - y) * pa5;
-                    w = res_post<MODE>(q[3 + RS], y, f.z1[3 + RS], f.z2[3 + RS]);
+                    w = res_post<MODE>(q[RS + 1], y, f.z1[RS + 1], f.z2[RS + 1]);
                     par += (w - y) * pa6;
                     par = fade_value(par, y, bypass);
                     const sig_t mix = o + par;

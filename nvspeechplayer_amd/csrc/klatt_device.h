@@ -90,7 +90,7 @@ struct UttResult {           // written by the kernel
 //           (voiceAmplitude, aspirationAmplitude) (preFormantGain, -)           -- S0 (the pitch itself glides: not in a track)
 // On fade sample 1 everything is re-evaluated (see fade_update below): every kind has an entry for it, kTrackFirst entries (N0
 // takes two).  Fade samples 2..F change only the kinds that MOVE in the fade (mask).  A fade's track is four PARTS, one per flat
-// stage (S0: kinds 20..23 | S1: 0..4, 14 | final stage: 5..7, 12, 13, 15, 16 | parallel stage: 8..11, 17..19), so that what a
+// stage (S0: kinds 0, 1, 14, 20..23 | S1: 2..7 | final stage: 12, 13, 15, 16 | parallel stage: 8..11, 17..19 -- KLATT_FLAT_LAYOUT below), so that what a
 // stage streams through is contiguous and no cache line is shared by two stages -- which work 16 to 32 samples apart: with the
 // kinds of all stages interleaved in one row a line was fetched once per stage, 34 GB from HBM per launch of a batch with 445 MB
 // of tracks, for 22 GB of rows.  Layout of a part:

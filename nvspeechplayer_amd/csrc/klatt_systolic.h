@@ -185,12 +185,13 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
     f.nextFrame++;
     f.newMin = m.minSamples; f.newFade = m.fadeSamples; f.newNull = (m.flags & FRAME_NULL) != 0;
     constexpr int GI = D::GAIN >= 0 ? D::GAIN : 0;
+    double pNew0 = 0.0, pNewInc = 0.0, pOld0 = D::PITCH ? ps->old0 : 0.0;
     if (f.newNull) {   // silence keeps the old shape, gain gated off (:59-63)
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) f.setNew(k, f.oldL[k * kLanes]);
         uint32_t pm = 0;
         if (D::GAIN >= 0) { pm = (f.oldL[GI * kLanes] != 0.0) ? (1u << GI) : 0u; f.setNew(GI, 0.0); }
-        if (D::PITCH) { ps->new0 = ps->cur0; ps->newInc = 0.0; }
+        if (D::PITCH) { pNew0 = ps->cur0; pNewInc = 0.0; }
         f.resMask = 0; f.parMask = pm;
     } else {
         uint32_t pm = 0, mk = 0;
@@ -215,12 +216,15 @@ __device__ __forceinline__ bool stage_event(SF& f, PitchState* ps, int32_t* last
         }
         if (D::PITCH) {
             const double g0 = g[0], g46 = g[46];
-            ps->new0 = g0;
-            ps->newInc = (g46 - g0) / (double)f.newMin;   // reference src/frame.cpp:98
-            if (f.oldNull) ps->old0 = g0;
+            pNew0 = g0;
+            pNewInc = (g46 - g0) / (double)f.newMin;   // reference src/frame.cpp:98
+            if (f.oldNull) pOld0 = g0;
         }
         f.resMask = mk; f.parMask = pm;
     }
+    // (one store per field after the branches: stores to different fields in different branches are merged by the optimiser into
+    // one store through a selected POINTER, which keeps the whole PitchState in scratch memory)
+    if (D::PITCH) { ps->new0 = pNew0; ps->newInc = pNewInc; ps->old0 = pOld0; }
     if (lastIndex && m.userIndex != -1) *lastIndex = m.userIndex;   // (:69)
     f.cnt = 0;                                                       // (:70)
     if (D::PITCH) {

@@ -692,6 +692,57 @@ def test_live_handles_with_more_frames_than_their_rings(ref):
     assert total == 0
 
 
+def test_live_queueing_thread_beside_pulling_thread(ref):
+    """speechPlayer_queueFrame from one thread while another pulls OTHER handles (the NVDA driver queues from the speech thread while
+    its audio thread pulls): the queueing thread fills the pinned log (and sends it on its way when no pull is running), the pulls
+    upload what is left of it.  Two groups of 40 handles; while group A is pulled four times, a second thread queues group B's
+    frames; then B is pulled.  Every handle against its own oracle player."""
+    import threading
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(99)
+    cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=80)]
+    players = [eng.SpeechPlayer(22050, noiseSeed=700 + k) for k in range(80)]
+    oracles = [oracle.OraclePlayer(22050, seed=700 + k) for k in range(80)]
+    for k in range(40):
+        for j, (fr, m, f) in enumerate(cases[k]):
+            players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, j)
+            oracles[k].queue(fr, m, f, j)
+
+    def queue_b():
+        for rep in range(6):                      # 6 x the case: ~1.7 MB of log per handle group and repetition
+            for k in range(40, 80):
+                for j, (fr, m, f) in enumerate(cases[k]):
+                    players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, 100 * rep + j)
+    t = threading.Thread(target=queue_b)
+    t.start()
+    got = [[] for _ in range(80)]
+    exp = [[] for _ in range(80)]
+    ga = eng.LiveGroup(players[:40])
+    out = np.zeros((40, 8192), dtype=np.int16)
+    for _ in range(4):
+        prod = ga.pull(8192, out).copy()
+        for k in range(40):
+            got[k].append(out[k, :prod[k]].copy())
+    t.join()
+    for rep in range(6):
+        for k in range(40, 80):
+            for j, (fr, m, f) in enumerate(cases[k]):
+                oracles[k].queue(fr, m, f, 100 * rep + j)
+    gb = eng.LiveGroup(players[40:])
+    for _ in range(5):
+        prod = gb.pull(8192, out).copy()
+        for k in range(40):
+            got[40 + k].append(out[k, :prod[k]].copy())
+    total = 0
+    for k in range(80):
+        for _ in range(4 if k < 40 else 5):
+            exp[k].append(oracles[k].synthesize(8192))
+        total += compare(np.concatenate(got[k]), np.concatenate(exp[k]), "threaded live stream %d" % k)
+        assert players[k].getLastIndex() == oracles[k].last_index(), k
+        players[k].close()
+    assert total == 0
+
+
 def test_random_ragged_batch_large():
     """One big random batch (20 000 utterances, ~8e7 samples, both launch groups, two workgroups per CU):
     bit-for-bit against the oracle.  Bounds the rate of differing samples well below 1e-7."""

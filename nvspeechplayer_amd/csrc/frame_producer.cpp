@@ -774,6 +774,20 @@ void speechPlayer_internal_setError(int code, const char* message);      // klat
 
 namespace {
 void set_text_error(const char* msg) { speechPlayer_internal_setError(SPEECHPLAYER_ERR_TEXT_FRONTEND, msg); }
+void set_arg_error(const char* msg) { speechPlayer_internal_setError(SPEECHPLAYER_ERR_ARGUMENT, msg); }
+// Every text entry point runs through this: the error code of an earlier call is cleared, and nothing a host allocation throws
+// (std::bad_alloc, std::length_error) crosses the C ABI -- the caller gets `fail` and a message instead.
+template <class R, class F>
+R text_call(const char* what, R fail, F body)
+{
+    speechPlayer_internal_setError(0, "");
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        set_text_error((std::string(what) + ": " + e.what()).c_str());
+        return fail;
+    }
+}
 }
 
 extern "C" {
@@ -788,89 +802,97 @@ int speechPlayer_text_available(void)
 
 long long speechPlayer_text_fixups(const char* ipaUtf8, char* out, long long capacity)
 {
-    if (!ipaUtf8) return -1;
-    const std::string s = ipa_fixups(ipaUtf8);
-    if (out && capacity > (long long)s.size()) memcpy(out, s.c_str(), s.size() + 1);
-    return (long long)s.size() + 1;
+    return text_call<long long>("speechPlayer_text_fixups", -1, [&]() -> long long {
+        if (!ipaUtf8) { set_arg_error("speechPlayer_text_fixups: NULL text"); return -1; }
+        const std::string s = ipa_fixups(ipaUtf8);
+        if (out && capacity > (long long)s.size()) memcpy(out, s.c_str(), s.size() + 1);
+        return (long long)s.size() + 1;
+    });
 }
 
 long long speechPlayer_text_clauses(const char* textUtf8, long long* begin, long long* end, char* clauseType, double* endPauseMs, long long capacity)
 {
-    if (!textUtf8) return -1;
-    std::vector<Clause> cl;
-    split_clauses(textUtf8, cl);
-    for (size_t i = 0; i < cl.size() && (long long)i < capacity; ++i) {
-        if (begin) begin[i] = (long long)cl[i].begin;
-        if (end) end[i] = (long long)cl[i].end;
-        if (clauseType) clauseType[i] = cl[i].type;
-        if (endPauseMs) endPauseMs[i] = cl[i].endPauseMs;
-    }
-    return (long long)cl.size();
+    return text_call<long long>("speechPlayer_text_clauses", -1, [&]() -> long long {
+        if (!textUtf8) { set_arg_error("speechPlayer_text_clauses: NULL text"); return -1; }
+        std::vector<Clause> cl;
+        split_clauses(textUtf8, cl);
+        for (size_t i = 0; i < cl.size() && (long long)i < capacity; ++i) {
+            if (begin) begin[i] = (long long)cl[i].begin;
+            if (end) end[i] = (long long)cl[i].end;
+            if (clauseType) clauseType[i] = cl[i].type;
+            if (endPauseMs) endPauseMs[i] = cl[i].endPauseMs;
+        }
+        return (long long)cl.size();
+    });
 }
 
 long long speechPlayer_text_toIpa(const char* textUtf8, const char* espeakVoice, char* out, long long capacity)
 {
-    if (!textUtf8) return -1;
-    std::lock_guard<std::mutex> g(g_espeakMutex);
-    std::string ipa;
-    if (!clause_to_ipa(textUtf8, strlen(textUtf8), espeakVoice, ipa)) { set_text_error(g_espeak.why.c_str()); return -3; }
-    if (out && capacity > (long long)ipa.size()) memcpy(out, ipa.c_str(), ipa.size() + 1);
-    return (long long)ipa.size() + 1;
+    return text_call<long long>("speechPlayer_text_toIpa", -1, [&]() -> long long {
+        if (!textUtf8) { set_arg_error("speechPlayer_text_toIpa: NULL text"); return -1; }
+        std::lock_guard<std::mutex> g(g_espeakMutex);
+        std::string ipa;
+        if (!clause_to_ipa(textUtf8, strlen(textUtf8), espeakVoice, ipa)) { set_text_error(g_espeak.why.c_str()); return -3; }
+        if (out && capacity > (long long)ipa.size()) memcpy(out, ipa.c_str(), ipa.size() + 1);
+        return (long long)ipa.size() + 1;
+    });
 }
 
 int speechPlayer_batch_setText(speechPlayer_batch_t batch, long long nTexts, const char* const* textUtf8, const char* espeakVoice, double speed,
                                const double* basePitch, double inflection, const char* voiceName, const unsigned int* noiseSeed)
 {
-    const int rate = speechPlayer_batch_sampleRate(batch);
-    if (rate <= 0 || nTexts < 0 || (nTexts > 0 && !textUtf8) || !(speed > 0.0)) return -1;
-    const VoiceRow* voice = find_voice(voiceName);
-    if (voiceName && *voiceName && !voice) return -1;
-    Producer p(speed, inflection, voice);
-    std::vector<long long> start((size_t)nTexts + 1, 0);
-    std::vector<speechPlayer_frame_t> frames;
-    std::vector<unsigned int> mins, fades;
-    std::vector<unsigned char> nul;
-    std::vector<Clause> cl;
-    std::unordered_map<std::string, std::string> ipaOf;       // clause text -> IPA: a batch repeats its sentences
-    {
-        std::lock_guard<std::mutex> g(g_espeakMutex);
-        for (long long i = 0; i < nTexts; ++i) {
-            start[(size_t)i] = (long long)nul.size();
-            if (!textUtf8[i]) return -1;
-            split_clauses(textUtf8[i], cl);
-            double endPause = 20.0;                           // reference __init__.py:182
-            for (const Clause& c : cl) {
-                endPause = c.endPauseMs;
-                const std::string key(textUtf8[i] + c.begin, c.end - c.begin);
-                auto it = ipaOf.find(key);
-                if (it == ipaOf.end()) {
-                    std::string ipa;
-                    if (!clause_to_ipa(key.c_str(), key.size(), espeakVoice, ipa)) { set_text_error(g_espeak.why.c_str()); return -3; }
-                    it = ipaOf.emplace(key, ipa).first;
+    return text_call<int>("speechPlayer_batch_setText", -1, [&]() -> int {
+        const int rate = speechPlayer_batch_sampleRate(batch);
+        if (rate <= 0 || nTexts < 0 || (nTexts > 0 && !textUtf8) || !(speed > 0.0)) { set_arg_error("speechPlayer_batch_setText: bad batch, text array or speed"); return -1; }
+        const VoiceRow* voice = find_voice(voiceName);
+        if (voiceName && *voiceName && !voice) { set_arg_error("speechPlayer_batch_setText: unknown voice preset"); return -1; }
+        Producer p(speed, inflection, voice);
+        std::vector<long long> start((size_t)nTexts + 1, 0);
+        std::vector<speechPlayer_frame_t> frames;
+        std::vector<unsigned int> mins, fades;
+        std::vector<unsigned char> nul;
+        std::vector<Clause> cl;
+        std::unordered_map<std::string, std::string> ipaOf;       // clause text -> IPA: a batch repeats its sentences
+        {
+            std::lock_guard<std::mutex> g(g_espeakMutex);
+            for (long long i = 0; i < nTexts; ++i) {
+                start[(size_t)i] = (long long)nul.size();
+                if (!textUtf8[i]) { set_arg_error("speechPlayer_batch_setText: NULL text"); return -1; }
+                split_clauses(textUtf8[i], cl);
+                double endPause = 20.0;                           // reference __init__.py:182: not divided by the rate unless a clause sets it (:204)
+                for (const Clause& c : cl) {
+                    endPause = c.endPauseMs / speed;
+                    const std::string key(textUtf8[i] + c.begin, c.end - c.begin);
+                    auto it = ipaOf.find(key);
+                    if (it == ipaOf.end()) {
+                        std::string ipa;
+                        if (!clause_to_ipa(key.c_str(), key.size(), espeakVoice, ipa)) { set_text_error(g_espeak.why.c_str()); return -3; }
+                        it = ipaOf.emplace(key, ipa).first;
+                    }
+                    if (it->second.empty()) continue;             // :219
+                    const Stream& s = p.stream(it->second.c_str(), (int)(unsigned char)c.type, basePitch ? basePitch[i] : 100.0);
+                    const size_t n = s.size(), at = nul.size();
+                    frames.resize(at + n); mins.resize(at + n); fades.resize(at + n); nul.resize(at + n);
+                    if (n) {
+                        memcpy(&frames[at], s.frames.data(), n * sizeof(speechPlayer_frame_t));
+                        memcpy(&nul[at], s.isNull.data(), n);
+                    }
+                    for (size_t k = 0; k < n; ++k) {
+                        mins[at + k] = ms_to_samples(s.durationMs[k], rate);
+                        fades[at + k] = ms_to_samples(s.fadeMs[k], rate);
+                    }
                 }
-                if (it->second.empty()) continue;             // :219
-                const Stream& s = p.stream(it->second.c_str(), (int)(unsigned char)c.type, basePitch ? basePitch[i] : 100.0);
-                const size_t n = s.size(), at = nul.size();
-                frames.resize(at + n); mins.resize(at + n); fades.resize(at + n); nul.resize(at + n);
-                if (n) {
-                    memcpy(&frames[at], s.frames.data(), n * sizeof(speechPlayer_frame_t));
-                    memcpy(&nul[at], s.isNull.data(), n);
-                }
-                for (size_t k = 0; k < n; ++k) {
-                    mins[at + k] = ms_to_samples(s.durationMs[k], rate);
-                    fades[at + k] = ms_to_samples(s.fadeMs[k], rate);
-                }
+                // silence after the last clause (:234): queueFrame(None, endPause / rate, max(10, 10 / rate))
+                speechPlayer_frame_t zero;
+                memset(&zero, 0, sizeof zero);
+                frames.push_back(zero); nul.push_back(1);
+                mins.push_back(ms_to_samples(endPause, rate));
+                fades.push_back(ms_to_samples(std::max(10.0, 10.0 / speed), rate));
             }
-            // silence after the last clause (:234): queueFrame(None, endPause / rate, max(10, 10 / rate))
-            speechPlayer_frame_t zero;
-            memset(&zero, 0, sizeof zero);
-            frames.push_back(zero); nul.push_back(1);
-            mins.push_back(ms_to_samples(endPause / speed, rate));
-            fades.push_back(ms_to_samples(std::max(10.0, 10.0 / speed), rate));
+            start[(size_t)nTexts] = (long long)nul.size();
         }
-        start[(size_t)nTexts] = (long long)nul.size();
-    }
-    return speechPlayer_batch_setUtterances(batch, nTexts, start.data(), frames.data(), mins.data(), fades.data(), nullptr, nul.data(), noiseSeed);
+        return speechPlayer_batch_setUtterances(batch, nTexts, start.data(), frames.data(), mins.data(), fades.data(), nullptr, nul.data(), noiseSeed);
+    });
 }
 
 }  // extern "C"

@@ -372,8 +372,6 @@ long long lanepipe_count(const Batch* b)
 #define KLATT_FLAT_WPS 2
 #endif
 constexpr size_t kTrackPad = 64;   // slack past the last track
-constexpr int kResFHost[kNumRes] = {13, 14, 12, 11, 10, 9, 8, 7, 25, 26, 27, 28, 29, 30};
-constexpr int kResBHost[kNumRes] = {21, 22, 20, 19, 18, 17, 16, 15, 31, 32, 33, 34, 35, 36};
 // ---- planning the tracks of a batch (host only; klatt_tracks.h, klatt_device.h for the track layout) --------------------
 // Per frame of an eligible utterance: which entry kinds its fade moves and where the fade's track will be.  The state walked
 // here is the part of the frame state machine that decides a fade's end points (reference src/frame.cpp:55-72, restated by
@@ -558,7 +556,8 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     // whose fades are all different is given up after a few milliseconds instead of after the parts have filled a quarter of the budget.
     {
         TrackPlan probe;
-        const long long nProbe = std::max<long long>(nUtterances / 128, 256);
+        // (never past the batch: the threaded path is entered with as few as 2 x 64 utterances -- ADVICE r3)
+        const long long nProbe = std::min<long long>(nUtterances, std::max<long long>(nUtterances / 128, 256));
         std::vector<unsigned char> none;
         plan_tracks_pass(nProbe, frameStart, frames, meta, eligible, budgetMB, false, nullptr, probe);
         TrackPlan half;
@@ -662,6 +661,21 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
         }
     });
     lap("merged");
+}
+
+// Timing-only experiment switches (KLATT_EXP & 1 / & 4 in klatt_systolic.h, KLATT_LP_EXP in klatt_systolic.h / klatt_lanepipe.h) build a
+// library with the same ABI whose PCM is garbage: such a build refuses to hand PCM out, it only times.
+#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0)
+constexpr bool kTimingOnlyBuild = true;
+#else
+constexpr bool kTimingOnlyBuild = false;
+#endif
+bool refuse_timing_only(const char* what)
+{
+    if (!kTimingOnlyBuild || getenv("SPEECHPLAYER_ALLOW_TIMING_ONLY_PCM")) return false;
+    set_error_code(SPEECHPLAYER_ERR_ARGUMENT);
+    set_error("%s: this library was built with a timing-only experiment switch (KLATT_EXP / KLATT_LP_EXP); its PCM is not valid", what);
+    return true;
 }
 
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
@@ -1609,7 +1623,6 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     }
     for (const auto& r : rerouted)
         if (!(utt[r.first].flags & UTT_TRACKED)) utt[r.first].flags = r.second;
-    std::vector<TrackRef>& trackRef = plan.ref;
     std::vector<FlatRef> flatRef;
     std::vector<SourceRef> sourceRef;
     if (!plan.jobs.empty()) {
@@ -1763,6 +1776,7 @@ static int fetch_results(Batch* b)
 long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long u, sample* sampleBuf, long long capacity)
 {
     begin_call();
+    if (refuse_timing_only("speechPlayer_batch_read")) return -1;
     Batch* b = static_cast<Batch*>(batch);
     if (!b || u < 0 || u >= b->nUtt || !sampleBuf) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -1776,6 +1790,7 @@ long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long u, sampl
 long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart)
 {
     begin_call();
+    if (refuse_timing_only("speechPlayer_batch_readAll")) return -1;
     Batch* b = static_cast<Batch*>(batch);
     if (!b || !sampleBuf) return -1;
     HIP_TRY(hipSetDevice(b->device));
@@ -1822,6 +1837,7 @@ long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleB
 long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long u, float* sampleBuf, long long capacity)
 {
     begin_call();
+    if (refuse_timing_only("speechPlayer_batch_readFloat")) return -1;
     Batch* b = static_cast<Batch*>(batch);
     if (!b || u < 0 || u >= b->nUtt || !sampleBuf) return -1;
     HIP_TRY(hipSetDevice(b->device));

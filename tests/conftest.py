@@ -12,20 +12,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-_BUILD_ERROR = None
-
-
 def pytest_sessionstart(session):
     """The tests run against the library built from the sources in the tree: rebuild it when a source, header or
     generated table is newer (a no-op otherwise; hipcc cross-compiles without a GPU).  A host without hipcc and without
     a current library does not lose the whole session: the oracle-only tests still run, the ones that load the library
     fail with the build's message when they try."""
-    global _BUILD_ERROR
     from nvspeechplayer_amd import _native
     try:
         _native.build()
     except Exception as e:      # noqa: BLE001 -- reported by the tests that need the library
-        _BUILD_ERROR = e
         sys.stderr.write("conftest: the engine library could not be built (%s); tests that load it will fail\n" % e)
 
 

@@ -158,3 +158,39 @@ def test_planning_in_parts_gives_the_plan_of_one_pass(monkeypatch):
             assert one[4][~hit].all() and not one[4][hit].all()  # (a hit utterance stays in when its long fade moves few kinds)
         else:
             assert not one[4].any()
+
+
+def test_probe_of_a_short_batch_of_long_utterances(monkeypatch):
+    """the look at the first utterances (plan_tracks) read past the batch when the threaded path was entered with
+    fewer than 256 utterances (130 utterances x 1600 frames, two plan threads).  The arrays are placed so that the bytes behind
+    frameStart are a PROT_NONE page: an overrun is a segfault, not a silent read."""
+    import mmap
+    rng = np.random.default_rng(3)
+    n_utt, per = 130, 1600
+    shapes = rng.uniform(100, 5000, size=(5, 47))
+    frames = shapes[rng.integers(0, 5, n_utt * per)]
+    fade = rng.choice([1, 2, 50, 300], n_utt * per).astype(np.uint32)
+    nul = (rng.random(n_utt * per) < 0.1).astype(np.uint8)
+    page = mmap.PAGESIZE
+    libc = ctypes.CDLL(None, use_errno=True)
+    libc.mmap.restype = ctypes.c_void_p
+    libc.mmap.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_long]
+    libc.mprotect.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+    nbytes = (n_utt + 1) * 8
+    span = (nbytes + page - 1) // page * page
+    base = libc.mmap(None, span + page, mmap.PROT_READ | mmap.PROT_WRITE, mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS, -1, 0)
+    assert base not in (None, ctypes.c_void_p(-1).value)
+    assert libc.mprotect(base + span, page, 0) == 0      # PROT_NONE
+    fs = np.frombuffer((ctypes.c_char * nbytes).from_address(base + span - nbytes), dtype=np.int64)
+    fs[:] = np.arange(n_utt + 1, dtype=np.int64) * per
+    L = _native.load()
+    off = np.zeros(n_utt * per, np.uint64); mask = np.zeros(n_utt * per, np.uint32); tracked = np.zeros(n_utt, np.uint8)
+    entries = ctypes.c_ulonglong(0)
+    out = {}
+    for threads in ("1", "2"):
+        monkeypatch.setenv("SPEECHPLAYER_PLAN_THREADS", threads)
+        n = L.speechPlayer_planTracks(n_utt, fs.ctypes.data, np.ascontiguousarray(frames).ctypes.data, fade.ctypes.data, nul.ctypes.data, None, 16384,
+                                      off.ctypes.data, mask.ctypes.data, tracked.ctypes.data, ctypes.byref(entries))
+        out[threads] = (n, int(entries.value), off.copy(), mask.copy(), tracked.copy())
+    assert out["1"][:2] == out["2"][:2] and all(np.array_equal(a, b) for a, b in zip(out["1"][2:], out["2"][2:]))
+    assert out["1"][4].all()

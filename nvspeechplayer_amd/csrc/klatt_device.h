@@ -50,6 +50,7 @@ constexpr int MODE_FAST = 1;
 constexpr uint32_t FRAME_NULL = 1u;       // FrameMeta.flags
 constexpr uint32_t UTT_NEEDS_NOISE = 1u;  // UttDesc.flags
 constexpr uint32_t UTT_TRACKED = 4u;      // UttDesc.flags: noisy, every parameter finite, tracks planned (2u: UTT_NO_NASAL, klatt_lanepipe.h)
+constexpr uint32_t UTT_DIRECT = 8u;       // UttDesc.flags: noisy, every parameter finite and in the range of klatt_math.h, no tracks: direct stages (klatt_direct.h)
 constexpr int kUttKindShift = 8;          // UttDesc.flags bits 8..31 of a tracked utterance: the entry kinds (klatt_tracks) whose values change after the first sample
                                           // of its first fade -- a kind outside the mask of every lane of a wavefront is loaded once and never again (flat stages)
 
@@ -172,7 +173,44 @@ __host__ __device__ inline uint32_t track_part(uint32_t mask, uint32_t F, int s)
     return at;
 }
 
+// ---- direct stages (klatt_direct.h): what a fade needs, per frame and stage, evaluated by klatt_seeds before the launch --------
+struct DirectHdr {           // 16 B per (frame, stage), loaded one fade ahead (stages: direct_stage_kind below)
+    uint32_t fadeSamples;
+    uint32_t span;           // samples from this frame's dequeue to the next frame's: max(minSamples, fadeSamples + 1) + 1
+    uint32_t bits;           // of the stage's kinds e = 0, 1, ...: bit e -- the fade moves kind e; bit 8 + r -- it moves resonator r's bandwidth;
+                             // bits 14 + 2r, 15 + 2r -- resonator r's arguments leave the unreduced range / the range of cosine quadrant -1 somewhere in the fade
+    uint32_t pad;
+};
+struct DirectJob {           // host -> klatt_seeds: the end points of one frame's fade (reference src/frame.cpp:55-72, walked on the host)
+    uint32_t frame;          // the frame (durations: meta[frame])
+    uint32_t from, to;       // the frames whose values the fade starts from / ends on; kNoFrame: all zero (a fresh handle)
+    uint32_t flags;          // bit 0: the start's preFormantGain is gated off, bit 1: the end's (silence, reference src/frame.cpp:61,66)
+};
+constexpr uint32_t kNoFrame = 0xFFFFFFFFu;
+constexpr uint32_t kDirectBwShift = 8, kDirectClsShift = 14, kDirectAllBits = 0x3FFFFFFu;
+// Which direct stage runs what (kinds as in the tracks above; resonator kinds first).  EIGHT stages, one wavefront each:
+//   T0 source | T1 N0, NP (caNP mix) | T2 r6, r5 | T3 r4, r3 | T4 r2, r1 | T5 frication, parallel 1, 2 | T6 parallel 3, 4 |
+//   T7 parallel 5, 6, bypass mix, gain, clip, PCM
+// -- two resonators per stage: what a direct stage carries per resonator (coefficients, memories, the running fade's end points:
+// ten doubles) does not fit the register budget of a wavefront four or six at a time (klatt_direct.h has the census).
+// A stage's record of one frame: 4 entries (16 B) per resonator kind, then 3 per gain kind (layouts: klatt_direct.h).
+constexpr int kDirectStages = 8;
+__host__ __device__ constexpr int direct_stage_res(int s) { return s == 0 ? 0 : 2; }
+__host__ __device__ constexpr int direct_stage_gains(int s) { return s == 0 ? 4 : s == 1 ? 1 : s == 5 ? 2 : s == 6 ? 1 : s == 7 ? 2 : 0; }
+__host__ __device__ constexpr int direct_stage_entries(int s) { return 4 * direct_stage_res(s) + 3 * direct_stage_gains(s); }
+__host__ __device__ constexpr int direct_stage_first(int s) { int at = 0; for (int k = 0; k < s; ++k) at += direct_stage_entries(k); return at; }      // (no recursion: a recursive device function is a real call)
+constexpr int kDirectEntries = direct_stage_first(kDirectStages);      // 16-byte entries per frame over the stages: 86 (1376 B)
+__host__ __device__ constexpr int direct_stage_kind(int s, int e)
+{
+    constexpr int k[kDirectStages][4] = {{20, 21, 22, 23}, {0, 1, 14, -1}, {2, 3, -1, -1}, {4, 5, -1, -1}, {6, 7, -1, -1}, {8, 9, 17, 18}, {10, 11, 19, -1}, {12, 13, 15, 16}};
+    return k[s][e];
+}
+
 struct KernelArgs {
+    const DirectHdr* directHdr;  // [8][nDirect] direct launches only: stage s's headers at directHdr + s * nDirect
+    const double2* directRec;    // stage s's records at directRec + direct_stage_first(s) * nDirect, direct_stage_entries(s) entries per frame
+    const uint32_t* directFirst; // [nUtt] the record number of an utterance's first frame
+    uint32_t nDirect;            // frames of the launch's direct utterances
     const FlatRef* flatRef;      // [nFrames] tracked launches only
     const SourceRef* sourceRef;  // [nFrames] tracked launches only
     uint32_t trackBytes;         // size of `track` (below 4 GB: the flat stages address it through a buffer descriptor with 32-bit offsets)
@@ -301,6 +339,7 @@ enum { COEF_UNREDUCED = 0, COEF_QUADRANT_M1 = 1, COEF_UNKNOWN = 2 };
 #ifndef KLATT_COLD_CALL
 #define KLATT_COLD_CALL 2
 #endif
+struct RadCos { double rad, cs; };
 #if KLATT_COLD_CALL
 // exp and cos OUTSIDE the validated range of klatt_math.h (|arg| > 700 / 1e4: no frame a speech front-end produces): the device
 // library's, out of line.  Inlined, its two dozen polynomial and reduction constants are materialised in the kernel's prologue and
@@ -311,7 +350,6 @@ enum { COEF_UNREDUCED = 0, COEF_QUADRANT_M1 = 1, COEF_UNKNOWN = 2 };
 // Results come back by value (registers): no address of a caller's local is taken.  Only the kernels call it (one level deep); the
 // lane kernel's out-of-line resonator_coefficients() keeps the library calls inline (NESTED = false) -- a noinline function calling
 // this one from inside a divergent branch gave wrong coefficients now and then (tests: MODE_FAST, layout 0, NaN parameters).
-struct RadCos { double rad, cs; };
 __device__ __attribute__((noinline)) RadCos exp_cos_reduced(double ex, double th)
 {
     RadCos o;
@@ -323,9 +361,9 @@ __device__ __attribute__((noinline)) RadCos exp_cos_reduced(double ex, double th
     return o;
 }
 #endif
-template <int MODE, bool NESTED = true>
-__device__ __forceinline__ Coef resonator_coefficients_inline(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr,
-                                                              int cls = COEF_UNKNOWN)
+// exp(-pi bw / sr) and cos(2 pi (-f) / sr) of one resonator (the two transcendental halves of resonator_coefficients_inline)
+template <bool NESTED = true>
+__device__ __forceinline__ RadCos coefficient_parts(double f, double bw, double negPiOverSr, double twoPiOverSr, int cls = COEF_UNKNOWN)
 {
     const double ex = negPiOverSr * bw;
     const double th = twoPiOverSr * -f;
@@ -348,6 +386,12 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
     else if (NESTED) { const RadCos o = exp_cos_reduced(ex, th); rad = o.rad; cs = o.cs; }
 #endif
     else { rad = exp(ex); cs = cos(th); }
+    RadCos o; o.rad = rad; o.cs = cs;
+    return o;
+}
+// the coefficients from the two parts (reference src/speechWaveGenerator.cpp:117-126)
+__device__ __forceinline__ Coef coefficient_finish(double rad, double cs, bool anti, double f)
+{
     double cc = -(rad * rad);
     double bb = rad * cs * 2.0;
     double aa = 1.0 - bb - cc;
@@ -358,6 +402,13 @@ __device__ __forceinline__ Coef resonator_coefficients_inline(double f, double b
     }
     Coef k; k.a = aa; k.b = bb; k.c = cc;
     return k;
+}
+template <int MODE, bool NESTED = true>
+__device__ __forceinline__ Coef resonator_coefficients_inline(double f, double bw, bool anti, double negPiOverSr, double twoPiOverSr,
+                                                              int cls = COEF_UNKNOWN)
+{
+    const RadCos p = coefficient_parts<NESTED>(f, bw, negPiOverSr, twoPiOverSr, cls);
+    return coefficient_finish(p.rad, p.cs, anti, f);
 }
 // out-of-line copy for the lane kernel, whose 14 call sites would otherwise each inline exp and cos
 template <int MODE>

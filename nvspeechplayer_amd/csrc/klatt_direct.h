@@ -1,0 +1,930 @@
+// klatt_direct.h -- direct stages: the stage-parallel kernel for batches whose fades share NOTHING and whose lanes fade at
+// unrelated times (65 536 different sentences in different voices), and for batches that may not or cannot have tracks.
+//
+// The flat stages of klatt_systolic.h take every fade sample's coefficients from TRACKS: one dense evaluation per distinct fade of
+// the batch, shared by every utterance that makes the transition.  That pays when fades are shared.  When they are not, the
+// tracks are as large as the work itself (12 bytes per output sample), and before this file such batches fell back to stages that
+// carry a replica of the frame state machine, two copies of the fade's end points in LDS and a wave-uniform decision tree per
+// chunk (klatt_systolic.h, `stage_loop`): 60 ms for BASELINE configs[2]'s 65 536 utterances once their timings differ, against
+// 8.5 ms for the benchmark's aligned copies.
+//
+// Here the stages keep the flat stages' CONTROL -- sample positions from the durations alone (frame k is dequeued on sample T_k,
+// T_k+1 = T_k + max(min_k, fade_k + 1) + 1, its fade's samples are T_k + 1 .. T_k + fade_k; reference src/frame.cpp:41-80), one
+// counter per lane, no dequeue / fade-end events, nothing in LDS but the pipes and the PCM tile -- and COMPUTE what the tracks
+// would have held, in the gap between the two halves of a sample's filter arithmetic (where the flat stages load their rows):
+//
+//   * per lane: the fade-sample index `cnt` of the values now in registers (saturating at the fade's length F: a lane that is not
+//     fading sits at cnt == F, ratio 1), and per parameter the pair (from, to - from) of the running fade;
+//   * every lane evaluates, on every sample of a chunk in which SOME lane moves a kind, that kind for itself:
+//         value = from + ((to - from) * (cnt / F))                       (reference src/frame.cpp:48-53, src/utils.h:20-23)
+//     and for a resonator r = exp(-pi bw / sr), cs = cos(2 pi (-f) / sr), c = -(r r), b = r cs 2, a = 1 - b - c (reference
+//     src/speechWaveGenerator.cpp:112-127) with the straight-line kernels of klatt_math.h, classified ONCE per chunk and wave
+//     (no range reduction / cosine quadrant -1 / general) from bits the seeds carry.  For a lane that is not fading this
+//     reproduces the value it holds, bit for bit (ratio 1 is the fade's last sample; the reference keeps exactly that value
+//     until the next fade's first sample), so nothing is masked: a sample is straight-line code whatever the lanes are doing.
+//     Which kinds are evaluated is a wave-uniform mask per chunk (the OR over the lanes of what their running or starting
+//     fades move): scalar branches, no ballots per sample.
+//   * MODE_FAST replaces the polynomials by SURVEY section 7's recurrences: with f and bw linear in the fade-sample index,
+//     the pole P = 2 r e^(i theta) advances by a constant complex factor w = q e^(i delta) per sample and r^2 by q^2:
+//         P <- P w (4 operations), r^2 <- r^2 q^2, b = Re P, c = -r^2, a = 1 - b - c           (7 instead of ~36)
+//     re-seeded EXACTLY at every fade's first sample (klatt_seeds evaluates P_1, w, q^2 with the polynomials, in double), so the
+//     error of a coefficient grows by at most ~3 ulp per fade sample: <= 4 F 2^-53 relative at the end of a fade of F samples
+//     (1e-12 for the longest fades of speech, F ~ 1500; tests/test_gpu_parity.py holds MODE_FAST to the usual bar).  The
+//     anti-resonator N0, whose a needs a division either way, keeps the polynomials in both modes.
+//   * a fade START is one masked block of 16-byte loads: klatt_seeds (below) has evaluated, densely and before the launch, per
+//     frame and stage a RECORD -- for every kind the fade's (from, to - from) pairs (MODE_FAST: P_1, w, q^2) and the values of
+//     the fade's FIRST sample, on which the reference re-evaluates everything (the previous fade's last interpolated value need
+//     not equal the frame value) -- so kinds that no lane moves are never evaluated in the sample loop at all.  The record's
+//     lines are touched ~9..24 samples ahead (a dummy load per line: they sit in the L2 / L1 when the switch comes), the
+//     16-byte header of the NEXT fade is loaded at the previous switch, as the flat stages do.
+//
+// Same arithmetic as every other kernel of the engine in MODE_EXACT (the seeds and the stages call the functions the tracks
+// and the untracked stages call, on the same operands): the PCM is the same bytes (tests: tracked = direct = untracked).
+//
+// EIGHT stages, one wavefront each (klatt_device.h, direct_stage_kind): T0 source | T1 N0, NP | T2 r6, r5 | T3 r4, r3 | T4 r2, r1 |
+// T5 frication, parallel 1, 2 | T6 parallel 3, 4 | T7 parallel 5, 6, mix, clip, PCM.  A direct stage carries ten doubles per
+// resonator (coefficients, memories, the running fade's end points) and three per gain, and MODE_EXACT's polynomials want ~30
+// constants in registers: four resonators per wavefront, the flat stages' split, compiled to 350-470 VGPRs (150-600 spilled);
+// two fit with room to spare, and evaluating coefficients -- not filtering with them -- is what there is to balance:
+// 2 resonators per stage, the source and the mix / PCM tail apart.
+#pragma once
+
+#include "klatt_systolic.h"
+
+namespace klatt {
+
+#ifndef KLATT_DIRECT_UNROLL
+#define KLATT_DIRECT_UNROLL 2
+#endif
+#ifndef KLATT_DIRECT_EXP
+#define KLATT_DIRECT_EXP 0      // timing experiments (wrong PCM; the library then refuses to hand PCM out): 1 a switch loads nothing; 2 nothing is evaluated
+#endif
+#ifndef KLATT_DIRECT_STEADY_UNROLL
+#define KLATT_DIRECT_STEADY_UNROLL 16
+#endif
+#ifndef KLATT_DIRECT_TOUCH
+#define KLATT_DIRECT_TOUCH 1
+#endif
+#ifndef KLATT_DIRECT_PAIRING
+#define KLATT_DIRECT_PAIRING 1
+#endif
+#ifndef KLATT_DIRECT_STAGES
+#define KLATT_DIRECT_STAGES 0x3F     // (register census, tools/direct_census.sh: compile the kernel with some stages' bodies left out)
+#endif
+
+// ---- klatt_seeds: one record per (frame, stage) of the launch's direct utterances -------------------------------------------
+// Record of stage s for one frame: direct_stage_entries(s) 16-byte entries,
+//   resonator kind r (4 entries at 4 r):
+//       MODE_EXACT (and N0 in both modes)   (f_from, f_to - f_from) (bw_from, bw_to - bw_from) (b_1, c_1) (a_1, r_1)
+//       MODE_FAST                           (Im P_1, Re w) (Im w, q^2) (b_1 = Re P_1, c_1 = -r_1^2) (a_1, -)
+//   gain kind g (3 entries at 4 NRES + 3 g): (x_from, x_to - x_from) (y_from, y_to - y_from) (x_1, y_1)     for its two parameters
+// where _1 is the value on the fade's first sample.  The end points follow reference src/frame.cpp:55-72 (host: DirectJob).
+struct SeedArgs {
+    const DirectJob* jobs;
+    uint32_t nJobs;
+    const double* frames;
+    const FrameMeta* meta;
+    DirectHdr* hdr;
+    double2* rec;
+    double negPiOverSr, twoPiOverSr;
+};
+
+template <int MODE, int S>
+__device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool mine)
+{
+    constexpr int NR = direct_stage_res(S), NG = direct_stage_gains(S);
+    const DirectJob job = A.jobs[j];
+    const FrameMeta m = A.meta[job.frame];
+    const double nf = (double)m.fadeSamples, invF = 1.0 / nf;
+    const double ratio1 = div_by(1.0, nf, invF);
+    auto value = [&](uint32_t fr, bool gate, int p) __attribute__((always_inline)) -> double {
+        if (fr == kNoFrame || (p == 44 && gate)) return 0.0;
+        return A.frames[(size_t)fr * kNumParams + p];
+    };
+    const bool gateFrom = job.flags & 1u, gateTo = job.flags & 2u;
+    constexpr int kFirst = direct_stage_first(S), kEntries = direct_stage_entries(S);
+    double2* const out = A.rec + (size_t)kFirst * A.nJobs + (size_t)j * kEntries;
+    uint32_t bits = 0;
+#pragma unroll
+    for (int r = 0; r < NR; ++r) {
+        const int kind = direct_stage_kind(S, r);
+        const double fF = value(job.from, gateFrom, kResF[kind]), fT = value(job.to, gateTo, kResF[kind]);
+        const double bF = value(job.from, gateFrom, kResB[kind]), bT = value(job.to, gateTo, kResB[kind]);
+        const double fd = fT - fF, bd = bT - bF;
+        const bool anti = kind == 0;
+        // the fade's first sample (what fade_update / klatt_tracks evaluate there)
+        const double f1 = fF + (fd * ratio1), bw1 = bF + (bd * ratio1);
+        const RadCos p1 = coefficient_parts(f1, bw1, A.negPiOverSr, A.twoPiOverSr);
+        const Coef k1 = coefficient_finish(p1.rad, p1.cs, anti, f1);
+        // what the fade moves; the classes of its arguments (fade_classes, klatt_systolic.h: the interpolated values stay between the
+        // end points, with a margin against the one-ulp overshoot of from + (to - from) * ratio)
+        const bool bwMoves = !(bT == bF), moves = bwMoves || !(fT == fF);
+        const double xo = A.negPiOverSr * bF * kLog2e, xn = A.negPiOverSr * bT * kLog2e;
+        const double to = A.twoPiOverSr * -fF * kTwoOverPi, tn = A.twoPiOverSr * -fT * kTwoOverPi;
+        const bool eu = __builtin_fabs(xo) <= 0.499 && __builtin_fabs(xn) <= 0.499;
+        const bool c0 = __builtin_fabs(to) <= 0.499 && __builtin_fabs(tn) <= 0.499;
+        const bool c1 = to <= -0.501 && to >= -1.499 && tn <= -0.501 && tn >= -1.499;
+        bits |= (moves ? 1u << r : 0u) | (bwMoves ? 1u << (kDirectBwShift + r) : 0u) |
+                ((eu && c0) ? 0u : 1u << (kDirectClsShift + 2 * r)) | ((eu && c1) ? 0u : 2u << (kDirectClsShift + 2 * r));
+        double2 e0, e1, e2, e3;
+        if (MODE == MODE_FAST && !anti) {
+            // P_1 = 2 r_1 e^(i theta_1); per fade sample theta advances by delta = (2 pi / sr) (-(f_to - f_from) / F) and r by the
+            // factor q = exp((-pi / sr) ((bw_to - bw_from) / F)).  A fade of one sample never advances.
+            const double th1 = A.twoPiOverSr * -f1;
+            const double sn1 = fast_sin(th1);
+            const double delta = A.twoPiOverSr * -(fd * invF), lq = A.negPiOverSr * (bd * invF);
+            const bool one = m.fadeSamples <= 1u;
+            const double q = one ? 1.0 : fast_exp(lq);
+            e0 = make_double2(p1.rad * sn1 * 2.0, one ? 1.0 : q * fast_cos(delta));
+            e1 = make_double2(one ? 0.0 : q * fast_sin(delta), q * q);
+            e2 = make_double2(k1.b, k1.c);
+            e3 = make_double2(k1.a, 0.0);
+        } else {
+            e0 = make_double2(fF, fd);
+            e1 = make_double2(bF, bd);
+            e2 = make_double2(k1.b, k1.c);
+            e3 = make_double2(k1.a, p1.rad);
+        }
+        if (mine) { out[4 * r] = e0; out[4 * r + 1] = e1; out[4 * r + 2] = e2; out[4 * r + 3] = e3; }
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        const int kind = direct_stage_kind(S, NR + g);
+        const int px = shape_param(entry_value(kind, 0)), py = entry_value(kind, 1) >= 0 ? shape_param(entry_value(kind, 1)) : -1;
+        const double xF = value(job.from, gateFrom, px), xT = value(job.to, gateTo, px);
+        const double yF = py >= 0 ? value(job.from, gateFrom, py) : 0.0, yT = py >= 0 ? value(job.to, gateTo, py) : 0.0;
+        const double xd = xT - xF, yd = yT - yF;
+        const bool moves = !(xT == xF) || !(yT == yF);
+        bits |= moves ? 1u << (NR + g) : 0u;
+        const double x1 = MODE == MODE_FAST ? __builtin_fma(xd, ratio1, xF) : xF + (xd * ratio1);
+        const double y1 = MODE == MODE_FAST ? __builtin_fma(yd, ratio1, yF) : yF + (yd * ratio1);
+        if (mine) {
+            out[4 * NR + 3 * g] = make_double2(xF, xd);
+            out[4 * NR + 3 * g + 1] = make_double2(yF, yd);
+            out[4 * NR + 3 * g + 2] = make_double2(x1, y1);
+        }
+    }
+    if (mine) {
+        const unsigned long long mm = m.minSamples, ff = m.fadeSamples;
+        const unsigned long long span = (mm > ff + 1ull ? mm : ff + 1ull) + 1ull;
+        A.hdr[(size_t)S * A.nJobs + j] = DirectHdr{m.fadeSamples, (uint32_t)(span < 0xFFFFFFFFull ? span : 0xFFFFFFFFull), bits, 0u};
+    }
+}
+
+// grid (ceil(nJobs / 256), 8): blockIdx.y is the stage, so the kinds a thread loops over are block-uniform and the wave-uniform
+// short cuts of coefficient_parts ballot over full wavefronts (the last block repeats the last job in its idle lanes)
+template <int MODE>
+__global__ void __launch_bounds__(256) klatt_seeds(const SeedArgs A)
+{
+    const uint32_t jj = blockIdx.x * 256u + threadIdx.x;
+    const bool mine = jj < A.nJobs;
+    const uint32_t j = mine ? jj : A.nJobs - 1u;
+    switch (blockIdx.y) {
+    case 0: seed_stage<MODE, 0>(A, j, mine); break;
+    case 1: seed_stage<MODE, 1>(A, j, mine); break;
+    case 2: seed_stage<MODE, 2>(A, j, mine); break;
+    case 3: seed_stage<MODE, 3>(A, j, mine); break;
+    case 4: seed_stage<MODE, 4>(A, j, mine); break;
+    case 5: seed_stage<MODE, 5>(A, j, mine); break;
+    case 6: seed_stage<MODE, 6>(A, j, mine); break;
+    default: seed_stage<MODE, 7>(A, j, mine); break;
+    }
+}
+
+// ---- the polynomial kernels of klatt_math.h with their constants in SCALAR registers ------------------------------------------
+// Same operations on the same operands as exp_kernel / cos_kernel / sin_kernel (so the same bits: the tests compare the direct
+// stages' PCM with the tracked and the untracked kernels' byte for byte), spelled as v_fma_f64 with the constant as a scalar
+// operand.  Left to the compiler a Horner step `p = fma(p, z, C)` becomes `v_mov_b64 tmp, C; v_fmac_f64 tmp, p, z` -- the
+// two-address form needs the addend in the destination, and C, which lives in a VGPR pair, must survive: TWO issue slots per step
+// (a v_mov_b64 costs a wavefront what an f64 FMA costs), 130 of ~230 instructions per sample and stage in MODE_EXACT's mixed loop.
+__device__ __forceinline__ double fma_sc(double a, double b, double c)      // a * b + c, c from scalar registers
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double fma_sa(double a, double b, double c)      // a * b + c, a from scalar registers
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));
+    return d;
+}
+__device__ __forceinline__ double exp_kernel_s(double r)
+{
+    double p = fma_sa(1.6059043836821613e-10, r, 2.0876756987868100e-09);      // (1/13!) r + 1/12!: what fma(p, r, C) is with p = 1/13!
+    p = fma_sc(p, r, 2.5052108385441720e-08);
+    p = fma_sc(p, r, 2.7557319223985890e-07);
+    p = fma_sc(p, r, 2.7557319223985893e-06);
+    p = fma_sc(p, r, 2.4801587301587302e-05);
+    p = fma_sc(p, r, 1.9841269841269841e-04);
+    p = fma_sc(p, r, 1.3888888888888889e-03);
+    p = fma_sc(p, r, 8.3333333333333332e-03);
+    p = fma_sc(p, r, 4.1666666666666664e-02);
+    p = fma_sc(p, r, 1.6666666666666666e-01);
+    p = __builtin_fma(p, r, 0.5);
+    return __builtin_fma(r * r, p, r) + 1.0;
+}
+__device__ __forceinline__ double sin_kernel_s(double r, double z)
+{
+    double s = fma_sa(2.8114572543455206e-15, z, -7.6471637318198164e-13);
+    s = fma_sc(s, z, 1.6059043836821613e-10);
+    s = fma_sc(s, z, -2.5052108385441720e-08);
+    s = fma_sc(s, z, 2.7557319223985893e-06);
+    s = fma_sc(s, z, -1.9841269841269841e-04);
+    s = fma_sc(s, z, 8.3333333333333332e-03);
+    s = fma_sc(s, z, -1.6666666666666666e-01);
+    return __builtin_fma(r * z, s, r);
+}
+__device__ __forceinline__ double cos_kernel_s(double z)
+{
+    double c = fma_sa(4.7794773323873853e-14, z, -1.1470745597729725e-11);
+    c = fma_sc(c, z, 2.0876756987868100e-09);
+    c = fma_sc(c, z, -2.7557319223985890e-07);
+    c = fma_sc(c, z, 2.4801587301587302e-05);
+    c = fma_sc(c, z, -1.3888888888888889e-03);
+    c = fma_sc(c, z, 4.1666666666666664e-02);
+    return __builtin_fma(z, __builtin_fma(z, c, -0.5), 1.0);
+}
+__device__ __forceinline__ double add_sc(double a, double c)      // a + c, c from scalar registers
+{
+    double d;
+    asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double mul_sc(double a, double c)
+{
+    double d;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double cos_quadrant_m1_s(double t)
+{
+    // fma(1.0, C, t) is one rounded addition
+    double r = add_sc(t, 1.5707963267948965580e+00);
+    r = add_sc(r, 6.1232339957367660359e-17);
+    return sin_kernel_s(r, r * r);
+}
+// the general case (arguments that need a range reduction): fast_exp / fast_cos of klatt_math.h, operation for operation
+__device__ __forceinline__ double fast_exp_s(double x)
+{
+    const double k = __builtin_rint(mul_sc(x, kLog2e));
+    double r = fma_sa(-6.93147180369123816490e-01, k, x);      // fma(-k, ln2_hi, x): the product's sign is the same rounded value
+    r = fma_sa(-1.90821492927058770002e-10, k, r);
+    return __builtin_ldexp(exp_kernel_s(r), (int)k);
+}
+__device__ __forceinline__ double fast_cos_s(double t)
+{
+    const double n = __builtin_rint(mul_sc(t, kTwoOverPi));
+    double r = fma_sa(-1.5707963267948965580e+00, n, t);
+    r = fma_sa(-6.1232339957367660359e-17, n, r);
+    const double z = r * r;
+    const double sinr = sin_kernel_s(r, z);
+    const double cosr = cos_kernel_s(z);
+    const int q = (int)n & 3;
+    const double v = (q & 1) ? sinr : cosr;
+    return (q == 1 || q == 2) ? -v : v;
+}
+
+// ---- a direct stage's state ----------------------------------------------------------------------------------------------------
+template <int STAGE_>
+struct DirectDesc {
+    static constexpr int NST = kDirectStages, STAGE = STAGE_;
+    static constexpr int NRES = direct_stage_res(STAGE_), NGAIN = direct_stage_gains(STAGE_), NE = NRES + NGAIN;
+    static constexpr bool ANTI0 = direct_stage_kind(STAGE_, 0) == 0;      // the stage's first resonator is N0
+    static constexpr int ENTRIES = direct_stage_entries(STAGE_);
+};
+template <class DD>
+struct DirectState {
+    static constexpr int NR = DD::NRES > 0 ? DD::NRES : 1, NG2 = DD::NGAIN > 0 ? 2 * DD::NGAIN : 1;
+    double ra[NR], rb[NR], rc[NR], z1[NR], z2[NR];      // names as in FlatState2: the stages' sample code is written against them
+    double cur[NG2];
+    // the running fade, per resonator: MODE_EXACT (f_from, f_delta, bw_from, bw_delta, r); MODE_FAST (Im P, Re w, Im w, q^2, -)
+    double p0[NR], p1[NR], p2[NR], p3[NR], rad[NR];
+    double gf[NG2], gd[NG2];                            // per gain parameter: from, to - from
+    double nfD, invF;                                   // (double)F, 1 / F
+    uint32_t cnt, F;                                    // the fade-sample index of the values in registers; cnt == F: not fading
+    uint32_t startAt, next, nFrames, length, produced;  // startAt: the sample the next fade's first values apply to
+    uint32_t curBits;                                   // DirectHdr.bits of the running (or last) fade
+    uint32_t rec0;                                      // the record number of the utterance's first frame
+    DirectHdr nextHdr;                                  // frame `next`'s, loaded ahead
+    uint32_t touched[3];                                // what touching the next record's lines returned (direct_touch): owned until the switch
+    bool live;
+};
+struct DirectCtx {
+    const KernelArgs& A;
+    const DirectHdr* hdr;      // the stage's headers [nDirect]
+    const double2* rec;        // the stage's records
+};
+template <class DD>
+__device__ __forceinline__ void direct_init(DirectState<DD>& f, bool live, const UttDesc& d, uint32_t rec0, const DirectCtx& X)
+{
+#pragma unroll
+    for (int r = 0; r < DD::NRES; ++r) {
+        f.ra[r] = 0; f.rb[r] = 2; f.rc[r] = -1; f.z1[r] = 0; f.z2[r] = 0;      // the coefficients of f = bw = 0
+        f.p0[r] = 0; f.p1[r] = 0; f.p2[r] = 0; f.p3[r] = 0; f.rad[r] = 1.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 2 * DD::NGAIN; ++k) { f.cur[k] = 0; f.gf[k] = 0; f.gd[k] = 0; }
+    f.live = live && d.length > 0u;
+    f.nFrames = d.nFrames; f.length = d.length; f.next = 0; f.produced = 0;
+    f.cnt = 1u; f.F = 1u; f.nfD = 1.0; f.invF = 1.0; f.curBits = 0u; f.rec0 = rec0;
+    const bool any = live && d.nFrames > 0u;
+    f.startAt = any ? 1u : 0xFFFFFFFFu;      // frame 0 is dequeued on sample 0, its fade's first values apply to sample 1
+    f.nextHdr = DirectHdr{1u, 0u, 0u, 0u};
+    f.touched[0] = f.touched[1] = f.touched[2] = 0u;
+    if (any) f.nextHdr = X.hdr[rec0];
+}
+// OR over the wavefront, as a scalar
+__device__ __forceinline__ uint32_t wave_or(uint32_t v)
+{
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v |= (uint32_t)__shfl_xor((int)v, m, kLanes);
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+// Called by a stage's sample BETWEEN its two halves (the flat stages' FlatMid): the first half has read every coefficient and gain
+// of the sample; here every lane advances its fade-sample index and evaluates, for the NEXT sample, the kinds the chunk's mask
+// `wm` names; then the lanes whose next fade's first values apply to the next sample (`sw`) switch: everything of the new fade
+// comes from its record, in one block of loads that have the second half of this sample (and the SIMD's other wave) to land.
+template <class DD, int MODE>
+struct DirectMid {
+    DirectState<DD>& f;
+    const DirectCtx& X;
+    uint32_t wm;       // wave-uniform (SGPR): DirectHdr.bits OR-ed over the lanes that fade or start a fade in this chunk
+    bool sw;
+    __device__ __forceinline__ void operator()() const
+    {
+        const KernelArgs& A = X.A;
+        // ONE masked block for the lanes inside a fade (a lane that is not keeps what it has: the fade's last values, as the reference
+        // does until the next fade's first sample); skipped altogether on a sample on which no lane of the wavefront fades
+        if (f.cnt < f.F) {
+            const uint32_t cn = f.cnt + 1u;
+            f.cnt = cn;
+            // ratio = (double)counter / numFadeSamples, correctly rounded (reference src/frame.cpp:49) -- in MODE_FAST too: the last sample
+            // of a fade must land on its target EXACTLY where the reference tests a parameter for a value (`frequency != 0` decides whether
+            // N0 is inverted, src/speechWaveGenerator.cpp:122: with counter * (1 / F) = 1 - 1e-16 a target of 0 Hz arrives as 1e-14 Hz)
+            const double ratio = div_by((double)cn, f.nfD, f.invF);
+#pragma unroll
+            for (int r = 0; r < DD::NRES; ++r) {
+                if (!(wm & (1u << r))) continue;                       // scalar branch
+                const bool anti = DD::ANTI0 && r == 0;
+                const uint32_t cls = (wm >> (kDirectClsShift + 2 * r)) & 3u;
+                if (MODE == MODE_FAST && !anti) {
+                    // P <- P w, r^2 <- r^2 q^2: rb = Re P, p0 = Im P, (p1, p2) = w, rc = -r^2, p3 = q^2
+                    const double re = __builtin_fma(-f.p0[r], f.p2[r], f.rb[r] * f.p1[r]);
+                    const double im = __builtin_fma(f.rb[r], f.p2[r], f.p0[r] * f.p1[r]);
+                    const double c = f.rc[r] * f.p3[r];
+                    f.rb[r] = re; f.p0[r] = im; f.rc[r] = c;
+                    f.ra[r] = (1.0 - re) - c;
+                } else {
+                    const double fr = f.p0[r] + (f.p1[r] * ratio);      // reference src/utils.h:22
+                    const double th = A.twoPiOverSr * -fr;
+                    const double cs = !(cls & 1u) ? cos_kernel_s(th * th) : (!(cls & 2u) ? cos_quadrant_m1_s(th) : fast_cos_s(th));
+                    if (wm & (1u << (kDirectBwShift + r))) {
+                        const double bw = f.p2[r] + (f.p3[r] * ratio);
+                        const double ex = A.negPiOverSr * bw;
+                        f.rad[r] = cls != 3u ? exp_kernel_s(ex) : fast_exp_s(ex);
+                    }
+                    const Coef k = coefficient_finish(f.rad[r], cs, anti, fr);      // reference src/speechWaveGenerator.cpp:117-126
+                    f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < DD::NGAIN; ++g) {
+                if (!(wm & (1u << (DD::NRES + g)))) continue;
+                if (MODE == MODE_FAST) {
+                    f.cur[2 * g] = __builtin_fma(f.gd[2 * g], ratio, f.gf[2 * g]);
+                    f.cur[2 * g + 1] = __builtin_fma(f.gd[2 * g + 1], ratio, f.gf[2 * g + 1]);
+                } else {
+                    f.cur[2 * g] = f.gf[2 * g] + (f.gd[2 * g] * ratio);
+                    f.cur[2 * g + 1] = f.gf[2 * g + 1] + (f.gd[2 * g + 1] * ratio);
+                }
+            }
+        }
+        if (sw) {
+            const DirectHdr h = f.nextHdr;
+            const double2* const rec = X.rec + (size_t)(f.rec0 + f.next) * DD::ENTRIES;
+#if !(KLATT_DIRECT_EXP & 1)
+#pragma unroll
+            for (int r = 0; r < DD::NRES; ++r) {
+                const double2 e0 = rec[4 * r], e1 = rec[4 * r + 1], e2 = rec[4 * r + 2], e3 = rec[4 * r + 3];
+                f.p0[r] = e0.x; f.p1[r] = e0.y; f.p2[r] = e1.x; f.p3[r] = e1.y;
+                f.rb[r] = e2.x; f.rc[r] = e2.y; f.ra[r] = e3.x;
+                if (MODE != MODE_FAST || (DD::ANTI0 && r == 0)) f.rad[r] = e3.y;
+            }
+#pragma unroll
+            for (int g = 0; g < DD::NGAIN; ++g) {
+                const double2 e0 = rec[4 * DD::NRES + 3 * g], e1 = rec[4 * DD::NRES + 3 * g + 1], e2 = rec[4 * DD::NRES + 3 * g + 2];
+                f.gf[2 * g] = e0.x; f.gd[2 * g] = e0.y; f.gf[2 * g + 1] = e1.x; f.gd[2 * g + 1] = e1.y;
+                f.cur[2 * g] = e2.x; f.cur[2 * g + 1] = e2.y;
+            }
+#endif
+            f.cnt = 1u; f.F = h.fadeSamples; f.curBits = h.bits;
+            f.nfD = (double)h.fadeSamples; f.invF = 1.0 / f.nfD;
+            f.next++;
+            const bool more = f.next < f.nFrames;
+            f.startAt = more ? f.startAt + h.span : 0xFFFFFFFFu;
+            f.nextHdr = X.hdr[f.rec0 + (more ? f.next : f.nFrames - 1u)];      // (past the last frame: any valid header; never used)
+            // Everything loaded is waited for HERE, inside the block that only switching lanes enter (its record's lines were touched a
+            // chunk or more ago: they come from the L2): left to the compiler, the waits sit at the first uses -- on every sample of the
+            // loop, where they also wait for the touches of the NEXT records, at the full latency of HBM.
+#pragma unroll
+            for (int r = 0; r < DD::NRES; ++r) { flat_pin(f.p0[r]); flat_pin(f.p1[r]); flat_pin(f.p2[r]); flat_pin(f.p3[r]); flat_pin(f.rb[r]); flat_pin(f.rc[r]); flat_pin(f.ra[r]); flat_pin(f.rad[r]); }
+#pragma unroll
+            for (int k = 0; k < 2 * DD::NGAIN; ++k) { flat_pin(f.gf[k]); flat_pin(f.gd[k]); flat_pin(f.cur[k]); }
+            flat_pin(f.touched[0]); flat_pin(f.touched[1]); flat_pin(f.touched[2]);
+        }
+    }
+};
+
+// The chunk's mask: what the lanes that fade, or start a fade, in samples t0 + 1 .. t1 + 1 move, and the classes of their arguments.
+// A lane whose next TWO fades start inside the chunk (frames of a few samples) asks for everything.
+template <class DD>
+__device__ __forceinline__ uint32_t direct_chunk_mask(const DirectState<DD>& f, uint32_t t1)
+{
+    uint32_t lb = 0;
+    if (f.cnt < f.F) lb |= f.curBits;
+    if (f.startAt <= t1) {
+        lb |= f.nextHdr.bits;
+        if (f.nextHdr.span <= t1 - f.startAt) lb |= kDirectAllBits;
+    }
+    return (KLATT_DIRECT_EXP & 2) ? 0u : wave_or(lb);
+}
+// Lanes whose next fade starts 9 .. 8 + CH samples after the end of this chunk touch its record's lines now (one dword per 128-byte
+// line), so that the switch finds them in the L2 instead of waiting for HBM inside its block.  The dwords land in registers that
+// stay theirs until that switch names them (flat_pin above): a load whose result nobody owns may arrive in a register that has
+// been given to something else by then (a first version loaded into a scratch register from inline assembly: right PCM in small
+// batches, a different digest from run to run at 65 536 utterances).  Plain loads: a `volatile` one compiles to a system-scope
+// flat load with a wait right behind it.
+template <class DD, int CH>
+__device__ __forceinline__ void direct_touch(DirectState<DD>& f, const DirectCtx& X, uint32_t t1)
+{
+#if KLATT_DIRECT_TOUCH
+    const bool soon = f.startAt - t1 - 9u < (uint32_t)CH;      // (0xFFFFFFFF: no further fade)
+    if (soon) {
+        const uint32_t* p = reinterpret_cast<const uint32_t*>(X.rec + (size_t)(f.rec0 + f.next) * DD::ENTRIES);
+        constexpr int kDwords = DD::ENTRIES * 4;
+        f.touched[0] = p[0];
+        if (kDwords > 32) f.touched[1] = p[32];
+        f.touched[2] = p[kDwords - 1];
+    }
+#endif
+}
+
+// body(c, i, mid): one sample of the stage; barrier discipline of flat2_loop (klatt_systolic.h)
+template <class DD, int MODE, int CH, class FBody, class FChunk>
+__device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, int stampSlot, DirectState<DD>& f, const DirectCtx& X, FBody body, FChunk perChunk)
+{
+#ifdef KLATT_STAMPS
+    Stamps st;
+#endif
+    for (int iter = 0; iter < nIter; ++iter) {
+        STAMP_BEGIN();
+        STAMP_IDLE();
+        const int c = iter - depth;
+        if (c >= 0 && c < nChunks) {
+            const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
+            if (f.length <= t0) f.live = false;                               // this lane has emitted its last sample
+            // a chunk is steady when no lane evaluates anything in it: none fading, no fade whose first values apply to t0 + 1 .. t1
+            const bool busy = f.cnt < f.F || f.startAt <= t1;
+            if (!__any(busy)) {
+                // decided once: the chunks until some live lane's next fade comes into reach run in a tight loop
+                uint32_t run = f.live ? (f.startAt - t0 - 1u) / (uint32_t)CH : 0xFFFFFFFFu;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
+                run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                const uint32_t room = (uint32_t)(nChunks - c);
+                run = run < room ? run : room;
+                run = run < 1u ? 1u : run;
+                int cc = c;
+                STAMP_KIND(0);
+                for (uint32_t q = 0; q < run; ++q) {
+                    if (f.live) {
+#pragma unroll KLATT_DIRECT_STEADY_UNROLL
+                        for (int i = 0; i < CH; ++i) body(cc, i, NoMid{});
+                    }
+                    { const uint32_t e1 = (uint32_t)(cc + 1) * (uint32_t)CH; f.produced = f.length < e1 ? f.length : e1; }
+                    perChunk();
+                    direct_touch<DD, CH>(f, X, (uint32_t)(cc + 1) * (uint32_t)CH);
+                    if (q + 1 < run) {
+                        STAMP_WORKED();
+                        __syncthreads();
+                        STAMP_SYNCED();
+                        STAMP_BEGIN();
+                        ++iter; ++cc;
+                    }
+                }
+            } else {
+                STAMP_KIND(-1);
+                const uint32_t wm = direct_chunk_mask<DD>(f, t1);
+#pragma unroll KLATT_DIRECT_UNROLL
+                for (int i = 0; i < CH; ++i) {
+                    const bool sw = t0 + (uint32_t)i + 1u == f.startAt;
+                    body(c, i, DirectMid<DD, MODE>{f, X, wm, sw});
+                }
+                f.produced = f.length < t1 ? f.length : t1;
+                perChunk();
+                direct_touch<DD, CH>(f, X, t1);
+            }
+        }
+        STAMP_WORKED();
+        __syncthreads();
+        STAMP_SYNCED();
+    }
+#ifdef KLATT_STAMPS
+    if (X.A.debug && (threadIdx.x & (kLanes - 1)) == 0) {
+        unsigned long long* o = X.A.debug + (blockIdx.x * DD::NST + stampSlot) * 8;
+        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
+    }
+#endif
+    (void)stampSlot;
+}
+
+
+// sin() of the vibrato (reference src/speechWaveGenerator.cpp:77), out of line: inlined, the device library's sine brings its two dozen
+// constants and its temporaries into the source stage's sample loop, which runs it for the rare utterance with vibrato only
+#ifndef KLATT_DIRECT_VIB_CALL
+#define KLATT_DIRECT_VIB_CALL 1
+#endif
+#if KLATT_DIRECT_VIB_CALL
+__device__ __attribute__((noinline)) double direct_vib_sin(double x) { return sin(x); }
+#else
+__device__ __forceinline__ double direct_vib_sin(double x) { return sin(x); }
+#endif
+
+// ---- the source stage (T0; with HEAD it would run N0 and NP as well: the 4-stage census of DESIGN.md) ------------------------------
+// The pitch glides with the sample count of THIS utterance (reference src/frame.cpp:76-79, :98, :71): per sample a lane is
+// dequeuing (sets up the pitch fade; the sample itself is emitted unchanged), fading (pitch interpolated), ending its fade
+// or steady (glide) -- the flat source stage's selects (klatt_systolic.h).  What a dequeue reads (the frame's two pitch values,
+// index mark) is a SourceRef loaded when the previous frame was dequeued.  CB: f.cur[CB + k] = vibratoPitchOffset, vibratoSpeed,
+// turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain.
+template <class DD, int MODE, int CH, int CB, bool HEAD>
+__device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const UttDesc& d, bool live, uint32_t u, uint32_t rec0, const DirectCtx& X, int lane,
+                                                    int nIter, int nChunks, double* pipeOut, uint32_t nkey, uint32_t ninc, uint32_t ninc2)
+{
+#define SRC_PIPE(c, i) pipeOut[(((c) & 1) * CH + (i)) * kLanes + lane]
+    DirectState<DD> f;
+    direct_init<DD>(f, live, d, rec0, X);
+    const SourceRef* const mySrc = A.sourceRef + d.frameStart;
+    PitchState ps;
+    ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
+    double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, invFade = 1.0, nfD = 1.0;
+    uint32_t noiseSt = noise_first(nkey, ninc), cntF = 0, nfU = 0;    // aspiration: noise values 0, 2, 4, ...; cntF of nfU pitch-fade samples done
+    uint32_t fadeEndAt = 0xFFFFFFFFu;
+    int32_t lastIndex = -1;
+    bool oldNull = true, newNull = false;
+    SourceRef nextSrc{0.0, 0.0, 1.0, -1, 0u};     // frame `f.next`, loaded ahead like f.nextHdr
+    if (live && d.nFrames > 0u) nextSrc = mySrc[0];
+    auto source = [&](bool waveVib, const auto& mid) __attribute__((always_inline)) -> double {
+        double vib = 1.0;
+        if (waveVib) {
+            const double vs = f.cur[CB + 1];
+            const double adv = frac_toward_zero(div_by(vs, A.sampleRateF, A.invSampleRate) + vibPhase);
+            vibPhase = (vs != 0.0) ? adv : vibPhase;
+            vib = (direct_vib_sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[CB + 0]) + 1.0;
+        }
+        const double turbGain = f.cur[CB + 2], openQ = f.cur[CB + 3], voiceAmp = f.cur[CB + 4], aspAmp = f.cur[CB + 5], preGain = f.cur[CB + 6];
+        pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
+        double voice = (pitchPhase * 2.0) - 1.0;
+        aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
+        noiseSt = noise_step2(noiseSt, ninc2);
+        double asp = aspNoise * 0.2;
+        double turb = asp * turbGain;
+        turb = (pitchPhase >= openQ) ? turb : turb * 0.01;
+        voice += turb;
+        voice *= voiceAmp;
+        asp *= aspAmp;
+        const double src = asp + voice;
+        double out = (src * preGain) * 0.5;
+        if constexpr (HEAD) {
+            // N0 (anti), NP mixed in by caNP (reference src/speechWaveGenerator.cpp:149-152)
+            const double n0 = dot3<MODE>(f.ra[0], out, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
+            f.z2[0] = f.z1[0]; f.z1[0] = out;                              // the anti-resonator remembers its INPUT (reference :133)
+            const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
+            out = fade_value(out, np, f.cur[0]);
+        }
+        mid();      // the next sample's values: every parameter of this one has been used
+        return out;
+    };
+    auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[CB + 0] != 0.0 || f.cur[CB + 1] != 0.0 || vibPhase != vibPhase; };
+#ifdef KLATT_STAMPS
+    Stamps st;
+#endif
+    for (int iter = 0; iter < nIter; ++iter) {
+        STAMP_BEGIN();
+        STAMP_IDLE();
+        const int c = iter;
+        if (c < nChunks) {
+            const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
+            if (f.length <= t0) f.live = false;
+            const bool busy = f.cnt < f.F || f.startAt <= t1 || cntF < nfU || fadeEndAt < t1 || vib_live();
+            STAMP_KIND(__any(busy) ? -1 : 0);
+            if (!__any(busy)) {
+                // steady stretch, decided once: the pitch glides, nothing else changes
+                uint32_t run = f.live ? (f.startAt - t0 - 1u) / (uint32_t)CH : 0xFFFFFFFFu;
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) { const uint32_t o = (uint32_t)__shfl_xor((int)run, m, kLanes); run = o < run ? o : run; }
+                run = (uint32_t)__builtin_amdgcn_readfirstlane((int)run);
+                const uint32_t room = (uint32_t)(nChunks - c);
+                run = run < room ? run : room;
+                run = run < 1u ? 1u : run;
+                int cc = c;
+                for (uint32_t q = 0; q < run; ++q) {
+                    if (f.live) {
+#pragma unroll KLATT_DIRECT_STEADY_UNROLL
+                        for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; SRC_PIPE(cc, i) = source(false, NoMid{}); }
+                        ps.old0 = ps.cur0;
+                    }
+                    direct_touch<DD, CH>(f, X, (uint32_t)(cc + 1) * (uint32_t)CH);
+                    if (q + 1 < run) { STAMP_WORKED(); __syncthreads(); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; }
+                }
+            } else {
+                const uint32_t wm = direct_chunk_mask<DD>(f, t1);
+                // vibrato can only come alive in this chunk through its kind (the phase only turns NaN while it advances)
+                const bool vibChunk = (wm & (1u << (DD::NRES + CB / 2))) != 0u || __any(vib_live());
+#pragma unroll KLATT_DIRECT_UNROLL
+                for (int i = 0; i < CH; ++i) {
+                    const uint32_t t = t0 + (uint32_t)i;
+                    const bool deq = t + 1u == f.startAt;
+                    if (deq) {   // reference src/frame.cpp:55-72; the sample itself is emitted as it is
+                        const SourceRef m = nextSrc;
+                        const uint32_t nf = f.nextHdr.fadeSamples;
+                        newNull = (m.flags & FRAME_NULL) != 0;
+                        ps.new0 = newNull ? ps.cur0 : m.pitch;
+                        ps.newInc = newNull ? 0.0 : m.pitchInc;                // reference src/frame.cpp:98 (the division: host)
+                        if (!newNull && oldNull) ps.old0 = m.pitch;
+                        oldNull = newNull;                                    // for the NEXT dequeue: this fade has ended by then (:44-47)
+                        if (m.userIndex != -1) lastIndex = m.userIndex;       // (:69)
+                        nfD = (double)nf; nfU = nf;
+                        ps.new0 += ps.newInc * nfD;                           // (:71)
+                        invFade = m.invFade;
+                        cntF = 0;
+                        fadeEndAt = t + nf + 1u;
+                        nextSrc = mySrc[f.next + 1u < f.nFrames ? f.next + 1u : f.nFrames - 1u];
+                    }
+                    // the pitch of this sample, as selects: fading -> interpolated; the sample after the fade -> the fade's target becomes
+                    // the glide's start; steady -> glide (reference src/frame.cpp:48-53, :44-47, :76-79); a dequeuing lane leaves it alone
+                    const bool fad = !deq && cntF < nfU;
+                    const bool ending = !deq && !fad && t == fadeEndAt;
+                    const bool glide = !deq && !fad && !ending;
+                    const uint32_t cn = cntF + 1u;
+                    const double ratio = div_by((double)cn, nfD, invFade);
+                    const double fv = fade_value(ps.old0, ps.new0, ratio);
+                    const double gv = ps.cur0 + ps.oldInc;
+                    ps.cur0 = fad ? fv : (glide ? gv : ps.cur0);
+                    ps.old0 = ending ? ps.new0 : (glide ? gv : ps.old0);
+                    ps.oldInc = ending ? ps.newInc : ps.oldInc;
+                    cntF = fad ? cn : cntF;
+                    fadeEndAt = ending ? 0xFFFFFFFFu : fadeEndAt;
+                    const bool waveVib = vibChunk && __any(vib_live());
+                    SRC_PIPE(c, i) = source(waveVib, DirectMid<DD, MODE>{f, X, wm, deq});
+                }
+                direct_touch<DD, CH>(f, X, t1);
+            }
+        }
+        STAMP_WORKED();
+        __syncthreads();
+        STAMP_SYNCED();
+    }
+#ifdef KLATT_STAMPS
+    if (A.debug && lane == 0) {
+        unsigned long long* o = A.debug + (blockIdx.x * DD::NST + 0) * 8;
+        o[0] = st.work; o[1] = st.wait; o[2] = st.n[0]; o[3] = st.n[1]; o[4] = st.n[2]; o[5] = st.c[0]; o[6] = st.c[1]; o[7] = st.c[2];
+    }
+#endif
+    if (live) {
+        UttResult res;
+        res.produced = d.length; res.framesTaken = f.next; res.lastIndex = lastIndex; res.drained = 1u;
+        A.result[u] = res;
+    }
+#undef SRC_PIPE
+}
+
+// ---- the kernel: 8 wavefronts = 8 direct stages over the same 64 utterances ----------------------------------------------------
+// Pipes [2 buffers][CH][64 lanes] f64, one workgroup barrier per chunk, a stage of depth d on chunk iter - d (klatt_systolic.h):
+//   T0 --x0--> T1 --x1--> T2 --x2--> T3 --x3--> T4 --o--> T7          depths 0 1 2 3 4 . . 5
+//   T5 --(y, part)--> T6 --(y, part)--> T7                            depths 3 4 5   (T5 has no input: it starts three chunks late)
+template <int CH>
+struct DirectLds {
+    static constexpr int kPipeBytes = 2 * CH * kLanes * 8;
+    static constexpr int kNumPipes = 9;
+    static constexpr int kTileOff = kNumPipes * kPipeBytes;
+    static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
+    static constexpr int kRowCount = kRowBase + kLanes * 8;
+    static constexpr int kMaxLen = kRowCount + kLanes * 4;
+    static constexpr int kBytes = kMaxLen + 32;      // (longest utterance; waves per SIMD) CH = 16: 152 864 B: one workgroup per CU
+};
+// WPE: wavefronts per SIMD the register budget is set for (2: one workgroup per CU, 256 VGPRs; 4: two, 128)
+template <int MODE, int CH, int WPE>
+__global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs A)
+{
+    using L = DirectLds<CH>;
+    constexpr int kChunk = CH;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    auto pipe = [&](int k) __attribute__((always_inline)) { return reinterpret_cast<double*>(lds + k * L::kPipeBytes); };
+    double* const pipeX0 = pipe(0); double* const pipeX1 = pipe(1); double* const pipeX2 = pipe(2); double* const pipeX3 = pipe(3);
+    double* const pipeO = pipe(4); double* const pipeY = pipe(5); double* const pipeP = pipe(6); double* const pipeY2 = pipe(7); double* const pipeP2 = pipe(8);
+    unsigned char* const tile = lds + L::kTileOff;
+    long long* const rowBase = reinterpret_cast<long long*>(lds + L::kRowBase);
+    uint32_t* const rowCount = reinterpret_cast<uint32_t*>(lds + L::kRowCount);
+    uint32_t* const maxLenP = reinterpret_cast<uint32_t*>(lds + L::kMaxLen);
+
+    const int lane = threadIdx.x & (kLanes - 1);
+    const long long slot = (long long)blockIdx.x * kLanes + lane;
+    const uint32_t u = (slot < A.nSlots) ? A.order[slot] : 0xFFFFFFFFu;
+    const bool live = (u != 0xFFFFFFFFu);
+
+    UttDesc d;
+    d.frameStart = 0; d.outStart = 0; d.nFrames = 0; d.seed = 0; d.flags = 0; d.length = 0;
+    uint32_t rec0 = 0;
+    if (live) { d = A.utt[u]; rec0 = A.directFirst[u]; }
+    const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed), ninc2 = noise_inc2(ninc);
+    constexpr int FINAL = 7;
+
+    // Which wave runs which stage.  The eight waves of the workgroup sit two to a SIMD, and a SIMD issues for one of them at a time:
+    // what bounds a sample-step is the pair of stages with the most instructions between them.  So a wave takes its stage from the
+    // SIMD it finds itself on (HW_REG_HW_ID) and its rank among the workgroup's waves there, pairing a heavy stage with a light one
+    // (kPairs, by arithmetic mode: the stamps of tools/direct_stamps.py); if the hardware placed the waves otherwise than two per SIMD,
+    // stage = wave index (any bijection is correct -- the waves are interchangeable until they pick a stage).
+    uint32_t* const simdCount = maxLenP + 4;
+    if (threadIdx.x < 5) maxLenP[threadIdx.x < 1 ? 0 : threadIdx.x + 3] = 0;
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    int stage = wave;
+#if KLATT_DIRECT_PAIRING
+    {
+        const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
+        const uint32_t simd = (hw >> 4) & 3u;
+        uint32_t rank = 0;
+        if (lane == 0) rank = atomicAdd(&simdCount[simd], 1u);
+        rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
+        __syncthreads();
+        const bool two = simdCount[0] == 2u && simdCount[1] == 2u && simdCount[2] == 2u && simdCount[3] == 2u;
+        // heavy with light: MODE_FAST T1 + T2 | T0 + T3 | T5 + T4 | T7 + T6;  MODE_EXACT T7 + T2 | T5 + T3 | T1 + T4 | T6 + T0
+        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = {7, 2, 5, 3, 1, 4, 6, 0};
+        const int key = (int)(simd * 2u + (rank & 1u));
+        int pick = wave;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) if (key == k) pick = MODE == MODE_FAST ? kPairsFast[k] : kPairsExact[k];
+        stage = __builtin_amdgcn_readfirstlane(two ? pick : wave);
+    }
+#endif
+    if (wave == 0) atomicMax(maxLenP, d.length);
+    __syncthreads();
+    if (stage == FINAL) { rowBase[lane] = d.outStart; rowCount[lane] = 0; }   // read by this wave only
+    const uint32_t maxLen = *maxLenP;
+    const int nChunks = (int)((maxLen + kChunk - 1) / kChunk);
+    const int nIter = nChunks + 5;   // the final stage lags 5 chunks; same trip count in every wave
+#define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
+    auto noChunk = [&]() __attribute__((always_inline)) {};
+    auto ctx = [&](auto stageTag) __attribute__((always_inline)) {
+        constexpr int S = decltype(stageTag)::value, kFirst = direct_stage_first(S);
+        return DirectCtx{A, A.directHdr + (size_t)S * A.nDirect, A.directRec + (size_t)kFirst * A.nDirect};
+    };
+
+    if (stage == 0 && (KLATT_DIRECT_STAGES & 1)) {
+        // ================= T0: glottal source + aspiration noise =================
+        using DD = DirectDesc<0>;      // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain, -
+        const DirectCtx X = ctx(std::integral_constant<int, 0>{});
+        direct_source_stage<DD, MODE, CH, 0, false>(A, d, live, u, rec0, X, lane, nIter, nChunks, pipeX0, nkey, ninc, ninc2);
+    } else if (stage == 1 && (KLATT_DIRECT_STAGES & 2)) {
+        // ================= T1: N0 (anti), NP mixed in by caNP (reference src/speechWaveGenerator.cpp:149-152) =================
+        using DD = DirectDesc<1>;      // cur: caNP, -
+        const DirectCtx X = ctx(std::integral_constant<int, 1>{});
+        DirectState<DD> f;
+        direct_init<DD>(f, live, d, rec0, X);
+        direct_loop<DD, MODE, CH>(1, nIter, nChunks, stage, f, X,
+            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
+                const double x = PIPE(pipeX0, c, i);
+                const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
+                f.z2[0] = f.z1[0]; f.z1[0] = x;                              // the anti-resonator remembers its INPUT (reference :133)
+                const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
+                PIPE(pipeX1, c, i) = fade_value(x, np, f.cur[0]);
+                mid();      // the next sample's values: every coefficient and gain of this one has been used
+            },
+            noChunk);
+    } else if (stage >= 2 && stage <= 4 && (KLATT_DIRECT_STAGES & 4)) {
+        // ================= T2, T3, T4: two resonators of the cascade each (r6 r5 | r4 r3 | r2 r1) =================
+        auto pair = [&](auto stageTag, double* pin, double* pout) __attribute__((always_inline)) {
+            constexpr int ST = decltype(stageTag)::value;
+            using DD = DirectDesc<ST>;
+            const DirectCtx X = ctx(stageTag);
+            DirectState<DD> f;
+            direct_init<DD>(f, live, d, rec0, X);
+                direct_loop<DD, MODE, CH>(ST, nIter, nChunks, stage, f, X,
+                [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
+                    double o = PIPE(pin, c, i);
+                    o = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], o);
+                    o = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], o);
+                    PIPE(pout, c, i) = o;
+                    mid();
+                },
+                noChunk);
+        };
+        if (stage == 2) pair(std::integral_constant<int, 2>{}, pipeX1, pipeX2);
+        else if (stage == 3) pair(std::integral_constant<int, 3>{}, pipeX2, pipeX3);
+        else pair(std::integral_constant<int, 4>{}, pipeX3, pipeO);
+    } else if (stage == 5 && (KLATT_DIRECT_STAGES & 8)) {
+        // ================= T5: frication noise, parallel 1, 2 =================
+        using DD = DirectDesc<5>;      // cur: fricationAmplitude, preFormantGain, pa1, pa2
+        const DirectCtx X = ctx(std::integral_constant<int, 5>{});
+        DirectState<DD> f;
+        direct_init<DD>(f, live, d, rec0, X);
+        double fricNoise = 0;
+        uint32_t noiseSt = noise_step(noise_first(nkey, ninc), ninc);     // frication: noise values 1, 3, 5, ...
+        direct_loop<DD, MODE, CH>(3, nIter, nChunks, stage, f, X,
+            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
+                fricNoise = noise_uniform(noiseSt) + 0.75 * fricNoise;
+                noiseSt = noise_step2(noiseSt, ninc2);
+                const double fric = fricNoise * 0.3 * f.cur[0];
+                const double y = (fric * f.cur[1]) * 0.5;
+                double par = 0;
+                double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
+                par += (w - y) * f.cur[2];
+                w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
+                par += (w - y) * f.cur[3];
+                PIPE(pipeY, c, i) = y; PIPE(pipeP, c, i) = par;
+                mid();
+            },
+            noChunk);
+    } else if (stage == 6 && (KLATT_DIRECT_STAGES & 16)) {
+        // ================= T6: parallel 3, 4 (the sum continues in the reference's order; y travels on) =================
+        using DD = DirectDesc<6>;      // cur: pa3, pa4
+        const DirectCtx X = ctx(std::integral_constant<int, 6>{});
+        DirectState<DD> f;
+        direct_init<DD>(f, live, d, rec0, X);
+        direct_loop<DD, MODE, CH>(4, nIter, nChunks, stage, f, X,
+            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
+                const double y = PIPE(pipeY, c, i);
+                double par = PIPE(pipeP, c, i);
+                double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
+                par += (w - y) * f.cur[0];
+                w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
+                par += (w - y) * f.cur[1];
+                PIPE(pipeY2, c, i) = y; PIPE(pipeP2, c, i) = par;
+                mid();
+            },
+            noChunk);
+    } else if (stage == FINAL && (KLATT_DIRECT_STAGES & 32)) {
+        // ================= T7: parallel 5, 6, bypass | cascade + parallel, gain, clip, int16 -> PCM =================
+        using DD = DirectDesc<7>;      // cur: pa5, pa6, parallelBypass, outputGain
+        const DirectCtx X = ctx(std::integral_constant<int, 7>{});
+        DirectState<DD> f;
+        direct_init<DD>(f, live, d, rec0, X);
+        int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
+        uint32_t it = 0;
+        auto flush_tile = [&](uint32_t tileStart, uint32_t validTo) __attribute__((always_inline)) {
+            rowCount[lane] = f.produced;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave alone owns the tile: wave-level ordering is enough
+            constexpr int kChunksPerRow = kTile / 8;
+            constexpr int kRowsPerPass = kLanes / kChunksPerRow;
+            constexpr int kPasses = kLanes / kRowsPerPass;
+            const int chunk = lane % kChunksPerRow;
+            const uint32_t first = tileStart + (uint32_t)chunk * 8u;
+            uint2 lo[kPasses], hi[kPasses];
+            uint32_t cnt[kPasses];
+            long long base[kPasses];
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                const int row = p * kRowsPerPass + lane / kChunksPerRow;
+                const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
+                lo[p] = src[0]; hi[p] = src[1];
+                cnt[p] = rowCount[row];
+                base[p] = rowBase[row];
+            }
+#pragma unroll
+            for (int p = 0; p < kPasses; ++p) {
+                if (cnt[p] > first && first < validTo) {
+                    uint4* dst = reinterpret_cast<uint4*>(A.pcm + base[p] + first);
+                    *dst = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        };
+        direct_loop<DD, MODE, CH>(5, nIter, nChunks, stage, f, X,
+            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
+                const double o = PIPE(pipeO, c, i);
+                const double y = PIPE(pipeY2, c, i);
+                double par = PIPE(pipeP2, c, i);
+                double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
+                par += (w - y) * f.cur[0];
+                w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
+                par += (w - y) * f.cur[1];
+                par = fade_value(par, y, f.cur[2]);
+                const double mix = o + par;
+                const double v = (mix * f.cur[3]) * 4000.0;
+                const double lo = (v < 32000.0) ? v : 32000.0;       // windows.h min(): NaN -> 32000
+                const double cl = (lo > -32000.0) ? lo : -32000.0;
+                myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (reference :208)
+                mid();
+            },
+            [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
+        if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
+    } else {
+        // (register census builds, KLATT_DIRECT_STAGES: a stage left out still takes part in every barrier)
+        for (int iter = 0; iter < nIter; ++iter) __syncthreads();
+    }
+#undef PIPE
+}
+
+}  // namespace klatt

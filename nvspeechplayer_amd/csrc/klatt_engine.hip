@@ -13,6 +13,7 @@
 #include "klatt_systolic.h"
 #include "klatt_lanepipe.h"
 #include "klatt_tracks.h"
+#include "klatt_direct.h"
 
 #include <algorithm>
 #include <cmath>
@@ -219,6 +220,28 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     return 0;
 }
 
+// the direct stages (klatt_direct.h): eight wavefronts per workgroup, one workgroup per CU (152 KB of pipes)
+int launch_direct(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
+{
+    if (nGroups <= 0) return 0;
+    if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
+    constexpr int ldsBytes = DirectLds<16>::kBytes;
+    auto go = [&](auto kernel) -> int {
+        if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
+        hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kDirectStages), ldsBytes, stream, a);
+        return 0;
+    };
+    int rc;
+    switch (mode) {
+    case MODE_EXACT: rc = go(klatt_direct<MODE_EXACT, 16, 2>); break;
+    case MODE_FAST: rc = go(klatt_direct<MODE_FAST, 16, 2>); break;
+    default: set_error("unknown arithmetic mode %d", mode); return -1;
+    }
+    if (rc) return rc;
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 #ifndef KLATT_LP_CH
 #define KLATT_LP_CH 32     // hand-over size of the lane-pipelined kernel with one workgroup per CU
 #endif
@@ -319,13 +342,17 @@ struct Batch {
     hipStream_t stream = nullptr;
     int tracks = 1;                        // 1: noisy utterances with finite parameters run on flat stages fed by tracks (klatt_tracks.h)
     long long trackBudgetMB = 4096;        // the tracks of a batch may take this much device memory (at most 4 GB: the flat stages address them with 32-bit byte offsets); utterances beyond it run untracked
-    hipStream_t side[4] = {nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
-    hipEvent_t forkEvent = nullptr, join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
+    hipEvent_t forkEvent = nullptr, join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     long long nUtt = 0, nFrames = 0, nSlots = 0;
     long long nQuiet = 0;                  // order[0..nQuiet) = utterances without noise, the rest with
     long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with tracks (slots: utterances + padding)
     long long nTrackedUtt = 0;             // the utterances among them
     long long nJobs = 0, trackEntries = 0; // distinct tracks of the batch, their entries (16 B each)
+    int direct = 1;                        // noisy utterances with finite, bounded parameters and no tracks: 1 the direct stages (klatt_direct.h) unless their
+                                           // lanes are time-aligned (setUtterances), 2 the direct stages always, 0 the stages with the frame state machine
+    long long nDirect = 0;                 // order[nQuiet + nTracked .. + nDirect) = such utterances (slots)
+    long long nDirectUtt = 0, nDirectFrames = 0;
     long long nNoNasal = 0;                // order[0..nNoNasal) = quiet utterances that never couple the nasal pair (UTT_NO_NASAL)
     long long totalSamples = 0, poolSamples = 0;
     std::vector<uint32_t> lens;
@@ -343,6 +370,10 @@ struct Batch {
     DeviceBuffer<TrackJob> dJobs;
     DeviceBuffer<double> dShapes;              // [nShapes][kShapeStride]
     DeviceBuffer<double2> dTrack;
+    DeviceBuffer<DirectJob> dDirectJobs;       // [nDirectFrames] the end points of every direct frame's fade (host walk of reference src/frame.cpp:55-72)
+    DeviceBuffer<uint32_t> dDirectFirst;       // [nUtt] record number of an utterance's first frame
+    DeviceBuffer<DirectHdr> dDirectHdr;        // [8][nDirectFrames] written by klatt_seeds in every launch
+    DeviceBuffer<double2> dDirectRec;          // [kDirectEntries][nDirectFrames]
     DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
     DeviceBuffer<unsigned long long> dDigest;  // per-utterance digests (speechPlayer_batch_digest)
@@ -665,7 +696,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
 
 // Timing-only experiment switches (KLATT_EXP & 1 / & 4 in klatt_systolic.h, KLATT_LP_EXP in klatt_systolic.h / klatt_lanepipe.h) build a
 // library with the same ABI whose PCM is garbage: such a build refuses to hand PCM out, it only times.
-#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0)
+#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0) || ((KLATT_DIRECT_EXP & 3) != 0)
 constexpr bool kTimingOnlyBuild = true;
 #else
 constexpr bool kTimingOnlyBuild = false;
@@ -679,6 +710,8 @@ bool refuse_timing_only(const char* what)
 }
 
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
+// (setUtterances only forms the direct group under the stage-parallel layouts)
+long long direct_count(const Batch* b) { return b->nDirect; }
 
 int batch_launch(Batch* b)
 {
@@ -701,10 +734,14 @@ int batch_launch(Batch* b)
     const long long nLp = lanepipe_count(b);
     const bool laneKernel = b->layout == 0;
     const long long nTr = tracked_count(b);
-    const long long nNoisy = b->nSlots - b->nQuiet - nTr;
+    const long long nDir = direct_count(b);
+    // the noisy utterances that run on the stages with the frame state machine: the tail of `order`, and the tracked group's slots
+    // when the tracks were planned but have been switched off since (options are read by setUtterances; "tracks" also here)
+    const long long nNoisyHead = b->nTracked - nTr;
+    const long long nNoisy = b->nSlots - b->nQuiet - b->nTracked - nDir;
     const long long nNn = laneKernel ? 0 : b->nNoNasal - nLp;
     const long long nQ = b->nQuiet - nLp - nNn;
-    const int parts = (nLp > 0) + (nNn > 0) + (nQ > 0) + (nNoisy > 0) + (nTr > 0);
+    const int parts = (nLp > 0) + (nNn > 0) + (nQ > 0) + (nNoisy > 0) + (nNoisyHead > 0) + (nTr > 0) + (nDir > 0);
     const bool fork = parts > 1;
     if (fork) HIP_TRY(hipEventRecord(b->forkEvent, b->stream));
     int sideUsed = 0, seen = 0;
@@ -754,12 +791,31 @@ int batch_launch(Batch* b)
                           : launch_systolic<true, 16, 1, true, false, true>(a, b->mode, g, st)) return -1;
         a.flatRef = nullptr; a.sourceRef = nullptr; a.track = nullptr;
     }
-    if (nNoisy > 0) {
-        a.order = b->dOrder.ptr + b->nQuiet + nTr; a.nSlots = nNoisy;
-        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy, b->cus);
-        const long long g = (nNoisy + kLanes - 1) / kLanes;
-        if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, 2>(a, b->mode, g, b->stream) : launch_systolic<true, 16>(a, b->mode, g, b->stream))
-                        : launch<false, true>(a, b->mode, g, b->stream)) return -1;
+    if (nDir > 0) {
+        hipStream_t st = next_stream();
+        SeedArgs sa;
+        sa.jobs = b->dDirectJobs.ptr; sa.nJobs = (uint32_t)b->nDirectFrames; sa.frames = b->dFrames.ptr; sa.meta = b->dMeta.ptr;
+        sa.hdr = b->dDirectHdr.ptr; sa.rec = b->dDirectRec.ptr; sa.negPiOverSr = a.negPiOverSr; sa.twoPiOverSr = a.twoPiOverSr;
+        const dim3 sg((unsigned)((b->nDirectFrames + 255) / 256), (unsigned)kDirectStages);
+        if (b->mode == MODE_FAST) hipLaunchKernelGGL(klatt_seeds<MODE_FAST>, sg, dim3(256), 0, st, sa);
+        else hipLaunchKernelGGL(klatt_seeds<MODE_EXACT>, sg, dim3(256), 0, st, sa);
+        HIP_TRY(hipGetLastError());
+        a.order = b->dOrder.ptr + b->nQuiet + b->nTracked; a.nSlots = nDir;
+        a.directHdr = b->dDirectHdr.ptr; a.directRec = b->dDirectRec.ptr; a.directFirst = b->dDirectFirst.ptr; a.nDirect = (uint32_t)b->nDirectFrames;
+        a.sourceRef = b->dSourceRef.ptr;
+        const long long g = (nDir + kLanes - 1) / kLanes;
+        if (launch_direct(a, b->mode, g, st)) return -1;
+        a.directHdr = nullptr; a.directRec = nullptr; a.directFirst = nullptr; a.nDirect = 0; a.sourceRef = nullptr;
+    }
+    for (int half = 0; half < 2; ++half) {
+        const long long n = half ? nNoisy : nNoisyHead;
+        if (n <= 0) continue;
+        hipStream_t st = next_stream();
+        a.order = b->dOrder.ptr + b->nQuiet + (half ? b->nTracked + nDir : 0); a.nSlots = n;
+        const GroupPlan pl = plan_group(b->layout, true, b->nSlots, nTr + nNoisy + nNoisyHead, b->cus);
+        const long long g = (n + kLanes - 1) / kLanes;
+        if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, 2>(a, b->mode, g, st) : launch_systolic<true, 16>(a, b->mode, g, st))
+                        : launch<false, true>(a, b->mode, g, st)) return -1;
     }
     for (int i = 0; i < sideUsed; ++i) {
         HIP_TRY(hipEventRecord(b->join[i], b->side[i]));
@@ -1424,7 +1480,8 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess;
     { const char* e = getenv("SPEECHPLAYER_TRACKS"); if (e) b->tracks = atoi(e) ? 1 : 0; }
-    for (int i = 0; i < 4 && ok; ++i)
+    { const char* e = getenv("SPEECHPLAYER_DIRECT"); if (e) b->direct = std::min(2, std::max(0, atoi(e))); }
+    for (int i = 0; i < 6 && ok; ++i)
         ok = hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&b->join[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) {
@@ -1441,7 +1498,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (!b) return;
     (void)hipSetDevice(b->device);
     if (b->stream) { (void)hipStreamSynchronize(b->stream); (void)hipStreamDestroy(b->stream); }
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < 6; ++i) {
         if (b->side[i]) { (void)hipStreamSynchronize(b->side[i]); (void)hipStreamDestroy(b->side[i]); }
         if (b->join[i]) (void)hipEventDestroy(b->join[i]);
     }
@@ -1449,6 +1506,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
     b->dFlatRef.release(); b->dSourceRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
+    b->dDirectJobs.release(); b->dDirectFirst.release(); b->dDirectHdr.release(); b->dDirectRec.release();
     delete b;
 }
 
@@ -1467,6 +1525,8 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     // tracks: planned by setUtterances (set the option before it), used by the stage-parallel layouts
     if (!strcmp(name, "tracks")) { b->tracks = value ? 1 : 0; return 0; }
     if (!strcmp(name, "track_budget_mb")) { b->trackBudgetMB = value < 0 ? 0 : value; return 0; }
+    // direct: read by setUtterances (set the option before it); 0 never, 1 unless the lanes are time-aligned (default), 2 always
+    if (!strcmp(name, "direct")) { b->direct = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
     set_error("unknown option %s", name);
     return -1;
 }
@@ -1590,7 +1650,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     // utterance goes with the noisy ones instead -- same PCM (its noise gains are zero: the sources add exactly 0), flat stages.
     constexpr long long kQuietRunMin = 32;
     std::vector<std::pair<long long, uint32_t>> rerouted;      // (utterance, its flags as a quiet one): back to the quiet kernels if it gets no tracks
-    if (b->tracks && nF > 0 && b->layout == -1) {      // (an explicit layout is taken at its word)
+    const bool wantDirect = b->direct && b->layout != 0 && nF > 0 && nF < 0xFFFFFFFFll;
+    if ((b->tracks || wantDirect) && nF > 0 && b->layout == -1) {      // (an explicit layout is taken at its word)
         std::unordered_map<unsigned long long, long long> runOf;
         for (long long u = 0; u < nUtterances; ++u)
             if (!(utt[u].flags & UTT_NEEDS_NOISE)) ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)];
@@ -1601,36 +1662,97 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             }
     }
     // ---- tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite: plan_tracks -----
+    // ---- and the direct stages (klatt_direct.h) for those among them that get none ------------------------
     TrackPlan plan;
-    if (b->tracks && nF > 0) {
-        std::vector<unsigned char> eligible((size_t)nUtterances, 0);
+    std::vector<unsigned char> eligible;
+    if ((b->tracks || wantDirect) && nF > 0) {
+        eligible.assign((size_t)nUtterances, 0);
+        // the direct stages evaluate exp / cos with klatt_math.h alone, whose range is |arg| <= 700 / 1e4: the frequencies and
+        // bandwidths of their utterances are bounded accordingly (bit 1; no frame a speech front-end produces comes near)
+        const double maxBw = 690.0 * b->sampleRate / M_PI, maxF = 9900.0 * b->sampleRate / (2.0 * M_PI);
         for (long long u = 0; u < nUtterances; ++u) {
             if (!(utt[u].flags & UTT_NEEDS_NOISE)) continue;
-            bool finite = true;
+            bool finite = true, bounded = true;
             for (long long k = frameStart[u]; k < frameStart[u + 1] && finite; ++k) {
                 if (meta[k].flags & FRAME_NULL) continue;
                 const double* p = reinterpret_cast<const double*>(frames + k);
                 for (int i = 0; i < kNumParams && finite; ++i) finite = std::isfinite(p[i]);
+                for (int r = 0; r < kNumRes && bounded; ++r)
+                    bounded = std::fabs(p[shape_param(2 * r)]) <= maxF && std::fabs(p[shape_param(2 * r + 1)]) <= maxBw;
             }
             // A NaN anywhere ("hold" targets, reference src/utils.h:21) or an infinite parameter keeps an utterance with the untracked kernel.
             // Finite parameters whose COEFFICIENTS overflow (a huge bandwidth or frequency) are tracked all the same: klatt_tracks evaluates
             // the same expressions as the kernels' own coefficient code, so the track holds the same inf / NaN the kernel would have computed.
-            eligible[u] = finite ? 1 : 0;
+            eligible[u] = finite ? (bounded ? 3 : 1) : 0;
         }
+    }
+    if (b->tracks && nF > 0) {
         plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible.data(), b->trackBudgetMB, plan);
         for (long long u = 0; u < nUtterances; ++u)
             if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED | (plan.kinds[u] << kUttKindShift);
     }
+    if (wantDirect) {
+        // The direct stages are for lanes that fade at unrelated times.  A group whose wavefronts hold equally timed utterances (the
+        // BASELINE recipes without their tracks, a batch of few sentences in many voices) runs whole chunks on the uniform paths of the
+        // stages with the frame state machine, two workgroups per CU, and is faster there (cfg2 without tracks 13.9 against 19.1 ms,
+        // DESIGN.md section 4.7): "direct" = 1 decides by the share of the candidates that sit in runs of 32 or more equally long,
+        // equally timed utterances; 2 takes the direct stages whatever the timing.
+        bool take = true;
+        if (b->direct == 1) {
+            std::unordered_map<unsigned long long, long long> runOf;
+            long long candidates = 0, inRuns = 0;
+            for (long long u = 0; u < nUtterances; ++u)
+                if ((eligible[u] & 2) && !(utt[u].flags & UTT_TRACKED)) { ++candidates; ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)]; }
+            for (const auto& kv : runOf) if (kv.second >= 32) inRuns += kv.second;
+            take = inRuns * 2 <= candidates;
+        }
+        if (take)
+            for (long long u = 0; u < nUtterances; ++u)
+                if ((eligible[u] & 2) && !(utt[u].flags & UTT_TRACKED)) utt[u].flags |= UTT_DIRECT;
+    }
+    // (a re-routed quiet utterance that got neither tracks nor the direct stages goes back to the quiet kernels)
     for (const auto& r : rerouted)
-        if (!(utt[r.first].flags & UTT_TRACKED)) utt[r.first].flags = r.second;
+        if (!(utt[r.first].flags & (UTT_TRACKED | UTT_DIRECT))) utt[r.first].flags = r.second;
+    // the direct utterances' fades: per frame where its fade starts from and ends on (reference src/frame.cpp:55-72: silence keeps
+    // the previous request's values with the gain gated off; the first frame after silence starts from its own values with the gain
+    // gated off; any other frame fades from the previous request's values) -- klatt_seeds reads the values themselves on the device
+    std::vector<DirectJob> directJobs;
+    std::vector<uint32_t> directFirst;
+    long long nDirectUtt = 0;
+    if (wantDirect) {
+        directFirst.assign((size_t)nUtterances, 0u);
+        for (long long u = 0; u < nUtterances; ++u) {
+            if (!(utt[u].flags & UTT_DIRECT)) continue;
+            ++nDirectUtt;
+            directFirst[u] = (uint32_t)directJobs.size();
+            uint32_t prevReal = kNoFrame;
+            bool prevNull = true;
+            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+                DirectJob j;
+                j.frame = (uint32_t)k;
+                if (meta[k].flags & FRAME_NULL) {
+                    j.from = prevReal; j.to = prevReal;
+                    j.flags = (prevNull ? 1u : 0u) | 2u;
+                    prevNull = true;
+                } else {
+                    j.to = (uint32_t)k;
+                    j.from = prevNull ? (uint32_t)k : prevReal;
+                    j.flags = prevNull ? 1u : 0u;
+                    prevReal = (uint32_t)k;
+                    prevNull = false;
+                }
+                directJobs.push_back(j);
+            }
+        }
+    }
     std::vector<FlatRef> flatRef;
     std::vector<SourceRef> sourceRef;
-    if (!plan.jobs.empty()) {
-        flatRef.resize((size_t)nF);
+    if (!plan.jobs.empty() || nDirectUtt > 0) {
+        if (!plan.jobs.empty()) flatRef.resize((size_t)nF);
         sourceRef.resize((size_t)nF);
         for (long long k = 0; k < nF; ++k) {
             const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
-            flatRef[k] = FlatRef{(uint32_t)plan.ref[k].off, plan.ref[k].mask, meta[k].fadeSamples, (uint32_t)std::min<unsigned long long>(std::max(m, f + 1) + 1, 0xFFFFFFFFull)};
+            if (!plan.jobs.empty()) flatRef[k] = FlatRef{(uint32_t)plan.ref[k].off, plan.ref[k].mask, meta[k].fadeSamples, (uint32_t)std::min<unsigned long long>(std::max(m, f + 1) + 1, 0xFFFFFFFFull)};
             const bool isNullFrame = (meta[k].flags & FRAME_NULL) != 0;
             const double* p = reinterpret_cast<const double*>(frames + k);
             const double g0 = isNullFrame ? 0.0 : p[0], g46 = isNullFrame ? 0.0 : p[46];
@@ -1652,6 +1774,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     auto trackedEnd = std::stable_partition(quietEnd, order.end(), [&](uint32_t x) { return (utt[x].flags & UTT_TRACKED) != 0; });
     const long long nTrackedUtt = trackedEnd - quietEnd;
     long long nTracked = nTrackedUtt;      // slots of the tracked group (utterances + padding, below)
+    auto directEnd = std::stable_partition(trackedEnd, order.end(), [&](uint32_t x) { return (utt[x].flags & UTT_DIRECT) != 0; });
+    long long nDirectSlots = directEnd - trackedEnd;      // slots of the direct group (utterances + padding to whole wavefronts, below)
     if (b->sortByLength) {
         // Within a group: longest first, and utterances with the same TIMING (the same sequence of frame durations, fades and
         // silences: the same text at the same speed, whatever the pitch, the voice or the noise seed) side by side.  Lanes
@@ -1660,7 +1784,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         std::stable_sort(order.begin(), noNasalEnd, before);
         std::stable_sort(noNasalEnd, quietEnd, before);
         std::stable_sort(quietEnd, trackedEnd, before);
-        std::stable_sort(trackedEnd, order.end(), before);
+        std::stable_sort(trackedEnd, directEnd, before);
+        std::stable_sort(directEnd, order.end(), before);
         // The noisy groups (64 utterances per wavefront): a wavefront that holds two timings runs every chunk on the general
         // path -- ~2.6 times the time of a pure one for the whole length of its utterances, and it is the last to finish.  So a
         // run of equally timed utterances that filled at least a quarter of its last wavefront, or that is followed by a run
@@ -1680,14 +1805,33 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
                 it = runEnd;
             }
         };
-        std::vector<uint32_t> tracked, untracked;
+        std::vector<uint32_t> tracked, direct(trackedEnd, directEnd), untracked;
         pad_runs(quietEnd, trackedEnd, tracked);
-        if (!tracked.empty() && trackedEnd != order.end()) tracked.insert(tracked.end(), (kLanes - tracked.size() % kLanes) % kLanes, 0xFFFFFFFFu);   // the untracked group starts its own wavefront
-        pad_runs(trackedEnd, order.end(), untracked);
+        if (!tracked.empty() && trackedEnd != order.end()) tracked.insert(tracked.end(), (kLanes - tracked.size() % kLanes) % kLanes, 0xFFFFFFFFu);   // the next group starts its own wavefront
+        // (the direct stages do not care whether their lanes fade together: packed densely, longest first)
+        if (!direct.empty() && directEnd != order.end()) direct.insert(direct.end(), (kLanes - direct.size() % kLanes) % kLanes, 0xFFFFFFFFu);
+        pad_runs(directEnd, order.end(), untracked);
         nTracked = (long long)tracked.size();
+        nDirectSlots = (long long)direct.size();
         order.resize((size_t)nQuiet);
         order.insert(order.end(), tracked.begin(), tracked.end());
+        order.insert(order.end(), direct.begin(), direct.end());
         order.insert(order.end(), untracked.begin(), untracked.end());
+    } else if (nDirectSlots > 0 && directEnd != order.end()) {
+        // unsorted: the groups still start on wavefront boundaries (each is a launch of its own)
+        std::vector<uint32_t> head(order.begin(), directEnd), tail(directEnd, order.end());
+        const size_t padT = nTrackedUtt > 0 ? (size_t)((kLanes - nTrackedUtt % kLanes) % kLanes) : 0;
+        head.insert(head.begin() + nQuiet + nTrackedUtt, padT, 0xFFFFFFFFu);
+        nTracked = nTrackedUtt + (long long)padT;
+        const size_t padD = (size_t)((kLanes - nDirectSlots % kLanes) % kLanes);
+        head.insert(head.end(), padD, 0xFFFFFFFFu);
+        nDirectSlots += (long long)padD;
+        order.swap(head);
+        order.insert(order.end(), tail.begin(), tail.end());
+    } else if (nDirectSlots > 0 && nTrackedUtt > 0) {
+        const size_t padT = (size_t)((kLanes - nTrackedUtt % kLanes) % kLanes);
+        order.insert(order.begin() + nQuiet + nTrackedUtt, padT, 0xFFFFFFFFu);
+        nTracked = nTrackedUtt + (long long)padT;
     }
     const long long nSlotsAll = (long long)order.size();
 
@@ -1697,12 +1841,22 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
         if (nTrackedUtt > 0) {
-            if (b->dFlatRef.reserve((size_t)nF) || b->dSourceRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
+            if (b->dFlatRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
                 b->dTrack.reserve((size_t)trackEntries + kTrackPad)) return -1;
             HIP_TRY(hipMemcpyAsync(b->dShapes.ptr, plan.shapes.data(), plan.shapes.size() * sizeof(double), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dFlatRef.ptr, flatRef.data(), (size_t)nF * sizeof(FlatRef), hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->dSourceRef.ptr, sourceRef.data(), (size_t)nF * sizeof(SourceRef), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dJobs.ptr, jobs.data(), jobs.size() * sizeof(TrackJob), hipMemcpyHostToDevice, b->stream));
+        }
+        if (nTrackedUtt > 0 || nDirectUtt > 0) {
+            if (b->dSourceRef.reserve((size_t)nF)) return -1;
+            HIP_TRY(hipMemcpyAsync(b->dSourceRef.ptr, sourceRef.data(), (size_t)nF * sizeof(SourceRef), hipMemcpyHostToDevice, b->stream));
+        }
+        if (nDirectUtt > 0) {
+            const size_t nD = directJobs.size();
+            if (b->dDirectJobs.reserve(nD) || b->dDirectFirst.reserve((size_t)nUtterances) || b->dDirectHdr.reserve((size_t)kDirectStages * nD) ||
+                b->dDirectRec.reserve((size_t)kDirectEntries * nD)) return -1;
+            HIP_TRY(hipMemcpyAsync(b->dDirectJobs.ptr, directJobs.data(), nD * sizeof(DirectJob), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dDirectFirst.ptr, directFirst.data(), (size_t)nUtterances * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
         }
         if (nF) {
             HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
@@ -1720,6 +1874,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         // the device buffers may hold a mix of the old and the new batch now: the object becomes an empty batch
         b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
         b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0;
+        b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
         b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
         return -1;
     }
@@ -1727,6 +1882,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     b->nQuiet = nQuiet; b->nNoNasal = nNoNasal;
     b->nTracked = nTrackedUtt > 0 ? nTracked : 0; b->nTrackedUtt = nTrackedUtt;
     b->nJobs = nTrackedUtt > 0 ? (long long)jobs.size() : 0; b->trackEntries = nTrackedUtt > 0 ? (long long)trackEntries : 0;
+    b->nDirect = nDirectUtt > 0 ? nDirectSlots : 0; b->nDirectUtt = nDirectUtt; b->nDirectFrames = (long long)directJobs.size();
     b->totalSamples = total; b->poolSamples = pool;
     b->lens.swap(lens); b->outStart.swap(outStart);
     b->results.clear();
@@ -2151,7 +2307,9 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     const GroupPlan pl = plan_group(b->layout, noisy, b->nSlots, nNoisy, b->cus);
     const bool fast = b->mode == MODE_FAST;
     const long long nTr = tracked_count(b);
-    const bool tracked = noisy && nTr > 0 && nTr >= nNoisy - nTr;
+    const long long nDir = direct_count(b);
+    const bool directG = noisy && nDir > 0 && nDir >= nTr && nDir >= nNoisy - nTr - nDir;
+    const bool tracked = noisy && !directG && nTr > 0 && nTr >= nNoisy - nTr - nDir;
     const void* fn;
     int ldsBytes = LdsLayout<false>::kBytes, chunk = 0, wavesPerGroup = 1;
     long long groups = (nNn + kLanes - 1) / kLanes + (nQ + kLanes - 1) / kLanes + (nNoisy + kLanes - 1) / kLanes;
@@ -2166,6 +2324,10 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         else { fn = fast ? (const void*)klatt_lanepipe<MODE_FAST, 16, 2> : (const void*)klatt_lanepipe<MODE_EXACT, 16, 2>; ldsBytes = LpLds<16>::kBytes; chunk = 16; }
         wavesPerGroup = kStages;
         groups = g;
+    } else if (directG) {
+        fn = fast ? (const void*)klatt_direct<MODE_FAST, 16, 2> : (const void*)klatt_direct<MODE_EXACT, 16, 2>;
+        ldsBytes = DirectLds<16>::kBytes; chunk = 16;
+        wavesPerGroup = kDirectStages;
     } else if (tracked) {
         if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_FLAT_CH, true>::kBytes; chunk = KLATT_FLAT_CH; }
         else { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, 16, 1, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, 16, 1, true, false, true>; ldsBytes = SysLds<true, 16, true>::kBytes; chunk = 16; }
@@ -2196,6 +2358,11 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     if (nInfo >= 16) {
         info[12] = (int)std::min<long long>(nTr > 0 ? b->nTrackedUtt : 0, 0x7FFFFFFF); info[13] = (int)std::min<long long>(b->nJobs, 0x7FFFFFFF);
         info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? 1 : 0;
+    }
+    if (nInfo >= 20) {
+        info[16] = (int)std::min<long long>(b->nDirectUtt, 0x7FFFFFFF); info[17] = directG ? 1 : 0;
+        info[18] = (int)std::min<long long>(b->nDirectFrames * (long long)(kDirectEntries * sizeof(double2) + kDirectStages * sizeof(DirectHdr)) >> 20, 0x7FFFFFFF);
+        info[19] = 0;
     }
     return 0;
 }

@@ -88,6 +88,21 @@ KLATT_HD double fast_cos(double t)
     return (q == 1 || q == 2) ? -v : v;
 }
 
+// sin(t), |t| <= 1e4: the same reduction as fast_cos.  (Used by klatt_seeds.h, once per fade: the start of MODE_FAST's coefficient
+// recurrences; nothing on the MODE_EXACT path calls it.)
+KLATT_HD double fast_sin(double t)
+{
+    const double n = __builtin_rint(t * kTwoOverPi);
+    double r = __builtin_fma(-n, 1.5707963267948965580e+00, t);
+    r = __builtin_fma(-n, 6.1232339957367660359e-17, r);
+    const double z = r * r;
+    const double sinr = sin_kernel(r, z);
+    const double cosr = cos_kernel(z);
+    const int q = (int)n & 3;
+    const double v = (q & 1) ? cosr : sinr;
+    return (q >= 2) ? -v : v;
+}
+
 // The arguments of a formant are small: exp(-pi bw / sr) has k = 0 up to bw = 2433 Hz at 22.05 kHz and
 // cos(2 pi f / sr) has n = 0 up to f = 2756 Hz.  With k = 0 and n = 0 the reductions above are the identity
 // (r = x - 0, ldexp(e, 0) = e, quadrant 0 = the cosine kernel), so these two return bit for bit what fast_exp

@@ -347,14 +347,15 @@ class BatchPlayer(object):
         return ms
 
     def kernelInfo(self):
-        info = np.zeros(16, dtype=np.int32)
+        info = np.zeros(20, dtype=np.int32)
         self._check(self._dll.speechPlayer_batch_kernelInfo(self._h, info.ctypes.data, len(info)))
         return dict(vgprs=int(info[0]), lds_bytes=int(info[1]), wavefronts=int(info[2]), cus=int(info[3]),
                     workgroups_per_cu_by_lds=int(info[4]), scratch_bytes=int(info[5]),
                     stage_parallel_chunk=int(info[6]), noisy_group=bool(info[7]),
                     lane_pipelined=bool(info[8]), lane_pipelined_utterances=int(info[9]),
                     nasal_free=bool(info[10]), nasal_free_utterances=int(info[11]),
-                    tracked_utterances=int(info[12]), tracks=int(info[13]), track_mbytes=int(info[14]), tracked=bool(info[15]))
+                    tracked_utterances=int(info[12]), tracks=int(info[13]), track_mbytes=int(info[14]), tracked=bool(info[15]),
+                    direct_utterances=int(info[16]), direct=bool(info[17]), direct_mbytes=int(info[18]))
 
     def devicePcm(self):
         return self._dll.speechPlayer_batch_devicePcm(self._h)

@@ -216,3 +216,20 @@ def jittered(b, seed=1):
     out["min"] = np.maximum(1, (b["min"] * k)).astype(np.uint32)
     out["fade"] = (b["fade"] * k).astype(np.uint32)
     return Batch(frame_start=b["frame_start"], seeds=b["seeds"], name=b["name"] + " jittered", sr=b["sr"], **out)
+
+
+def distinct(b, seed=1):
+    """Every frame's formant frequencies scaled by its own random factor (1 +- 0.5 %): no two fades of the batch are alike, so
+    nothing shares a track (klatt_tracks.h).  With `jittered` on top: a batch in which nothing is shared AND nothing is aligned --
+    65 536 different sentences in different voices, as the kernels see them (bench.py: all_different)."""
+    rng = np.random.default_rng(seed)
+    fr = b["frames"].copy()
+    k = rng.uniform(0.995, 1.005, size=(len(fr), 1))
+    fr[:, 7:15] *= k
+    fr[:, 25:31] *= k
+    out = {key: b[key] for key in ("min", "fade", "index", "isnull")}
+    return Batch(frame_start=b["frame_start"], seeds=b["seeds"], name=b["name"] + " distinct", sr=b["sr"], frames=fr, **out)
+
+
+def all_different(b, seed=1):
+    return jittered(distinct(b, seed), seed)

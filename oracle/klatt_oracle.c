@@ -404,3 +404,33 @@ long long oracle_batchSynthesize(int sampleRate, const double *frames, const uns
     (void)threads;
     return total;
 }
+
+/* As above, and lastIndex[u - first] = what getLastIndex() answers once utterance u has been pulled to its end (reference
+ * src/frame.cpp:69, :117-119): the check of speechPlayer_batch_getLastIndex.  pcm may be NULL (the samples are thrown away). */
+long long oracle_batchLastIndex(int sampleRate, const double *frames, const unsigned *minDur,
+                                const unsigned *fadeDur, const int *userIndex,
+                                const unsigned char *isNull, const long long *frameStart,
+                                const unsigned *seeds, int *lastIndex, long long first, long long count, int threads)
+{
+    long long total = 0;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 1) reduction(+ : total) num_threads(threads > 0 ? threads : 1)
+#endif
+    for (long long u = first; u < first + count; ++u) {
+        short buf[4096];
+        oracle_player *s = oracle_initialize(sampleRate);
+        oracle_setNoise(s, ORACLE_NOISE_COUNTER, seeds ? seeds[u] : (uint32_t)u);
+        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k)
+            oracle_queueFrame(s, isNull[k] ? NULL : frames + (size_t)k * NP, minDur[k], fadeDur[k],
+                              userIndex ? userIndex[k] : -1, 0);
+        for (;;) {
+            int got = oracle_synthesize(s, 4096, buf);
+            total += got;
+            if (got < 4096) break;
+        }
+        lastIndex[u - first] = oracle_getLastIndex(s);
+        oracle_terminate(s);
+    }
+    (void)threads;
+    return total;
+}

@@ -131,3 +131,25 @@ def batch_synthesize(sample_rate, batch, first=0, count=None, threads=1):
                                          idx.ctypes.data, isn.ctypes.data, fs.ctypes.data, seeds.ctypes.data,
                                          out_start.ctypes.data, pcm.ctypes.data, first, count, threads)
     return pcm, out_start, total
+
+
+def batch_last_index(sample_rate, batch, first=0, count=None, threads=1):
+    """What getLastIndex() answers for each utterance of `batch` once it has been pulled to its end (the oracle's own frame
+    state machine, reference src/frame.cpp:69, :117-119)."""
+    fs = np.ascontiguousarray(batch["frame_start"], dtype=np.int64)
+    n_utt = len(fs) - 1
+    if count is None:
+        count = n_utt - first
+    m = np.ascontiguousarray(batch["min"], dtype=np.uint32)
+    f = np.ascontiguousarray(batch["fade"], dtype=np.uint32)
+    frames = np.ascontiguousarray(batch["frames"], dtype=np.float64)
+    idx = np.ascontiguousarray(batch["index"], dtype=np.int32)
+    isn = np.ascontiguousarray(batch["isnull"], dtype=np.uint8)
+    seeds = np.ascontiguousarray(batch["seeds"], dtype=np.uint32)
+    out = np.full(count, -2, dtype=np.int32)
+    L = lib()
+    L.oracle_batchLastIndex.restype = ctypes.c_longlong
+    L.oracle_batchLastIndex.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 8 + [ctypes.c_longlong, ctypes.c_longlong, ctypes.c_int]
+    L.oracle_batchLastIndex(sample_rate, frames.ctypes.data, m.ctypes.data, f.ctypes.data, idx.ctypes.data, isn.ctypes.data,
+                            fs.ctypes.data, seeds.ctypes.data, out.ctypes.data, first, count, threads)
+    return out

@@ -111,6 +111,8 @@ def test_batch_all_scenarios(all_scenarios, mode, layout):
     import nvspeechplayer_amd as eng
     sel = [s for s in all_scenarios if s.batchable and s.sr == 22050]
     batch = make_batch(sel)
+    k = np.arange(len(batch["index"]))
+    batch["index"] = np.where((batch["index"] == -1) & (k % 5 == 2), (k % 997).astype(np.int32), batch["index"]).astype(np.int32)   # marks on frames that had none
     bp = eng.BatchPlayer(22050, mode=mode, layout=layout)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
                      batch["isnull"], batch["seeds"])
@@ -124,6 +126,9 @@ def test_batch_all_scenarios(all_scenarios, mode, layout):
         flips += compare(got[got_start[i]:got_start[i + 1]], exp[exp_start[i]:exp_start[i + 1]], s.name)
         assert np.array_equal(bp.read(i), got[got_start[i]:got_start[i + 1]])
     print("mode %d layout %d: batch of %d utterances, %d samples: %d one-LSB differences" % (mode, layout, len(sel), total, flips))
+    # index marks (reference src/frame.cpp:69, :117-119) against the oracle's frame state machine (the scenarios carry real marks)
+    assert (batch["index"] != -1).any()
+    assert [bp.getLastIndex(i) for i in range(len(sel))] == oracle.batch_last_index(22050, batch, threads=4).tolist()
     # unsorted lane packing gives the same PCM
     bp.setOption("sort", 0)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
@@ -493,6 +498,8 @@ def test_full_size_cfg2_properties():
     import nvspeechplayer_amd as eng
     from nvspeechplayer_amd import workloads
     batch = workloads.make("cfg2", 65536)
+    k = np.arange(len(batch["index"]))
+    batch["index"] = np.where(k % 11 == 4, (k % 30011).astype(np.int32), -1).astype(np.int32)      # index marks on every eleventh frame
     bp = eng.BatchPlayer(22050)
     bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
                      batch["isnull"], batch["seeds"])
@@ -514,6 +521,7 @@ def test_full_size_cfg2_properties():
     for u in range(5, 65536, 1637):
         exp, _, _ = oracle.batch_synthesize(22050, batch.slice(u, 1))
         compare(a[starts[u]:starts[u + 1]], exp, "cfg2 utt %d" % u)
+        assert bp.getLastIndex(u) == int(oracle.batch_last_index(22050, batch.slice(u, 1))[0])      # reference src/frame.cpp:69, :117-119
     bp.close()
 
 
@@ -839,6 +847,8 @@ def test_full_size_cfg3_cfg4_properties(workload, n_utt):
     from nvspeechplayer_amd.speechPlayer import pcm_digest
     batch = workloads.make(workload, n_utt)
     assert batch.n_utt == n_utt
+    k = np.arange(len(batch["index"]))
+    batch["index"] = np.where(k % 11 == 4, (k % 30011).astype(np.int32), -1).astype(np.int32)      # index marks on every eleventh frame
     counts = batch.sample_counts()
     assert np.array_equal(counts, workloads.sample_counts(workload, n_utt))
     if workload == "cfg4":
@@ -860,6 +870,7 @@ def test_full_size_cfg3_cfg4_properties(workload, n_utt):
                 assert pcm_digest(got) == int(per[(1, 0)][u]), u                 # the digest kernel agrees with numpy
                 exp, _, _ = oracle.batch_synthesize(22050, batch.slice(u, 1))
                 compare(got, exp, "%s utt %d" % (workload, u))
+                assert bp.getLastIndex(u) == int(oracle.batch_last_index(22050, batch.slice(u, 1))[0])      # reference src/frame.cpp:69, :117-119
             for u in (0, n_utt - 1):
                 assert bp.utteranceSamples(u) == counts[u] and len(bp.read(u)) == counts[u]
             keep = bp
@@ -1215,6 +1226,7 @@ def test_coefficient_tracks_change_nothing(seed, wild):
     def run(mode, tracks, sort=1, budget=None):
         bp = eng.BatchPlayer(22050, mode=mode)
         bp.setOption("tracks", tracks)
+        bp.setOption("direct", 0)      # (the direct stages have their own test: test_direct_stages_change_nothing)
         bp.setOption("sort", sort)
         if budget is not None:
             bp.setOption("track_budget_mb", budget)
@@ -1291,3 +1303,90 @@ def test_text_input_without_espeak_fails_loudly():
     bp.synthesize()
     assert bp.totalSamples > 0
     bp.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("seed,wild", [(21, False), (22, True)])
+def test_direct_stages_change_nothing(seed, wild):
+    """The direct stages (klatt_direct.h: flat control, every fade sample's coefficients computed in place from per-frame records
+    that klatt_seeds evaluates before the launch) against the stages with the frame state machine and against the tracked flat
+    stages, on random ragged batches (NULL frames anywhere, fades longer than their frame, 1-sample fades and frames, vibrato,
+    M = 0 frames; wild: NaN "hold" utterances, which must stay with the frame state machine).
+    MODE_EXACT: the same bytes from all three.  MODE_FAST: the direct stages advance the coefficients by recurrences
+    (re-seeded at every fade's first sample): held to the usual bar against the oracle, like every kernel."""
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(seed)
+    batch = random_batch(rng, 900, quiet_fraction=0.15, wild=wild)
+    n_utt = len(batch["seeds"])
+    exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
+
+    def run(mode, tracks, direct, sort=1):
+        bp = eng.BatchPlayer(22050, mode=mode)
+        bp.setOption("tracks", tracks); bp.setOption("direct", direct); bp.setOption("sort", sort)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
+        bp.synthesize()
+        pcm, start = bp.readAll()
+        info = bp.kernelInfo()
+        marks = [bp.getLastIndex(u) for u in range(0, n_utt, 37)]
+        bp.close()
+        assert np.array_equal(start, exp_start)
+        return pcm.copy(), info, marks
+
+    nan_utts = sum(1 for u in range(n_utt) if np.isnan(batch["frames"][batch["frame_start"][u]:batch["frame_start"][u + 1]]).any())
+    for mode in (0, 1):
+        legacy, info0, marks0 = run(mode, 0, 0)
+        assert info0["direct_utterances"] == 0 and info0["tracked_utterances"] == 0
+        for tracks, direct, sort in ((0, 2, 1), (0, 2, 0), (0, 1, 1), (1, 2, 1)):
+            pcm, info, marks = run(mode, tracks, direct, sort)
+            assert marks == marks0
+            if tracks == 0:
+                assert info["tracked_utterances"] == 0 and info["direct_utterances"] > n_utt // (4 if wild else 2)
+                assert info["direct_utterances"] <= n_utt - nan_utts
+                assert info["scratch_bytes"] == 0 and info["direct"]
+            else:
+                assert info["direct_utterances"] == 0 and info["tracked_utterances"] > 0      # every candidate got its tracks
+            d = pcm.astype(np.int32) - exp.astype(np.int32)
+            nbad = int(np.count_nonzero(d))
+            print("seed %d wild %s mode %d tracks %d direct %d sort %d: %d direct, %d tracked of %d utterances; %d of %d samples differ from the oracle" % (
+                seed, wild, mode, tracks, direct, sort, info["direct_utterances"], info["tracked_utterances"], n_utt, nbad, total))
+            if mode == 0 or tracks == 1:
+                assert np.array_equal(pcm, legacy), "%d samples differ from the stages with the frame state machine" % int(np.count_nonzero(pcm != legacy))
+            assert np.abs(d).max() <= 1 and nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
+            assert float(np.sqrt(np.mean((d / 32768.0) ** 2))) < RMS_TOL
+
+
+@pytest.mark.gpu
+def test_batch_in_which_nothing_is_shared_and_nothing_is_aligned():
+    """BASELINE configs[2]'s utterances with every frame's duration and fade scaled by its own random factor AND every frame's
+    formants by another (workloads.all_different: what 2048 different sentences in different voices look like to the kernels):
+    with a track budget that such a batch exceeds at its real size (65 536 utterances: 57 GB of tracks; here 8 MB stand in for the
+    4 GB) the engine sends them to the direct stages by itself; against the oracle utterance by utterance, both modes; index marks
+    on every seventh frame against the oracle's."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    base = workloads.make("cfg2", 2048)
+    b = workloads.all_different(base)
+    b["index"] = np.where(np.arange(len(b["min"])) % 7 == 3, np.arange(len(b["min"]), dtype=np.int32) % 1000, -1).astype(np.int32)
+    exp, exp_start, total = oracle.batch_synthesize(b["sr"], b, threads=8)
+    ref_marks = oracle.batch_last_index(b["sr"], b, threads=8)
+    for mode in (0, 1):
+        bp = eng.BatchPlayer(b["sr"], mode=mode)
+        bp.setOption("track_budget_mb", 8)
+        bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+        info = bp.kernelInfo()
+        assert info["direct"] and info["direct_utterances"] == 2048 and info["tracked_utterances"] == 0 and info["scratch_bytes"] == 0, info
+        bp.synthesize()
+        pcm, start = bp.readAll()
+        assert np.array_equal(start, exp_start)
+        d = pcm.astype(np.int32) - exp.astype(np.int32)
+        nbad = int(np.count_nonzero(d))
+        print("all_different x 2048, mode %d: %d samples, %d differ from the oracle (max %d)" % (mode, total, nbad, int(np.abs(d).max())))
+        assert np.abs(d).max() <= 1 and nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
+        assert float(np.sqrt(np.mean((d / 32768.0) ** 2))) < RMS_TOL
+        # index marks (reference src/frame.cpp:69, :117-119) against the oracle's own frame state machine
+        assert [bp.getLastIndex(u) for u in range(2048)] == ref_marks.tolist()
+        # the aligned parent batch without tracks stays with the stages that run whole chunks on uniform paths ("direct" = 1: by timing)
+        bp.setOption("tracks", 0)
+        bp.setUtterances(base["frame_start"], base["frames"], base["min"], base["fade"], base["index"], base["isnull"], base["seeds"])
+        assert bp.kernelInfo()["direct_utterances"] == 0
+        bp.close()

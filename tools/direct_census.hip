@@ -1,0 +1,12 @@
+// register census of the direct kernel, stage by stage (tools/direct_census.sh); not part of the library
+#include "../nvspeechplayer_amd/csrc/klatt_direct.h"
+#ifndef CENSUS_MODE
+#define CENSUS_MODE 0
+#endif
+#ifndef CENSUS_CH
+#define CENSUS_CH 16
+#endif
+#ifndef CENSUS_WPE
+#define CENSUS_WPE 2
+#endif
+template __global__ void klatt::klatt_direct<CENSUS_MODE, CENSUS_CH, CENSUS_WPE>(const klatt::KernelArgs);

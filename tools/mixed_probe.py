@@ -43,16 +43,7 @@ rotate = workloads.rotated
 jitter = workloads.jittered
 
 
-def distinct(b, seed=1):
-    """Every frame's formant frequencies scaled by its own random factor (1 +- 0.5 %): no two fades of the batch are alike,
-    so nothing shares a track (klatt_tracks.h) -- the worst case for the tracked kernels' memory."""
-    rng = np.random.default_rng(seed)
-    fr = b["frames"].copy()
-    k = rng.uniform(0.995, 1.005, size=(len(fr), 1))
-    fr[:, 7:15] *= k
-    fr[:, 25:31] *= k
-    out = {key: b[key] for key in ("min", "fade", "index", "isnull")}
-    return workloads.Batch(frame_start=b["frame_start"], seeds=b["seeds"], name=b["name"] + " distinct", sr=b["sr"], frames=fr, **out)
+distinct = workloads.distinct
 
 
 def run(name, b, sort, mode=0):

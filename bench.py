@@ -38,7 +38,7 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s
 # f64 VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz; a wave64 f64 instruction occupies a SIMD for 4 cycles by the datasheet
 # (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz) and for 4.8 measured (profiles/r1_ubench_issue_rates.txt)
 SIMDS, CLOCK_HZ, F64_CYCLES_SPEC, F64_CYCLES_MEASURED = 1024, 2.4e9, 4.0, 4.8
-PMC_FILE = os.path.join(ROOT, "profiles", "r3_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r4_pmc.json")
 
 
 def parse(argv=None):
@@ -75,6 +75,8 @@ def kernel_name(info):
     """The kernel of the batch's largest group (speechPlayer_batch_kernelInfo)."""
     if info.get("lane_pipelined"):
         return "klatt_lanepipe (cascade across lanes, %d-sample hand-overs)" % info["stage_parallel_chunk"]
+    if info.get("direct"):
+        return "klatt_direct (8 stages, coefficients computed in place from %d MB of per-frame seeds, %d-sample hand-overs)" % (info.get("direct_mbytes", 0), info["stage_parallel_chunk"])
     if info["stage_parallel_chunk"]:
         return "klatt_systolic (stage-parallel%s%s%s, %d-sample hand-overs)" % (
             ", noisy" if info.get("noisy_group") else "", ", nasal-free" if info.get("nasal_free") else "",
@@ -225,6 +227,10 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", device))
         assert dist.get_world_size() == world and dist.get_rank() == rank
 
+    if world > 1 and "SPEECHPLAYER_PLAN_THREADS" not in os.environ:
+        # the ranks of a node share its host cores (a 16-CPU quota for 8 ranks on the driver's box): setUtterances plans with up to 8
+        # threads by default, which at N = 8 would be 64 threads on 16 cores -- outside the timed region, but inside the driver's timeout
+        os.environ["SPEECHPLAYER_PLAN_THREADS"] = str(max(1, usable_cores() // world))
     t_build = time.perf_counter()
     batch, shard = build_shard(args, rank, world)
     t_build = time.perf_counter() - t_build
@@ -275,11 +281,15 @@ def main():
             bounds = shard_bounds(counts, world)
             first, n = int(bounds[rank]), int(bounds[rank + 1] - bounds[rank])
             mine = int(counts[first:first + n].sum())
-            x_ms, x_el, x_info = [0.0], 0.0, {}
+            x_ms, x_el, x_info, x_build, x_set = [0.0], 0.0, {}, 0.0, 0.0
             if not dry:
+                x_build = time.perf_counter()
                 xb = workloads.make(wl, n, first=first)
+                x_build = time.perf_counter() - x_build
                 x = BatchPlayer(xb["sr"], device=device, mode=args.mode, layout=args.layout)
+                x_set = time.perf_counter()
                 x.setUtterances(xb["frame_start"], xb["frames"], xb["min"], xb["fade"], xb["index"], xb["isnull"], xb["seeds"])
+                x_set = time.perf_counter() - x_set
                 assert x.totalSamples == mine
                 xb = None
                 x.time(1)
@@ -296,6 +306,8 @@ def main():
                                 "value": None if dry else x_total * launches / x_el, "unit": "samples/s",
                                 "ms_per_launch": None if dry else x_el / launches * 1e3, "kernel_ms_rank0": None if dry else float(np.mean(x_ms)),
                                 "shard_bounds": [int(v) for v in bounds],
+                                "host_rank0": {"build_batch_s": round(x_build, 3), "set_utterances_s": round(x_set, 3),
+                                               "plan_threads": os.environ.get("SPEECHPLAYER_PLAN_THREADS")},
                                 "tracks_rank0": None if dry else {"tracked_utterances": x_info.get("tracked_utterances"), "tracks": x_info.get("tracks"), "mbytes": x_info.get("track_mbytes")}}
     else:
         head_name, head_sr, head_frames = batch["name"], batch["sr"], int(len(batch["min"]))
@@ -338,8 +350,9 @@ def main():
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "kernel": kernel_name(info), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                     "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "scratch_bytes": info["scratch_bytes"],
-                    "note": "declared bound: HBM (2 B per sample + 388 B per frame). What binds is f64 VALU issue -- a sample is a strict "
-                            "recurrence of ~190 dependent-ish f64 operations -- see `valu` and DESIGN.md section 4"}
+                    "note": "declared bound: HBM (2 B per sample + 388 B per frame). What binds is f64 VALU issue with two barrier-coupled waves per SIMD: "
+                            "~138 VALU instructions per 64-sample row (of which ~100 f64), issued 72 % of the cycles at the held clock of 2.06 GHz "
+                            "(profiles/r4_cfg2_exact_summary.txt) -- see `valu` and DESIGN.md section 4, Roofline"}
             # HBM bytes and VALU instructions per launch come from the PMC passes of tools/profile.sh (bench.py cannot run rocprofv3 on
             # itself); the file names the engine sources it was collected from, and is ignored when they have changed since
             try:
@@ -348,17 +361,17 @@ def main():
                 if ent and not args.utterances and world == 1 and args.mode == 0 and args.layout == -1:
                     if pj.get("engine_sources_sha") == engine_source_digest():
                         roof["traffic"] = ent["hbm_bytes_per_launch"]
-                        roof["traffic_source"] = "profiles/r3_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
+                        roof["traffic_source"] = "profiles/r4_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
                         insts = ent["valu_insts_per_launch"]
                         peak = SIMDS * CLOCK_HZ / F64_CYCLES_MEASURED
                         roof["valu"] = {"insts_per_launch": insts, "achieved": insts / (k_ms * 1e-3), "peak": peak,
                                         "unit": "wave64 VALU instructions/s", "frac": insts / (k_ms * 1e-3) / peak,
                                         "peak_spec": SIMDS * CLOCK_HZ / F64_CYCLES_SPEC,
                                         "insts_per_64_samples": insts * 64.0 / samples,
-                                        "source": "profiles/r3_pmc.json SQ_INSTS_VALU; peak = 1024 SIMDs x 2.4 GHz / 4.8 cycles per f64 wave instruction "
+                                        "source": "profiles/r4_pmc.json SQ_INSTS_VALU; peak = 1024 SIMDs x 2.4 GHz / 4.8 cycles per f64 wave instruction "
                                                   "(measured; 4 by the datasheet = peak_spec); instructions that are not f64 (a quarter to a third of them) issue in about half that, so frac is an upper bound on issue-slot use"}
                     else:
-                        roof["traffic_source"] = "profiles/r3_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
+                        roof["traffic_source"] = "profiles/r4_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
             except Exception:
                 pass
             out["roofline"] = roof
@@ -392,6 +405,29 @@ def main():
                 out["jittered_durations"] = dict(timed(jit, 1), tracks_off=timed(jit, 0))
                 # and the benchmarked batch itself without the engine's sort by length and timing: wavefronts of 64 arbitrary neighbours
                 out["unsorted"] = dict(timed(batch, 1, 0), tracks_off=timed(batch, 0, 0))
+                # The general case: nothing shared AND nothing aligned (every frame's formants scaled by its own factor on top of the jitter:
+                # 65 536 different sentences in different voices).  Its tracks would take 57 GB: the planner gives up, the direct stages
+                # (klatt_direct.h) compute every fade sample's coefficients in place -- polynomials in MODE_EXACT, pole recurrences in MODE_FAST;
+                # "legacy": the stages with the frame state machine, which ran such batches until round 4.
+                def timed_mode(b, mode, direct, tracks=1):
+                    x = BatchPlayer(b["sr"], device=device, mode=mode, layout=args.layout)
+                    x.setOption("tracks", tracks)
+                    x.setOption("direct", direct)
+                    x.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+                    x.time(1)
+                    ms = float(np.median(x.time(6)))
+                    xi = x.kernelInfo()
+                    n = x.totalSamples
+                    x.close()
+                    return {"value": n / (ms * 1e-3), "unit": "samples/s", "kernel_ms": ms, "roofline_frac": b.algorithmic_bytes() / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                            "kernel": kernel_name(xi), "direct_utterances": xi.get("direct_utterances"), "tracked_utterances": xi.get("tracked_utterances"),
+                            "scratch_bytes": xi.get("scratch_bytes")}
+                alld = workloads.all_different(batch)
+                out["all_different"] = dict(timed_mode(alld, 0, 1), mode_fast=timed_mode(alld, 1, 1), legacy=timed_mode(alld, 0, 0))
+                dst = workloads.distinct(batch)
+                out["distinct"] = dict(timed_mode(dst, 0, 1), mode_fast=timed_mode(dst, 1, 1), direct_forced=timed_mode(dst, 0, 2), direct_forced_fast=timed_mode(dst, 1, 2))
+                out["jittered_durations"]["mode_fast"] = timed_mode(jit, 1, 1)
+                out["jittered_durations"]["direct_fast"] = timed_mode(jit, 1, 2, tracks=0)
             if world == 1 and not args.utterances and not args.no_extras:
                 # the other single-GPU configuration (BASELINE configs[1], 4096 steady vowels) and its recipe at 65 536 utterances
                 bp.close()

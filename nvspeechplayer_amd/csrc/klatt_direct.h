@@ -302,6 +302,8 @@ struct DirectState {
     double p0[NR], p1[NR], p2[NR], p3[NR], rad[NR];
     double gf[NG2], gd[NG2];                            // per gain parameter: from, to - from
     double nfD, invF;                                   // (double)F, 1 / F
+    double ratio;                                       // source stage only: cnt / F of the values in registers (the pitch fades with them)
+    bool inFade;                                        // source stage only: the values in registers belong to a fade sample
     uint32_t cnt, F;                                    // the fade-sample index of the values in registers; cnt == F: not fading
     uint32_t startAt, next, nFrames, length, produced;  // startAt: the sample the next fade's first values apply to
     uint32_t curBits;                                   // DirectHdr.bits of the running (or last) fade
@@ -327,7 +329,7 @@ __device__ __forceinline__ void direct_init(DirectState<DD>& f, bool live, const
     for (int k = 0; k < 2 * DD::NGAIN; ++k) { f.cur[k] = 0; f.gf[k] = 0; f.gd[k] = 0; }
     f.live = live && d.length > 0u;
     f.nFrames = d.nFrames; f.length = d.length; f.next = 0; f.produced = 0;
-    f.cnt = 1u; f.F = 1u; f.nfD = 1.0; f.invF = 1.0; f.curBits = 0u; f.rec0 = rec0;
+    f.cnt = 1u; f.F = 1u; f.nfD = 1.0; f.invF = 1.0; f.ratio = 1.0; f.inFade = false; f.curBits = 0u; f.rec0 = rec0;
     const bool any = live && d.nFrames > 0u;
     f.startAt = any ? 1u : 0xFFFFFFFFu;      // frame 0 is dequeued on sample 0, its fade's first values apply to sample 1
     f.nextHdr = DirectHdr{1u, 0u, 0u, 0u};
@@ -357,13 +359,16 @@ struct DirectMid {
         const KernelArgs& A = X.A;
         // ONE masked block for the lanes inside a fade (a lane that is not keeps what it has: the fade's last values, as the reference
         // does until the next fade's first sample); skipped altogether on a sample on which no lane of the wavefront fades
-        if (f.cnt < f.F) {
+        const bool adv = f.cnt < f.F;
+        if (DD::STAGE == 0) f.inFade = adv || sw;
+        if (adv) {
             const uint32_t cn = f.cnt + 1u;
             f.cnt = cn;
             // ratio = (double)counter / numFadeSamples, correctly rounded (reference src/frame.cpp:49) -- in MODE_FAST too: the last sample
             // of a fade must land on its target EXACTLY where the reference tests a parameter for a value (`frequency != 0` decides whether
             // N0 is inverted, src/speechWaveGenerator.cpp:122: with counter * (1 / F) = 1 - 1e-16 a target of 0 Hz arrives as 1e-14 Hz)
             const double ratio = div_by((double)cn, f.nfD, f.invF);
+            if (DD::STAGE == 0) f.ratio = ratio;
 #pragma unroll
             for (int r = 0; r < DD::NRES; ++r) {
                 if (!(wm & (1u << r))) continue;                       // scalar branch
@@ -421,6 +426,7 @@ struct DirectMid {
 #endif
             f.cnt = 1u; f.F = h.fadeSamples; f.curBits = h.bits;
             f.nfD = (double)h.fadeSamples; f.invF = 1.0 / f.nfD;
+            if (DD::STAGE == 0) f.ratio = div_by(1.0, f.nfD, f.invF);
             f.next++;
             const bool more = f.next < f.nFrames;
             f.startAt = more ? f.startAt + h.span : 0xFFFFFFFFu;
@@ -471,9 +477,16 @@ __device__ __forceinline__ void direct_touch(DirectState<DD>& f, const DirectCtx
 #endif
 }
 
-// body(c, i, mid): one sample of the stage; barrier discipline of flat2_loop (klatt_systolic.h)
-template <class DD, int MODE, int CH, class FBody, class FChunk>
-__device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, int stampSlot, DirectState<DD>& f, const DirectCtx& X, FBody body, FChunk perChunk)
+// load(c, i): the stage's pipe inputs of sample i (a struct of doubles); body(c, i, in, mid): one sample of the stage.  In a mixed chunk
+// the inputs of sample i + 1 are read while sample i is computed (an LDS read issued at the top of a sample is waited for right there,
+// in front of the sample's dependent chain; the read past the chunk's last sample lands in the pipe's other buffer and is dropped).
+// Barrier discipline of flat2_loop (klatt_systolic.h).
+struct In0 {};
+struct In1 { double a; };
+struct In2 { double a, b; };
+struct In3 { double a, b, c; };
+template <class DD, int MODE, int CH, class FLoad, class FBody, class FChunk>
+__device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, int stampSlot, DirectState<DD>& f, const DirectCtx& X, FLoad load, FBody body, FChunk perChunk)
 {
 #ifdef KLATT_STAMPS
     Stamps st;
@@ -501,7 +514,7 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
                 for (uint32_t q = 0; q < run; ++q) {
                     if (f.live) {
 #pragma unroll KLATT_DIRECT_STEADY_UNROLL
-                        for (int i = 0; i < CH; ++i) body(cc, i, NoMid{});
+                        for (int i = 0; i < CH; ++i) body(cc, i, load(cc, i), NoMid{});
                     }
                     { const uint32_t e1 = (uint32_t)(cc + 1) * (uint32_t)CH; f.produced = f.length < e1 ? f.length : e1; }
                     perChunk();
@@ -517,10 +530,13 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
             } else {
                 STAMP_KIND(-1);
                 const uint32_t wm = direct_chunk_mask<DD>(f, t1);
+                auto ahead = load(c, 0);
 #pragma unroll KLATT_DIRECT_UNROLL
                 for (int i = 0; i < CH; ++i) {
                     const bool sw = t0 + (uint32_t)i + 1u == f.startAt;
-                    body(c, i, DirectMid<DD, MODE>{f, X, wm, sw});
+                    const auto in = ahead;
+                    ahead = load(c, i + 1);
+                    body(c, i, in, DirectMid<DD, MODE>{f, X, wm, sw});
                 }
                 f.produced = f.length < t1 ? f.length : t1;
                 perChunk();
@@ -568,9 +584,9 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
     const SourceRef* const mySrc = A.sourceRef + d.frameStart;
     PitchState ps;
     ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
-    double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0, invFade = 1.0, nfD = 1.0;
-    uint32_t noiseSt = noise_first(nkey, ninc), cntF = 0, nfU = 0;    // aspiration: noise values 0, 2, 4, ...; cntF of nfU pitch-fade samples done
-    uint32_t fadeEndAt = 0xFFFFFFFFu;
+    double pitchPhase = 0.0, vibPhase = 0.0, aspNoise = 0.0;
+    uint32_t noiseSt = noise_first(nkey, ninc);    // aspiration: noise values 0, 2, 4, ...
+    bool wasFade = false;                          // the previous sample was a fade sample
     int32_t lastIndex = -1;
     bool oldNull = true, newNull = false;
     SourceRef nextSrc{0.0, 0.0, 1.0, -1, 0u};     // frame `f.next`, loaded ahead like f.nextHdr
@@ -617,7 +633,7 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
         if (c < nChunks) {
             const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
             if (f.length <= t0) f.live = false;
-            const bool busy = f.cnt < f.F || f.startAt <= t1 || cntF < nfU || fadeEndAt < t1 || vib_live();
+            const bool busy = f.cnt < f.F || f.startAt <= t1 || f.inFade || wasFade || vib_live();
             STAMP_KIND(__any(busy) ? -1 : 0);
             if (!__any(busy)) {
                 // steady stretch, decided once: the pitch glides, nothing else changes
@@ -648,34 +664,29 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
                     const bool deq = t + 1u == f.startAt;
                     if (deq) {   // reference src/frame.cpp:55-72; the sample itself is emitted as it is
                         const SourceRef m = nextSrc;
-                        const uint32_t nf = f.nextHdr.fadeSamples;
                         newNull = (m.flags & FRAME_NULL) != 0;
                         ps.new0 = newNull ? ps.cur0 : m.pitch;
                         ps.newInc = newNull ? 0.0 : m.pitchInc;                // reference src/frame.cpp:98 (the division: host)
                         if (!newNull && oldNull) ps.old0 = m.pitch;
                         oldNull = newNull;                                    // for the NEXT dequeue: this fade has ended by then (:44-47)
                         if (m.userIndex != -1) lastIndex = m.userIndex;       // (:69)
-                        nfD = (double)nf; nfU = nf;
-                        ps.new0 += ps.newInc * nfD;                           // (:71)
-                        invFade = m.invFade;
-                        cntF = 0;
-                        fadeEndAt = t + nf + 1u;
+                        ps.new0 += ps.newInc * (double)f.nextHdr.fadeSamples; // (:71)
                         nextSrc = mySrc[f.next + 1u < f.nFrames ? f.next + 1u : f.nFrames - 1u];
                     }
-                    // the pitch of this sample, as selects: fading -> interpolated; the sample after the fade -> the fade's target becomes
-                    // the glide's start; steady -> glide (reference src/frame.cpp:48-53, :44-47, :76-79); a dequeuing lane leaves it alone
-                    const bool fad = !deq && cntF < nfU;
-                    const bool ending = !deq && !fad && t == fadeEndAt;
-                    const bool glide = !deq && !fad && !ending;
-                    const uint32_t cn = cntF + 1u;
-                    const double ratio = div_by((double)cn, nfD, invFade);
-                    const double fv = fade_value(ps.old0, ps.new0, ratio);
+                    // The pitch of this sample, as selects.  A fade sample (the stage's values in registers are a fade's: f.inFade, set
+                    // by the previous sample's DirectMid together with f.ratio = cnt / F) -> interpolated; the sample after a fade's last ->
+                    // the fade's target becomes the glide's start; a steady sample -> glide; a dequeuing lane leaves it alone
+                    // (reference src/frame.cpp:48-53, :44-47, :76-79, :55-72).  A fade is at least one sample, a frame at least two more:
+                    // the four cases never coincide.
+                    const bool fad = f.inFade;
+                    const bool ending = !fad && wasFade;
+                    const bool glide = !fad && !ending && !deq;
+                    const double fv = fade_value(ps.old0, ps.new0, f.ratio);
                     const double gv = ps.cur0 + ps.oldInc;
                     ps.cur0 = fad ? fv : (glide ? gv : ps.cur0);
                     ps.old0 = ending ? ps.new0 : (glide ? gv : ps.old0);
                     ps.oldInc = ending ? ps.newInc : ps.oldInc;
-                    cntF = fad ? cn : cntF;
-                    fadeEndAt = ending ? 0xFFFFFFFFu : fadeEndAt;
+                    wasFade = fad;
                     const bool waveVib = vibChunk && __any(vib_live());
                     SRC_PIPE(c, i) = source(waveVib, DirectMid<DD, MODE>{f, X, wm, deq});
                 }
@@ -760,8 +771,8 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
         __syncthreads();
         const bool two = simdCount[0] == 2u && simdCount[1] == 2u && simdCount[2] == 2u && simdCount[3] == 2u;
-        // heavy with light: MODE_FAST T1 + T2 | T0 + T3 | T5 + T4 | T7 + T6;  MODE_EXACT T7 + T2 | T5 + T3 | T1 + T4 | T6 + T0
-        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = {7, 2, 5, 3, 1, 4, 6, 0};
+        // heavy with light: MODE_FAST T1 + T2 | T0 + T3 | T5 + T4 | T7 + T6;  MODE_EXACT T5 + T2 | T1 + T0 | T4 + T3 | T7 + T6
+        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = {5, 2, 1, 0, 4, 3, 7, 6};
         const int key = (int)(simd * 2u + (rank & 1u));
         int pick = wave;
 #pragma unroll
@@ -794,8 +805,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         DirectState<DD> f;
         direct_init<DD>(f, live, d, rec0, X);
         direct_loop<DD, MODE, CH>(1, nIter, nChunks, stage, f, X,
-            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
-                const double x = PIPE(pipeX0, c, i);
+            [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pipeX0, c, i)}; },
+            [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
+                const double x = in.a;
                 const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
                 f.z2[0] = f.z1[0]; f.z1[0] = x;                              // the anti-resonator remembers its INPUT (reference :133)
                 const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
@@ -812,8 +824,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             DirectState<DD> f;
             direct_init<DD>(f, live, d, rec0, X);
                 direct_loop<DD, MODE, CH>(ST, nIter, nChunks, stage, f, X,
-                [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
-                    double o = PIPE(pin, c, i);
+                [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pin, c, i)}; },
+                [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
+                    double o = in.a;
                     o = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], o);
                     o = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], o);
                     PIPE(pout, c, i) = o;
@@ -833,7 +846,8 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         double fricNoise = 0;
         uint32_t noiseSt = noise_step(noise_first(nkey, ninc), ninc);     // frication: noise values 1, 3, 5, ...
         direct_loop<DD, MODE, CH>(3, nIter, nChunks, stage, f, X,
-            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
+            [&](int, int) __attribute__((always_inline)) { return In0{}; },
+            [&](int c, int i, const In0&, const auto& mid) __attribute__((always_inline)) {
                 fricNoise = noise_uniform(noiseSt) + 0.75 * fricNoise;
                 noiseSt = noise_step2(noiseSt, ninc2);
                 const double fric = fricNoise * 0.3 * f.cur[0];
@@ -854,9 +868,10 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         DirectState<DD> f;
         direct_init<DD>(f, live, d, rec0, X);
         direct_loop<DD, MODE, CH>(4, nIter, nChunks, stage, f, X,
-            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
-                const double y = PIPE(pipeY, c, i);
-                double par = PIPE(pipeP, c, i);
+            [&](int c, int i) __attribute__((always_inline)) { return In2{PIPE(pipeY, c, i), PIPE(pipeP, c, i)}; },
+            [&](int c, int i, const In2& in, const auto& mid) __attribute__((always_inline)) {
+                const double y = in.a;
+                double par = in.b;
                 double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
                 par += (w - y) * f.cur[0];
                 w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
@@ -902,10 +917,11 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
         direct_loop<DD, MODE, CH>(5, nIter, nChunks, stage, f, X,
-            [&](int c, int i, const auto& mid) __attribute__((always_inline)) {
-                const double o = PIPE(pipeO, c, i);
-                const double y = PIPE(pipeY2, c, i);
-                double par = PIPE(pipeP2, c, i);
+            [&](int c, int i) __attribute__((always_inline)) { return In3{PIPE(pipeO, c, i), PIPE(pipeY2, c, i), PIPE(pipeP2, c, i)}; },
+            [&](int c, int i, const In3& in, const auto& mid) __attribute__((always_inline)) {
+                const double o = in.a;
+                const double y = in.b;
+                double par = in.c;
                 double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
                 par += (w - y) * f.cur[0];
                 w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);

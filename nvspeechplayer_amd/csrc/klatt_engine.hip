@@ -958,6 +958,7 @@ std::vector<LiveContext*> g_live;   // per device
 // default), 0 = the lane kernel's (one wavefront per 64 handles).  Same saved state, same PCM; speechPlayer_setGlobalOption.
 int g_liveLayout = [] { const char* e = getenv("SPEECHPLAYER_LIVE_LAYOUT"); return e ? atoi(e) : 1; }();
 int g_liveCus = 0;
+bool g_liveCusForced = false;
 
 LiveContext* live_context(int device)
 {
@@ -1111,7 +1112,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     UttDesc* const hUtt = reinterpret_cast<UttDesc*>(c->hCtl.ptr);
     double** const hState = reinterpret_cast<double**>(c->hCtl.ptr + (size_t)n * sizeof(UttDesc));
     uint32_t* const hControl = reinterpret_cast<uint32_t*>(c->hCtl.ptr + (size_t)n * (sizeof(UttDesc) + sizeof(double*)));
-    if (g_liveCus == 0) {
+    if (g_liveCus == 0 && !g_liveCusForced) {
         hipDeviceProp_t prop;
         g_liveCus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
     }
@@ -1396,6 +1397,10 @@ int speechPlayer_setGlobalOption(const char* name, int value)
 {
     begin_call();
     if (name && !strcmp(name, "live_layout")) { g_liveLayout = value ? 1 : 0; return 0; }
+    // "live_cus": how many workgroups of live handles count as one per CU (0: the device's CU count).  Beyond it a pull of live handles
+    // takes the two-workgroups-per-CU instantiation of the stream kernel -- on a 256-CU device from 16 385 handles on; a small value
+    // lets a test (or a small device) reach that kernel with a few hundred handles.
+    if (name && !strcmp(name, "live_cus")) { g_liveCus = value < 0 ? 0 : value; g_liveCusForced = value > 0; return 0; }
     set_error("unknown global option %s", name ? name : "(null)");
     return -1;
 }

@@ -1137,6 +1137,77 @@ def test_live_handles_on_both_kernels(all_scenarios, ref):
         L.speechPlayer_setGlobalOption(b"live_layout", 1)
 
 
+def test_large_live_pulls_take_the_two_per_cu_stream_kernel(all_scenarios, ref):
+    """pulls of more live handles than CUs x 64 (16 384 on MI355X) launch klatt_systolic<MODE, true, 8, 2, true, true>
+    -- 8-sample hand-overs, two workgroups per CU -- which no test had ever run.  speechPlayer_setGlobalOption("live_cus", 1) makes
+    every pull of more than 64 handles take it: 330 handles (six workgroups, the last one ragged) with index marks, purge and late
+    queueing on the way, the kernel alternating with the lane kernel and with the one-per-CU instantiation between pulls of the
+    same handles, pulls that are not multiples of the hand-over size; then the 8 kHz / 16 kHz / 44.1 kHz golden scenarios through
+    70 live handles each on the same kernel -- against one oracle player per handle, sample for sample and mark for mark."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    try:
+        rng = np.random.default_rng(23)
+        cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=330)]
+        players = [eng.SpeechPlayer(22050, noiseSeed=5000 + k) for k in range(len(cases))]
+        oracles = [oracle.OraclePlayer(22050, seed=5000 + k) for k in range(len(cases))]
+        for k, case in enumerate(cases):
+            for j, (fr, m, f) in enumerate(case):
+                players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, j)
+                oracles[k].queue(fr, m, f, j)
+        late = cases[7]
+        # (live_cus, live_layout) per pull: the two-per-CU stream kernel, the one-per-CU one, the lane kernel
+        plan = ((1, 1, 4097), (1, 1, 13), (0, 1, 2500), (1, 1, 8192), (1, 0, 3001), (1, 1, 8192), (1, 1, 7), (1, 1, 8192), (1, 1, 8192), (1, 1, 8192))
+        for step, (cus, layout, n) in enumerate(plan):
+            assert L.speechPlayer_setGlobalOption(b"live_cus", cus) == 0 and L.speechPlayer_setGlobalOption(b"live_layout", layout) == 0
+            if step == 3:      # a purge inside whatever every fifth handle is doing, and new frames behind it (reference src/frame.cpp:103-112)
+                for k in range(0, len(players), 5):
+                    fr, m, f = late[2]
+                    players[k].queueFrameSamples(eng.Frame.from_array(fr), m, f, 777, True)
+                    oracles[k].queue(fr, m, f, 777, True)
+            if step == 5:      # late queueing: handles that have run dry speak again
+                for k in range(3, len(players), 4):
+                    for j, (fr, m, f) in enumerate(late):
+                        players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, 100 + j)
+                        oracles[k].queue(fr, m, f, 100 + j)
+            bufs = eng.SpeechPlayer.synthesizeMany(players, n)
+            for k, b in enumerate(bufs):
+                e = oracles[k].synthesize(n)
+                g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
+                assert np.array_equal(g, e), (step, k, len(g), len(e))
+                assert players[k].getLastIndex() == oracles[k].last_index(), (step, k)
+        for p in players:
+            p.close()
+        # the sample rates of the golden scenarios through live handles on the same kernel: 70 handles per scenario, pulled together
+        for name in ("ipa_l3_8k", "ipa_l0_16k", "ipa_l1_44k", "vowel_fric_nasal_44k", "vowel_fric_nasal_8k"):
+            scn = next(s for s in all_scenarios if s.name == name)
+            assert L.speechPlayer_setGlobalOption(b"live_cus", 1) == 0 and L.speechPlayer_setGlobalOption(b"live_layout", 1) == 0
+            ps = [eng.SpeechPlayer(scn.sr, noiseSeed=scn.seed + k) for k in range(70)]
+            os_ = [oracle.OraclePlayer(scn.sr, seed=scn.seed + k) for k in range(70)]
+            for op in scn.ops:
+                if op[0] == "q":
+                    for p, o in zip(ps, os_):
+                        p.queueFrameSamples(None if op[1] is None else eng.Frame.from_array(op[1]), op[2], op[3], op[4], op[5])
+                        o.queue(op[1], op[2], op[3], op[4], op[5])
+            while True:
+                bufs = eng.SpeechPlayer.synthesizeMany(ps, 3000)
+                done = True
+                for p, o, b in zip(ps, os_, bufs):
+                    e = o.synthesize(3000)
+                    g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
+                    assert np.array_equal(g, e), (name, len(g), len(e))
+                    assert p.getLastIndex() == o.last_index()
+                    done = done and len(e) < 3000
+                if done:
+                    break
+            for p in ps:
+                p.close()
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_cus", 0)
+        L.speechPlayer_setGlobalOption(b"live_layout", 1)
+
+
 def test_quiet_classification_needs_finite_parallel_coefficients(ref):
     """an utterance with zero noise gains skips the parallel bank only while the bank's coefficients stay finite. A large
     negative parallel bandwidth makes exp(-pi bw / sr) overflow: a = inf, a * 0 = NaN, and the reference's clip turns NaN into

@@ -9,12 +9,13 @@ OUT=$(realpath -m "$1"); shift
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 4 --warmup 1 --no-cpu-baseline --no-extras $*"
+ARGS="--steps ${PROF_STEPS:-20} --warmup 2 --no-cpu-baseline --no-extras $*"      # (>= 20 launches: VERDICT r3 -- five included a 9.6 ms outlier)
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/trace" -- python3 "$ROOT/bench.py" $ARGS > "$OUT/bench_trace.json" 2> "$OUT/trace.err"
-rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_insts" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_insts.err"
-rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_waits" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_waits.err"
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $ARGS > /dev/null 2> "$OUT/pmc_write.err"
+PMC_ARGS="--steps 6 --warmup 1 --no-cpu-baseline --no-extras $*"
+rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d "$OUT/pmc_insts" -- python3 "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_insts.err"
+rocprofv3 --pmc SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --output-format csv -d "$OUT/pmc_waits" -- python3 "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_waits.err"
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/pmc_fetch" -- python3 "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_fetch.err"
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/pmc_write" -- python3 "$ROOT/bench.py" $PMC_ARGS > /dev/null 2> "$OUT/pmc_write.err"
 if [ -n "${PMC_KEY:-}" ] && [ -n "${PMC_JSON:-}" ]; then
   python3 "$ROOT/tools/summarize_prof.py" "$OUT" "$PMC_KEY" "$PMC_JSON" > "$OUT/summary.txt" 2>&1
 else

@@ -81,6 +81,12 @@ def main(outdir):
     if tr:
         rows = [r for r in csv.DictReader(open(tr)) if "klatt" in r["Kernel_Name"]]
         if rows:
+            dur = defaultdict(list)
+            for r in rows:
+                dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+            for k, v in sorted(dur.items()):
+                v.sort()
+                print("%-70s calls=%d median_ns=%d min_ns=%d max_ns=%d" % (k[:70], len(v), v[len(v) // 2], v[0], v[-1]))
             r = rows[-1]
             print("dispatch: grid=%s wg=%s lds=%s scratch=%s vgpr=%s agpr=%s sgpr=%s" % (
                 r["Grid_Size_X"], r["Workgroup_Size_X"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"],

@@ -39,7 +39,14 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
  * coefficients, interpolated gains -- from tracks: evaluated densely by a kernel of its own before the synthesis kernel, one
  * track per distinct fade of the batch, instead of exp/cos, interpolation and a frame state machine inside the sample
  * recurrence; 0: never) and "track_budget_mb" (device memory the tracks of a batch may take, default 4096, which is also the most: the flat stages address the tracks with 32-bit byte offsets; a batch whose
- * tracks do not fit runs without them): both are read by speechPlayer_batch_setUtterances, set them before it.  No option changes the PCM. */
+ * tracks do not fit runs without them);
+ * "direct" (what runs the noisy, finite utterances that got no tracks -- a batch whose fades share nothing would need 12 bytes of
+ * track per output sample: 1, default: the direct stages (every fade sample's coefficients computed in place from per-frame
+ * seeds, eight wavefronts per 64 utterances) unless the utterances are time-aligned copies of few sentences, which the stages
+ * with the frame state machine run faster; 2: the direct stages always; 0: never).
+ * "tracks", "track_budget_mb" and "direct" are read by speechPlayer_batch_setUtterances: set them before it.  No option changes the
+ * PCM of MODE_EXACT; MODE_FAST stays within its tolerance whichever kernel runs (the direct stages advance the coefficients of a
+ * fade by recurrences, re-seeded exactly at every fade's first sample: relative error <= 4 F 2^-53 after F fade samples). */
 int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, int value);
 
 /*
@@ -95,7 +102,9 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
 /* Kernel resource facts for reports: fills vgprs, ldsBytes, wavefronts launched, workgroups per CU. */
 int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nInfo);
 /* info[12..15] (nInfo >= 16): utterances that take their coefficients from tracks, distinct tracks of the batch, their size in
- * MB, 1 if the reported kernel is the tracked (flat-stage) instantiation. */
+ * MB, 1 if the reported kernel is the tracked (flat-stage) instantiation.
+ * info[16..19] (nInfo >= 20): utterances on the direct stages, 1 if the reported kernel is the direct one, the size in MB of the
+ * per-frame seeds every launch writes (1376 + 128 bytes per frame of those utterances), 0. */
 
 /* Host-only view of the track planning of speechPlayer_batch_setUtterances (tests, tools; touches no device):
  * the plan for these utterances under a budget of budgetMB.  eligible[u] != 0: utterance u may be tracked (NULL: all; the
@@ -160,7 +169,12 @@ float speechPlayer_lastLiveKernelMs(int device);
  * ring's frames ended before sampleCount samples -- such a call proceeds in pieces, with the same result. */
 int speechPlayer_lastLiveLaunches(int device);
 /* Process-wide options.  "live_layout": the kernel that advances live handles -- 1 (default): the stage-parallel kernel, four
- * wavefronts per 64 handles; 0: the lane kernel, one wavefront per 64 handles.  Same saved state, same PCM. */
+ * wavefronts per 64 handles; 0: the lane kernel, one wavefront per 64 handles.  Same saved state, same PCM.
+ * "live_cus": pulls of more than live_cus x 64 handles take the two-workgroups-per-CU instantiation of the stream kernel (0, default:
+ * the device's CU count -- 16 384 handles on MI355X; a small value lets a test reach that kernel with a few hundred handles).
+ * Memory: every live handle owns a slot of ~100 KB of HBM in a per-device arena (a ring of 256 queued frames with their durations
+ * and a 240-double state block); the arena doubles when the slots run out (old and new coexist during the move: ~2.4 GB transient
+ * at 16 384 slots), never shrinks, and speechPlayer_initialize fails with SPEECHPLAYER_ERR_HIP when the device cannot hold it. */
 int speechPlayer_setGlobalOption(const char* name, int value);
 /* Choose a handle's noise stream (default 0); see DESIGN.md "Noise". */
 int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int seed);

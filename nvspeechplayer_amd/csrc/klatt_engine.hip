@@ -564,6 +564,22 @@ void run_parts(unsigned n, F fn)
     for (auto& th : pool) th.join();
 }
 
+// Host threads of setUtterances (the planner's setting: SPEECHPLAYER_PLAN_THREADS, else up to 8), and a loop over [0, n) cut into
+// one contiguous range per thread (small loops stay on the caller's thread).
+unsigned host_threads()
+{
+    unsigned n = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("SPEECHPLAYER_PLAN_THREADS")) n = (unsigned)std::max(1, atoi(e));
+    return n;
+}
+template <class F>
+void parallel_ranges(long long n, long long grain, F fn)
+{
+    const unsigned t = (unsigned)std::min<long long>(host_threads(), std::max<long long>(1, n / std::max<long long>(grain, 1)));
+    if (t < 2) { fn(0ll, n); return; }
+    run_parts(t, [&](unsigned k) { fn(n * (long long)k / t, n * (long long)(k + 1) / t); });
+}
+
 // The plan of a batch.  Large batches are planned in parts, one host thread each (the walk is a hash of 45 values and two map
 // look-ups per frame: 0.2 s for BASELINE configs[2] on one thread), and the parts' shapes and fades merged: equal fades of
 // different parts end up with one track.  If the merged tracks fit the budget that is the plan; if not -- or if the parts gave
@@ -577,8 +593,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     auto lap = [&](const char* what) {
         if (trace) fprintf(stderr, "[speechPlayer/plan] %s: %.1f ms since the start\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tStart).count());
     };
-    unsigned nThreads = std::min(8u, std::max(1u, std::thread::hardware_concurrency()));
-    if (const char* e = getenv("SPEECHPLAYER_PLAN_THREADS")) nThreads = (unsigned)std::max(1, atoi(e));
+    const unsigned nThreads = host_threads();
     if (nThreads < 2 || nF < 200000 || nUtterances < (long long)nThreads * 64) {
         plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
         return;
@@ -1561,6 +1576,11 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     Batch* b = static_cast<Batch*>(batch);
     if (!b || nUtterances < 0 || !frameStart) { set_error("setUtterances: bad arguments"); return -1; }
     if (nUtterances >= 0xFFFFFFFFll) { set_error("setUtterances: too many utterances"); return -1; }
+    static const bool setTrace = getenv("SPEECHPLAYER_SET_TRACE") != nullptr;      // where the call's time goes, on stderr
+    const auto tSet = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (setTrace) fprintf(stderr, "[speechPlayer/set] %s: %.1f ms since the start\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tSet).count());
+    };
     HIP_TRY(hipSetDevice(b->device));
     // validate the index array before anything reads through it
     if (frameStart[0] != 0) { set_error("setUtterances: frameStart[0] must be 0"); return -1; }
@@ -1576,79 +1596,119 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     std::vector<uint32_t> lens((size_t)nUtterances, 0);
     std::vector<long long> outStart((size_t)nUtterances + 1, 0);
     std::vector<FrameMeta> meta((size_t)nF);
-    for (long long k = 0; k < nF; ++k) {
-        meta[k].minSamples = minFrameDuration[k];
-        meta[k].fadeSamples = std::max(fadeDuration[k], 1u);   // reference src/speechPlayer.cpp:36
-        meta[k].userIndex = userIndex ? userIndex[k] : -1;
-        meta[k].flags = (isNull && isNull[k]) ? FRAME_NULL : 0u;
-    }
-    std::vector<UttDesc> utt((size_t)nUtterances);
-    long long total = 0, pool = 0;
-    for (long long u = 0; u < nUtterances; ++u) {
-        unsigned long long len = 0;
-        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
-            const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
-            len += std::max(m, f + 1) + 1;   // samples one request spans (follows from reference src/frame.cpp:41-80)
+    parallel_ranges(nF, 1 << 16, [&](long long a, long long e) {
+        for (long long k = a; k < e; ++k) {
+            meta[k].minSamples = minFrameDuration[k];
+            meta[k].fadeSamples = std::max(fadeDuration[k], 1u);   // reference src/speechPlayer.cpp:36
+            meta[k].userIndex = userIndex ? userIndex[k] : -1;
+            meta[k].flags = (isNull && isNull[k]) ? FRAME_NULL : 0u;
         }
-        if (len >= 0xFFFFFFFFull) { set_error("utterance %lld too long (%llu samples)", u, len); return -1; }
-        lens[u] = (uint32_t)len;
-        outStart[u] = pool;
-        memset(&utt[u], 0, sizeof(UttDesc));
-        utt[u].frameStart = frameStart[u];
-        utt[u].outStart = pool;
-        utt[u].nFrames = (uint32_t)(frameStart[u + 1] - frameStart[u]);
-        utt[u].seed = noiseSeed ? noiseSeed[u] : (uint32_t)u;
-        utt[u].length = (uint32_t)len;
-        // Noise sources and the parallel bank can be skipped for an utterance only if every frame has
-        // all three noise gains exactly zero (voiceTurbulenceAmplitude, aspirationAmplitude,
-        // fricationAmplitude) and no non-finite parameter that could turn 0*x into NaN.
-        bool needsNoise = false;
-        for (long long k = frameStart[u]; k < frameStart[u + 1] && !needsNoise; ++k) {
-            if (meta[k].flags & FRAME_NULL) continue;
-            const double* p = reinterpret_cast<const double*>(frames + k);
-            if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) needsNoise = true;
-            for (int i = 0; i < kNumParams && !needsNoise; ++i)
-                if (!std::isfinite(p[i])) needsNoise = true;
+    });
+    std::vector<UttDesc> utt((size_t)nUtterances);
+    // per utterance, ONE pass over its frames (on several host threads: the utterances are independent): its length, whether it needs
+    // its noise sources, whether it may skip the nasal pair, and -- for the tracks and the direct stages below -- whether all its
+    // parameters are finite (bit 0 of `shape`) and within the range of klatt_math.h (bit 1)
+    std::vector<unsigned char> shape((size_t)nUtterances, 0);
+    std::atomic<long long> tooLong{-1};
+    const double maxBwDirect = 690.0 * b->sampleRate / M_PI, maxFDirect = 9900.0 * b->sampleRate / (2.0 * M_PI);
+    parallel_ranges(nUtterances, 512, [&](long long ua, long long ue) {
+        for (long long u = ua; u < ue; ++u) {
+            unsigned long long len = 0;
+            // Noise sources and the parallel bank can be skipped for an utterance only if every frame has
+            // all three noise gains exactly zero (voiceTurbulenceAmplitude, aspirationAmplitude,
+            // fricationAmplitude) and no non-finite parameter that could turn 0*x into NaN.
             // The skipped parallel bank contributes exactly 0 only while its coefficients are finite (a * 0 with a = inf
             // is NaN, which the reference clips to 32000): a negative bandwidth makes exp(-pi bw / sr) grow without
             // bound, so the bandwidths must be in [0, 1e6] and the frequencies bounded (reference :112-127).
-            for (int i = 25; i <= 30 && !needsNoise; ++i)
-                if (!(std::fabs(p[i]) <= 1e6) || !(p[i + 6] >= 0.0) || !(p[i + 6] <= 1e6)) needsNoise = true;
-        }
-        utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : 0u;
-        // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152).
-        // With caNP == 0 in every frame that is x + (np - x) * 0 == x as long as np stays finite, and nothing else
-        // reads N0's or NP's memories: such an utterance may skip the pair.  np stays finite when the source is
-        // bounded (gains <= 1e30), N0's zero pair is not degenerate (bandwidth >= 1 Hz keeps 1 - b - c away from 0,
-        // reference :122) and NP does not grow (bandwidth >= 0).  Frequencies and bandwidths are bounded so that
-        // the coefficients stay finite.
-        if (!needsNoise) {
-            bool noNasal = true;
-            for (long long k = frameStart[u]; k < frameStart[u + 1] && noNasal; ++k) {
+            // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152).
+            // With caNP == 0 in every frame that is x + (np - x) * 0 == x as long as np stays finite, and nothing else
+            // reads N0's or NP's memories: such an utterance may skip the pair.  np stays finite when the source is
+            // bounded (gains <= 1e30), N0's zero pair is not degenerate (bandwidth >= 1 Hz keeps 1 - b - c away from 0,
+            // reference :122) and NP does not grow (bandwidth >= 0).  Frequencies and bandwidths are bounded so that
+            // the coefficients stay finite.
+            bool needsNoise = false, noNasal = true, finite = true, bounded = true;
+            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+                const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
+                len += std::max(m, f + 1) + 1;   // samples one request spans (follows from reference src/frame.cpp:41-80)
                 if (meta[k].flags & FRAME_NULL) continue;
                 const double* p = reinterpret_cast<const double*>(frames + k);
+                if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) needsNoise = true;
+                for (int i = 0; i < kNumParams; ++i)
+                    if (!std::isfinite(p[i])) finite = false;
+                for (int i = 25; i <= 30; ++i)
+                    if (!(std::fabs(p[i]) <= 1e6) || !(p[i + 6] >= 0.0) || !(p[i + 6] <= 1e6)) needsNoise = true;
                 if (p[23] != 0.0 || !(p[21] >= 1.0) || !(p[22] >= 0.0) || !(p[21] <= 1e6) || !(p[22] <= 1e6) ||
                     !(std::fabs(p[13]) <= 1e6) || !(std::fabs(p[14]) <= 1e6) || !(std::fabs(p[5]) <= 1e30) || !(std::fabs(p[44]) <= 1e30) ||
                     !(std::fabs(p[0]) <= 1e30) || !(std::fabs(p[46]) <= 1e30))
                     noNasal = false;
+                // the direct stages evaluate exp / cos with klatt_math.h alone, whose range is |arg| <= 700 / 1e4: the frequencies and
+                // bandwidths of their utterances are bounded accordingly (no frame a speech front-end produces comes near)
+                for (int r = 0; r < kNumRes; ++r)
+                    if (!(std::fabs(p[shape_param(2 * r)]) <= maxFDirect) || !(std::fabs(p[shape_param(2 * r + 1)]) <= maxBwDirect)) bounded = false;
             }
-            if (noNasal) utt[u].flags |= UTT_NO_NASAL;
+            if (!finite) needsNoise = true;
+            if (len >= 0xFFFFFFFFull) { long long none = -1; tooLong.compare_exchange_strong(none, u); len = 0; }
+            lens[u] = (uint32_t)len;
+            memset(&utt[u], 0, sizeof(UttDesc));
+            utt[u].frameStart = frameStart[u];
+            utt[u].nFrames = (uint32_t)(frameStart[u + 1] - frameStart[u]);
+            utt[u].seed = noiseSeed ? noiseSeed[u] : (uint32_t)u;
+            utt[u].length = (uint32_t)len;
+            utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : (noNasal ? UTT_NO_NASAL : 0u);
+            shape[u] = finite ? (bounded ? 3 : 1) : 0;
         }
-        total += (long long)len;
-        pool += ((long long)len + kTile - 1) / kTile * kTile;
+    });
+    if (tooLong.load() >= 0) { set_error("utterance %lld too long (4294967295 samples or more)", tooLong.load()); return -1; }
+    // From here on nothing but an allocation or a copy can fail (which leaves an empty batch): the frames -- by far the largest upload,
+    // 0.6 GB for BASELINE configs[2] -- start on their way now, on a thread of their own (a copy from pageable memory keeps its caller
+    // until it is done), beside the planning below.
+    int earlyRc = 0;
+    std::string earlyErr;
+    std::thread early;
+    bool earlyStarted = false;
+    if (nF > 0 && (size_t)nF * kNumParams * sizeof(double) >= (32u << 20)) {
+        if (b->dFrames.reserve((size_t)nF * kNumParams)) {
+            b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
+            b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
+            b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
+            return -1;
+        }
+        // the batch on the device is the old frames with the new ones over them from now on: it no longer exists
+        b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
+        b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
+        b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
+        try {
+            early = std::thread([&, dev = b->device, dst = b->dFrames.ptr]() {
+                hipError_t e = hipSetDevice(dev);
+                if (e == hipSuccess) e = hipMemcpy(dst, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice);
+                if (e != hipSuccess) { earlyRc = -1; earlyErr = hipGetErrorString(e); }
+            });
+            earlyStarted = true;
+        } catch (const std::system_error&) {}
+    }
+    struct JoinEarly { std::thread& t; ~JoinEarly() { if (t.joinable()) t.join(); } } joinEarly{early};
+    long long total = 0, pool = 0;
+    for (long long u = 0; u < nUtterances; ++u) {
+        outStart[u] = pool;
+        utt[u].outStart = pool;
+        total += (long long)lens[u];
+        pool += ((long long)lens[u] + kTile - 1) / kTile * kTile;
     }
     outStart[nUtterances] = pool;
+    lap("meta, lengths, classification");
     // An utterance's TIMING: a hash of its sequence of frame durations, fades and silences -- the same text at the same speed, whatever
     // the pitch, the voice or the noise seed.  Lanes with one timing dequeue and fade on the same samples (lane packing, below).
     std::vector<unsigned long long> timing((size_t)nUtterances);
-    for (long long u = 0; u < nUtterances; ++u) {
-        unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(frameStart[u + 1] - frameStart[u]);
-        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
-            h ^= ((unsigned long long)meta[k].minSamples << 32) ^ meta[k].fadeSamples ^ ((unsigned long long)(meta[k].flags & FRAME_NULL) << 63);
-            h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29;
+    parallel_ranges(nUtterances, 4096, [&](long long ua, long long ue) {
+        for (long long u = ua; u < ue; ++u) {
+            unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(frameStart[u + 1] - frameStart[u]);
+            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+                h ^= ((unsigned long long)meta[k].minSamples << 32) ^ meta[k].fadeSamples ^ ((unsigned long long)(meta[k].flags & FRAME_NULL) << 63);
+                h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29;
+            }
+            timing[u] = h;
         }
-        timing[u] = h;
-    }
+    });
     // A quiet utterance whose timing too few others share cannot fill a wavefront of the quiet kernels with lanes that fade together:
     // its wavefront would run every chunk sample by sample, evaluating exp / cos for whichever lane is fading (a few workgroups that
     // take longer than the whole flat launch: 24 ms for the 8192 quiet utterances of a batch with 65 536 different timings).  Such an
@@ -1666,33 +1726,23 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
                 utt[u].flags = (utt[u].flags | UTT_NEEDS_NOISE) & ~UTT_NO_NASAL;
             }
     }
+    lap("timing hashes, quiet runs");
     // ---- tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite: plan_tracks -----
     // ---- and the direct stages (klatt_direct.h) for those among them that get none ------------------------
     TrackPlan plan;
     std::vector<unsigned char> eligible;
     if ((b->tracks || wantDirect) && nF > 0) {
+        // A NaN anywhere ("hold" targets, reference src/utils.h:21) or an infinite parameter keeps an utterance with the untracked kernel.
+        // Finite parameters whose COEFFICIENTS overflow (a huge bandwidth or frequency) are tracked all the same: klatt_tracks evaluates
+        // the same expressions as the kernels' own coefficient code, so the track holds the same inf / NaN the kernel would have computed.
         eligible.assign((size_t)nUtterances, 0);
-        // the direct stages evaluate exp / cos with klatt_math.h alone, whose range is |arg| <= 700 / 1e4: the frequencies and
-        // bandwidths of their utterances are bounded accordingly (bit 1; no frame a speech front-end produces comes near)
-        const double maxBw = 690.0 * b->sampleRate / M_PI, maxF = 9900.0 * b->sampleRate / (2.0 * M_PI);
-        for (long long u = 0; u < nUtterances; ++u) {
-            if (!(utt[u].flags & UTT_NEEDS_NOISE)) continue;
-            bool finite = true, bounded = true;
-            for (long long k = frameStart[u]; k < frameStart[u + 1] && finite; ++k) {
-                if (meta[k].flags & FRAME_NULL) continue;
-                const double* p = reinterpret_cast<const double*>(frames + k);
-                for (int i = 0; i < kNumParams && finite; ++i) finite = std::isfinite(p[i]);
-                for (int r = 0; r < kNumRes && bounded; ++r)
-                    bounded = std::fabs(p[shape_param(2 * r)]) <= maxF && std::fabs(p[shape_param(2 * r + 1)]) <= maxBw;
-            }
-            // A NaN anywhere ("hold" targets, reference src/utils.h:21) or an infinite parameter keeps an utterance with the untracked kernel.
-            // Finite parameters whose COEFFICIENTS overflow (a huge bandwidth or frequency) are tracked all the same: klatt_tracks evaluates
-            // the same expressions as the kernels' own coefficient code, so the track holds the same inf / NaN the kernel would have computed.
-            eligible[u] = finite ? (bounded ? 3 : 1) : 0;
-        }
+        for (long long u = 0; u < nUtterances; ++u)
+            if (utt[u].flags & UTT_NEEDS_NOISE) eligible[u] = shape[u];
     }
+    lap("eligibility");
     if (b->tracks && nF > 0) {
         plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible.data(), b->trackBudgetMB, plan);
+        lap("tracks planned");
         for (long long u = 0; u < nUtterances; ++u)
             if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED | (plan.kinds[u] << kUttKindShift);
     }
@@ -1709,7 +1759,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             for (long long u = 0; u < nUtterances; ++u)
                 if ((eligible[u] & 2) && !(utt[u].flags & UTT_TRACKED)) { ++candidates; ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)]; }
             for (const auto& kv : runOf) if (kv.second >= 32) inRuns += kv.second;
-            take = inRuns * 2 <= candidates;
+            take = !b->sortByLength || inRuns * 2 <= candidates;      // (without the sort by length and timing nothing is side by side)
         }
         if (take)
             for (long long u = 0; u < nUtterances; ++u)
@@ -1755,7 +1805,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     if (!plan.jobs.empty() || nDirectUtt > 0) {
         if (!plan.jobs.empty()) flatRef.resize((size_t)nF);
         sourceRef.resize((size_t)nF);
-        for (long long k = 0; k < nF; ++k) {
+        parallel_ranges(nF, 1 << 16, [&](long long ka, long long ke) {
+        for (long long k = ka; k < ke; ++k) {
             const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
             if (!plan.jobs.empty()) flatRef[k] = FlatRef{(uint32_t)plan.ref[k].off, plan.ref[k].mask, meta[k].fadeSamples, (uint32_t)std::min<unsigned long long>(std::max(m, f + 1) + 1, 0xFFFFFFFFull)};
             const bool isNullFrame = (meta[k].flags & FRAME_NULL) != 0;
@@ -1765,7 +1816,9 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             volatile double num = g46 - g0, den = (double)meta[k].minSamples, one = 1.0, fd = (double)meta[k].fadeSamples;
             sourceRef[k] = SourceRef{g0, isNullFrame ? 0.0 : num / den, one / fd, meta[k].userIndex, meta[k].flags & FRAME_NULL};
         }
+        });
     }
+    lap("direct jobs, flat / source references");
     std::vector<TrackJob>& jobs = plan.jobs;
     const unsigned long long trackEntries = plan.entries;
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
@@ -1839,6 +1892,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         nTracked = nTrackedUtt + (long long)padT;
     }
     const long long nSlotsAll = (long long)order.size();
+    lap("lane packing");
 
     auto upload = [&]() -> int {
         if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>(nF, 1)) ||
@@ -1864,7 +1918,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             HIP_TRY(hipMemcpyAsync(b->dDirectFirst.ptr, directFirst.data(), (size_t)nUtterances * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
         }
         if (nF) {
-            HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
+            if (!earlyStarted) HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dMeta.ptr, meta.data(), (size_t)nF * sizeof(FrameMeta), hipMemcpyHostToDevice, b->stream));
         }
         if (nUtterances) {
@@ -1873,6 +1927,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nUtterances * sizeof(UttResult), b->stream));
         }
         HIP_TRY(hipStreamSynchronize(b->stream));
+        if (early.joinable()) early.join();
+        if (earlyRc) { set_error_code(SPEECHPLAYER_ERR_HIP); set_error("setUtterances: uploading the frames failed: %s", earlyErr.c_str()); return -1; }
         return 0;
     };
     if (upload()) {
@@ -1883,6 +1939,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
         return -1;
     }
+    lap("uploads");
     b->nUtt = nUtterances; b->nFrames = nF; b->nSlots = nSlotsAll;
     b->nQuiet = nQuiet; b->nNoNasal = nNoNasal;
     b->nTracked = nTrackedUtt > 0 ? nTracked : 0; b->nTrackedUtt = nTrackedUtt;

@@ -191,100 +191,6 @@ __global__ void __launch_bounds__(256) klatt_seeds(const SeedArgs A)
     }
 }
 
-// ---- the polynomial kernels of klatt_math.h with their constants in SCALAR registers ------------------------------------------
-// Same operations on the same operands as exp_kernel / cos_kernel / sin_kernel (so the same bits: the tests compare the direct
-// stages' PCM with the tracked and the untracked kernels' byte for byte), spelled as v_fma_f64 with the constant as a scalar
-// operand.  Left to the compiler a Horner step `p = fma(p, z, C)` becomes `v_mov_b64 tmp, C; v_fmac_f64 tmp, p, z` -- the
-// two-address form needs the addend in the destination, and C, which lives in a VGPR pair, must survive: TWO issue slots per step
-// (a v_mov_b64 costs a wavefront what an f64 FMA costs), 130 of ~230 instructions per sample and stage in MODE_EXACT's mixed loop.
-__device__ __forceinline__ double fma_sc(double a, double b, double c)      // a * b + c, c from scalar registers
-{
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
-    return d;
-}
-__device__ __forceinline__ double fma_sa(double a, double b, double c)      // a * b + c, a from scalar registers
-{
-    double d;
-    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(a), "v"(b), "v"(c));
-    return d;
-}
-__device__ __forceinline__ double exp_kernel_s(double r)
-{
-    double p = fma_sa(1.6059043836821613e-10, r, 2.0876756987868100e-09);      // (1/13!) r + 1/12!: what fma(p, r, C) is with p = 1/13!
-    p = fma_sc(p, r, 2.5052108385441720e-08);
-    p = fma_sc(p, r, 2.7557319223985890e-07);
-    p = fma_sc(p, r, 2.7557319223985893e-06);
-    p = fma_sc(p, r, 2.4801587301587302e-05);
-    p = fma_sc(p, r, 1.9841269841269841e-04);
-    p = fma_sc(p, r, 1.3888888888888889e-03);
-    p = fma_sc(p, r, 8.3333333333333332e-03);
-    p = fma_sc(p, r, 4.1666666666666664e-02);
-    p = fma_sc(p, r, 1.6666666666666666e-01);
-    p = __builtin_fma(p, r, 0.5);
-    return __builtin_fma(r * r, p, r) + 1.0;
-}
-__device__ __forceinline__ double sin_kernel_s(double r, double z)
-{
-    double s = fma_sa(2.8114572543455206e-15, z, -7.6471637318198164e-13);
-    s = fma_sc(s, z, 1.6059043836821613e-10);
-    s = fma_sc(s, z, -2.5052108385441720e-08);
-    s = fma_sc(s, z, 2.7557319223985893e-06);
-    s = fma_sc(s, z, -1.9841269841269841e-04);
-    s = fma_sc(s, z, 8.3333333333333332e-03);
-    s = fma_sc(s, z, -1.6666666666666666e-01);
-    return __builtin_fma(r * z, s, r);
-}
-__device__ __forceinline__ double cos_kernel_s(double z)
-{
-    double c = fma_sa(4.7794773323873853e-14, z, -1.1470745597729725e-11);
-    c = fma_sc(c, z, 2.0876756987868100e-09);
-    c = fma_sc(c, z, -2.7557319223985890e-07);
-    c = fma_sc(c, z, 2.4801587301587302e-05);
-    c = fma_sc(c, z, -1.3888888888888889e-03);
-    c = fma_sc(c, z, 4.1666666666666664e-02);
-    return __builtin_fma(z, __builtin_fma(z, c, -0.5), 1.0);
-}
-__device__ __forceinline__ double add_sc(double a, double c)      // a + c, c from scalar registers
-{
-    double d;
-    asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
-    return d;
-}
-__device__ __forceinline__ double mul_sc(double a, double c)
-{
-    double d;
-    asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(a), "s"(c));
-    return d;
-}
-__device__ __forceinline__ double cos_quadrant_m1_s(double t)
-{
-    // fma(1.0, C, t) is one rounded addition
-    double r = add_sc(t, 1.5707963267948965580e+00);
-    r = add_sc(r, 6.1232339957367660359e-17);
-    return sin_kernel_s(r, r * r);
-}
-// the general case (arguments that need a range reduction): fast_exp / fast_cos of klatt_math.h, operation for operation
-__device__ __forceinline__ double fast_exp_s(double x)
-{
-    const double k = __builtin_rint(mul_sc(x, kLog2e));
-    double r = fma_sa(-6.93147180369123816490e-01, k, x);      // fma(-k, ln2_hi, x): the product's sign is the same rounded value
-    r = fma_sa(-1.90821492927058770002e-10, k, r);
-    return __builtin_ldexp(exp_kernel_s(r), (int)k);
-}
-__device__ __forceinline__ double fast_cos_s(double t)
-{
-    const double n = __builtin_rint(mul_sc(t, kTwoOverPi));
-    double r = fma_sa(-1.5707963267948965580e+00, n, t);
-    r = fma_sa(-6.1232339957367660359e-17, n, r);
-    const double z = r * r;
-    const double sinr = sin_kernel_s(r, z);
-    const double cosr = cos_kernel_s(z);
-    const int q = (int)n & 3;
-    const double v = (q & 1) ? sinr : cosr;
-    return (q == 1 || q == 2) ? -v : v;
-}
-
 // ---- a direct stage's state ----------------------------------------------------------------------------------------------------
 template <int STAGE_>
 struct DirectDesc {
@@ -384,11 +290,11 @@ struct DirectMid {
                 } else {
                     const double fr = f.p0[r] + (f.p1[r] * ratio);      // reference src/utils.h:22
                     const double th = A.twoPiOverSr * -fr;
-                    const double cs = !(cls & 1u) ? cos_kernel_s(th * th) : (!(cls & 2u) ? cos_quadrant_m1_s(th) : fast_cos_s(th));
+                    const double cs = !(cls & 1u) ? cos_unreduced(th) : (!(cls & 2u) ? cos_quadrant_m1(th) : fast_cos(th));      // (constants as scalar operands: klatt_math.h)
                     if (wm & (1u << (kDirectBwShift + r))) {
                         const double bw = f.p2[r] + (f.p3[r] * ratio);
                         const double ex = A.negPiOverSr * bw;
-                        f.rad[r] = cls != 3u ? exp_kernel_s(ex) : fast_exp_s(ex);
+                        f.rad[r] = cls != 3u ? exp_unreduced(ex) : fast_exp(ex);
                     }
                     const Coef k = coefficient_finish(f.rad[r], cs, anti, fr);      // reference src/speechWaveGenerator.cpp:117-126
                     f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;

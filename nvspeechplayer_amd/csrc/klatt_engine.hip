@@ -225,7 +225,11 @@ int launch_direct(const KernelArgs& a, int mode, long long nGroups, hipStream_t 
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = DirectLds<16>::kBytes;
+#ifndef KLATT_DIRECT_CH
+#define KLATT_DIRECT_CH 16      // hand-over size / wavefronts per SIMD of the direct kernel: 16 / 2 (one workgroup per CU); 8 / 4: two per CU, 128 VGPRs (spills: A/B only)
+#define KLATT_DIRECT_WPE 2
+#endif
+    constexpr int ldsBytes = DirectLds<KLATT_DIRECT_CH>::kBytes;
     auto go = [&](auto kernel) -> int {
         if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kDirectStages), ldsBytes, stream, a);
@@ -233,8 +237,8 @@ int launch_direct(const KernelArgs& a, int mode, long long nGroups, hipStream_t 
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_direct<MODE_EXACT, 16, 2>); break;
-    case MODE_FAST: rc = go(klatt_direct<MODE_FAST, 16, 2>); break;
+    case MODE_EXACT: rc = go(klatt_direct<MODE_EXACT, KLATT_DIRECT_CH, KLATT_DIRECT_WPE>); break;
+    case MODE_FAST: rc = go(klatt_direct<MODE_FAST, KLATT_DIRECT_CH, KLATT_DIRECT_WPE>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -2387,8 +2391,8 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         wavesPerGroup = kStages;
         groups = g;
     } else if (directG) {
-        fn = fast ? (const void*)klatt_direct<MODE_FAST, 16, 2> : (const void*)klatt_direct<MODE_EXACT, 16, 2>;
-        ldsBytes = DirectLds<16>::kBytes; chunk = 16;
+        fn = fast ? (const void*)klatt_direct<MODE_FAST, KLATT_DIRECT_CH, KLATT_DIRECT_WPE> : (const void*)klatt_direct<MODE_EXACT, KLATT_DIRECT_CH, KLATT_DIRECT_WPE>;
+        ldsBytes = DirectLds<KLATT_DIRECT_CH>::kBytes; chunk = KLATT_DIRECT_CH;
         wavesPerGroup = kDirectStages;
     } else if (tracked) {
         if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_FLAT_CH, true>::kBytes; chunk = KLATT_FLAT_CH; }

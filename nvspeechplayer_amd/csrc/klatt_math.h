@@ -16,20 +16,58 @@
 
 namespace klatt {
 
+// A Horner step p * x + C with a literal C.  On the device the constant is a SCALAR operand of one v_fma_f64: left to the compiler
+// the step becomes `v_mov_b64 tmp, C; v_fmac_f64 tmp, p, x` -- the two-address form wants the addend in the destination, and C,
+// kept in a VGPR pair for the whole kernel, must survive: two issue slots per step and two dozen constants' worth of VGPRs in
+// every kernel that evaluates coefficients (klatt_direct.h has the count: 130 of ~230 instructions per sample and stage).  Same
+// operation, same operands: the same bits.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(KLATT_NO_SCALAR_CONSTANTS)
+__device__ __forceinline__ double horner(double p, double x, double c)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(p), "v"(x), "s"(c));
+    return d;
+}
+// c * x + a with the literal as the multiplicand (the first step of a polynomial, the reductions' k * ln2 terms)
+__device__ __forceinline__ double horner0(double c, double x, double a)
+{
+    double d;
+    asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(c), "v"(x), "v"(a));
+    return d;
+}
+// x + c and x * c with a literal c
+__device__ __forceinline__ double add_const(double x, double c)
+{
+    double d;
+    asm("v_add_f64 %0, %1, %2" : "=v"(d) : "v"(x), "s"(c));
+    return d;
+}
+__device__ __forceinline__ double mul_const(double x, double c)
+{
+    double d;
+    asm("v_mul_f64 %0, %1, %2" : "=v"(d) : "v"(x), "s"(c));
+    return d;
+}
+#else
+KLATT_HD double horner(double p, double x, double c) { return __builtin_fma(p, x, c); }
+KLATT_HD double horner0(double c, double x, double a) { return __builtin_fma(c, x, a); }
+KLATT_HD double add_const(double x, double c) { return x + c; }
+KLATT_HD double mul_const(double x, double c) { return x * c; }
+#endif
+
 // e^r for |r| <= ln2/2: 1 + r + r^2 P(r), Taylor through r^13 (truncation < 4e-18 relative)
 KLATT_HD double exp_kernel(double r)
 {
-    double p = 1.6059043836821613e-10;            // 1/13!
-    p = __builtin_fma(p, r, 2.0876756987868100e-09);   // 1/12!
-    p = __builtin_fma(p, r, 2.5052108385441720e-08);   // 1/11!
-    p = __builtin_fma(p, r, 2.7557319223985890e-07);   // 1/10!
-    p = __builtin_fma(p, r, 2.7557319223985893e-06);   // 1/9!
-    p = __builtin_fma(p, r, 2.4801587301587302e-05);   // 1/8!
-    p = __builtin_fma(p, r, 1.9841269841269841e-04);   // 1/7!
-    p = __builtin_fma(p, r, 1.3888888888888889e-03);   // 1/6!
-    p = __builtin_fma(p, r, 8.3333333333333332e-03);   // 1/5!
-    p = __builtin_fma(p, r, 4.1666666666666664e-02);   // 1/4!
-    p = __builtin_fma(p, r, 1.6666666666666666e-01);   // 1/3!
+    double p = horner0(1.6059043836821613e-10, r, 2.0876756987868100e-09);   // (1/13!) r + 1/12!
+    p = horner(p, r, 2.5052108385441720e-08);   // 1/11!
+    p = horner(p, r, 2.7557319223985890e-07);   // 1/10!
+    p = horner(p, r, 2.7557319223985893e-06);   // 1/9!
+    p = horner(p, r, 2.4801587301587302e-05);   // 1/8!
+    p = horner(p, r, 1.9841269841269841e-04);   // 1/7!
+    p = horner(p, r, 1.3888888888888889e-03);   // 1/6!
+    p = horner(p, r, 8.3333333333333332e-03);   // 1/5!
+    p = horner(p, r, 4.1666666666666664e-02);   // 1/4!
+    p = horner(p, r, 1.6666666666666666e-01);   // 1/3!
     p = __builtin_fma(p, r, 0.5);
     return __builtin_fma(r * r, p, r) + 1.0;
 }
@@ -40,36 +78,34 @@ constexpr double kTwoOverPi = 0.63661977236758134308;
 // e^x, |x| <= 700.  x = k ln2 + r, |r| <= ln2/2 (fdlibm's two-part ln2), scaled by 2^k.
 KLATT_HD double fast_exp(double x)
 {
-    const double k = __builtin_rint(x * kLog2e);
-    double r = __builtin_fma(-k, 6.93147180369123816490e-01, x);   // ln2 high part
-    r = __builtin_fma(-k, 1.90821492927058770002e-10, r);           // ln2 low part
+    const double k = __builtin_rint(mul_const(x, kLog2e));
+    double r = horner0(-6.93147180369123816490e-01, k, x);   // -k ln2_hi + x (the sign moved to the constant: the same product)
+    r = horner0(-1.90821492927058770002e-10, k, r);           // ln2 low part
     return __builtin_ldexp(exp_kernel(r), (int)k);
 }
 
 // sin r = r + r z S(z), z = r^2, |r| <= pi/4, Taylor through r^17
 KLATT_HD double sin_kernel(double r, double z)
 {
-    double s = 2.8114572543455206e-15;                 // 1/17!
-    s = __builtin_fma(s, z, -7.6471637318198164e-13);  // -1/15!
-    s = __builtin_fma(s, z, 1.6059043836821613e-10);   // 1/13!
-    s = __builtin_fma(s, z, -2.5052108385441720e-08);  // -1/11!
-    s = __builtin_fma(s, z, 2.7557319223985893e-06);   // 1/9!
-    s = __builtin_fma(s, z, -1.9841269841269841e-04);  // -1/7!
-    s = __builtin_fma(s, z, 8.3333333333333332e-03);   // 1/5!
-    s = __builtin_fma(s, z, -1.6666666666666666e-01);  // -1/3!
+    double s = horner0(2.8114572543455206e-15, z, -7.6471637318198164e-13);  // (1/17!) z - 1/15!
+    s = horner(s, z, 1.6059043836821613e-10);   // 1/13!
+    s = horner(s, z, -2.5052108385441720e-08);  // -1/11!
+    s = horner(s, z, 2.7557319223985893e-06);   // 1/9!
+    s = horner(s, z, -1.9841269841269841e-04);  // -1/7!
+    s = horner(s, z, 8.3333333333333332e-03);   // 1/5!
+    s = horner(s, z, -1.6666666666666666e-01);  // -1/3!
     return __builtin_fma(r * z, s, r);
 }
 
 // cos r = 1 + z (-1/2 + z C(z)), z = r^2, |r| <= pi/4, Taylor through r^16
 KLATT_HD double cos_kernel(double z)
 {
-    double c = 4.7794773323873853e-14;                 // 1/16!
-    c = __builtin_fma(c, z, -1.1470745597729725e-11);  // -1/14!
-    c = __builtin_fma(c, z, 2.0876756987868100e-09);   // 1/12!
-    c = __builtin_fma(c, z, -2.7557319223985890e-07);  // -1/10!
-    c = __builtin_fma(c, z, 2.4801587301587302e-05);   // 1/8!
-    c = __builtin_fma(c, z, -1.3888888888888889e-03);  // -1/6!
-    c = __builtin_fma(c, z, 4.1666666666666664e-02);   // 1/4!
+    double c = horner0(4.7794773323873853e-14, z, -1.1470745597729725e-11);  // (1/16!) z - 1/14!
+    c = horner(c, z, 2.0876756987868100e-09);   // 1/12!
+    c = horner(c, z, -2.7557319223985890e-07);  // -1/10!
+    c = horner(c, z, 2.4801587301587302e-05);   // 1/8!
+    c = horner(c, z, -1.3888888888888889e-03);  // -1/6!
+    c = horner(c, z, 4.1666666666666664e-02);   // 1/4!
     return __builtin_fma(z, __builtin_fma(z, c, -0.5), 1.0);
 }
 
@@ -77,9 +113,9 @@ KLATT_HD double cos_kernel(double z)
 // cosine kernel in r by quadrant (truncation < 3e-18).
 KLATT_HD double fast_cos(double t)
 {
-    const double n = __builtin_rint(t * kTwoOverPi);
-    double r = __builtin_fma(-n, 1.5707963267948965580e+00, t);
-    r = __builtin_fma(-n, 6.1232339957367660359e-17, r);
+    const double n = __builtin_rint(mul_const(t, kTwoOverPi));
+    double r = horner0(-1.5707963267948965580e+00, n, t);
+    r = horner0(-6.1232339957367660359e-17, n, r);
     const double z = r * r;
     const double sinr = sin_kernel(r, z);
     const double cosr = cos_kernel(z);
@@ -92,9 +128,9 @@ KLATT_HD double fast_cos(double t)
 // recurrences; nothing on the MODE_EXACT path calls it.)
 KLATT_HD double fast_sin(double t)
 {
-    const double n = __builtin_rint(t * kTwoOverPi);
-    double r = __builtin_fma(-n, 1.5707963267948965580e+00, t);
-    r = __builtin_fma(-n, 6.1232339957367660359e-17, r);
+    const double n = __builtin_rint(mul_const(t, kTwoOverPi));
+    double r = horner0(-1.5707963267948965580e+00, n, t);
+    r = horner0(-6.1232339957367660359e-17, n, r);
     const double z = r * r;
     const double sinr = sin_kernel(r, z);
     const double cosr = cos_kernel(z);
@@ -115,8 +151,8 @@ KLATT_HD double fast_sin(double t)
 KLATT_HD bool cos_is_quadrant_m1(double t) { return __builtin_rint(t * kTwoOverPi) == -1.0; }
 KLATT_HD double cos_quadrant_m1(double t)
 {
-    double r = __builtin_fma(1.0, 1.5707963267948965580e+00, t);
-    r = __builtin_fma(1.0, 6.1232339957367660359e-17, r);
+    double r = add_const(t, 1.5707963267948965580e+00);      // fma(1.0, pi/2_hi, t): one rounded addition
+    r = add_const(r, 6.1232339957367660359e-17);
     return sin_kernel(r, r * r);
 }
 KLATT_HD bool exp_is_unreduced(double x) { return __builtin_rint(x * kLog2e) == 0.0; }

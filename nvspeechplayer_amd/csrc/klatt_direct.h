@@ -62,6 +62,9 @@ namespace klatt {
 #ifndef KLATT_DIRECT_STEADY_UNROLL
 #define KLATT_DIRECT_STEADY_UNROLL 16
 #endif
+#ifndef KLATT_DIRECT_FAST_BRANCHLESS
+#define KLATT_DIRECT_FAST_BRANCHLESS 1
+#endif
 #ifndef KLATT_DIRECT_TOUCH
 #define KLATT_DIRECT_TOUCH 1
 #endif
@@ -260,9 +263,14 @@ struct DirectMid {
     const DirectCtx& X;
     uint32_t wm;       // wave-uniform (SGPR): DirectHdr.bits OR-ed over the lanes that fade or start a fade in this chunk
     bool sw;
-    __device__ __forceinline__ void operator()() const
+    // `token`: the last value the sample computed.  The fade-sample counter is tied to it below (an empty asm statement that "modifies"
+    // the counter with the token as input), so that the block that overwrites the stage's coefficients and gains cannot be scheduled
+    // ABOVE the arithmetic that reads them -- the compiler did exactly that (the block depends on nothing the sample computes), and
+    // then kept a copy of every value for the lanes the block masks off: six to eight v_mov_b64 per stage and sample.
+    __device__ __forceinline__ void operator()(double token) const
     {
         const KernelArgs& A = X.A;
+        asm volatile("" : "+v"(f.cnt) : "v"(token));
         // ONE masked block for the lanes inside a fade (a lane that is not keeps what it has: the fade's last values, as the reference
         // does until the next fade's first sample); skipped altogether on a sample on which no lane of the wavefront fades
         const bool adv = f.cnt < f.F;
@@ -277,8 +285,10 @@ struct DirectMid {
             if (DD::STAGE == 0) f.ratio = ratio;
 #pragma unroll
             for (int r = 0; r < DD::NRES; ++r) {
-                if (!(wm & (1u << r))) continue;                       // scalar branch
                 const bool anti = DD::ANTI0 && r == 0;
+                // (MODE_FAST's recurrences are seven instructions: cheaper to run for a kind nobody moves -- its factor is the identity --
+                // than to branch around; the polynomials are worth a scalar branch)
+                if (!(MODE == MODE_FAST && !anti && KLATT_DIRECT_FAST_BRANCHLESS) && !(wm & (1u << r))) continue;
                 const uint32_t cls = (wm >> (kDirectClsShift + 2 * r)) & 3u;
                 if (MODE == MODE_FAST && !anti) {
                     // P <- P w, r^2 <- r^2 q^2: rb = Re P, p0 = Im P, (p1, p2) = w, rc = -r^2, p3 = q^2
@@ -302,7 +312,7 @@ struct DirectMid {
             }
 #pragma unroll
             for (int g = 0; g < DD::NGAIN; ++g) {
-                if (!(wm & (1u << (DD::NRES + g)))) continue;
+                if (!(MODE == MODE_FAST && KLATT_DIRECT_FAST_BRANCHLESS) && !(wm & (1u << (DD::NRES + g)))) continue;
                 if (MODE == MODE_FAST) {
                     f.cur[2 * g] = __builtin_fma(f.gd[2 * g], ratio, f.gf[2 * g]);
                     f.cur[2 * g + 1] = __builtin_fma(f.gd[2 * g + 1], ratio, f.gf[2 * g + 1]);
@@ -525,7 +535,7 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
             const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
             out = fade_value(out, np, f.cur[0]);
         }
-        mid();      // the next sample's values: every parameter of this one has been used
+        mid(out);      // the next sample's values: every parameter of this one has been used
         return out;
     };
     auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[CB + 0] != 0.0 || f.cur[CB + 1] != 0.0 || vibPhase != vibPhase; };
@@ -717,8 +727,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
                 f.z2[0] = f.z1[0]; f.z1[0] = x;                              // the anti-resonator remembers its INPUT (reference :133)
                 const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
-                PIPE(pipeX1, c, i) = fade_value(x, np, f.cur[0]);
-                mid();      // the next sample's values: every coefficient and gain of this one has been used
+                const double o = fade_value(x, np, f.cur[0]);
+                PIPE(pipeX1, c, i) = o;
+                mid(o);      // the next sample's values: every coefficient and gain of this one has been used
             },
             noChunk);
     } else if (stage >= 2 && stage <= 4 && (KLATT_DIRECT_STAGES & 4)) {
@@ -736,7 +747,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                     o = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], o);
                     o = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], o);
                     PIPE(pout, c, i) = o;
-                    mid();
+                    mid(o);
                 },
                 noChunk);
         };
@@ -764,7 +775,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
                 par += (w - y) * f.cur[3];
                 PIPE(pipeY, c, i) = y; PIPE(pipeP, c, i) = par;
-                mid();
+                mid(par);
             },
             noChunk);
     } else if (stage == 6 && (KLATT_DIRECT_STAGES & 16)) {
@@ -783,7 +794,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
                 par += (w - y) * f.cur[1];
                 PIPE(pipeY2, c, i) = y; PIPE(pipeP2, c, i) = par;
-                mid();
+                mid(par);
             },
             noChunk);
     } else if (stage == FINAL && (KLATT_DIRECT_STAGES & 32)) {
@@ -838,7 +849,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 const double lo = (v < 32000.0) ? v : 32000.0;       // windows.h min(): NaN -> 32000
                 const double cl = (lo > -32000.0) ? lo : -32000.0;
                 myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (reference :208)
-                mid();
+                mid(cl);
             },
             [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
         if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);

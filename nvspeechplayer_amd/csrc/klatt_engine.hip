@@ -417,6 +417,19 @@ constexpr size_t kTrackPad = 64;   // slack past the last track
 // Tracks pay when (nearly) the whole noisy group has them: a batch whose fades share nothing may need more memory than the
 // budget, and splitting such a batch into a tracked and an untracked launch measured slower than either kernel alone
 // (tools/track_probe.py +distinct).  So once more than a tenth of the eligible utterances did not fit, nothing is tracked.
+// hash of a shape's 45 values: four independent multiply-xor chains (one chain of 45 dependent steps was half the planning's time)
+inline unsigned long long hash_shape(const double* v)
+{
+    unsigned long long h[4] = {0x9E3779B97F4A7C15ull, 0xC2B2AE3D27D4EB4Full, 0x165667B19E3779F9ull, 0x27D4EB2F165667C5ull};
+    int i = 0;
+    for (; i + 4 <= kShapeValues; i += 4)
+        for (int j = 0; j < 4; ++j) { unsigned long long w; memcpy(&w, &v[i + j], 8); h[j] = (h[j] ^ w) * 0xFF51AFD7ED558CCDull; h[j] ^= h[j] >> 29; }
+    for (; i < kShapeValues; ++i) { unsigned long long w; memcpy(&w, &v[i], 8); h[0] = (h[0] ^ w) * 0xFF51AFD7ED558CCDull; h[0] ^= h[0] >> 29; }
+    unsigned long long x = h[0] ^ (h[1] * 0x9E3779B97F4A7C15ull) ^ (h[2] << 21 | h[2] >> 43) ^ (h[3] * 0xC2B2AE3D27D4EB4Full);
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+    return x;
+}
+
 struct TrackPlan {
     std::vector<TrackRef> ref;              // [nFrames]
     std::vector<TrackJob> jobs;             // one per distinct track
@@ -454,7 +467,7 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
         return mask;
     };
     struct Shape { double v[kShapeValues]; bool operator==(const Shape& o) const { return !memcmp(v, o.v, sizeof v); } };
-    struct ShapeHash { size_t operator()(const Shape& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (double d : k.v) { unsigned long long w; memcpy(&w, &d, 8); h ^= w; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
+    struct ShapeHash { size_t operator()(const Shape& k) const { return (size_t)hash_shape(k.v); } };
     struct Fade { uint32_t from, to, len; bool operator==(const Fade& o) const { return from == o.from && to == o.to && len == o.len; } };
     struct FadeHash { size_t operator()(const Fade& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
     std::unordered_map<Shape, uint32_t, ShapeHash> shapes;          // values -> id (row of out.shapes)
@@ -644,7 +657,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     lap("parts planned");
     // merge: shapes by value, fades by (from, to, length)
     struct ShapeKey { const double* v; bool operator==(const ShapeKey& o) const { return !memcmp(v, o.v, kShapeValues * sizeof(double)); } };
-    struct ShapeKeyHash { size_t operator()(const ShapeKey& k) const { unsigned long long h = 0x9E3779B97F4A7C15ull; for (int i = 0; i < kShapeValues; ++i) { unsigned long long w; memcpy(&w, &k.v[i], 8); h ^= w; h *= 0xFF51AFD7ED558CCDull; h ^= h >> 32; } return (size_t)h; } };
+    struct ShapeKeyHash { size_t operator()(const ShapeKey& k) const { return (size_t)hash_shape(k.v); } };
     struct FadeKey { uint32_t from, to, len; bool operator==(const FadeKey& o) const { return from == o.from && to == o.to && len == o.len; } };
     struct FadeKeyHash { size_t operator()(const FadeKey& k) const { unsigned long long h = ((unsigned long long)k.from << 32 | k.to) * 0x9E3779B97F4A7C15ull; h ^= h >> 29; h += k.len; h *= 0xFF51AFD7ED558CCDull; return (size_t)(h ^ (h >> 32)); } };
     long long eligibleAll = 0, missedSize = 0, missedBudget = 0;
@@ -1599,7 +1612,26 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     // validation leaves the previous batch in place, one that fails while uploading leaves an empty batch
     std::vector<uint32_t> lens((size_t)nUtterances, 0);
     std::vector<long long> outStart((size_t)nUtterances + 1, 0);
-    std::vector<FrameMeta> meta((size_t)nF);
+    // Per-frame work arrays are kept between calls (per calling thread): a fresh 25-50 MB vector costs its page faults on first touch
+    // and its unmapping on release -- together ~15 ms of a 65 ms call for BASELINE configs[2].  Every element is written below before it
+    // is read.  (Released again when a batch was very large: kScratchKeepFrames.)
+    constexpr long long kScratchKeepFrames = 4000000;
+    static thread_local std::vector<FrameMeta> metaScratch;
+    static thread_local std::vector<FlatRef> flatRefScratch;
+    static thread_local std::vector<SourceRef> sourceRefScratch;
+    static thread_local std::vector<DirectJob> directJobsScratch;
+    struct ScratchRelease {
+        long long nF;
+        ~ScratchRelease()
+        {
+            if (nF > kScratchKeepFrames) {
+                std::vector<FrameMeta>().swap(metaScratch); std::vector<FlatRef>().swap(flatRefScratch);
+                std::vector<SourceRef>().swap(sourceRefScratch); std::vector<DirectJob>().swap(directJobsScratch);
+            }
+        }
+    } scratchRelease{nF};
+    std::vector<FrameMeta>& meta = metaScratch;
+    meta.resize((size_t)nF);
     parallel_ranges(nF, 1 << 16, [&](long long a, long long e) {
         for (long long k = a; k < e; ++k) {
             meta[k].minSamples = minFrameDuration[k];
@@ -1775,7 +1807,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     // the direct utterances' fades: per frame where its fade starts from and ends on (reference src/frame.cpp:55-72: silence keeps
     // the previous request's values with the gain gated off; the first frame after silence starts from its own values with the gain
     // gated off; any other frame fades from the previous request's values) -- klatt_seeds reads the values themselves on the device
-    std::vector<DirectJob> directJobs;
+    std::vector<DirectJob>& directJobs = directJobsScratch;
+    directJobs.clear();
     std::vector<uint32_t> directFirst;
     long long nDirectUtt = 0;
     if (wantDirect) {
@@ -1804,8 +1837,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             }
         }
     }
-    std::vector<FlatRef> flatRef;
-    std::vector<SourceRef> sourceRef;
+    std::vector<FlatRef>& flatRef = flatRefScratch;
+    std::vector<SourceRef>& sourceRef = sourceRefScratch;
     if (!plan.jobs.empty() || nDirectUtt > 0) {
         if (!plan.jobs.empty()) flatRef.resize((size_t)nF);
         sourceRef.resize((size_t)nF);

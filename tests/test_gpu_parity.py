@@ -1461,3 +1461,46 @@ def test_batch_in_which_nothing_is_shared_and_nothing_is_aligned():
         bp.setUtterances(base["frame_start"], base["frames"], base["min"], base["fade"], base["index"], base["isnull"], base["seeds"])
         assert bp.kernelInfo()["direct_utterances"] == 0
         bp.close()
+
+
+@pytest.mark.gpu
+def test_direct_stages_long_fades_hold_the_recurrence_bound(ref):
+    """MODE_FAST on the direct stages advances a moving resonator's pole by a constant complex factor per fade sample, re-seeded at
+    every fade's first sample: the relative error of a coefficient is bounded by ~4 F 2^-53 after F samples (klatt_direct.h).  The
+    longest fades of speech are ~1500 samples; here fades of 350 000 samples (16 s; every formant, bandwidth and gain moving, the
+    nasal pair included) -- bound 1.6e-10 -- against the oracle at the usual bar, in both modes, with a short fade in front and a
+    one-sample fade behind (the recurrences must stop on the fade's last sample and start again exactly)."""
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(41)
+    frames, mins, fades, nul, start, seeds = [], [], [], [], [0], []
+    for u in range(24):
+        def vowel():
+            f = np.zeros(47)
+            f[0] = rng.uniform(80, 300); f[46] = f[0] * rng.uniform(0.8, 1.3)
+            f[5] = rng.uniform(0.3, 1); f[3] = rng.uniform(0, 0.3); f[4] = rng.uniform(0, 1); f[6] = rng.uniform(0, 0.5); f[24] = rng.uniform(0, 1)
+            f[7:13] = np.sort(rng.uniform(200, 5200, 6)); f[13] = rng.uniform(200, 600); f[14] = rng.uniform(200, 500)
+            f[15:23] = rng.uniform(40, 900, 8); f[23] = rng.uniform(0, 1)
+            f[25:31] = np.sort(rng.uniform(200, 5200, 6)); f[31:37] = rng.uniform(40, 900, 6); f[37:43] = rng.uniform(0, 1, 6)
+            f[43] = rng.uniform(0, 1); f[44] = rng.uniform(0.2, 1.2); f[45] = rng.uniform(0.3, 2)
+            return f
+        seq = [(vowel(), 800, 120, 0), (vowel(), int(rng.integers(1, 400000)), 350000 + int(rng.integers(0, 999)), 0), (vowel(), 3, 1, 0), (np.zeros(47), 500, 300, 1)]
+        for f, m, fd, n in seq:
+            frames.append(f); mins.append(m); fades.append(fd); nul.append(n)
+        start.append(start[-1] + len(seq)); seeds.append(1000 + u)
+    batch = dict(frames=np.array(frames), min=np.array(mins, np.uint32), fade=np.array(fades, np.uint32), index=np.full(len(mins), -1, np.int32),
+                 isnull=np.array(nul, np.uint8), frame_start=np.array(start, np.int64), seeds=np.array(seeds, np.uint32))
+    exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
+    for mode in (0, 1):
+        bp = eng.BatchPlayer(22050, mode=mode)
+        bp.setOption("tracks", 0); bp.setOption("direct", 2)
+        bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
+        assert bp.kernelInfo()["direct_utterances"] == 24
+        bp.synthesize()
+        pcm, st = bp.readAll()
+        bp.close()
+        assert np.array_equal(st, exp_start)
+        d = pcm.astype(np.int32) - exp.astype(np.int32)
+        nbad = int(np.count_nonzero(d))
+        print("long fades, mode %d: %d samples, %d differ from the oracle (max %d)" % (mode, total, nbad, int(np.abs(d).max())))
+        assert np.abs(d).max() <= 1 and nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
+        assert float(np.sqrt(np.mean((d / 32768.0) ** 2))) < RMS_TOL

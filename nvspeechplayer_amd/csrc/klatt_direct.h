@@ -11,42 +11,46 @@
 // Here the stages keep the flat stages' CONTROL -- sample positions from the durations alone (frame k is dequeued on sample T_k,
 // T_k+1 = T_k + max(min_k, fade_k + 1) + 1, its fade's samples are T_k + 1 .. T_k + fade_k; reference src/frame.cpp:41-80), one
 // counter per lane, no dequeue / fade-end events, nothing in LDS but the pipes and the PCM tile -- and COMPUTE what the tracks
-// would have held, in the gap between the two halves of a sample's filter arithmetic (where the flat stages load their rows):
+// would have held, behind a sample's filter arithmetic (DirectMid):
 //
-//   * per lane: the fade-sample index `cnt` of the values now in registers (saturating at the fade's length F: a lane that is not
-//     fading sits at cnt == F, ratio 1), and per parameter the pair (from, to - from) of the running fade;
-//   * every lane evaluates, on every sample of a chunk in which SOME lane moves a kind, that kind for itself:
-//         value = from + ((to - from) * (cnt / F))                       (reference src/frame.cpp:48-53, src/utils.h:20-23)
+//   * per lane: the fade-sample index `cnt` of the values now in registers (cnt == F, the fade's length: the lane is not fading
+//     and keeps the fade's last values, as the reference does until the next fade's first sample), and per parameter the pair
+//     (from, to - from) of the running fade;
+//   * ONE masked block per sample for the lanes with cnt < F (skipped when the wavefront has none): cnt + 1,
+//         ratio = cnt / F  (correctly rounded in both modes: the fade's last sample must land on its target exactly),
+//         value = from + ((to - from) * ratio)                           (reference src/frame.cpp:48-53, src/utils.h:20-23)
 //     and for a resonator r = exp(-pi bw / sr), cs = cos(2 pi (-f) / sr), c = -(r r), b = r cs 2, a = 1 - b - c (reference
-//     src/speechWaveGenerator.cpp:112-127) with the straight-line kernels of klatt_math.h, classified ONCE per chunk and wave
-//     (no range reduction / cosine quadrant -1 / general) from bits the seeds carry.  For a lane that is not fading this
-//     reproduces the value it holds, bit for bit (ratio 1 is the fade's last sample; the reference keeps exactly that value
-//     until the next fade's first sample), so nothing is masked: a sample is straight-line code whatever the lanes are doing.
-//     Which kinds are evaluated is a wave-uniform mask per chunk (the OR over the lanes of what their running or starting
-//     fades move): scalar branches, no ballots per sample.
+//     src/speechWaveGenerator.cpp:112-127) with the straight-line kernels of klatt_math.h (constants as scalar operands of the
+//     FMAs), classified ONCE per chunk and wave (no range reduction / cosine quadrant -1 / general) from bits the seeds carry.
+//     Which kinds are evaluated is a wave-uniform mask per chunk (the OR over the lanes of what their running or starting fades
+//     move): scalar branches, no ballots per sample.  The block is tied BEHIND the sample's arithmetic (an empty asm statement
+//     makes the counter depend on the sample's last value): the compiler otherwise hoists it above the filters and keeps a
+//     copy of every coefficient for the lanes it masks off;
 //   * MODE_FAST replaces the polynomials by SURVEY section 7's recurrences: with f and bw linear in the fade-sample index,
 //     the pole P = 2 r e^(i theta) advances by a constant complex factor w = q e^(i delta) per sample and r^2 by q^2:
 //         P <- P w (4 operations), r^2 <- r^2 q^2, b = Re P, c = -r^2, a = 1 - b - c           (7 instead of ~36)
 //     re-seeded EXACTLY at every fade's first sample (klatt_seeds evaluates P_1, w, q^2 with the polynomials, in double), so the
 //     error of a coefficient grows by at most ~3 ulp per fade sample: <= 4 F 2^-53 relative at the end of a fade of F samples
-//     (1e-12 for the longest fades of speech, F ~ 1500; tests/test_gpu_parity.py holds MODE_FAST to the usual bar).  The
-//     anti-resonator N0, whose a needs a division either way, keeps the polynomials in both modes.
-//   * a fade START is one masked block of 16-byte loads: klatt_seeds (below) has evaluated, densely and before the launch, per
-//     frame and stage a RECORD -- for every kind the fade's (from, to - from) pairs (MODE_FAST: P_1, w, q^2) and the values of
-//     the fade's FIRST sample, on which the reference re-evaluates everything (the previous fade's last interpolated value need
-//     not equal the frame value) -- so kinds that no lane moves are never evaluated in the sample loop at all.  The record's
-//     lines are touched ~9..24 samples ahead (a dummy load per line: they sit in the L2 / L1 when the switch comes), the
-//     16-byte header of the NEXT fade is loaded at the previous switch, as the flat stages do.
+//     (1e-12 for the longest fades of speech, F ~ 1500; tests/test_gpu_parity.py holds MODE_FAST to the usual bar, and fades of
+//     350 000 samples in test_direct_stages_long_fades_hold_the_recurrence_bound).  Run without per-kind branches: a kind nobody
+//     moves has the identity as its factor.  The anti-resonator N0, whose a needs a division either way, keeps the polynomials;
+//   * a fade START is a second masked block of 16-byte loads: klatt_seeds (below) has evaluated, densely and before the launch,
+//     per frame and stage a RECORD -- for every kind the fade's (from, to - from) pairs (MODE_FAST: P_1, w, q^2) and the values
+//     of the fade's FIRST sample, on which the reference re-evaluates everything (the previous fade's last interpolated value
+//     need not equal the frame value).  The 16-byte header of the NEXT fade is loaded at the previous switch, as the flat stages
+//     do; the record's lines are touched a chunk ahead (plain loads into registers the lane owns until the switch names them:
+//     measured no gain, kept because it is harmless; a load whose result nobody owns raced, a volatile one waits).
 //
 // Same arithmetic as every other kernel of the engine in MODE_EXACT (the seeds and the stages call the functions the tracks
 // and the untracked stages call, on the same operands): the PCM is the same bytes (tests: tracked = direct = untracked).
 //
 // EIGHT stages, one wavefront each (klatt_device.h, direct_stage_kind): T0 source | T1 N0, NP | T2 r6, r5 | T3 r4, r3 | T4 r2, r1 |
-// T5 frication, parallel 1, 2 | T6 parallel 3, 4 | T7 parallel 5, 6, mix, clip, PCM.  A direct stage carries ten doubles per
-// resonator (coefficients, memories, the running fade's end points) and three per gain, and MODE_EXACT's polynomials want ~30
-// constants in registers: four resonators per wavefront, the flat stages' split, compiled to 350-470 VGPRs (150-600 spilled);
-// two fit with room to spare, and evaluating coefficients -- not filtering with them -- is what there is to balance:
-// 2 resonators per stage, the source and the mix / PCM tail apart.
+// T5 frication, parallel 1, 2 | T6 parallel 3, 4 | T7 parallel 5, 6, mix, clip, PCM: one workgroup per CU (152 KB of pipes at
+// 16-sample hand-overs), two wavefronts per SIMD, which stage sits beside which chosen from HW_ID (the pairs that balance the SIMDs
+// differ between the modes).  A direct stage carries ten doubles per resonator (coefficients, memories, the running fade's end points)
+// and three per gain: four resonators per wavefront, the flat stages' split, compiled to 350-470 VGPRs (150-600 spilled), and so
+// did eight stages at the 128 registers of two workgroups per CU; two resonators per stage at 256 fit with room to spare.
+// DESIGN.md section 4.7 has the measurements (instructions per stage and sample, what bounds the launch, what was tried).
 #pragma once
 
 #include "klatt_systolic.h"

@@ -116,6 +116,13 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
 	const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible, long long budgetMB,
 	unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked, unsigned long long* nEntries);
 
+/* Host-only view of the fade end points speechPlayer_batch_setUtterances derives for the utterances it sends to the direct stages
+ * (tests; touches no device; follows reference src/frame.cpp:55-72): per frame the frames its fade starts from and ends on
+ * (0xFFFFFFFF: none -- all values zero) and flags (bit 0: the start's preFormantGain is gated off -- silence --, bit 1: the end's).
+ * Returns the number of frames; -1 on bad arguments. */
+long long speechPlayer_planDirect(long long nUtterances, const long long* frameStart, const unsigned char* isNull,
+                                  unsigned int* from, unsigned int* to, unsigned int* flags);
+
 /*
  * One batch over the GPUs of a node.  Utterances are independent (the reference's only cross-handle coupling
  * is rand(), src/speechWaveGenerator.cpp:40, replaced by per-utterance noise streams), so the batch is cut into contiguous

@@ -741,6 +741,32 @@ bool refuse_timing_only(const char* what)
     return true;
 }
 
+// The end points of the fades of one utterance's frames [k0, k1), appended to `out` (reference src/frame.cpp:55-72: a NULL request
+// -- silence -- keeps the previous request's values with the gain gated off; the first frame after silence starts from its own
+// values with the gain gated off; any other frame fades from the previous request's values).  klatt_seeds reads the values
+// themselves on the device.  Host-only view for the tests: speechPlayer_planDirect.
+void walk_fade_ends(long long k0, long long k1, const FrameMeta* meta, std::vector<DirectJob>& out)
+{
+    uint32_t prevReal = kNoFrame;
+    bool prevNull = true;
+    for (long long k = k0; k < k1; ++k) {
+        DirectJob j;
+        j.frame = (uint32_t)k;
+        if (meta[k].flags & FRAME_NULL) {
+            j.from = prevReal; j.to = prevReal;
+            j.flags = (prevNull ? 1u : 0u) | 2u;
+            prevNull = true;
+        } else {
+            j.to = (uint32_t)k;
+            j.from = prevNull ? (uint32_t)k : prevReal;
+            j.flags = prevNull ? 1u : 0u;
+            prevReal = (uint32_t)k;
+            prevNull = false;
+        }
+        out.push_back(j);
+    }
+}
+
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
 // (setUtterances only forms the direct group under the stage-parallel layouts)
 long long direct_count(const Batch* b) { return b->nDirect; }
@@ -1817,24 +1843,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             if (!(utt[u].flags & UTT_DIRECT)) continue;
             ++nDirectUtt;
             directFirst[u] = (uint32_t)directJobs.size();
-            uint32_t prevReal = kNoFrame;
-            bool prevNull = true;
-            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
-                DirectJob j;
-                j.frame = (uint32_t)k;
-                if (meta[k].flags & FRAME_NULL) {
-                    j.from = prevReal; j.to = prevReal;
-                    j.flags = (prevNull ? 1u : 0u) | 2u;
-                    prevNull = true;
-                } else {
-                    j.to = (uint32_t)k;
-                    j.from = prevNull ? (uint32_t)k : prevReal;
-                    j.flags = prevNull ? 1u : 0u;
-                    prevReal = (uint32_t)k;
-                    prevNull = false;
-                }
-                directJobs.push_back(j);
-            }
+            walk_fade_ends(frameStart[u], frameStart[u + 1], meta.data(), directJobs);
         }
     }
     std::vector<FlatRef>& flatRef = flatRefScratch;
@@ -2504,6 +2513,31 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
     }
     if (nEntries) *nEntries = plan.entries;
     return (long long)plan.jobs.size();
+}
+
+// Host-only view of what speechPlayer_batch_setUtterances hands klatt_seeds for the utterances it sends to the direct stages
+// (tests; touches no device): per frame the frames its fade starts from and ends on (0xFFFFFFFF: none -- all zero) and the flags
+// (bit 0: the start's preFormantGain is gated off, bit 1: the end's).  Returns the number of frames; -1 on bad arguments.
+long long speechPlayer_planDirect(long long nUtterances, const long long* frameStart, const unsigned char* isNull,
+                                  unsigned int* from, unsigned int* to, unsigned int* flags)
+{
+    begin_call();
+    if (nUtterances < 0 || !frameStart || frameStart[0] != 0) { set_error("planDirect: bad arguments"); return -1; }
+    for (long long u = 0; u < nUtterances; ++u)
+        if (frameStart[u + 1] < frameStart[u]) { set_error("planDirect: frameStart not monotone at %lld", u); return -1; }
+    const long long nF = frameStart[nUtterances];
+    if (nF >= 0xFFFFFFFFll) { set_error("planDirect: too many frames"); return -1; }
+    std::vector<FrameMeta> meta((size_t)nF);
+    for (long long k = 0; k < nF; ++k) { meta[k].minSamples = 0; meta[k].fadeSamples = 1; meta[k].userIndex = -1; meta[k].flags = (isNull && isNull[k]) ? FRAME_NULL : 0u; }
+    std::vector<DirectJob> jobs;
+    jobs.reserve((size_t)nF);
+    for (long long u = 0; u < nUtterances; ++u) walk_fade_ends(frameStart[u], frameStart[u + 1], meta.data(), jobs);
+    for (long long k = 0; k < nF; ++k) {
+        if (from) from[k] = jobs[(size_t)k].from;
+        if (to) to[k] = jobs[(size_t)k].to;
+        if (flags) flags[k] = jobs[(size_t)k].flags;
+    }
+    return nF;
 }
 
 }  // extern "C"

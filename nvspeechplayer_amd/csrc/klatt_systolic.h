@@ -67,6 +67,12 @@ namespace klatt {
                                 // runs none of the untracked stages (it cannot tell that a stage number is 0..3): the kernel is half the code, 245
                                 // VGPRs instead of 256 and NO scratch instead of 128 bytes per lane (0: the test `stage == 2`, as before)
 #endif
+#ifndef KLATT_FLAT_BUFS
+#define KLATT_FLAT_BUFS 2       // buffers per pipe of the flat stages (more than 2 only with KLATT_FLAT_FREE: the barrier keeps the stages within one chunk)
+#endif
+#ifndef KLATT_FLAT_XBUFS
+#define KLATT_FLAT_XBUFS KLATT_FLAT_BUFS
+#endif
 constexpr int kStages = 4;
 #ifndef KLATT_FLAT_SOURCE
 #define KLATT_FLAT_SOURCE 1     // flat launches: S0 is a flat stage too (0: the source stage of the noisy launches, with its frame state machine)
@@ -76,13 +82,18 @@ constexpr int kStages = 4;
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
 template <bool NOISE, int CH, bool FLAT = false>
 struct SysLds {
-    static constexpr int kPipeBytes = 2 * CH * kLanes * (FLAT ? (int)sizeof(sig_t) : 8);
+    static constexpr int kBufs = FLAT ? KLATT_FLAT_BUFS : 2;               // buffers of a pipe
+    static constexpr int kBufsX = FLAT ? KLATT_FLAT_XBUFS : 2;             // ... of pipe X (S0 -> S1), which sits behind the others
+    static constexpr int kBufBytes = CH * kLanes * (FLAT ? (int)sizeof(sig_t) : 8);
+    static constexpr int kPipeBytes = kBufs * kBufBytes;
     static constexpr int kNumPipes = NOISE ? 4 : 3;
-    static constexpr int kTileOff = kNumPipes * kPipeBytes;
+    static constexpr int kPipeX = (kNumPipes - 1) * kPipeBytes;            // the pipes in memory: O, A, (B,) X
+    static constexpr int kTileOff = kPipeX + kBufsX * kBufBytes;
     static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
-    static constexpr int kFrames = kMaxLen + 16;
+    static constexpr int kSync = kMaxLen + 16;         // FLAT, KLATT_FLAT_FREE: {produced, consumed} of the pipes X, O, A + B; a give-up flag
+    static constexpr int kFrames = kSync + 32;
     // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
     // flat launches (FLAT): the stages take everything from the tracks and keep no fade end points: 0, 0, 0, 0
     static constexpr int kParams0 = (FLAT && KLATT_FLAT_SOURCE) ? 0 : 7, kParams1 = FLAT ? 0 : (NOISE ? 11 : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
@@ -711,6 +722,62 @@ struct FlatDesc {
     static constexpr uint32_t USUAL = USUAL_, USUAL2 = USUAL2_;
 };
 
+// ---- hand-overs of the flat stages: the workgroup barrier, or counters per pipe (KLATT_FLAT_FREE) ---------------------------------
+// With the barrier every stage waits, in every iteration, for the slowest stage OF THAT ITERATION -- and which one that is changes
+// from chunk to chunk (a stage in a mixed chunk beside three in steady ones): the stamps show four stages within 15 % of each other
+// in work and each waiting 23-34 % of its time (profiles/r4_stage_balance.txt).  KLATT_FLAT_FREE = 1 replaces the barrier by two
+// counters per pipe in LDS -- chunks written by its producer, chunks read by its consumer -- so that a stage starts chunk c as soon as
+// ITS inputs are there (produced > c) and ITS output buffer is free (c - consumed < buffers), whatever the other stages are doing.
+// A release store after the chunk's LDS traffic (s_waitcnt lgkmcnt(0) first), an acquire load in the wait; every wait gives up
+// after 2^22 polls (the launch then ends with wrong PCM and UttResult.drained = 2 instead of hanging the GPU -- no test has seen it).
+#ifndef KLATT_FLAT_FREE
+#define KLATT_FLAT_FREE 0
+#endif
+struct BarrierSync {
+    __device__ __forceinline__ void begin(int) const {}
+    __device__ __forceinline__ void end(int) const { __syncthreads(); }
+    __device__ __forceinline__ void idle() const { __syncthreads(); }
+};
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+template <int NBUF, int NIN, int NOUT>
+struct PipeSync {
+    // (counts, not null pointers: the null of the LDS address space is -1 where a generic pointer is cast and 0 where an LDS pointer
+    // is tested -- a "null" input was waited for, at LDS address 0xFFFFFFFF, in the first build)
+    lds_u32* in[2];       // {produced, consumed} of the NIN pipes this stage reads
+    lds_u32* out[1];      // ... of the NOUT pipes it writes
+    lds_u32* gaveUp;
+    static __device__ __forceinline__ uint32_t peek(lds_u32* p)
+    {
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+    }
+    __device__ __forceinline__ void wait_until(lds_u32* p, uint32_t atLeast) const
+    {
+        uint32_t polls = 0;
+        while (peek(p) < atLeast) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++polls > (1u << 22)) { *gaveUp = 1u; break; }
+        }
+    }
+    __device__ __forceinline__ void begin(int c) const
+    {
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) wait_until(in[k], (uint32_t)c + 1u);                       // produced > c
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) wait_until(out[k] + 1, (uint32_t)(c + 1 > NBUF ? c + 1 - NBUF : 0));      // c - consumed < NBUF
+    }
+    __device__ __forceinline__ void end(int c) const
+    {
+        // the chunk's LDS writes have landed and its reads have returned: lgkmcnt alone (a release fence would also wait for the final
+        // stage's PCM stores to reach memory, once per chunk)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < NOUT; ++k) __hip_atomic_store(out[k], (uint32_t)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#pragma unroll
+        for (int k = 0; k < NIN; ++k) __hip_atomic_store(in[k] + 1, (uint32_t)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
+    __device__ __forceinline__ void idle() const {}
+};
+
 // ---- flat filter stages, second form (round 3): rows loaded one sample ahead, straight into the coefficients ---------------------
 // The sample-by-sample path above pays, on every sample in which ANY lane fades: two ballots and two divergent blocks, the row's
 // loads, their full latency (a wait right behind them, ~900 cycles with the tracks beyond the L2) and then the filters, in a
@@ -875,8 +942,9 @@ __device__ __forceinline__ R res_post(const ResPre<R>& p, R in, R& z1, R& z2)
 }
 
 // body(c, i, std::bool_constant<MIXED>, gate, mid): one sample of the stage; same barrier discipline as flat_loop
-template <class FD, int CH, class FBody, class FChunk>
-__device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, int stampSlot, FlatState2<FD>& f, const StageCtx& X, const int* GE, FBody body, FChunk perChunk)
+template <class FD, int CH, class FBody, class FChunk, class FSync = BarrierSync>
+__device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, int stampSlot, FlatState2<FD>& f, const StageCtx& X, const int* GE, FBody body, FChunk perChunk,
+                                           const FSync& sync = FSync{})
 {
 #ifdef KLATT_STAMPS
     Stamps st;
@@ -888,7 +956,9 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
         STAMP_BEGIN();
         STAMP_IDLE();
         const int c = iter - depth;
-        if (c >= 0 && c < nChunks) {
+        const bool inRange = c >= 0 && c < nChunks;
+        if (inRange) {
+            sync.begin(c);
             const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
             if (f.length <= t0) f.live = false;                               // this lane has emitted its last sample
             // a chunk is steady when no lane loads a row in it: none pending, no fade whose first row applies to t0 + 1 .. t1
@@ -918,10 +988,11 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
                     { const uint32_t e1 = (uint32_t)(cc + 1) * (uint32_t)CH; f.produced = f.length < e1 ? f.length : e1; }
                     perChunk();
                     STAMP_WORKED();
-                    __syncthreads();
+                    sync.end(cc);
                     STAMP_SYNCED();
                     STAMP_BEGIN();
                     ++iter; ++cc;
+                    sync.begin(cc);
                 }
                 if (f.live) {
 #pragma unroll
@@ -930,7 +1001,7 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
                 { const uint32_t e1 = (uint32_t)(cc + 1) * (uint32_t)CH; f.produced = f.length < e1 ? f.length : e1; }
                 perChunk();
                 STAMP_WORKED();
-                __syncthreads();
+                sync.end(cc);
                 STAMP_SYNCED();
                 continue;
             }
@@ -973,7 +1044,7 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
             perChunk();
         }
         STAMP_WORKED();
-        __syncthreads();
+        if (inRange) sync.end(c); else sync.idle();
         STAMP_SYNCED();
     }
 #ifdef KLATT_STAMPS
@@ -1008,10 +1079,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     using PipeT = typename std::conditional<FLAT, sig_t, double>::type;                // what the stages hand over
-    PipeT* const pipeX = reinterpret_cast<PipeT*>(lds);                             // S0 -> S1
-    PipeT* const pipeO = reinterpret_cast<PipeT*>(lds + L::kPipeBytes);             // S1 -> S2
-    PipeT* const pipeA = reinterpret_cast<PipeT*>(lds + 2 * L::kPipeBytes);         // noisy: y      | quiet: S2 -> S3
-    PipeT* const pipeB = reinterpret_cast<PipeT*>(lds + (NOISE ? 3 : 2) * L::kPipeBytes);     // noisy: partial sum
+    PipeT* const pipeX = reinterpret_cast<PipeT*>(lds + L::kPipeX);                 // S0 -> S1
+    PipeT* const pipeO = reinterpret_cast<PipeT*>(lds);                             // S1 -> S2
+    PipeT* const pipeA = reinterpret_cast<PipeT*>(lds + L::kPipeBytes);             // noisy: y      | quiet: S2 -> S3
+    PipeT* const pipeB = reinterpret_cast<PipeT*>(lds + (NOISE ? 2 : 1) * L::kPipeBytes);     // noisy: partial sum
+    constexpr int nbuf_pipeX = L::kBufsX, nbuf_pipeO = L::kBufs, nbuf_pipeA = L::kBufs, nbuf_pipeB = L::kBufs;
+    (void)nbuf_pipeX; (void)nbuf_pipeO; (void)nbuf_pipeA; (void)nbuf_pipeB;
     unsigned char* const tile = lds + L::kTileOff;
     long long* const rowBase = reinterpret_cast<long long*>(lds + L::kRowBase);
     uint32_t* const rowCount = reinterpret_cast<uint32_t*>(lds + L::kRowCount);
@@ -1046,7 +1119,9 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // four waves four different stages (checked through LDS); otherwise stage = wave index.  Any bijection is
     // correct -- the waves are interchangeable until they pick a stage.
     uint32_t* const stageMaskP = maxLenP + 1;
+    uint32_t* const syncP = reinterpret_cast<uint32_t*>(lds + L::kSync);
     if (threadIdx.x == 0) { *maxLenP = 0; *stageMaskP = 0; }
+    if (threadIdx.x < 8) syncP[threadIdx.x] = 0;
     __syncthreads();
     int cand = wave;
     if (KLATT_PAIR && WPS == 2 && (NOISE || !NASAL)) {
@@ -1067,7 +1142,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     double* const streamState = (STREAM && live) ? (A.statePtrs ? A.statePtrs[u] : A.state + (size_t)u * kStateDoubles) : nullptr;
     const bool streamPurge = STREAM && live && A.control && (A.control[u] & 1u);
     // pipe slot of sample i of chunk c
-#define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
+#define PIPE(p, c, i) (p)[(((nbuf_##p) == 2 ? ((c) & 1) : ((c) % (nbuf_##p))) * kChunk + (i)) * kLanes + lane]
     // the chunk loop's knobs: quiet launches preload a steady chunk's inputs and run uniform stretches inside event chunks
     using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;      // stages without a pipe input
     using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;       // stages that read a pipe
@@ -1080,6 +1155,14 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     auto nothing = [&](int) __attribute__((always_inline)) {};
     auto noChunk = [&]() __attribute__((always_inline)) {};
 
+    // hand-overs of the flat stages (BarrierSync / PipeSync above): pipe X = S0 -> S1, O = S1 -> final, A and B = S3 -> final
+    constexpr bool kFree = FLAT && KLATT_FLAT_FREE && KLATT_FLAT_SOURCE && KLATT_FLAT_LAYOUT == 2 && KLATT_FLAT_EXHAUSTIVE;
+    lds_u32* const syncL = (lds_u32*)syncP;
+    auto make_sync = [&](auto nBuf, auto nIn, auto nOut, int in0, int in1, int out0) __attribute__((always_inline)) {      // nBuf: buffers of the pipe written
+        if constexpr (kFree) return PipeSync<decltype(nBuf)::value, decltype(nIn)::value, decltype(nOut)::value>{{syncL + in0, syncL + in1}, {syncL + out0}, syncL + 6};
+        else return BarrierSync{};
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     if (FLAT && KLATT_FLAT_SOURCE && stage == 0) {
         // ================= flat S0, second form: the source stage with its rows loaded one sample ahead (see flat2_loop) =================
         // Its seven parameters come from the tracks (entry kinds 20..23); what stays here is the pitch, which glides with the sample
@@ -1157,11 +1240,15 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
 #ifdef KLATT_STAMPS
             Stamps st;
 #endif
+            const auto sync = make_sync(std::integral_constant<int, L::kBufsX>{}, I0{}, I1{}, 0, 0, 0);
             for (int iter = 0; iter < nIter; ++iter) {
                 STAMP_BEGIN();
                 STAMP_IDLE();
                 const int c = iter;
+                int lastChunk = -1;      // the chunk this iteration ends on (the steady stretch below runs several)
                 if (c < nChunks) {
+                    sync.begin(c);
+                    lastChunk = c;
                     const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
                     if (f.length <= t0) f.live = false;
                     const bool busy = (KLATT_EXP & 8) || f.left > 0u || f.startAt <= t1 || cntF < nfU || fadeEndAt < t1 || vib_live();
@@ -1183,7 +1270,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                                 for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; PIPE(pipeX, cc, i) = source(false, std::integral_constant<uint32_t, 0u>{}, NoMid{}); }
                                 ps.old0 = ps.cur0;
                             }
-                            if (q + 1 < run) { STAMP_WORKED(); __syncthreads(); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; }
+                            if (q + 1 < run) { STAMP_WORKED(); sync.end(cc); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; sync.begin(cc); lastChunk = cc; }
                         }
                     } else {
                         // the kinds loaded in this chunk (as in flat2_loop): all in chunk 0, afterwards the usual two -- the amplitudes and
@@ -1253,7 +1340,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     }
                 }
                 STAMP_WORKED();
-                __syncthreads();
+                if (lastChunk >= 0) sync.end(lastChunk); else sync.idle();
                 STAMP_SYNCED();
             }
 #ifdef KLATT_STAMPS
@@ -1421,7 +1508,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     for (int r = 0; r < 6; ++r) o = res_post<MODE>(q[r], o, f.z1[r], f.z2[r]);
                     PIPE(pipeO, c, i) = o;
                 },
-                noChunk);
+                noChunk, make_sync(std::integral_constant<int, L::kBufs>{}, I1{}, I1{}, 0, 0, 2));
 #else
             using FD = FlatDesc<1, 6, 1, true, 0x63u>;                 // usually N0, NP, r3 and caNP, when anything
             constexpr int GE[7] = {0, 1, 2, 3, 4, 5, 14};        // N0, NP, r6, r5, r4, r3 | cur: caNP
@@ -1486,7 +1573,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     par += (w - y) * pa4;
                     PIPE(pipeA, c, i) = y; PIPE(pipeB, c, i) = par;
                 },
-                noChunk);
+                noChunk, make_sync(std::integral_constant<int, L::kBufs>{}, I0{}, I1{}, 0, 0, 4));
         }
     } else if (FLAT && (KLATT_FLAT_EXHAUSTIVE || stage == 2)) {
         // ================= flat final stage: r3, r2, r1 | parallel 5, 6, bypass | gain, clip, int16 -> PCM =================
@@ -1560,8 +1647,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     const sig_t cl = (lo > (sig_t)-32000.0) ? lo : (sig_t)-32000.0;
                     myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (:208)
                 },
-                [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
+                [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); },
+                make_sync(std::integral_constant<int, L::kBufs>{}, I2{}, I0{}, 2, 4, 0));
             if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
+            if (kFree && live && syncP[6] != 0u) A.result[u].drained = 2u;      // some wait of the workgroup gave up: the PCM is not valid
         }
     } else if (!NOISE && !NASAL && (stage == 1 || stage == 2)) {
         // ================= quiet, nasal-free S1: r6, r5, r4 and S2: r3, r2, r1 =================
@@ -1573,6 +1662,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         stage_frame_init(f, live, lds + (s1 ? L::kFrames1 : L::kFrames2), lane);
         PipeT* const pin = s1 ? pipeX : pipeO;
         PipeT* const pout = s1 ? pipeO : pipeA;
+        constexpr int nbuf_pin = 2, nbuf_pout = 2;      // (quiet launches: two buffers per pipe)
         auto dsp = [&](double o) __attribute__((always_inline)) -> double {
 #pragma unroll
             for (int r = 0; r < 3; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);

@@ -60,7 +60,7 @@ namespace klatt {
 #define KLATT_STR(x) KLATT_STR2(x)
 
 #ifndef KLATT_EXP
-#define KLATT_EXP 0             // timing experiments of the flat stages (wrong PCM): 1 rows without loads, 4 no fade ever starts; (same PCM) 8 every chunk a mixed one
+#define KLATT_EXP 0             // timing experiments of the flat stages (wrong PCM): 1 rows without loads, 4 no fade ever starts, 16 one load per row; (same PCM) 8 every chunk a mixed one
 #endif
 #ifndef KLATT_FLAT_EXHAUSTIVE
 #define KLATT_FLAT_EXHAUSTIVE 1 // flat launches: the final stage is the chain's unconditional last branch, so that the compiler sees that a flat launch
@@ -83,12 +83,12 @@ constexpr int kStages = 4;
 template <bool NOISE, int CH, bool FLAT = false>
 struct SysLds {
     static constexpr int kBufs = FLAT ? KLATT_FLAT_BUFS : 2;               // buffers of a pipe
-    static constexpr int kBufsX = FLAT ? KLATT_FLAT_XBUFS : 2;             // ... of pipe X (S0 -> S1), which sits behind the others
+    static constexpr int kBufsX = FLAT ? KLATT_FLAT_XBUFS : 2;             // ... of pipe X (S0 -> S1), the first in memory
     static constexpr int kBufBytes = CH * kLanes * (FLAT ? (int)sizeof(sig_t) : 8);
     static constexpr int kPipeBytes = kBufs * kBufBytes;
     static constexpr int kNumPipes = NOISE ? 4 : 3;
-    static constexpr int kPipeX = (kNumPipes - 1) * kPipeBytes;            // the pipes in memory: O, A, (B,) X
-    static constexpr int kTileOff = kPipeX + kBufsX * kBufBytes;
+    static constexpr int kPipeO = kBufsX * kBufBytes;                      // the pipes in memory: X, O, A(, B)
+    static constexpr int kTileOff = kPipeO + (kNumPipes - 1) * kPipeBytes;
     static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
@@ -900,11 +900,21 @@ struct FlatMid {
         return;
 #endif
         if (ALLROWS || has) {
+#if KLATT_EXP & 16     // timing experiment (wrong PCM): ONE 16-byte load per row and stage, its value given to every kind
+            flat_d2 first = {0.0, 0.0};
+            bool haveFirst = false;
+#endif
 #pragma unroll
             for (int e = 0; e < FD::NE; ++e) {
                 if (!(SET & (1u << e))) continue;
                 const uint32_t off = f.idx[e];
+#if KLATT_EXP & 16
+                if (!haveFirst) { first = __builtin_bit_cast(flat_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0)); haveFirst = true; }
+                const flat_d2 v = first;
+                if (FD::STAGE == 0 && e == 3) { f.idx[e] = off + f.stride[e]; continue; }      // (the source stage's vibrato stays off: garbage there would switch the sine on)
+#else
                 const flat_d2 v = __builtin_bit_cast(flat_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
+#endif
                 if (e < FD::NRES) {
                     f.rb[e < FD::NRES ? e : 0] = (R)v.x; f.rc[e < FD::NRES ? e : 0] = (R)v.y;
                     if (FD::ANTI0 && e == 0) f.ra[0] = (R)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0));
@@ -1079,10 +1089,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     using PipeT = typename std::conditional<FLAT, sig_t, double>::type;                // what the stages hand over
-    PipeT* const pipeX = reinterpret_cast<PipeT*>(lds + L::kPipeX);                 // S0 -> S1
-    PipeT* const pipeO = reinterpret_cast<PipeT*>(lds);                             // S1 -> S2
-    PipeT* const pipeA = reinterpret_cast<PipeT*>(lds + L::kPipeBytes);             // noisy: y      | quiet: S2 -> S3
-    PipeT* const pipeB = reinterpret_cast<PipeT*>(lds + (NOISE ? 2 : 1) * L::kPipeBytes);     // noisy: partial sum
+    PipeT* const pipeX = reinterpret_cast<PipeT*>(lds);                             // S0 -> S1
+    PipeT* const pipeO = reinterpret_cast<PipeT*>(lds + L::kPipeO);                 // S1 -> S2
+    PipeT* const pipeA = reinterpret_cast<PipeT*>(lds + L::kPipeO + L::kPipeBytes); // noisy: y      | quiet: S2 -> S3
+    PipeT* const pipeB = reinterpret_cast<PipeT*>(lds + L::kPipeO + (NOISE ? 2 : 1) * L::kPipeBytes);     // noisy: partial sum
     constexpr int nbuf_pipeX = L::kBufsX, nbuf_pipeO = L::kBufs, nbuf_pipeA = L::kBufs, nbuf_pipeB = L::kBufs;
     (void)nbuf_pipeX; (void)nbuf_pipeO; (void)nbuf_pipeA; (void)nbuf_pipeB;
     unsigned char* const tile = lds + L::kTileOff;

@@ -195,15 +195,32 @@ constexpr uint32_t kDirectBwShift = 8, kDirectClsShift = 14, kDirectAllBits = 0x
 // ten doubles) does not fit the register budget of a wavefront four or six at a time (klatt_direct.h has the census).
 // A stage's record of one frame: 4 entries (16 B) per resonator kind, then 3 per gain kind (layouts: klatt_direct.h).
 constexpr int kDirectStages = 8;
-__host__ __device__ constexpr int direct_stage_res(int s) { return s == 0 ? 0 : 2; }
-__host__ __device__ constexpr int direct_stage_gains(int s) { return s == 0 ? 4 : s == 1 ? 1 : s == 5 ? 2 : s == 6 ? 1 : s == 7 ? 2 : 0; }
-__host__ __device__ constexpr int direct_stage_entries(int s) { return 4 * direct_stage_res(s) + 3 * direct_stage_gains(s); }
-__host__ __device__ constexpr int direct_stage_first(int s) { int at = 0; for (int k = 0; k < s; ++k) at += direct_stage_entries(k); return at; }      // (no recursion: a recursive device function is a real call)
-constexpr int kDirectEntries = direct_stage_first(kDirectStages);      // 16-byte entries per frame over the stages: 86 (1376 B)
-__host__ __device__ constexpr int direct_stage_kind(int s, int e)
+// Two layouts (L): 0 as above -- what MODE_EXACT runs, whose stages are bound by the coefficient polynomials, two resonators each --,
+// and 1 for MODE_FAST, whose recurrences leave the SOURCE stage the slowest by far (88 instructions per row against 31 for a pair of
+// cascade resonators): there the source is two stages and the cascade's six resonators are two stages of three,
+//   T0 pitch, vibrato, phase | T1 glottal wave, aspiration noise, gains | T2 N0, NP | T3 r6, r5, r4 | T4 r3, r2, r1 | T5, T6, T7 as in layout 0.
+#ifndef KLATT_DIRECT_FAST_LAYOUT
+#define KLATT_DIRECT_FAST_LAYOUT 1
+#endif
+__host__ __device__ constexpr int direct_layout(int mode) { return mode == MODE_FAST ? KLATT_DIRECT_FAST_LAYOUT : 0; }
+__host__ __device__ constexpr int direct_stage_res(int s, int L = 0)
 {
-    constexpr int k[kDirectStages][4] = {{20, 21, 22, 23}, {0, 1, 14, -1}, {2, 3, -1, -1}, {4, 5, -1, -1}, {6, 7, -1, -1}, {8, 9, 17, 18}, {10, 11, 19, -1}, {12, 13, 15, 16}};
-    return k[s][e];
+    return L == 1 ? (s < 2 ? 0 : (s == 3 || s == 4) ? 3 : 2) : (s == 0 ? 0 : 2);
+}
+__host__ __device__ constexpr int direct_stage_gains(int s, int L = 0)
+{
+    return L == 1 ? (s == 0 ? 1 : s == 1 ? 3 : s == 2 ? 1 : s == 5 ? 2 : s == 6 ? 1 : s == 7 ? 2 : 0)
+                  : (s == 0 ? 4 : s == 1 ? 1 : s == 5 ? 2 : s == 6 ? 1 : s == 7 ? 2 : 0);
+}
+__host__ __device__ constexpr int direct_stage_entries(int s, int L = 0) { return 4 * direct_stage_res(s, L) + 3 * direct_stage_gains(s, L); }
+__host__ __device__ constexpr int direct_stage_first(int s, int L = 0) { int at = 0; for (int k = 0; k < s; ++k) at += direct_stage_entries(k, L); return at; }      // (no recursion: a recursive device function is a real call)
+constexpr int kDirectEntries = direct_stage_first(kDirectStages);      // 16-byte entries per frame over the stages: 86 (1376 B), in both layouts
+static_assert(direct_stage_first(kDirectStages, 1) == kDirectEntries, "both layouts hold the same kinds");
+__host__ __device__ constexpr int direct_stage_kind(int s, int e, int L = 0)
+{
+    constexpr int k0[kDirectStages][4] = {{20, 21, 22, 23}, {0, 1, 14, -1}, {2, 3, -1, -1}, {4, 5, -1, -1}, {6, 7, -1, -1}, {8, 9, 17, 18}, {10, 11, 19, -1}, {12, 13, 15, 16}};
+    constexpr int k1[kDirectStages][4] = {{20, -1, -1, -1}, {21, 22, 23, -1}, {0, 1, 14, -1}, {2, 3, 4, -1}, {5, 6, 7, -1}, {8, 9, 17, 18}, {10, 11, 19, -1}, {12, 13, 15, 16}};
+    return L == 1 ? k1[s][e] : k0[s][e];
 }
 
 struct KernelArgs {

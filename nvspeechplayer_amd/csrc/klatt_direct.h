@@ -33,7 +33,8 @@
 //     error of a coefficient grows by at most ~3 ulp per fade sample: <= 4 F 2^-53 relative at the end of a fade of F samples
 //     (1e-12 for the longest fades of speech, F ~ 1500; tests/test_gpu_parity.py holds MODE_FAST to the usual bar, and fades of
 //     350 000 samples in test_direct_stages_long_fades_hold_the_recurrence_bound).  Run without per-kind branches: a kind nobody
-//     moves has the identity as its factor.  The anti-resonator N0, whose a needs a division either way, keeps the polynomials;
+//     moves has the identity as its factor.  The anti-resonator N0 runs the recurrence on its plain pole pair and inverts per sample
+//     (fast_anti_finish; until the end of round 4 it kept the polynomials);
 //   * a fade START is a second masked block of 16-byte loads: klatt_seeds (below) has evaluated, densely and before the launch,
 //     per frame and stage a RECORD -- for every kind the fade's (from, to - from) pairs (MODE_FAST: P_1, w, q^2) and the values
 //     of the fade's FIRST sample, on which the reference re-evaluates everything (the previous fade's last interpolated value
@@ -50,6 +51,8 @@
 // differ between the modes).  A direct stage carries ten doubles per resonator (coefficients, memories, the running fade's end points)
 // and three per gain: four resonators per wavefront, the flat stages' split, compiled to 350-470 VGPRs (150-600 spilled), and so
 // did eight stages at the 128 registers of two workgroups per CU; two resonators per stage at 256 fit with room to spare.
+// MODE_FAST runs a second layout (klatt_device.h, direct_layout): the source in two stages (pitch / vibrato / phase | glottal wave,
+// noise, gains), the cascade in two stages of three, N0 on the recurrence of its plain pole pair (KLATT_DIRECT_FAST_ANTI).
 // DESIGN.md section 4.7 has the measurements (instructions per stage and sample, what bounds the launch, what was tried).
 #pragma once
 
@@ -72,11 +75,14 @@ namespace klatt {
 #ifndef KLATT_DIRECT_TOUCH
 #define KLATT_DIRECT_TOUCH 1
 #endif
+#ifndef KLATT_DIRECT_FAST_ANTI
+#define KLATT_DIRECT_FAST_ANTI 1     // MODE_FAST: the anti-resonator N0 advances by the pole recurrence too (0: it keeps the polynomials, as in round 4's first builds)
+#endif
 #ifndef KLATT_DIRECT_PAIRING
 #define KLATT_DIRECT_PAIRING 1
 #endif
 #ifndef KLATT_DIRECT_STAGES
-#define KLATT_DIRECT_STAGES 0x3F     // (register census, tools/direct_census.sh: compile the kernel with some stages' bodies left out)
+#define KLATT_DIRECT_STAGES 0x7F     // (register census, tools/direct_census.sh: compile the kernel with some stages' bodies left out; 64: layout 1's glottal stage)
 #endif
 
 // ---- klatt_seeds: one record per (frame, stage) of the launch's direct utterances -------------------------------------------
@@ -99,7 +105,8 @@ struct SeedArgs {
 template <int MODE, int S>
 __device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool mine)
 {
-    constexpr int NR = direct_stage_res(S), NG = direct_stage_gains(S);
+    constexpr int LAY = direct_layout(MODE);
+    constexpr int NR = direct_stage_res(S, LAY), NG = direct_stage_gains(S, LAY);
     const DirectJob job = A.jobs[j];
     const FrameMeta m = A.meta[job.frame];
     const double nf = (double)m.fadeSamples, invF = 1.0 / nf;
@@ -109,12 +116,12 @@ __device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool m
         return A.frames[(size_t)fr * kNumParams + p];
     };
     const bool gateFrom = job.flags & 1u, gateTo = job.flags & 2u;
-    constexpr int kFirst = direct_stage_first(S), kEntries = direct_stage_entries(S);
+    constexpr int kFirst = direct_stage_first(S, LAY), kEntries = direct_stage_entries(S, LAY);
     double2* const out = A.rec + (size_t)kFirst * A.nJobs + (size_t)j * kEntries;
     uint32_t bits = 0;
 #pragma unroll
     for (int r = 0; r < NR; ++r) {
-        const int kind = direct_stage_kind(S, r);
+        const int kind = direct_stage_kind(S, r, LAY);
         const double fF = value(job.from, gateFrom, kResF[kind]), fT = value(job.to, gateTo, kResF[kind]);
         const double bF = value(job.from, gateFrom, kResB[kind]), bT = value(job.to, gateTo, kResB[kind]);
         const double fd = fT - fF, bd = bT - bF;
@@ -134,7 +141,7 @@ __device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool m
         bits |= (moves ? 1u << r : 0u) | (bwMoves ? 1u << (kDirectBwShift + r) : 0u) |
                 ((eu && c0) ? 0u : 1u << (kDirectClsShift + 2 * r)) | ((eu && c1) ? 0u : 2u << (kDirectClsShift + 2 * r));
         double2 e0, e1, e2, e3;
-        if (MODE == MODE_FAST && !anti) {
+        if (MODE == MODE_FAST && (!anti || KLATT_DIRECT_FAST_ANTI)) {
             // P_1 = 2 r_1 e^(i theta_1); per fade sample theta advances by delta = (2 pi / sr) (-(f_to - f_from) / F) and r by the
             // factor q = exp((-pi / sr) ((bw_to - bw_from) / F)).  A fade of one sample never advances.
             const double th1 = A.twoPiOverSr * -f1;
@@ -146,6 +153,12 @@ __device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool m
             e1 = make_double2(one ? 0.0 : q * fast_sin(delta), q * q);
             e2 = make_double2(k1.b, k1.c);
             e3 = make_double2(k1.a, 0.0);
+            if (anti) {
+                // N0's coefficients are its pole pair's inverted (reference src/speechWaveGenerator.cpp:121-125): the recurrence runs on the
+                // PLAIN pair (Re P = 2 r cos theta, r^2) and the stage inverts per sample; the frequency travels along for the `!= 0` test
+                e2 = make_double2(p1.rad * p1.cs * 2.0, p1.rad * p1.rad);
+                e3 = make_double2(fF, fd);
+            }
         } else {
             e0 = make_double2(fF, fd);
             e1 = make_double2(bF, bd);
@@ -156,7 +169,7 @@ __device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool m
     }
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
-        const int kind = direct_stage_kind(S, NR + g);
+        const int kind = direct_stage_kind(S, NR + g, LAY);
         const int px = shape_param(entry_value(kind, 0)), py = entry_value(kind, 1) >= 0 ? shape_param(entry_value(kind, 1)) : -1;
         const double xF = value(job.from, gateFrom, px), xT = value(job.to, gateTo, px);
         const double yF = py >= 0 ? value(job.from, gateFrom, py) : 0.0, yT = py >= 0 ? value(job.to, gateTo, py) : 0.0;
@@ -199,12 +212,12 @@ __global__ void __launch_bounds__(256) klatt_seeds(const SeedArgs A)
 }
 
 // ---- a direct stage's state ----------------------------------------------------------------------------------------------------
-template <int STAGE_>
+template <int STAGE_, int LAY_ = 0>
 struct DirectDesc {
-    static constexpr int NST = kDirectStages, STAGE = STAGE_;
-    static constexpr int NRES = direct_stage_res(STAGE_), NGAIN = direct_stage_gains(STAGE_), NE = NRES + NGAIN;
-    static constexpr bool ANTI0 = direct_stage_kind(STAGE_, 0) == 0;      // the stage's first resonator is N0
-    static constexpr int ENTRIES = direct_stage_entries(STAGE_);
+    static constexpr int NST = kDirectStages, STAGE = STAGE_, LAYOUT = LAY_;
+    static constexpr int NRES = direct_stage_res(STAGE_, LAY_), NGAIN = direct_stage_gains(STAGE_, LAY_), NE = NRES + NGAIN;
+    static constexpr bool ANTI0 = direct_stage_kind(STAGE_, 0, LAY_) == 0;      // the stage's first resonator is N0
+    static constexpr int ENTRIES = direct_stage_entries(STAGE_, LAY_);
 };
 template <class DD>
 struct DirectState {
@@ -214,6 +227,7 @@ struct DirectState {
     // the running fade, per resonator: MODE_EXACT (f_from, f_delta, bw_from, bw_delta, r); MODE_FAST (Im P, Re w, Im w, q^2, -)
     double p0[NR], p1[NR], p2[NR], p3[NR], rad[NR];
     double gf[NG2], gd[NG2];                            // per gain parameter: from, to - from
+    double n0r2, n0f, n0fd;                             // MODE_FAST, N0 only: r^2 of its plain pole pair, its frequency's (from, to - from) (rad[0]: Re P)
     double nfD, invF;                                   // (double)F, 1 / F
     double ratio;                                       // source stage only: cnt / F of the values in registers (the pitch fades with them)
     bool inFade;                                        // source stage only: the values in registers belong to a fade sample
@@ -240,6 +254,7 @@ __device__ __forceinline__ void direct_init(DirectState<DD>& f, bool live, const
     }
 #pragma unroll
     for (int k = 0; k < 2 * DD::NGAIN; ++k) { f.cur[k] = 0; f.gf[k] = 0; f.gd[k] = 0; }
+    f.n0r2 = 1.0; f.n0f = 0.0; f.n0fd = 0.0;
     f.live = live && d.length > 0u;
     f.nFrames = d.nFrames; f.length = d.length; f.next = 0; f.produced = 0;
     f.cnt = 1u; f.F = 1u; f.nfD = 1.0; f.invF = 1.0; f.ratio = 1.0; f.inFade = false; f.curBits = 0u; f.rec0 = rec0;
@@ -261,6 +276,22 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
 // of the sample; here every lane advances its fade-sample index and evaluates, for the NEXT sample, the kinds the chunk's mask
 // `wm` names; then the lanes whose next fade's first values apply to the next sample (`sw`) switch: everything of the new fade
 // comes from its record, in one block of loads that have the second half of this sample (and the SIMD's other wave) to land.
+// MODE_FAST, N0: the anti-resonator's coefficients from its plain pole pair (Re P = 2 r cos theta, r^2) and its frequency (reference
+// src/speechWaveGenerator.cpp:119-125: a = 1 - b - c, and for a frequency other than 0 the inversion a' = 1 / a, b' = -b a', c' = -c a').
+// The reciprocal is v_rcp_f64 with one Newton step.  A relative error e of (b, c) arrives in the coefficients as ~e (|b| + |c|) / a:
+// the recurrence's 4 F 2^-53 becomes <= 12 F 2^-53 / a with a = |1 - r e^(i theta)|^2 (5e-3 for a nasal zero at 300 Hz, 100 Hz wide).
+__device__ __forceinline__ void fast_anti_finish(double reP, double r2, double fr, double& ra, double& rb, double& rc)
+{
+    const double b = reP, c = -r2;
+    const double a0 = (1.0 - b) - c;
+    double inv = __builtin_amdgcn_rcp(a0);
+    inv = __builtin_fma(__builtin_fma(-a0, inv, 1.0), inv, inv);
+    const bool nz = fr != 0.0;
+    ra = nz ? inv : a0;
+    rb = nz ? b * -inv : b;
+    rc = nz ? c * -inv : c;
+}
+
 template <class DD, int MODE>
 struct DirectMid {
     DirectState<DD>& f;
@@ -292,9 +323,16 @@ struct DirectMid {
                 const bool anti = DD::ANTI0 && r == 0;
                 // (MODE_FAST's recurrences are seven instructions: cheaper to run for a kind nobody moves -- its factor is the identity --
                 // than to branch around; the polynomials are worth a scalar branch)
-                if (!(MODE == MODE_FAST && !anti && KLATT_DIRECT_FAST_BRANCHLESS) && !(wm & (1u << r))) continue;
+                constexpr bool kFastAnti = MODE == MODE_FAST && KLATT_DIRECT_FAST_ANTI;
+                if (!(MODE == MODE_FAST && (!anti || kFastAnti) && KLATT_DIRECT_FAST_BRANCHLESS) && !(wm & (1u << r))) continue;
                 const uint32_t cls = (wm >> (kDirectClsShift + 2 * r)) & 3u;
-                if (MODE == MODE_FAST && !anti) {
+                if (kFastAnti && anti) {
+                    // the plain pole pair advances like any other (rad: Re P, p0: Im P, (p1, p2) = w, n0r2 = r^2, p3 = q^2); then the inversion
+                    const double re = __builtin_fma(-f.p0[r], f.p2[r], f.rad[r] * f.p1[r]);
+                    const double im = __builtin_fma(f.rad[r], f.p2[r], f.p0[r] * f.p1[r]);
+                    f.rad[r] = re; f.p0[r] = im; f.n0r2 = f.n0r2 * f.p3[r];
+                    fast_anti_finish(re, f.n0r2, __builtin_fma(f.n0fd, ratio, f.n0f), f.ra[r], f.rb[r], f.rc[r]);
+                } else if (MODE == MODE_FAST && !anti) {
                     // P <- P w, r^2 <- r^2 q^2: rb = Re P, p0 = Im P, (p1, p2) = w, rc = -r^2, p3 = q^2
                     const double re = __builtin_fma(-f.p0[r], f.p2[r], f.rb[r] * f.p1[r]);
                     const double im = __builtin_fma(f.rb[r], f.p2[r], f.p0[r] * f.p1[r]);
@@ -334,8 +372,15 @@ struct DirectMid {
             for (int r = 0; r < DD::NRES; ++r) {
                 const double2 e0 = rec[4 * r], e1 = rec[4 * r + 1], e2 = rec[4 * r + 2], e3 = rec[4 * r + 3];
                 f.p0[r] = e0.x; f.p1[r] = e0.y; f.p2[r] = e1.x; f.p3[r] = e1.y;
+                if (MODE == MODE_FAST && KLATT_DIRECT_FAST_ANTI && DD::ANTI0 && r == 0) {
+                    // (klatt_seeds: Re P_1, r_1^2, and the frequency's end points; the first sample's coefficients as every later one's)
+                    f.rad[r] = e2.x; f.n0r2 = e2.y; f.n0f = e3.x; f.n0fd = e3.y;
+                    const double nf1 = (double)h.fadeSamples;
+                    fast_anti_finish(e2.x, e2.y, __builtin_fma(e3.y, div_by(1.0, nf1, 1.0 / nf1), e3.x), f.ra[r], f.rb[r], f.rc[r]);
+                } else {
                 f.rb[r] = e2.x; f.rc[r] = e2.y; f.ra[r] = e3.x;
                 if (MODE != MODE_FAST || (DD::ANTI0 && r == 0)) f.rad[r] = e3.y;
+                }
             }
 #pragma unroll
             for (int g = 0; g < DD::NGAIN; ++g) {
@@ -494,7 +539,9 @@ __device__ __forceinline__ double direct_vib_sin(double x) { return sin(x); }
 // or steady (glide) -- the flat source stage's selects (klatt_systolic.h).  What a dequeue reads (the frame's two pitch values,
 // index mark) is a SourceRef loaded when the previous frame was dequeued.  CB: f.cur[CB + k] = vibratoPitchOffset, vibratoSpeed,
 // turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain.
-template <class DD, int MODE, int CH, int CB, bool HEAD>
+// PHASE (layout 1, MODE_FAST): the stage ends with the pitch phase, which it hands to the glottal stage -- its only parameters are the
+// vibrato's (f.cur[CB], f.cur[CB + 1]).
+template <class DD, int MODE, int CH, int CB, bool HEAD, bool PHASE = false>
 __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const UttDesc& d, bool live, uint32_t u, uint32_t rec0, const DirectCtx& X, int lane,
                                                     int nIter, int nChunks, double* pipeOut, uint32_t nkey, uint32_t ninc, uint32_t ninc2)
 {
@@ -519,8 +566,12 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
             vibPhase = (vs != 0.0) ? adv : vibPhase;
             vib = (direct_vib_sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[CB + 0]) + 1.0;
         }
-        const double turbGain = f.cur[CB + 2], openQ = f.cur[CB + 3], voiceAmp = f.cur[CB + 4], aspAmp = f.cur[CB + 5], preGain = f.cur[CB + 6];
         pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
+        if constexpr (PHASE) {
+            mid(pitchPhase);
+            return pitchPhase;
+        } else {
+        const double turbGain = f.cur[CB + 2], openQ = f.cur[CB + 3], voiceAmp = f.cur[CB + 4], aspAmp = f.cur[CB + 5], preGain = f.cur[CB + 6];
         double voice = (pitchPhase * 2.0) - 1.0;
         aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
         noiseSt = noise_step2(noiseSt, ninc2);
@@ -541,6 +592,7 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
         }
         mid(out);      // the next sample's values: every parameter of this one has been used
         return out;
+        }
     };
     auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[CB + 0] != 0.0 || f.cur[CB + 1] != 0.0 || vibPhase != vibPhase; };
 #ifdef KLATT_STAMPS
@@ -651,6 +703,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
 {
     using L = DirectLds<CH>;
     constexpr int kChunk = CH;
+    constexpr int LAY = direct_layout(MODE);      // which stage runs what (klatt_device.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     auto pipe = [&](int k) __attribute__((always_inline)) { return reinterpret_cast<double*>(lds + k * L::kPipeBytes); };
     double* const pipeX0 = pipe(0); double* const pipeX1 = pipe(1); double* const pipeX2 = pipe(2); double* const pipeX3 = pipe(3);
@@ -692,11 +745,12 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         __syncthreads();
         const bool two = simdCount[0] == 2u && simdCount[1] == 2u && simdCount[2] == 2u && simdCount[3] == 2u;
         // heavy with light: MODE_FAST T1 + T2 | T0 + T3 | T5 + T4 | T7 + T6;  MODE_EXACT T5 + T2 | T1 + T0 | T4 + T3 | T7 + T6
-        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = {5, 2, 1, 0, 4, 3, 7, 6};
+        // layout 1 (MODE_FAST): final + phase | parallel 1, 2 + r6..r4 | nasal pair + r3..r1 | parallel 3, 4 + glottal
+        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = {5, 2, 1, 0, 4, 3, 7, 6}, kPairsFast1[8] = {7, 0, 5, 3, 2, 4, 6, 1};
         const int key = (int)(simd * 2u + (rank & 1u));
         int pick = wave;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (key == k) pick = MODE == MODE_FAST ? kPairsFast[k] : kPairsExact[k];
+        for (int k = 0; k < 8; ++k) if (key == k) pick = LAY == 1 ? kPairsFast1[k] : (MODE == MODE_FAST ? kPairsFast[k] : kPairsExact[k]);
         stage = __builtin_amdgcn_readfirstlane(two ? pick : wave);
     }
 #endif
@@ -709,38 +763,71 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
 #define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
     auto noChunk = [&]() __attribute__((always_inline)) {};
     auto ctx = [&](auto stageTag) __attribute__((always_inline)) {
-        constexpr int S = decltype(stageTag)::value, kFirst = direct_stage_first(S);
+        constexpr int S = decltype(stageTag)::value, kFirst = direct_stage_first(S, LAY);
         return DirectCtx{A, A.directHdr + (size_t)S * A.nDirect, A.directRec + (size_t)kFirst * A.nDirect};
     };
 
     if (stage == 0 && (KLATT_DIRECT_STAGES & 1)) {
         // ================= T0: glottal source + aspiration noise =================
-        using DD = DirectDesc<0>;      // cur: vibratoPitchOffset, vibratoSpeed, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain, -
+        using DD = DirectDesc<0, LAY>; // cur: vibratoPitchOffset, vibratoSpeed[, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain, -]
         const DirectCtx X = ctx(std::integral_constant<int, 0>{});
-        direct_source_stage<DD, MODE, CH, 0, false>(A, d, live, u, rec0, X, lane, nIter, nChunks, pipeX0, nkey, ninc, ninc2);
-    } else if (stage == 1 && (KLATT_DIRECT_STAGES & 2)) {
-        // ================= T1: N0 (anti), NP mixed in by caNP (reference src/speechWaveGenerator.cpp:149-152) =================
-        using DD = DirectDesc<1>;      // cur: caNP, -
+        direct_source_stage<DD, MODE, CH, 0, false, LAY == 1>(A, d, live, u, rec0, X, lane, nIter, nChunks, pipeX0, nkey, ninc, ninc2);
+    } else if (LAY == 1 && stage == 1 && (KLATT_DIRECT_STAGES & 64)) {
+        // ================= layout 1, T1: glottal wave + aspiration noise from the phase (reference src/speechWaveGenerator.cpp:63-86) =================
+        if constexpr (LAY == 1) {
+        using DD = DirectDesc<1, LAY>; // cur: turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain, -
         const DirectCtx X = ctx(std::integral_constant<int, 1>{});
         DirectState<DD> f;
         direct_init<DD>(f, live, d, rec0, X);
+        double aspNoise = 0.0;
+        uint32_t noiseSt = noise_first(nkey, ninc);    // aspiration: noise values 0, 2, 4, ...
         direct_loop<DD, MODE, CH>(1, nIter, nChunks, stage, f, X,
             [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pipeX0, c, i)}; },
+            [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
+                const double pitchPhase = in.a;
+                const double turbGain = f.cur[0], openQ = f.cur[1], voiceAmp = f.cur[2], aspAmp = f.cur[3], preGain = f.cur[4];
+                double voice = (pitchPhase * 2.0) - 1.0;
+                aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
+                noiseSt = noise_step2(noiseSt, ninc2);
+                double asp = aspNoise * 0.2;
+                double turb = asp * turbGain;
+                turb = (pitchPhase >= openQ) ? turb : turb * 0.01;
+                voice += turb;
+                voice *= voiceAmp;
+                asp *= aspAmp;
+                const double src = asp + voice;
+                const double out = (src * preGain) * 0.5;
+                PIPE(pipeX1, c, i) = out;
+                mid(out);
+            },
+            noChunk);
+        }
+    } else if (stage == (LAY == 1 ? 2 : 1) && (KLATT_DIRECT_STAGES & 2)) {
+        // ================= N0 (anti), NP mixed in by caNP (reference src/speechWaveGenerator.cpp:149-152) =================
+        constexpr int ST = LAY == 1 ? 2 : 1;
+        using DD = DirectDesc<ST, LAY>;      // cur: caNP, -
+        const DirectCtx X = ctx(std::integral_constant<int, ST>{});
+        double* const pin = LAY == 1 ? pipeX1 : pipeX0;
+        double* const pout = LAY == 1 ? pipeX2 : pipeX1;
+        DirectState<DD> f;
+        direct_init<DD>(f, live, d, rec0, X);
+        direct_loop<DD, MODE, CH>(ST, nIter, nChunks, stage, f, X,
+            [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pin, c, i)}; },
             [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
                 const double x = in.a;
                 const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
                 f.z2[0] = f.z1[0]; f.z1[0] = x;                              // the anti-resonator remembers its INPUT (reference :133)
                 const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
                 const double o = fade_value(x, np, f.cur[0]);
-                PIPE(pipeX1, c, i) = o;
+                PIPE(pout, c, i) = o;
                 mid(o);      // the next sample's values: every coefficient and gain of this one has been used
             },
             noChunk);
-    } else if (stage >= 2 && stage <= 4 && (KLATT_DIRECT_STAGES & 4)) {
-        // ================= T2, T3, T4: two resonators of the cascade each (r6 r5 | r4 r3 | r2 r1) =================
+    } else if (stage >= (LAY == 1 ? 3 : 2) && stage <= 4 && (KLATT_DIRECT_STAGES & 4)) {
+        // ================= the cascade: layout 0 T2, T3, T4 two resonators each (r6 r5 | r4 r3 | r2 r1); layout 1 T3, T4 three each =================
         auto pair = [&](auto stageTag, double* pin, double* pout) __attribute__((always_inline)) {
             constexpr int ST = decltype(stageTag)::value;
-            using DD = DirectDesc<ST>;
+            using DD = DirectDesc<ST, LAY>;
             const DirectCtx X = ctx(stageTag);
             DirectState<DD> f;
             direct_init<DD>(f, live, d, rec0, X);
@@ -748,19 +835,19 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pin, c, i)}; },
                 [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
                     double o = in.a;
-                    o = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], o);
-                    o = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], o);
+#pragma unroll
+                    for (int r = 0; r < DD::NRES; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
                     PIPE(pout, c, i) = o;
                     mid(o);
                 },
                 noChunk);
         };
-        if (stage == 2) pair(std::integral_constant<int, 2>{}, pipeX1, pipeX2);
-        else if (stage == 3) pair(std::integral_constant<int, 3>{}, pipeX2, pipeX3);
-        else pair(std::integral_constant<int, 4>{}, pipeX3, pipeO);
+        if constexpr (LAY == 0) { if (stage == 2) pair(std::integral_constant<int, 2>{}, pipeX1, pipeX2); }
+        if (stage == 3) pair(std::integral_constant<int, 3>{}, pipeX2, pipeX3);
+        else if (stage == 4) pair(std::integral_constant<int, 4>{}, pipeX3, pipeO);
     } else if (stage == 5 && (KLATT_DIRECT_STAGES & 8)) {
         // ================= T5: frication noise, parallel 1, 2 =================
-        using DD = DirectDesc<5>;      // cur: fricationAmplitude, preFormantGain, pa1, pa2
+        using DD = DirectDesc<5, LAY>; // cur: fricationAmplitude, preFormantGain, pa1, pa2
         const DirectCtx X = ctx(std::integral_constant<int, 5>{});
         DirectState<DD> f;
         direct_init<DD>(f, live, d, rec0, X);
@@ -784,7 +871,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             noChunk);
     } else if (stage == 6 && (KLATT_DIRECT_STAGES & 16)) {
         // ================= T6: parallel 3, 4 (the sum continues in the reference's order; y travels on) =================
-        using DD = DirectDesc<6>;      // cur: pa3, pa4
+        using DD = DirectDesc<6, LAY>; // cur: pa3, pa4
         const DirectCtx X = ctx(std::integral_constant<int, 6>{});
         DirectState<DD> f;
         direct_init<DD>(f, live, d, rec0, X);
@@ -803,7 +890,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             noChunk);
     } else if (stage == FINAL && (KLATT_DIRECT_STAGES & 32)) {
         // ================= T7: parallel 5, 6, bypass | cascade + parallel, gain, clip, int16 -> PCM =================
-        using DD = DirectDesc<7>;      // cur: pa5, pa6, parallelBypass, outputGain
+        using DD = DirectDesc<7, LAY>; // cur: pa5, pa6, parallelBypass, outputGain
         const DirectCtx X = ctx(std::integral_constant<int, 7>{});
         DirectState<DD> f;
         direct_init<DD>(f, live, d, rec0, X);

@@ -728,7 +728,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
 
 // Timing-only experiment switches (KLATT_EXP & 1 / & 4 in klatt_systolic.h, KLATT_LP_EXP in klatt_systolic.h / klatt_lanepipe.h) build a
 // library with the same ABI whose PCM is garbage: such a build refuses to hand PCM out, it only times.
-#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0) || ((KLATT_DIRECT_EXP & 3) != 0) || (KLATT_DIRECT_STAGES != 0x3F)
+#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0) || ((KLATT_DIRECT_EXP & 3) != 0) || (KLATT_DIRECT_STAGES != 0x7F)
 constexpr bool kTimingOnlyBuild = true;
 #else
 constexpr bool kTimingOnlyBuild = false;

@@ -5,7 +5,7 @@
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 W=${1:-all_different}
 cd /tmp && export TMPDIR=/tmp
-for v in base ds1 ds2 ds4 ds8 ds16 ds32; do
+for v in base ds1 ds64 ds2 ds4 ds8 ds16 ds32; do
   if [ $v != base ]; then export SPEECHPLAYER_LIB=$ROOT/nvspeechplayer_amd/lib/variants/libspeechPlayer_$v.so; else unset SPEECHPLAYER_LIB; fi
   out=/tmp/direct_stage_pmc_out
   rm -rf $out

@@ -61,7 +61,10 @@
 namespace klatt {
 
 #ifndef KLATT_DIRECT_UNROLL
-#define KLATT_DIRECT_UNROLL 2
+#define KLATT_DIRECT_UNROLL 2            // samples per trip of the mixed loops, MODE_EXACT (4: 51.8 -> 57.9 ms on the all-different batch)
+#endif
+#ifndef KLATT_DIRECT_UNROLL_FAST
+#define KLATT_DIRECT_UNROLL_FAST 4       // ... MODE_FAST (2: 30.2 instead of 29.0 ms)
 #endif
 #ifndef KLATT_DIRECT_EXP
 #define KLATT_DIRECT_EXP 0      // timing experiments (wrong PCM; the library then refuses to hand PCM out): 1 a switch loads nothing; 2 nothing is evaluated
@@ -77,6 +80,24 @@ namespace klatt {
 #endif
 #ifndef KLATT_DIRECT_FAST_ANTI
 #define KLATT_DIRECT_FAST_ANTI 1     // MODE_FAST: the anti-resonator N0 advances by the pole recurrence too (0: it keeps the polynomials, as in round 4's first builds)
+#endif
+#ifndef KLATT_DIRECT_PAIRS_EXACT_SEL
+#define KLATT_DIRECT_PAIRS_EXACT_SEL 1
+#endif
+#if KLATT_DIRECT_PAIRS_EXACT_SEL == 1
+#define KLATT_DIRECT_PAIRS_EXACT {5, 3, 7, 4, 0, 2, 6, 1}
+#elif KLATT_DIRECT_PAIRS_EXACT_SEL == 2
+#define KLATT_DIRECT_PAIRS_EXACT {5, 4, 7, 2, 0, 3, 6, 1}
+#else
+#define KLATT_DIRECT_PAIRS_EXACT {5, 2, 1, 0, 4, 3, 7, 6}
+#endif
+#ifndef KLATT_DIRECT_PAIRS_FAST1_SEL
+#define KLATT_DIRECT_PAIRS_FAST1_SEL 1
+#endif
+#if KLATT_DIRECT_PAIRS_FAST1_SEL == 1
+#define KLATT_DIRECT_PAIRS_FAST1 {7, 1, 5, 2, 6, 0, 3, 4}
+#else
+#define KLATT_DIRECT_PAIRS_FAST1 {7, 0, 5, 3, 2, 4, 6, 1}
 #endif
 #ifndef KLATT_DIRECT_PAIRING
 #define KLATT_DIRECT_PAIRING 1
@@ -496,7 +517,7 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
                 STAMP_KIND(-1);
                 const uint32_t wm = direct_chunk_mask<DD>(f, t1);
                 auto ahead = load(c, 0);
-#pragma unroll KLATT_DIRECT_UNROLL
+#pragma unroll (MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL)
                 for (int i = 0; i < CH; ++i) {
                     const bool sw = t0 + (uint32_t)i + 1u == f.startAt;
                     const auto in = ahead;
@@ -630,7 +651,7 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
                 const uint32_t wm = direct_chunk_mask<DD>(f, t1);
                 // vibrato can only come alive in this chunk through its kind (the phase only turns NaN while it advances)
                 const bool vibChunk = (wm & (1u << (DD::NRES + CB / 2))) != 0u || __any(vib_live());
-#pragma unroll KLATT_DIRECT_UNROLL
+#pragma unroll (MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL)
                 for (int i = 0; i < CH; ++i) {
                     const uint32_t t = t0 + (uint32_t)i;
                     const bool deq = t + 1u == f.startAt;
@@ -744,9 +765,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
         __syncthreads();
         const bool two = simdCount[0] == 2u && simdCount[1] == 2u && simdCount[2] == 2u && simdCount[3] == 2u;
-        // heavy with light: MODE_FAST T1 + T2 | T0 + T3 | T5 + T4 | T7 + T6;  MODE_EXACT T5 + T2 | T1 + T0 | T4 + T3 | T7 + T6
-        // layout 1 (MODE_FAST): final + phase | parallel 1, 2 + r6..r4 | nasal pair + r3..r1 | parallel 3, 4 + glottal
-        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = {5, 2, 1, 0, 4, 3, 7, 6}, kPairsFast1[8] = {7, 0, 5, 3, 2, 4, 6, 1};
+        // heavy with light (same-run A/B of the candidates: profiles/r4_direct_ab.txt): MODE_EXACT T5 + T3 | T7 + T4 | T0 + T2 | T6 + T1;
+        // MODE_FAST, layout 1: final + glottal | parallel 1, 2 + nasal pair | parallel 3, 4 + phase | the two cascade stages
+        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = KLATT_DIRECT_PAIRS_EXACT, kPairsFast1[8] = KLATT_DIRECT_PAIRS_FAST1;
         const int key = (int)(simd * 2u + (rank & 1u));
         int pick = wave;
 #pragma unroll

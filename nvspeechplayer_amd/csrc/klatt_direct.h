@@ -39,8 +39,8 @@
 //     per frame and stage a RECORD -- for every kind the fade's (from, to - from) pairs (MODE_FAST: P_1, w, q^2) and the values
 //     of the fade's FIRST sample, on which the reference re-evaluates everything (the previous fade's last interpolated value
 //     need not equal the frame value).  The 16-byte header of the NEXT fade is loaded at the previous switch, as the flat stages
-//     do; the record's lines are touched a chunk ahead (plain loads into registers the lane owns until the switch names them:
-//     measured no gain, kept because it is harmless; a load whose result nobody owns raced, a volatile one waits).
+//     do.  (Touching the record's lines a chunk ahead -- plain loads into registers the lane owns until the switch names them; a load
+//     whose result nobody owns raced, a volatile one waits -- measured no gain and is off: KLATT_DIRECT_TOUCH.)
 //
 // Same arithmetic as every other kernel of the engine in MODE_EXACT (the seeds and the stages call the functions the tracks
 // and the untracked stages call, on the same operands): the PCM is the same bytes (tests: tracked = direct = untracked).
@@ -76,7 +76,7 @@ namespace klatt {
 #define KLATT_DIRECT_FAST_BRANCHLESS 1
 #endif
 #ifndef KLATT_DIRECT_TOUCH
-#define KLATT_DIRECT_TOUCH 1
+#define KLATT_DIRECT_TOUCH 0      // 1: a fade's record is touched a chunk before its switch (direct_touch): 51.9 / 29.0 against 51.4 / 28.6 ms without
 #endif
 #ifndef KLATT_DIRECT_FAST_ANTI
 #define KLATT_DIRECT_FAST_ANTI 1     // MODE_FAST: the anti-resonator N0 advances by the pole recurrence too (0: it keeps the polynomials, as in round 4's first builds)

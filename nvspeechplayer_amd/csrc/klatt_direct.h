@@ -474,6 +474,7 @@ struct In3 { double a, b, c; };
 template <class DD, int MODE, int CH, class FLoad, class FBody, class FChunk>
 __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, int stampSlot, DirectState<DD>& f, const DirectCtx& X, FLoad load, FBody body, FChunk perChunk)
 {
+    constexpr int kMixedUnroll = MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL;
 #ifdef KLATT_STAMPS
     Stamps st;
 #endif
@@ -517,7 +518,7 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
                 STAMP_KIND(-1);
                 const uint32_t wm = direct_chunk_mask<DD>(f, t1);
                 auto ahead = load(c, 0);
-#pragma unroll (MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL)
+#pragma unroll kMixedUnroll
                 for (int i = 0; i < CH; ++i) {
                     const bool sw = t0 + (uint32_t)i + 1u == f.startAt;
                     const auto in = ahead;
@@ -567,6 +568,7 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
                                                     int nIter, int nChunks, double* pipeOut, uint32_t nkey, uint32_t ninc, uint32_t ninc2)
 {
 #define SRC_PIPE(c, i) pipeOut[(((c) & 1) * CH + (i)) * kLanes + lane]
+    constexpr int kMixedUnroll = MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL;
     DirectState<DD> f;
     direct_init<DD>(f, live, d, rec0, X);
     const SourceRef* const mySrc = A.sourceRef + d.frameStart;
@@ -651,7 +653,7 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
                 const uint32_t wm = direct_chunk_mask<DD>(f, t1);
                 // vibrato can only come alive in this chunk through its kind (the phase only turns NaN while it advances)
                 const bool vibChunk = (wm & (1u << (DD::NRES + CB / 2))) != 0u || __any(vib_live());
-#pragma unroll (MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL)
+#pragma unroll kMixedUnroll
                 for (int i = 0; i < CH; ++i) {
                     const uint32_t t = t0 + (uint32_t)i;
                     const bool deq = t + 1u == f.startAt;

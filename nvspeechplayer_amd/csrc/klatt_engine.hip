@@ -855,8 +855,9 @@ int batch_launch(Batch* b)
         sa.jobs = b->dDirectJobs.ptr; sa.nJobs = (uint32_t)b->nDirectFrames; sa.frames = b->dFrames.ptr; sa.meta = b->dMeta.ptr;
         sa.hdr = b->dDirectHdr.ptr; sa.rec = b->dDirectRec.ptr; sa.negPiOverSr = a.negPiOverSr; sa.twoPiOverSr = a.twoPiOverSr;
         const dim3 sg((unsigned)((b->nDirectFrames + 255) / 256), (unsigned)kDirectStages);
-        if (b->mode == MODE_FAST) hipLaunchKernelGGL(klatt_seeds<MODE_FAST>, sg, dim3(256), 0, st, sa);
-        else hipLaunchKernelGGL(klatt_seeds<MODE_EXACT>, sg, dim3(256), 0, st, sa);
+        constexpr int kSeedLds = 14 * 257 * (int)sizeof(double2);      // the largest record (14 entries) of 256 frames, pitch 257 (seed_stage)
+        if (b->mode == MODE_FAST) hipLaunchKernelGGL(klatt_seeds<MODE_FAST>, sg, dim3(256), kSeedLds, st, sa);
+        else hipLaunchKernelGGL(klatt_seeds<MODE_EXACT>, sg, dim3(256), kSeedLds, st, sa);
         HIP_TRY(hipGetLastError());
         a.order = b->dOrder.ptr + b->nQuiet + b->nTracked; a.nSlots = nDir;
         a.directHdr = b->dDirectHdr.ptr; a.directRec = b->dDirectRec.ptr; a.directFirst = b->dDirectFirst.ptr; a.nDirect = (uint32_t)b->nDirectFrames;

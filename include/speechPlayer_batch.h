@@ -42,8 +42,8 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
  * tracks do not fit runs without them);
  * "direct" (what runs the noisy, finite utterances that got no tracks -- a batch whose fades share nothing would need 12 bytes of
  * track per output sample: 1, default: the direct stages (every fade sample's coefficients computed in place from per-frame
- * seeds, eight wavefronts per 64 utterances) unless the utterances are time-aligned copies of few sentences, which the stages
- * with the frame state machine run faster; 2: the direct stages always; 0: never).
+ * seeds, eight wavefronts per 64 utterances) unless -- in MODE_EXACT -- the utterances are time-aligned copies of few sentences,
+ * which the stages with the frame state machine run faster; 2: the direct stages always; 0: never).
  * "tracks", "track_budget_mb" and "direct" are read by speechPlayer_batch_setUtterances: set them before it.  No option changes the
  * PCM of MODE_EXACT; MODE_FAST stays within its tolerance whichever kernel runs (the direct stages advance the coefficients of a
  * fade by recurrences, re-seeded exactly at every fade's first sample: relative error <= 4 F 2^-53 after F fade samples). */

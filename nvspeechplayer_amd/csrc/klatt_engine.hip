@@ -745,7 +745,8 @@ bool refuse_timing_only(const char* what)
 // -- silence -- keeps the previous request's values with the gain gated off; the first frame after silence starts from its own
 // values with the gain gated off; any other frame fades from the previous request's values).  klatt_seeds reads the values
 // themselves on the device.  Host-only view for the tests: speechPlayer_planDirect.
-void walk_fade_ends(long long k0, long long k1, const FrameMeta* meta, std::vector<DirectJob>& out)
+template <class V>
+void walk_fade_ends(long long k0, long long k1, const FrameMeta* meta, V& out)
 {
     uint32_t prevReal = kNoFrame;
     bool prevNull = true;
@@ -766,6 +767,18 @@ void walk_fade_ends(long long k0, long long k1, const FrameMeta* meta, std::vect
         out.push_back(j);
     }
 }
+
+// A vector whose resize() does not value-initialise (trivial element types only): the per-frame work arrays of setUtterances are
+// written in full, in parallel, right after they are sized -- a zero-fill by the calling thread first costs ~1 ms per 6 MB.
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U> struct rebind { using other = NoInitAlloc<U>; };
+    NoInitAlloc() = default;
+    template <class U> NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U> void construct(U* p) { ::new (static_cast<void*>(p)) U; }
+    template <class U, class... A> void construct(U* p, A&&... a) { ::new (static_cast<void*>(p)) U(std::forward<A>(a)...); }
+};
+template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
 
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
 // (setUtterances only forms the direct group under the stage-parallel layouts)
@@ -1643,21 +1656,22 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     // and its unmapping on release -- together ~15 ms of a 65 ms call for BASELINE configs[2].  Every element is written below before it
     // is read.  (Released again when a batch was very large: kScratchKeepFrames.)
     constexpr long long kScratchKeepFrames = 4000000;
-    static thread_local std::vector<FrameMeta> metaScratch;
-    static thread_local std::vector<FlatRef> flatRefScratch;
-    static thread_local std::vector<SourceRef> sourceRefScratch;
-    static thread_local std::vector<DirectJob> directJobsScratch;
+    // (RawVector: resize() leaves new elements uninitialised, so a fresh array is first touched by the threads that fill it)
+    static thread_local RawVector<FrameMeta> metaScratch;
+    static thread_local RawVector<FlatRef> flatRefScratch;
+    static thread_local RawVector<SourceRef> sourceRefScratch;
+    static thread_local RawVector<DirectJob> directJobsScratch;
     struct ScratchRelease {
         long long nF;
         ~ScratchRelease()
         {
             if (nF > kScratchKeepFrames) {
-                std::vector<FrameMeta>().swap(metaScratch); std::vector<FlatRef>().swap(flatRefScratch);
-                std::vector<SourceRef>().swap(sourceRefScratch); std::vector<DirectJob>().swap(directJobsScratch);
+                RawVector<FrameMeta>().swap(metaScratch); RawVector<FlatRef>().swap(flatRefScratch);
+                RawVector<SourceRef>().swap(sourceRefScratch); RawVector<DirectJob>().swap(directJobsScratch);
             }
         }
     } scratchRelease{nF};
-    std::vector<FrameMeta>& meta = metaScratch;
+    RawVector<FrameMeta>& meta = metaScratch;
     meta.resize((size_t)nF);
     parallel_ranges(nF, 1 << 16, [&](long long a, long long e) {
         for (long long k = a; k < e; ++k) {
@@ -1837,7 +1851,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     // the direct utterances' fades: per frame where its fade starts from and ends on (reference src/frame.cpp:55-72: silence keeps
     // the previous request's values with the gain gated off; the first frame after silence starts from its own values with the gain
     // gated off; any other frame fades from the previous request's values) -- klatt_seeds reads the values themselves on the device
-    std::vector<DirectJob>& directJobs = directJobsScratch;
+    RawVector<DirectJob>& directJobs = directJobsScratch;
     directJobs.clear();
     std::vector<uint32_t> directFirst;
     long long nDirectUtt = 0;
@@ -1850,8 +1864,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             walk_fade_ends(frameStart[u], frameStart[u + 1], meta.data(), directJobs);
         }
     }
-    std::vector<FlatRef>& flatRef = flatRefScratch;
-    std::vector<SourceRef>& sourceRef = sourceRefScratch;
+    RawVector<FlatRef>& flatRef = flatRefScratch;
+    RawVector<SourceRef>& sourceRef = sourceRefScratch;
     if (!plan.jobs.empty() || nDirectUtt > 0) {
         if (!plan.jobs.empty()) flatRef.resize((size_t)nF);
         sourceRef.resize((size_t)nF);

@@ -14,16 +14,15 @@
 // would have held, behind a sample's filter arithmetic (DirectMid):
 //
 //   * per lane: the fade-sample index `cnt` of the values now in registers (cnt == F, the fade's length: the lane is not fading
-//     and keeps the fade's last values, as the reference does until the next fade's first sample), and per parameter the pair
-//     (from, to - from) of the running fade;
-//   * ONE masked block per sample for the lanes with cnt < F (skipped when the wavefront has none): cnt + 1,
-//         ratio = cnt / F  (correctly rounded in both modes: the fade's last sample must land on its target exactly),
-//         value = from + ((to - from) * ratio)                           (reference src/frame.cpp:48-53, src/utils.h:20-23)
-//     and for a resonator r = exp(-pi bw / sr), cs = cos(2 pi (-f) / sr), c = -(r r), b = r cs 2, a = 1 - b - c (reference
-//     src/speechWaveGenerator.cpp:112-127) with the straight-line kernels of klatt_math.h (constants as scalar operands of the
-//     FMAs), classified ONCE per chunk and wave (no range reduction / cosine quadrant -1 / general) from bits the seeds carry.
-//     Which kinds are evaluated is a wave-uniform mask per chunk (the OR over the lanes of what their running or starting fades
-//     move): scalar branches, no ballots per sample.  The block is tied BEHIND the sample's arithmetic (an empty asm statement
+//     and keeps the fade's last values, as the reference does until the next fade's first sample), and per parameter what the
+//     running fade needs to advance it;
+//   * ONE masked block per sample for the lanes with cnt < F (skipped when the wavefront has none): cnt + 1, and
+//     MODE_EXACT: ratio = cnt / F (correctly rounded), value = from + ((to - from) * ratio) (reference src/frame.cpp:48-53,
+//     src/utils.h:20-23), and for a resonator r = exp(-pi bw / sr), cs = cos(2 pi (-f) / sr), c = -(r r), b = r cs 2, a = 1 - b - c
+//     (reference src/speechWaveGenerator.cpp:112-127) with the straight-line kernels of klatt_math.h (constants as scalar operands
+//     of the FMAs), classified ONCE per chunk and wave (no range reduction / cosine quadrant -1 / general) from bits the seeds
+//     carry.  Which kinds are evaluated is a wave-uniform mask per chunk (the OR over the lanes of what their running or starting
+//     fades move): scalar branches, no ballots per sample.  The block is tied BEHIND the sample's arithmetic (an empty asm statement
 //     makes the counter depend on the sample's last value): the compiler otherwise hoists it above the filters and keeps a
 //     copy of every coefficient for the lanes it masks off;
 //   * MODE_FAST replaces the polynomials by SURVEY section 7's recurrences: with f and bw linear in the fade-sample index,
@@ -34,84 +33,68 @@
 //     (1e-12 for the longest fades of speech, F ~ 1500; tests/test_gpu_parity.py holds MODE_FAST to the usual bar, and fades of
 //     350 000 samples in test_direct_stages_long_fades_hold_the_recurrence_bound).  Run without per-kind branches: a kind nobody
 //     moves has the identity as its factor.  The anti-resonator N0 runs the recurrence on its plain pole pair and inverts per sample
-//     (fast_anti_finish; until the end of round 4 it kept the polynomials);
+//     (fast_anti_finish).  A GAIN advances by a constant increment (to - from) / F per fade sample from its exact first value (round 5;
+//     the same bound: one rounding per sample), so only the source stage (the pitch) and N0 (whose frequency is TESTED for 0, reference
+//     src/speechWaveGenerator.cpp:122, and must land on its target exactly) still form cnt / F;
 //   * a fade START is a second masked block of 16-byte loads: klatt_seeds (below) has evaluated, densely and before the launch,
-//     per frame and stage a RECORD -- for every kind the fade's (from, to - from) pairs (MODE_FAST: P_1, w, q^2) and the values
-//     of the fade's FIRST sample, on which the reference re-evaluates everything (the previous fade's last interpolated value
-//     need not equal the frame value).  The 16-byte header of the NEXT fade is loaded at the previous switch, as the flat stages
-//     do.  (Touching the record's lines a chunk ahead -- plain loads into registers the lane owns until the switch names them; a load
-//     whose result nobody owns raced, a volatile one waits -- measured no gain and is off: KLATT_DIRECT_TOUCH.)
+//     per frame and stage a RECORD -- what every kind needs to advance through the fade and the values of the fade's FIRST sample,
+//     on which the reference re-evaluates everything (the previous fade's last interpolated value need not equal the frame value).
+//     The state a record fills is kept in PAIRS of doubles that mirror the record's 16-byte entries (round 5), so that a masked
+//     load lands in the very registers the sample loop reads: with one double per variable the compiler loaded into 44 temporaries
+//     and copied them under the mask, which alone put a stage over the 128 registers of two workgroups per CU.  The 16-byte header
+//     of the NEXT fade is loaded at the previous switch, as the flat stages do.
 //
 // Same arithmetic as every other kernel of the engine in MODE_EXACT (the seeds and the stages call the functions the tracks
 // and the untracked stages call, on the same operands): the PCM is the same bytes (tests: tracked = direct = untracked).
 //
 // EIGHT stages, one wavefront each (klatt_device.h, direct_stage_kind): T0 source | T1 N0, NP | T2 r6, r5 | T3 r4, r3 | T4 r2, r1 |
-// T5 frication, parallel 1, 2 | T6 parallel 3, 4 | T7 parallel 5, 6, mix, clip, PCM: one workgroup per CU (152 KB of pipes at
-// 16-sample hand-overs), two wavefronts per SIMD, which stage sits beside which chosen from HW_ID (the pairs that balance the SIMDs
-// differ between the modes).  A direct stage carries ten doubles per resonator (coefficients, memories, the running fade's end points)
-// and three per gain: four resonators per wavefront, the flat stages' split, compiled to 350-470 VGPRs (150-600 spilled), and so
-// did eight stages at the 128 registers of two workgroups per CU; two resonators per stage at 256 fit with room to spare.
-// MODE_FAST runs a second layout (klatt_device.h, direct_layout): the source in two stages (pitch / vibrato / phase | glottal wave,
-// noise, gains), the cascade in two stages of three, N0 on the recurrence of its plain pole pair (KLATT_DIRECT_FAST_ANTI).
-// DESIGN.md section 4.7 has the measurements (instructions per stage and sample, what bounds the launch, what was tried).
+// T5 frication, parallel 1, 2 | T6 parallel 3, 4 | T7 parallel 5, 6, mix, clip, PCM; which stage sits beside which on a SIMD is chosen
+// from HW_ID (the pairs that balance the SIMDs differ between the modes).  MODE_FAST runs a second layout (klatt_device.h,
+// direct_layout): the source in two stages (pitch / vibrato / phase | glottal wave, noise, gains), the cascade in two stages of three.
+// TWO RESIDENCIES (template parameter WPE, wavefronts per SIMD): 2 -- one workgroup per CU, 16-sample hand-overs (152 KB of pipes),
+// 256 registers per stage, round 4's kernel --, and 4 -- TWO workgroups per CU, 8-sample hand-overs (77 KB), 128 registers: the LEAN
+// stages of round 5 (`a = 1 - b - c` derived where it is used instead of carried, the PCM tile flushed two rows at a time, shorter
+// unrolls).  A launch of the unaligned batch is bound by the LATENCY of a sample through one workgroup's stage pipeline, which only a
+// second resident workgroup overlaps.  DESIGN.md section 4.7 has the measurements.
 #pragma once
 
 #include "klatt_systolic.h"
 
 namespace klatt {
 
+// samples per trip of the mixed loops / of the steady loops, by arithmetic mode and residency (same PCM whatever the values)
 #ifndef KLATT_DIRECT_UNROLL
-#define KLATT_DIRECT_UNROLL 2            // samples per trip of the mixed loops, MODE_EXACT (4: 51.8 -> 57.9 ms on the all-different batch)
+#define KLATT_DIRECT_UNROLL 2            // MODE_EXACT, one workgroup per CU (4: 51.8 -> 57.9 ms on the all-different batch)
 #endif
 #ifndef KLATT_DIRECT_UNROLL_FAST
-#define KLATT_DIRECT_UNROLL_FAST 4       // ... MODE_FAST (2: 30.2 instead of 29.0 ms)
-#endif
-#ifndef KLATT_DIRECT_EXP
-#define KLATT_DIRECT_EXP 0      // timing experiments (wrong PCM; the library then refuses to hand PCM out): 1 a switch loads nothing; 2 nothing is evaluated
+#define KLATT_DIRECT_UNROLL_FAST 4       // MODE_FAST, one workgroup per CU (2: 30.2 instead of 29.0 ms)
 #endif
 #ifndef KLATT_DIRECT_STEADY_UNROLL
 #define KLATT_DIRECT_STEADY_UNROLL 16
 #endif
-#ifndef KLATT_DIRECT_FAST_BRANCHLESS
-#define KLATT_DIRECT_FAST_BRANCHLESS 1
+#ifndef KLATT_DIRECT_LEAN_UNROLL
+#define KLATT_DIRECT_LEAN_UNROLL 1       // MODE_EXACT, two workgroups per CU
 #endif
-#ifndef KLATT_DIRECT_TOUCH
-#define KLATT_DIRECT_TOUCH 0      // 1: a fade's record is touched a chunk before its switch (direct_touch): 51.9 / 29.0 against 51.4 / 28.6 ms without
+#ifndef KLATT_DIRECT_LEAN_UNROLL_FAST
+#define KLATT_DIRECT_LEAN_UNROLL_FAST 2  // MODE_FAST, two workgroups per CU
 #endif
-#ifndef KLATT_DIRECT_FAST_ANTI
-#define KLATT_DIRECT_FAST_ANTI 1     // MODE_FAST: the anti-resonator N0 advances by the pole recurrence too (0: it keeps the polynomials, as in round 4's first builds)
+#ifndef KLATT_DIRECT_LEAN_STEADY_UNROLL
+#define KLATT_DIRECT_LEAN_STEADY_UNROLL 4
 #endif
-#ifndef KLATT_DIRECT_PAIRS_EXACT_SEL
-#define KLATT_DIRECT_PAIRS_EXACT_SEL 1
-#endif
-#if KLATT_DIRECT_PAIRS_EXACT_SEL == 1
-#define KLATT_DIRECT_PAIRS_EXACT {5, 3, 7, 4, 0, 2, 6, 1}
-#elif KLATT_DIRECT_PAIRS_EXACT_SEL == 2
-#define KLATT_DIRECT_PAIRS_EXACT {5, 4, 7, 2, 0, 3, 6, 1}
-#else
-#define KLATT_DIRECT_PAIRS_EXACT {5, 2, 1, 0, 4, 3, 7, 6}
-#endif
-#ifndef KLATT_DIRECT_PAIRS_FAST1_SEL
-#define KLATT_DIRECT_PAIRS_FAST1_SEL 1
-#endif
-#if KLATT_DIRECT_PAIRS_FAST1_SEL == 1
-#define KLATT_DIRECT_PAIRS_FAST1 {7, 1, 5, 2, 6, 0, 3, 4}
-#else
-#define KLATT_DIRECT_PAIRS_FAST1 {7, 0, 5, 3, 2, 4, 6, 1}
-#endif
-#ifndef KLATT_DIRECT_PAIRING
-#define KLATT_DIRECT_PAIRING 1
-#endif
-#ifndef KLATT_DIRECT_STAGES
-#define KLATT_DIRECT_STAGES 0x7F     // (register census, tools/direct_census.sh: compile the kernel with some stages' bodies left out; 64: layout 1's glottal stage)
-#endif
+
+// A pair of doubles in two adjacent register pairs: the unit a record entry is loaded in (global_load_dwordx4 into the state itself)
+typedef double dpair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ dpair make_dpair(double x, double y) { dpair v; v.x = x; v.y = y; return v; }
 
 // ---- klatt_seeds: one record per (frame, stage) of the launch's direct utterances -------------------------------------------
 // Record of stage s for one frame: direct_stage_entries(s) 16-byte entries,
 //   resonator kind r (4 entries at 4 r):
-//       MODE_EXACT (and N0 in both modes)   (f_from, f_to - f_from) (bw_from, bw_to - bw_from) (b_1, c_1) (a_1, r_1)
+//       MODE_EXACT                          (f_from, f_to - f_from) (bw_from, bw_to - bw_from) (b_1, c_1) (a_1, r_1)
 //       MODE_FAST                           (Im P_1, Re w) (Im w, q^2) (b_1 = Re P_1, c_1 = -r_1^2) (a_1, -)
-//   gain kind g (3 entries at 4 NRES + 3 g): (x_from, x_to - x_from) (y_from, y_to - y_from) (x_1, y_1)     for its two parameters
+//       MODE_FAST, N0                       (Im P_1, Re w) (Im w, q^2) (Re P_1, r_1^2 of the PLAIN pole pair) (f_from, f_to - f_from)
+//   gain kind g (3 entries at 4 NRES + 3 g) for its two parameters x, y:
+//       MODE_EXACT                          (x_from, x_to - x_from) (y_from, y_to - y_from) (x_1, y_1)
+//       MODE_FAST                           (x_1, y_1) ((x_to - x_from) / F, (y_to - y_from) / F) (-, -)
 // where _1 is the value on the fade's first sample.  The end points follow reference src/frame.cpp:55-72 (host: DirectJob).
 struct SeedArgs {
     const DirectJob* jobs;
@@ -168,7 +151,7 @@ __device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool m
         bits |= (moves ? 1u << r : 0u) | (bwMoves ? 1u << (kDirectBwShift + r) : 0u) |
                 ((eu && c0) ? 0u : 1u << (kDirectClsShift + 2 * r)) | ((eu && c1) ? 0u : 2u << (kDirectClsShift + 2 * r));
         double2 e0, e1, e2, e3;
-        if (MODE == MODE_FAST && (!anti || KLATT_DIRECT_FAST_ANTI)) {
+        if (MODE == MODE_FAST) {
             // P_1 = 2 r_1 e^(i theta_1); per fade sample theta advances by delta = (2 pi / sr) (-(f_to - f_from) / F) and r by the
             // factor q = exp((-pi / sr) ((bw_to - bw_from) / F)).  A fade of one sample never advances.
             const double th1 = A.twoPiOverSr * -f1;
@@ -203,11 +186,15 @@ __device__ __forceinline__ void seed_stage(const SeedArgs& A, uint32_t j, bool m
         const double xd = xT - xF, yd = yT - yF;
         const bool moves = !(xT == xF) || !(yT == yF);
         bits |= moves ? 1u << (NR + g) : 0u;
-        const double x1 = MODE == MODE_FAST ? __builtin_fma(xd, ratio1, xF) : xF + (xd * ratio1);
-        const double y1 = MODE == MODE_FAST ? __builtin_fma(yd, ratio1, yF) : yF + (yd * ratio1);
-        put(4 * NR + 3 * g, make_double2(xF, xd));
-        put(4 * NR + 3 * g + 1, make_double2(yF, yd));
-        put(4 * NR + 3 * g + 2, make_double2(x1, y1));
+        if (MODE == MODE_FAST) {
+            put(4 * NR + 3 * g, make_double2(__builtin_fma(xd, ratio1, xF), __builtin_fma(yd, ratio1, yF)));
+            put(4 * NR + 3 * g + 1, make_double2(xd * invF, yd * invF));
+            put(4 * NR + 3 * g + 2, make_double2(0.0, 0.0));
+        } else {
+            put(4 * NR + 3 * g, make_double2(xF, xd));
+            put(4 * NR + 3 * g + 1, make_double2(yF, yd));
+            put(4 * NR + 3 * g + 2, make_double2(xF + (xd * ratio1), yF + (yd * ratio1)));
+        }
     }
     __syncthreads();
     {
@@ -254,49 +241,60 @@ struct DirectDesc {
     static constexpr bool ANTI0 = direct_stage_kind(STAGE_, 0, LAY_) == 0;      // the stage's first resonator is N0
     static constexpr int ENTRIES = direct_stage_entries(STAGE_, LAY_);
 };
-template <class DD>
+// LEAN: the 128-register stages of two workgroups per CU -- `a` of a plain resonator is derived where it is used, not carried
+template <class DD, int MODE, bool LEAN>
 struct DirectState {
-    static constexpr int NR = DD::NRES > 0 ? DD::NRES : 1, NG2 = DD::NGAIN > 0 ? 2 * DD::NGAIN : 1;
-    double ra[NR], rb[NR], rc[NR], z1[NR], z2[NR];      // names as in FlatState2: the stages' sample code is written against them
-    double cur[NG2];
-    // the running fade, per resonator: MODE_EXACT (f_from, f_delta, bw_from, bw_delta, r); MODE_FAST (Im P, Re w, Im w, q^2, -)
-    double p0[NR], p1[NR], p2[NR], p3[NR], rad[NR];
-    double gf[NG2], gd[NG2];                            // per gain parameter: from, to - from
-    double n0r2, n0f, n0fd;                             // MODE_FAST, N0 only: r^2 of its plain pole pair, its frequency's (from, to - from) (rad[0]: Re P)
-    double nfD, invF;                                   // (double)F, 1 / F
+    static constexpr int NR = DD::NRES > 0 ? DD::NRES : 1, NG = DD::NGAIN > 0 ? DD::NGAIN : 1;
+    static constexpr bool FASTANTI = MODE == MODE_FAST && DD::ANTI0;          // resonator 0 is N0 on the recurrence of its plain pole pair
+    // whether cnt / F is formed per fade sample: MODE_EXACT interpolates with it; in MODE_FAST only the pitch (stage 0) and N0's frequency
+    static constexpr bool RATIO = MODE != MODE_FAST || DD::STAGE == 0 || DD::ANTI0;
+    // resonator r, in the pairs of its record: bc = (b, c) [N0 in MODE_FAST: (Re P, r^2) of the plain pole pair];
+    // MODE_EXACT e0 = (f_from, f_delta), e1 = (bw_from, bw_delta), rad = r;  MODE_FAST e0 = (Im P, Re w), e1 = (Im w, q^2)
+    dpair bc[NR], e0[NR], e1[NR];
+    double ra[NR];                                      // a: carried by the stages of one workgroup per CU, and for N0 (whose a is not 1 - b - c)
+    double rad[NR];
+    double z1[NR], z2[NR];
+    dpair fn;                                           // MODE_FAST, N0: its frequency's (from, to - from)
+    double n0b, n0c;                                    // MODE_FAST, N0: the inverted pair's b, c
+    // gain kind g: gv = the current (x, y); MODE_EXACT gx = (x_from, x_delta), gy = (y_from, y_delta); MODE_FAST gx = the increments of (x, y)
+    dpair gv[NG], gx[NG], gy[NG];
+    double invF;                                        // 1 / F
     double ratio;                                       // source stage only: cnt / F of the values in registers (the pitch fades with them)
     bool inFade;                                        // source stage only: the values in registers belong to a fade sample
     uint32_t cnt, F;                                    // the fade-sample index of the values in registers; cnt == F: not fading
-    uint32_t startAt, next, nFrames, length, produced;  // startAt: the sample the next fade's first values apply to
+    uint32_t startAt, next, nFrames, length;            // startAt: the sample the next fade's first values apply to
     uint32_t curBits;                                   // DirectHdr.bits of the running (or last) fade
     uint32_t rec0;                                      // the record number of the utterance's first frame
     DirectHdr nextHdr;                                  // frame `next`'s, loaded ahead
-    uint32_t touched[3];                                // what touching the next record's lines returned (direct_touch): owned until the switch
     bool live;
+    static __device__ __forceinline__ constexpr bool keepsA(int r) { return !LEAN || (DD::ANTI0 && r == 0); }
+    __device__ __forceinline__ double a(int r) const { return keepsA(r) ? ra[r] : (1.0 - bc[r].x) - bc[r].y; }      // reference src/speechWaveGenerator.cpp:119
+    __device__ __forceinline__ double b(int r) const { return (FASTANTI && r == 0) ? n0b : bc[r].x; }
+    __device__ __forceinline__ double c(int r) const { return (FASTANTI && r == 0) ? n0c : bc[r].y; }
 };
 struct DirectCtx {
     const KernelArgs& A;
     const DirectHdr* hdr;      // the stage's headers [nDirect]
-    const double2* rec;        // the stage's records
+    const dpair* rec;          // the stage's records
 };
-template <class DD>
-__device__ __forceinline__ void direct_init(DirectState<DD>& f, bool live, const UttDesc& d, uint32_t rec0, const DirectCtx& X)
+template <class DD, int MODE, bool LEAN>
+__device__ __forceinline__ void direct_init(DirectState<DD, MODE, LEAN>& f, bool live, const UttDesc& d, uint32_t rec0, const DirectCtx& X)
 {
 #pragma unroll
     for (int r = 0; r < DD::NRES; ++r) {
-        f.ra[r] = 0; f.rb[r] = 2; f.rc[r] = -1; f.z1[r] = 0; f.z2[r] = 0;      // the coefficients of f = bw = 0
-        f.p0[r] = 0; f.p1[r] = 0; f.p2[r] = 0; f.p3[r] = 0; f.rad[r] = 1.0;
+        f.ra[r] = 0; f.bc[r] = make_dpair(2.0, -1.0); f.z1[r] = 0; f.z2[r] = 0;      // the coefficients of f = bw = 0
+        f.e0[r] = make_dpair(0.0, 0.0); f.e1[r] = make_dpair(0.0, 0.0); f.rad[r] = 1.0;
     }
+    if (DirectState<DD, MODE, LEAN>::FASTANTI) f.bc[0] = make_dpair(2.0, 1.0);          // (Re P, r^2) of the plain pair
+    f.fn = make_dpair(0.0, 0.0); f.n0b = 2.0; f.n0c = -1.0;
 #pragma unroll
-    for (int k = 0; k < 2 * DD::NGAIN; ++k) { f.cur[k] = 0; f.gf[k] = 0; f.gd[k] = 0; }
-    f.n0r2 = 1.0; f.n0f = 0.0; f.n0fd = 0.0;
+    for (int g = 0; g < DD::NGAIN; ++g) { f.gv[g] = make_dpair(0.0, 0.0); f.gx[g] = make_dpair(0.0, 0.0); f.gy[g] = make_dpair(0.0, 0.0); }
     f.live = live && d.length > 0u;
-    f.nFrames = d.nFrames; f.length = d.length; f.next = 0; f.produced = 0;
-    f.cnt = 1u; f.F = 1u; f.nfD = 1.0; f.invF = 1.0; f.ratio = 1.0; f.inFade = false; f.curBits = 0u; f.rec0 = rec0;
+    f.nFrames = d.nFrames; f.length = d.length; f.next = 0;
+    f.cnt = 1u; f.F = 1u; f.invF = 1.0; f.ratio = 1.0; f.inFade = false; f.curBits = 0u; f.rec0 = rec0;
     const bool any = live && d.nFrames > 0u;
     f.startAt = any ? 1u : 0xFFFFFFFFu;      // frame 0 is dequeued on sample 0, its fade's first values apply to sample 1
     f.nextHdr = DirectHdr{1u, 0u, 0u, 0u};
-    f.touched[0] = f.touched[1] = f.touched[2] = 0u;
     if (any) f.nextHdr = X.hdr[rec0];
 }
 // OR over the wavefront, as a scalar
@@ -307,10 +305,6 @@ __device__ __forceinline__ uint32_t wave_or(uint32_t v)
     return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// Called by a stage's sample BETWEEN its two halves (the flat stages' FlatMid): the first half has read every coefficient and gain
-// of the sample; here every lane advances its fade-sample index and evaluates, for the NEXT sample, the kinds the chunk's mask
-// `wm` names; then the lanes whose next fade's first values apply to the next sample (`sw`) switch: everything of the new fade
-// comes from its record, in one block of loads that have the second half of this sample (and the SIMD's other wave) to land.
 // MODE_FAST, N0: the anti-resonator's coefficients from its plain pole pair (Re P = 2 r cos theta, r^2) and its frequency (reference
 // src/speechWaveGenerator.cpp:119-125: a = 1 - b - c, and for a frequency other than 0 the inversion a' = 1 / a, b' = -b a', c' = -c a').
 // The reciprocal is v_rcp_f64 with one Newton step.  A relative error e of (b, c) arrives in the coefficients as ~e (|b| + |c|) / a:
@@ -327,9 +321,13 @@ __device__ __forceinline__ void fast_anti_finish(double reP, double r2, double f
     rc = nz ? c * -inv : c;
 }
 
-template <class DD, int MODE>
+// Called by a stage's sample BETWEEN its two halves (the flat stages' FlatMid): the first half has read every coefficient and gain
+// of the sample; here every lane advances its fade-sample index and evaluates, for the NEXT sample, the kinds the chunk's mask
+// `wm` names; then the lanes whose next fade's first values apply to the next sample (`sw`) switch: everything of the new fade
+// comes from its record, in one block of loads into the state's own registers.
+template <class DD, int MODE, bool LEAN>
 struct DirectMid {
-    DirectState<DD>& f;
+    DirectState<DD, MODE, LEAN>& f;
     const DirectCtx& X;
     uint32_t wm;       // wave-uniform (SGPR): DirectHdr.bits OR-ed over the lanes that fade or start a fade in this chunk
     bool sw;
@@ -339,6 +337,7 @@ struct DirectMid {
     // then kept a copy of every value for the lanes the block masks off: six to eight v_mov_b64 per stage and sample.
     __device__ __forceinline__ void operator()(double token) const
     {
+        using ST = DirectState<DD, MODE, LEAN>;
         const KernelArgs& A = X.A;
         asm volatile("" : "+v"(f.cnt) : "v"(token));
         // ONE masked block for the lanes inside a fade (a lane that is not keeps what it has: the fade's last values, as the reference
@@ -351,102 +350,100 @@ struct DirectMid {
             // ratio = (double)counter / numFadeSamples, correctly rounded (reference src/frame.cpp:49) -- in MODE_FAST too: the last sample
             // of a fade must land on its target EXACTLY where the reference tests a parameter for a value (`frequency != 0` decides whether
             // N0 is inverted, src/speechWaveGenerator.cpp:122: with counter * (1 / F) = 1 - 1e-16 a target of 0 Hz arrives as 1e-14 Hz)
-            const double ratio = div_by((double)cn, f.nfD, f.invF);
+            double ratio = 0.0;
+            if (ST::RATIO) ratio = div_by((double)cn, (double)f.F, f.invF);
             if (DD::STAGE == 0) f.ratio = ratio;
 #pragma unroll
             for (int r = 0; r < DD::NRES; ++r) {
                 const bool anti = DD::ANTI0 && r == 0;
                 // (MODE_FAST's recurrences are seven instructions: cheaper to run for a kind nobody moves -- its factor is the identity --
                 // than to branch around; the polynomials are worth a scalar branch)
-                constexpr bool kFastAnti = MODE == MODE_FAST && KLATT_DIRECT_FAST_ANTI;
-                if (!(MODE == MODE_FAST && (!anti || kFastAnti) && KLATT_DIRECT_FAST_BRANCHLESS) && !(wm & (1u << r))) continue;
-                const uint32_t cls = (wm >> (kDirectClsShift + 2 * r)) & 3u;
-                if (kFastAnti && anti) {
-                    // the plain pole pair advances like any other (rad: Re P, p0: Im P, (p1, p2) = w, n0r2 = r^2, p3 = q^2); then the inversion
-                    const double re = __builtin_fma(-f.p0[r], f.p2[r], f.rad[r] * f.p1[r]);
-                    const double im = __builtin_fma(f.rad[r], f.p2[r], f.p0[r] * f.p1[r]);
-                    f.rad[r] = re; f.p0[r] = im; f.n0r2 = f.n0r2 * f.p3[r];
-                    fast_anti_finish(re, f.n0r2, __builtin_fma(f.n0fd, ratio, f.n0f), f.ra[r], f.rb[r], f.rc[r]);
-                } else if (MODE == MODE_FAST && !anti) {
-                    // P <- P w, r^2 <- r^2 q^2: rb = Re P, p0 = Im P, (p1, p2) = w, rc = -r^2, p3 = q^2
-                    const double re = __builtin_fma(-f.p0[r], f.p2[r], f.rb[r] * f.p1[r]);
-                    const double im = __builtin_fma(f.rb[r], f.p2[r], f.p0[r] * f.p1[r]);
-                    const double c = f.rc[r] * f.p3[r];
-                    f.rb[r] = re; f.p0[r] = im; f.rc[r] = c;
-                    f.ra[r] = (1.0 - re) - c;
+                if (MODE != MODE_FAST && !(wm & (1u << r))) continue;
+                if (MODE == MODE_FAST) {
+                    // P <- P w, r^2 <- r^2 q^2: bc.x = Re P, e0.x = Im P, (e0.y, e1.x) = w, bc.y = -r^2 (N0: r^2), e1.y = q^2
+                    const double re = __builtin_fma(-f.e0[r].x, f.e1[r].x, f.bc[r].x * f.e0[r].y);
+                    const double im = __builtin_fma(f.bc[r].x, f.e1[r].x, f.e0[r].x * f.e0[r].y);
+                    const double c = f.bc[r].y * f.e1[r].y;
+                    f.bc[r].x = re; f.e0[r].x = im; f.bc[r].y = c;
+                    if (anti) fast_anti_finish(re, c, __builtin_fma(f.fn.y, ratio, f.fn.x), f.ra[r], f.n0b, f.n0c);      // the plain pair advanced like any other; then the inversion
+                    else if (ST::keepsA(r)) f.ra[r] = (1.0 - re) - c;
                 } else {
-                    const double fr = f.p0[r] + (f.p1[r] * ratio);      // reference src/utils.h:22
+                    const uint32_t cls = (wm >> (kDirectClsShift + 2 * r)) & 3u;
+                    const double fr = f.e0[r].x + (f.e0[r].y * ratio);      // reference src/utils.h:22
                     const double th = A.twoPiOverSr * -fr;
                     const double cs = !(cls & 1u) ? cos_unreduced(th) : (!(cls & 2u) ? cos_quadrant_m1(th) : fast_cos(th));      // (constants as scalar operands: klatt_math.h)
                     if (wm & (1u << (kDirectBwShift + r))) {
-                        const double bw = f.p2[r] + (f.p3[r] * ratio);
+                        const double bw = f.e1[r].x + (f.e1[r].y * ratio);
                         const double ex = A.negPiOverSr * bw;
                         f.rad[r] = cls != 3u ? exp_unreduced(ex) : fast_exp(ex);
                     }
                     const Coef k = coefficient_finish(f.rad[r], cs, anti, fr);      // reference src/speechWaveGenerator.cpp:117-126
-                    f.ra[r] = k.a; f.rb[r] = k.b; f.rc[r] = k.c;
+                    f.bc[r].x = k.b; f.bc[r].y = k.c;
+                    if (ST::keepsA(r)) f.ra[r] = k.a;
                 }
             }
 #pragma unroll
             for (int g = 0; g < DD::NGAIN; ++g) {
-                if (!(MODE == MODE_FAST && KLATT_DIRECT_FAST_BRANCHLESS) && !(wm & (1u << (DD::NRES + g)))) continue;
                 if (MODE == MODE_FAST) {
-                    f.cur[2 * g] = __builtin_fma(f.gd[2 * g], ratio, f.gf[2 * g]);
-                    f.cur[2 * g + 1] = __builtin_fma(f.gd[2 * g + 1], ratio, f.gf[2 * g + 1]);
+                    f.gv[g] = f.gv[g] + f.gx[g];
                 } else {
-                    f.cur[2 * g] = f.gf[2 * g] + (f.gd[2 * g] * ratio);
-                    f.cur[2 * g + 1] = f.gf[2 * g + 1] + (f.gd[2 * g + 1] * ratio);
+                    if (!(wm & (1u << (DD::NRES + g)))) continue;
+                    f.gv[g].x = f.gx[g].x + (f.gx[g].y * ratio);
+                    f.gv[g].y = f.gy[g].x + (f.gy[g].y * ratio);
                 }
             }
         }
         if (sw) {
             const DirectHdr h = f.nextHdr;
-            const double2* const rec = X.rec + (size_t)(f.rec0 + f.next) * DD::ENTRIES;
-#if !(KLATT_DIRECT_EXP & 1)
+            const dpair* const rec = X.rec + (size_t)(f.rec0 + f.next) * DD::ENTRIES;
+            const double* const recD = reinterpret_cast<const double*>(rec);
 #pragma unroll
             for (int r = 0; r < DD::NRES; ++r) {
-                const double2 e0 = rec[4 * r], e1 = rec[4 * r + 1], e2 = rec[4 * r + 2], e3 = rec[4 * r + 3];
-                f.p0[r] = e0.x; f.p1[r] = e0.y; f.p2[r] = e1.x; f.p3[r] = e1.y;
-                if (MODE == MODE_FAST && KLATT_DIRECT_FAST_ANTI && DD::ANTI0 && r == 0) {
-                    // (klatt_seeds: Re P_1, r_1^2, and the frequency's end points; the first sample's coefficients as every later one's)
-                    f.rad[r] = e2.x; f.n0r2 = e2.y; f.n0f = e3.x; f.n0fd = e3.y;
-                    const double nf1 = (double)h.fadeSamples;
-                    fast_anti_finish(e2.x, e2.y, __builtin_fma(e3.y, div_by(1.0, nf1, 1.0 / nf1), e3.x), f.ra[r], f.rb[r], f.rc[r]);
-                } else {
-                f.rb[r] = e2.x; f.rc[r] = e2.y; f.ra[r] = e3.x;
-                if (MODE != MODE_FAST || (DD::ANTI0 && r == 0)) f.rad[r] = e3.y;
+                f.e0[r] = rec[4 * r]; f.e1[r] = rec[4 * r + 1]; f.bc[r] = rec[4 * r + 2];
+                if (ST::FASTANTI && r == 0) f.fn = rec[4 * r + 3];
+                else {
+                    if (ST::keepsA(r)) f.ra[r] = recD[2 * (4 * r + 3)];
+                    if (MODE != MODE_FAST) f.rad[r] = recD[2 * (4 * r + 3) + 1];
                 }
             }
 #pragma unroll
             for (int g = 0; g < DD::NGAIN; ++g) {
-                const double2 e0 = rec[4 * DD::NRES + 3 * g], e1 = rec[4 * DD::NRES + 3 * g + 1], e2 = rec[4 * DD::NRES + 3 * g + 2];
-                f.gf[2 * g] = e0.x; f.gd[2 * g] = e0.y; f.gf[2 * g + 1] = e1.x; f.gd[2 * g + 1] = e1.y;
-                f.cur[2 * g] = e2.x; f.cur[2 * g + 1] = e2.y;
+                const int at = 4 * DD::NRES + 3 * g;
+                if (MODE == MODE_FAST) { f.gv[g] = rec[at]; f.gx[g] = rec[at + 1]; }
+                else { f.gx[g] = rec[at]; f.gy[g] = rec[at + 1]; f.gv[g] = rec[at + 2]; }
             }
-#endif
             f.cnt = 1u; f.F = h.fadeSamples; f.curBits = h.bits;
-            f.nfD = (double)h.fadeSamples; f.invF = 1.0 / f.nfD;
-            if (DD::STAGE == 0) f.ratio = div_by(1.0, f.nfD, f.invF);
+            const double nfD = (double)h.fadeSamples;
+            if (ST::RATIO) f.invF = 1.0 / nfD;
+            if (DD::STAGE == 0) f.ratio = div_by(1.0, nfD, f.invF);
             f.next++;
             const bool more = f.next < f.nFrames;
             f.startAt = more ? f.startAt + h.span : 0xFFFFFFFFu;
             f.nextHdr = X.hdr[f.rec0 + (more ? f.next : f.nFrames - 1u)];      // (past the last frame: any valid header; never used)
-            // Everything loaded is waited for HERE, inside the block that only switching lanes enter (its record's lines were touched a
-            // chunk or more ago: they come from the L2): left to the compiler, the waits sit at the first uses -- on every sample of the
-            // loop, where they also wait for the touches of the NEXT records, at the full latency of HBM.
+            // Everything loaded is waited for HERE, inside the block that only switching lanes enter: left to the compiler, the waits
+            // sit at the first uses -- on every sample of the loop.
 #pragma unroll
-            for (int r = 0; r < DD::NRES; ++r) { flat_pin(f.p0[r]); flat_pin(f.p1[r]); flat_pin(f.p2[r]); flat_pin(f.p3[r]); flat_pin(f.rb[r]); flat_pin(f.rc[r]); flat_pin(f.ra[r]); flat_pin(f.rad[r]); }
+            for (int r = 0; r < DD::NRES; ++r) {
+                flat_pin(f.e0[r]); flat_pin(f.e1[r]); flat_pin(f.bc[r]);
+                if (ST::keepsA(r) && !(ST::FASTANTI && r == 0)) flat_pin(f.ra[r]);
+                if (MODE != MODE_FAST) flat_pin(f.rad[r]);
+            }
+            if (ST::FASTANTI) {
+                // (klatt_seeds: Re P_1, r_1^2, and the frequency's end points; the first sample's coefficients as every later one's)
+                flat_pin(f.fn);
+                fast_anti_finish(f.bc[0].x, f.bc[0].y, __builtin_fma(f.fn.y, div_by(1.0, nfD, f.invF), f.fn.x), f.ra[0], f.n0b, f.n0c);
+            }
 #pragma unroll
-            for (int k = 0; k < 2 * DD::NGAIN; ++k) { flat_pin(f.gf[k]); flat_pin(f.gd[k]); flat_pin(f.cur[k]); }
-            flat_pin(f.touched[0]); flat_pin(f.touched[1]); flat_pin(f.touched[2]);
+            for (int g = 0; g < DD::NGAIN; ++g) { flat_pin(f.gv[g]); flat_pin(f.gx[g]); if (MODE != MODE_FAST) flat_pin(f.gy[g]); }
+            flat_pin(f.nextHdr.fadeSamples); flat_pin(f.nextHdr.span); flat_pin(f.nextHdr.bits);
         }
     }
 };
 
 // The chunk's mask: what the lanes that fade, or start a fade, in samples t0 + 1 .. t1 + 1 move, and the classes of their arguments.
 // A lane whose next TWO fades start inside the chunk (frames of a few samples) asks for everything.
-template <class DD>
-__device__ __forceinline__ uint32_t direct_chunk_mask(const DirectState<DD>& f, uint32_t t1)
+template <class ST>
+__device__ __forceinline__ uint32_t direct_chunk_mask(const ST& f, uint32_t t1)
 {
     uint32_t lb = 0;
     if (f.cnt < f.F) lb |= f.curBits;
@@ -454,27 +451,7 @@ __device__ __forceinline__ uint32_t direct_chunk_mask(const DirectState<DD>& f, 
         lb |= f.nextHdr.bits;
         if (f.nextHdr.span <= t1 - f.startAt) lb |= kDirectAllBits;
     }
-    return (KLATT_DIRECT_EXP & 2) ? 0u : wave_or(lb);
-}
-// Lanes whose next fade starts 9 .. 8 + CH samples after the end of this chunk touch its record's lines now (one dword per 128-byte
-// line), so that the switch finds them in the L2 instead of waiting for HBM inside its block.  The dwords land in registers that
-// stay theirs until that switch names them (flat_pin above): a load whose result nobody owns may arrive in a register that has
-// been given to something else by then (a first version loaded into a scratch register from inline assembly: right PCM in small
-// batches, a different digest from run to run at 65 536 utterances).  Plain loads: a `volatile` one compiles to a system-scope
-// flat load with a wait right behind it.
-template <class DD, int CH>
-__device__ __forceinline__ void direct_touch(DirectState<DD>& f, const DirectCtx& X, uint32_t t1)
-{
-#if KLATT_DIRECT_TOUCH
-    const bool soon = f.startAt - t1 - 9u < (uint32_t)CH;      // (0xFFFFFFFF: no further fade)
-    if (soon) {
-        const uint32_t* p = reinterpret_cast<const uint32_t*>(X.rec + (size_t)(f.rec0 + f.next) * DD::ENTRIES);
-        constexpr int kDwords = DD::ENTRIES * 4;
-        f.touched[0] = p[0];
-        if (kDwords > 32) f.touched[1] = p[32];
-        f.touched[2] = p[kDwords - 1];
-    }
-#endif
+    return wave_or(lb);
 }
 
 // load(c, i): the stage's pipe inputs of sample i (a struct of doubles); body(c, i, in, mid): one sample of the stage.  In a mixed chunk
@@ -485,10 +462,14 @@ struct In0 {};
 struct In1 { double a; };
 struct In2 { double a, b; };
 struct In3 { double a, b, c; };
-template <class DD, int MODE, int CH, class FLoad, class FBody, class FChunk>
-__device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, int stampSlot, DirectState<DD>& f, const DirectCtx& X, FLoad load, FBody body, FChunk perChunk)
+template <int MODE, bool LEAN> struct DirectUnroll {
+    static constexpr int kMixed = LEAN ? (MODE == MODE_FAST ? KLATT_DIRECT_LEAN_UNROLL_FAST : KLATT_DIRECT_LEAN_UNROLL) : (MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL);
+    static constexpr int kSteady = LEAN ? KLATT_DIRECT_LEAN_STEADY_UNROLL : KLATT_DIRECT_STEADY_UNROLL;
+};
+template <class DD, int MODE, int CH, bool LEAN, class FLoad, class FBody, class FChunk>
+__device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, int stampSlot, DirectState<DD, MODE, LEAN>& f, const DirectCtx& X, FLoad load, FBody body, FChunk perChunk)
 {
-    constexpr int kMixedUnroll = MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL;
+    constexpr int kMixedUnroll = DirectUnroll<MODE, LEAN>::kMixed, kSteadyUnroll = DirectUnroll<MODE, LEAN>::kSteady;
 #ifdef KLATT_STAMPS
     Stamps st;
 #endif
@@ -501,7 +482,7 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
             if (f.length <= t0) f.live = false;                               // this lane has emitted its last sample
             // a chunk is steady when no lane evaluates anything in it: none fading, no fade whose first values apply to t0 + 1 .. t1
             const bool busy = f.cnt < f.F || f.startAt <= t1;
-            if (!__any(busy)) {
+            if (!LEAN && !__any(busy)) {
                 // decided once: the chunks until some live lane's next fade comes into reach run in a tight loop
                 uint32_t run = f.live ? (f.startAt - t0 - 1u) / (uint32_t)CH : 0xFFFFFFFFu;
 #pragma unroll
@@ -514,12 +495,10 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
                 STAMP_KIND(0);
                 for (uint32_t q = 0; q < run; ++q) {
                     if (f.live) {
-#pragma unroll KLATT_DIRECT_STEADY_UNROLL
+#pragma unroll kSteadyUnroll
                         for (int i = 0; i < CH; ++i) body(cc, i, load(cc, i), NoMid{});
                     }
-                    { const uint32_t e1 = (uint32_t)(cc + 1) * (uint32_t)CH; f.produced = f.length < e1 ? f.length : e1; }
-                    perChunk();
-                    direct_touch<DD, CH>(f, X, (uint32_t)(cc + 1) * (uint32_t)CH);
+                    perChunk((uint32_t)(cc + 1) * (uint32_t)CH);
                     if (q + 1 < run) {
                         STAMP_WORKED();
                         __syncthreads();
@@ -530,18 +509,16 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
                 }
             } else {
                 STAMP_KIND(-1);
-                const uint32_t wm = direct_chunk_mask<DD>(f, t1);
+                const uint32_t wm = direct_chunk_mask(f, t1);
                 auto ahead = load(c, 0);
 #pragma unroll kMixedUnroll
                 for (int i = 0; i < CH; ++i) {
                     const bool sw = t0 + (uint32_t)i + 1u == f.startAt;
                     const auto in = ahead;
                     ahead = load(c, i + 1);
-                    body(c, i, in, DirectMid<DD, MODE>{f, X, wm, sw});
+                    body(c, i, in, DirectMid<DD, MODE, LEAN>{f, X, wm, sw});
                 }
-                f.produced = f.length < t1 ? f.length : t1;
-                perChunk();
-                direct_touch<DD, CH>(f, X, t1);
+                perChunk(t1);
             }
         }
         STAMP_WORKED();
@@ -560,31 +537,24 @@ __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, i
 
 // sin() of the vibrato (reference src/speechWaveGenerator.cpp:77), out of line: inlined, the device library's sine brings its two dozen
 // constants and its temporaries into the source stage's sample loop, which runs it for the rare utterance with vibrato only
-#ifndef KLATT_DIRECT_VIB_CALL
-#define KLATT_DIRECT_VIB_CALL 1
-#endif
-#if KLATT_DIRECT_VIB_CALL
 __device__ __attribute__((noinline)) double direct_vib_sin(double x) { return sin(x); }
-#else
-__device__ __forceinline__ double direct_vib_sin(double x) { return sin(x); }
-#endif
 
-// ---- the source stage (T0; with HEAD it would run N0 and NP as well: the 4-stage census of DESIGN.md) ------------------------------
+// ---- the source stage (T0) -------------------------------------------------------------------------------------------------------
 // The pitch glides with the sample count of THIS utterance (reference src/frame.cpp:76-79, :98, :71): per sample a lane is
 // dequeuing (sets up the pitch fade; the sample itself is emitted unchanged), fading (pitch interpolated), ending its fade
 // or steady (glide) -- the flat source stage's selects (klatt_systolic.h).  What a dequeue reads (the frame's two pitch values,
-// index mark) is a SourceRef loaded when the previous frame was dequeued.  CB: f.cur[CB + k] = vibratoPitchOffset, vibratoSpeed,
-// turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain.
+// index mark) is a SourceRef loaded when the previous frame was dequeued.  Gains: gv[0] = (vibratoPitchOffset, vibratoSpeed),
+// and in layout 0 gv[1] = (turbulence, openQuotient), gv[2] = (voiceAmplitude, aspirationAmplitude), gv[3] = (preFormantGain, -).
 // PHASE (layout 1, MODE_FAST): the stage ends with the pitch phase, which it hands to the glottal stage -- its only parameters are the
-// vibrato's (f.cur[CB], f.cur[CB + 1]).
-template <class DD, int MODE, int CH, int CB, bool HEAD, bool PHASE = false>
+// vibrato's.
+template <class DD, int MODE, int CH, bool LEAN, bool PHASE>
 __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const UttDesc& d, bool live, uint32_t u, uint32_t rec0, const DirectCtx& X, int lane,
                                                     int nIter, int nChunks, double* pipeOut, uint32_t nkey, uint32_t ninc, uint32_t ninc2)
 {
 #define SRC_PIPE(c, i) pipeOut[(((c) & 1) * CH + (i)) * kLanes + lane]
-    constexpr int kMixedUnroll = MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL;
-    DirectState<DD> f;
-    direct_init<DD>(f, live, d, rec0, X);
+    constexpr int kMixedUnroll = DirectUnroll<MODE, LEAN>::kMixed, kSteadyUnroll = DirectUnroll<MODE, LEAN>::kSteady;
+    DirectState<DD, MODE, LEAN> f;
+    direct_init(f, live, d, rec0, X);
     const SourceRef* const mySrc = A.sourceRef + d.frameStart;
     PitchState ps;
     ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
@@ -598,40 +568,33 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
     auto source = [&](bool waveVib, const auto& mid) __attribute__((always_inline)) -> double {
         double vib = 1.0;
         if (waveVib) {
-            const double vs = f.cur[CB + 1];
+            const double vs = f.gv[0].y;
             const double adv = frac_toward_zero(div_by(vs, A.sampleRateF, A.invSampleRate) + vibPhase);
             vibPhase = (vs != 0.0) ? adv : vibPhase;
-            vib = (direct_vib_sin(vibPhase * 6.283185307179586) * 0.06 * f.cur[CB + 0]) + 1.0;
+            vib = (direct_vib_sin(vibPhase * 6.283185307179586) * 0.06 * f.gv[0].x) + 1.0;
         }
         pitchPhase = frac_toward_zero(div_by(ps.cur0 * vib, A.sampleRateF, A.invSampleRate) + pitchPhase);
         if constexpr (PHASE) {
             mid(pitchPhase);
             return pitchPhase;
         } else {
-        const double turbGain = f.cur[CB + 2], openQ = f.cur[CB + 3], voiceAmp = f.cur[CB + 4], aspAmp = f.cur[CB + 5], preGain = f.cur[CB + 6];
-        double voice = (pitchPhase * 2.0) - 1.0;
-        aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
-        noiseSt = noise_step2(noiseSt, ninc2);
-        double asp = aspNoise * 0.2;
-        double turb = asp * turbGain;
-        turb = (pitchPhase >= openQ) ? turb : turb * 0.01;
-        voice += turb;
-        voice *= voiceAmp;
-        asp *= aspAmp;
-        const double src = asp + voice;
-        double out = (src * preGain) * 0.5;
-        if constexpr (HEAD) {
-            // N0 (anti), NP mixed in by caNP (reference src/speechWaveGenerator.cpp:149-152)
-            const double n0 = dot3<MODE>(f.ra[0], out, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
-            f.z2[0] = f.z1[0]; f.z1[0] = out;                              // the anti-resonator remembers its INPUT (reference :133)
-            const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
-            out = fade_value(out, np, f.cur[0]);
-        }
-        mid(out);      // the next sample's values: every parameter of this one has been used
-        return out;
+            const double turbGain = f.gv[1].x, openQ = f.gv[1].y, voiceAmp = f.gv[2].x, aspAmp = f.gv[2].y, preGain = f.gv[3].x;
+            double voice = (pitchPhase * 2.0) - 1.0;
+            aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
+            noiseSt = noise_step2(noiseSt, ninc2);
+            double asp = aspNoise * 0.2;
+            double turb = asp * turbGain;
+            turb = (pitchPhase >= openQ) ? turb : turb * 0.01;
+            voice += turb;
+            voice *= voiceAmp;
+            asp *= aspAmp;
+            const double src = asp + voice;
+            const double out = (src * preGain) * 0.5;
+            mid(out);      // the next sample's values: every parameter of this one has been used
+            return out;
         }
     };
-    auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.cur[CB + 0] != 0.0 || f.cur[CB + 1] != 0.0 || vibPhase != vibPhase; };
+    auto vib_live = [&]() __attribute__((always_inline)) -> bool { return f.gv[0].x != 0.0 || f.gv[0].y != 0.0 || vibPhase != vibPhase; };
 #ifdef KLATT_STAMPS
     Stamps st;
 #endif
@@ -644,7 +607,7 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
             if (f.length <= t0) f.live = false;
             const bool busy = f.cnt < f.F || f.startAt <= t1 || f.inFade || wasFade || vib_live();
             STAMP_KIND(__any(busy) ? -1 : 0);
-            if (!__any(busy)) {
+            if (!LEAN && !__any(busy)) {
                 // steady stretch, decided once: the pitch glides, nothing else changes
                 uint32_t run = f.live ? (f.startAt - t0 - 1u) / (uint32_t)CH : 0xFFFFFFFFu;
 #pragma unroll
@@ -656,17 +619,16 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
                 int cc = c;
                 for (uint32_t q = 0; q < run; ++q) {
                     if (f.live) {
-#pragma unroll KLATT_DIRECT_STEADY_UNROLL
+#pragma unroll kSteadyUnroll
                         for (int i = 0; i < CH; ++i) { ps.cur0 += ps.oldInc; SRC_PIPE(cc, i) = source(false, NoMid{}); }
                         ps.old0 = ps.cur0;
                     }
-                    direct_touch<DD, CH>(f, X, (uint32_t)(cc + 1) * (uint32_t)CH);
                     if (q + 1 < run) { STAMP_WORKED(); __syncthreads(); STAMP_SYNCED(); STAMP_BEGIN(); ++iter; ++cc; }
                 }
             } else {
-                const uint32_t wm = direct_chunk_mask<DD>(f, t1);
+                const uint32_t wm = direct_chunk_mask(f, t1);
                 // vibrato can only come alive in this chunk through its kind (the phase only turns NaN while it advances)
-                const bool vibChunk = (wm & (1u << (DD::NRES + CB / 2))) != 0u || __any(vib_live());
+                const bool vibChunk = (wm & (1u << DD::NRES)) != 0u || __any(vib_live());
 #pragma unroll kMixedUnroll
                 for (int i = 0; i < CH; ++i) {
                     const uint32_t t = t0 + (uint32_t)i;
@@ -697,9 +659,8 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
                     ps.oldInc = ending ? ps.newInc : ps.oldInc;
                     wasFade = fad;
                     const bool waveVib = vibChunk && __any(vib_live());
-                    SRC_PIPE(c, i) = source(waveVib, DirectMid<DD, MODE>{f, X, wm, deq});
+                    SRC_PIPE(c, i) = source(waveVib, DirectMid<DD, MODE, LEAN>{f, X, wm, deq});
                 }
-                direct_touch<DD, CH>(f, X, t1);
             }
         }
         STAMP_WORKED();
@@ -732,14 +693,18 @@ struct DirectLds {
     static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
-    static constexpr int kBytes = kMaxLen + 32;      // (longest utterance; waves per SIMD) CH = 16: 152 864 B: one workgroup per CU
+    static constexpr int kBytes = kMaxLen + 32;      // (longest utterance; waves per SIMD) CH = 16: 152 864 B, one workgroup per CU; CH = 8: 79 136 B, two
 };
-// WPE: wavefronts per SIMD the register budget is set for (2: one workgroup per CU, 256 VGPRs; 4: two, 128)
-template <int MODE, int CH, int WPE>
+// WPE: wavefronts per SIMD the register budget is set for (2: one workgroup per CU, 256 VGPRs; 4: two, 128: the lean stages).
+// ONLY: the stages whose bodies are compiled in (register census, tools/direct_census.sh; bit 0 T0, 1 the nasal pair, 2 the cascade,
+// 3 T5, 4 T6, 5 T7, 6 layout 1's glottal stage); the library instantiates all of them.
+constexpr int kDirectAllStages = 0x7F;
+template <int MODE, int CH, int WPE, int ONLY = kDirectAllStages>
 __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs A)
 {
     using L = DirectLds<CH>;
     constexpr int kChunk = CH;
+    constexpr bool LEAN = WPE >= 4;
     constexpr int LAY = direct_layout(MODE);      // which stage runs what (klatt_device.h)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     auto pipe = [&](int k) __attribute__((always_inline)) { return reinterpret_cast<double*>(lds + k * L::kPipeBytes); };
@@ -765,14 +730,13 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
     // Which wave runs which stage.  The eight waves of the workgroup sit two to a SIMD, and a SIMD issues for one of them at a time:
     // what bounds a sample-step is the pair of stages with the most instructions between them.  So a wave takes its stage from the
     // SIMD it finds itself on (HW_REG_HW_ID) and its rank among the workgroup's waves there, pairing a heavy stage with a light one
-    // (kPairs, by arithmetic mode: the stamps of tools/direct_stamps.py); if the hardware placed the waves otherwise than two per SIMD,
+    // (same-run A/B of the candidates: profiles/r4_direct_ab.txt); if the hardware placed the waves otherwise than two per SIMD,
     // stage = wave index (any bijection is correct -- the waves are interchangeable until they pick a stage).
     uint32_t* const simdCount = maxLenP + 4;
     if (threadIdx.x < 5) maxLenP[threadIdx.x < 1 ? 0 : threadIdx.x + 3] = 0;
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int stage = wave;
-#if KLATT_DIRECT_PAIRING
     {
         const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
         const uint32_t simd = (hw >> 4) & 3u;
@@ -781,16 +745,15 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
         __syncthreads();
         const bool two = simdCount[0] == 2u && simdCount[1] == 2u && simdCount[2] == 2u && simdCount[3] == 2u;
-        // heavy with light (same-run A/B of the candidates: profiles/r4_direct_ab.txt): MODE_EXACT T5 + T3 | T7 + T4 | T0 + T2 | T6 + T1;
-        // MODE_FAST, layout 1: final + glottal | parallel 1, 2 + nasal pair | parallel 3, 4 + phase | the two cascade stages
-        constexpr int kPairsFast[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsExact[8] = KLATT_DIRECT_PAIRS_EXACT, kPairsFast1[8] = KLATT_DIRECT_PAIRS_FAST1;
+        // heavy with light: MODE_EXACT T5 + T3 | T7 + T4 | T0 + T2 | T6 + T1;
+        // MODE_FAST (layout 1): final + glottal | parallel 1, 2 + nasal pair | parallel 3, 4 + phase | the two cascade stages
+        constexpr int kPairsExact[8] = {5, 3, 7, 4, 0, 2, 6, 1}, kPairsFast0[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsFast1[8] = {7, 1, 5, 2, 6, 0, 3, 4};
         const int key = (int)(simd * 2u + (rank & 1u));
         int pick = wave;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) if (key == k) pick = LAY == 1 ? kPairsFast1[k] : (MODE == MODE_FAST ? kPairsFast[k] : kPairsExact[k]);
+        for (int k = 0; k < 8; ++k) if (key == k) pick = MODE != MODE_FAST ? kPairsExact[k] : (LAY == 1 ? kPairsFast1[k] : kPairsFast0[k]);
         stage = __builtin_amdgcn_readfirstlane(two ? pick : wave);
     }
-#endif
     if (wave == 0) atomicMax(maxLenP, d.length);
     __syncthreads();
     if (stage == FINAL) { rowBase[lane] = d.outStart; rowCount[lane] = 0; }   // read by this wave only
@@ -798,31 +761,31 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
     const int nChunks = (int)((maxLen + kChunk - 1) / kChunk);
     const int nIter = nChunks + 5;   // the final stage lags 5 chunks; same trip count in every wave
 #define PIPE(p, c, i) (p)[(((c) & 1) * kChunk + (i)) * kLanes + lane]
-    auto noChunk = [&]() __attribute__((always_inline)) {};
+    auto noChunk = [&](uint32_t) __attribute__((always_inline)) {};
     auto ctx = [&](auto stageTag) __attribute__((always_inline)) {
         constexpr int S = decltype(stageTag)::value, kFirst = direct_stage_first(S, LAY);
-        return DirectCtx{A, A.directHdr + (size_t)S * A.nDirect, A.directRec + (size_t)kFirst * A.nDirect};
+        return DirectCtx{A, A.directHdr + (size_t)S * A.nDirect, reinterpret_cast<const dpair*>(A.directRec) + (size_t)kFirst * A.nDirect};
     };
 
-    if (stage == 0 && (KLATT_DIRECT_STAGES & 1)) {
-        // ================= T0: glottal source + aspiration noise =================
-        using DD = DirectDesc<0, LAY>; // cur: vibratoPitchOffset, vibratoSpeed[, turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain, -]
+    if (stage == 0 && (ONLY & 1)) {
+        // ================= T0: glottal source + aspiration noise (layout 1: pitch, vibrato, phase) =================
+        using DD = DirectDesc<0, LAY>;
         const DirectCtx X = ctx(std::integral_constant<int, 0>{});
-        direct_source_stage<DD, MODE, CH, 0, false, LAY == 1>(A, d, live, u, rec0, X, lane, nIter, nChunks, pipeX0, nkey, ninc, ninc2);
-    } else if (LAY == 1 && stage == 1 && (KLATT_DIRECT_STAGES & 64)) {
+        direct_source_stage<DD, MODE, CH, LEAN, LAY == 1>(A, d, live, u, rec0, X, lane, nIter, nChunks, pipeX0, nkey, ninc, ninc2);
+    } else if (LAY == 1 && stage == 1 && (ONLY & 64)) {
         // ================= layout 1, T1: glottal wave + aspiration noise from the phase (reference src/speechWaveGenerator.cpp:63-86) =================
         if constexpr (LAY == 1) {
-        using DD = DirectDesc<1, LAY>; // cur: turbulence, openQuotient, voiceAmplitude, aspirationAmplitude, preFormantGain, -
+        using DD = DirectDesc<1, LAY>; // gains: (turbulence, openQuotient) (voiceAmplitude, aspirationAmplitude) (preFormantGain, -)
         const DirectCtx X = ctx(std::integral_constant<int, 1>{});
-        DirectState<DD> f;
-        direct_init<DD>(f, live, d, rec0, X);
+        DirectState<DD, MODE, LEAN> f;
+        direct_init(f, live, d, rec0, X);
         double aspNoise = 0.0;
         uint32_t noiseSt = noise_first(nkey, ninc);    // aspiration: noise values 0, 2, 4, ...
-        direct_loop<DD, MODE, CH>(1, nIter, nChunks, stage, f, X,
+        direct_loop<DD, MODE, CH, LEAN>(1, nIter, nChunks, stage, f, X,
             [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pipeX0, c, i)}; },
             [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
                 const double pitchPhase = in.a;
-                const double turbGain = f.cur[0], openQ = f.cur[1], voiceAmp = f.cur[2], aspAmp = f.cur[3], preGain = f.cur[4];
+                const double turbGain = f.gv[0].x, openQ = f.gv[0].y, voiceAmp = f.gv[1].x, aspAmp = f.gv[1].y, preGain = f.gv[2].x;
                 double voice = (pitchPhase * 2.0) - 1.0;
                 aspNoise = noise_uniform(noiseSt) + 0.75 * aspNoise;
                 noiseSt = noise_step2(noiseSt, ninc2);
@@ -839,150 +802,157 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             },
             noChunk);
         }
-    } else if (stage == (LAY == 1 ? 2 : 1) && (KLATT_DIRECT_STAGES & 2)) {
+    } else if (stage == (LAY == 1 ? 2 : 1) && (ONLY & 2)) {
         // ================= N0 (anti), NP mixed in by caNP (reference src/speechWaveGenerator.cpp:149-152) =================
         constexpr int ST = LAY == 1 ? 2 : 1;
-        using DD = DirectDesc<ST, LAY>;      // cur: caNP, -
+        using DD = DirectDesc<ST, LAY>;      // gains: (caNP, -)
         const DirectCtx X = ctx(std::integral_constant<int, ST>{});
         double* const pin = LAY == 1 ? pipeX1 : pipeX0;
         double* const pout = LAY == 1 ? pipeX2 : pipeX1;
-        DirectState<DD> f;
-        direct_init<DD>(f, live, d, rec0, X);
-        direct_loop<DD, MODE, CH>(ST, nIter, nChunks, stage, f, X,
+        DirectState<DD, MODE, LEAN> f;
+        direct_init(f, live, d, rec0, X);
+        direct_loop<DD, MODE, CH, LEAN>(ST, nIter, nChunks, stage, f, X,
             [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pin, c, i)}; },
             [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
                 const double x = in.a;
-                const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
+                const double n0 = dot3<MODE>(f.a(0), x, f.b(0), f.z1[0], f.c(0), f.z2[0]);
                 f.z2[0] = f.z1[0]; f.z1[0] = x;                              // the anti-resonator remembers its INPUT (reference :133)
-                const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
-                const double o = fade_value(x, np, f.cur[0]);
+                const double np = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), n0);
+                const double o = fade_value(x, np, f.gv[0].x);
                 PIPE(pout, c, i) = o;
                 mid(o);      // the next sample's values: every coefficient and gain of this one has been used
             },
             noChunk);
-    } else if (stage >= (LAY == 1 ? 3 : 2) && stage <= 4 && (KLATT_DIRECT_STAGES & 4)) {
+    } else if (stage >= (LAY == 1 ? 3 : 2) && stage <= 4 && (ONLY & 4)) {
         // ================= the cascade: layout 0 T2, T3, T4 two resonators each (r6 r5 | r4 r3 | r2 r1); layout 1 T3, T4 three each =================
-        auto pair = [&](auto stageTag, double* pin, double* pout) __attribute__((always_inline)) {
+        auto part = [&](auto stageTag, double* pin, double* pout) __attribute__((always_inline)) {
             constexpr int ST = decltype(stageTag)::value;
             using DD = DirectDesc<ST, LAY>;
             const DirectCtx X = ctx(stageTag);
-            DirectState<DD> f;
-            direct_init<DD>(f, live, d, rec0, X);
-                direct_loop<DD, MODE, CH>(ST, nIter, nChunks, stage, f, X,
+            DirectState<DD, MODE, LEAN> f;
+            direct_init(f, live, d, rec0, X);
+            direct_loop<DD, MODE, CH, LEAN>(ST, nIter, nChunks, stage, f, X,
                 [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pin, c, i)}; },
                 [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
                     double o = in.a;
 #pragma unroll
-                    for (int r = 0; r < DD::NRES; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
+                    for (int r = 0; r < DD::NRES; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.a(r), f.b(r), f.c(r), o);
                     PIPE(pout, c, i) = o;
                     mid(o);
                 },
                 noChunk);
         };
-        if constexpr (LAY == 0) { if (stage == 2) pair(std::integral_constant<int, 2>{}, pipeX1, pipeX2); }
-        if (stage == 3) pair(std::integral_constant<int, 3>{}, pipeX2, pipeX3);
-        else if (stage == 4) pair(std::integral_constant<int, 4>{}, pipeX3, pipeO);
-    } else if (stage == 5 && (KLATT_DIRECT_STAGES & 8)) {
+        if constexpr (LAY == 0) { if (stage == 2) part(std::integral_constant<int, 2>{}, pipeX1, pipeX2); }
+        if (stage == 3) part(std::integral_constant<int, 3>{}, pipeX2, pipeX3);
+        else if (stage == 4) part(std::integral_constant<int, 4>{}, pipeX3, pipeO);
+    } else if (stage == 5 && (ONLY & 8)) {
         // ================= T5: frication noise, parallel 1, 2 =================
-        using DD = DirectDesc<5, LAY>; // cur: fricationAmplitude, preFormantGain, pa1, pa2
+        using DD = DirectDesc<5, LAY>; // gains: (fricationAmplitude, preFormantGain) (pa1, pa2)
         const DirectCtx X = ctx(std::integral_constant<int, 5>{});
-        DirectState<DD> f;
-        direct_init<DD>(f, live, d, rec0, X);
+        DirectState<DD, MODE, LEAN> f;
+        direct_init(f, live, d, rec0, X);
         double fricNoise = 0;
         uint32_t noiseSt = noise_step(noise_first(nkey, ninc), ninc);     // frication: noise values 1, 3, 5, ...
-        direct_loop<DD, MODE, CH>(3, nIter, nChunks, stage, f, X,
+        direct_loop<DD, MODE, CH, LEAN>(3, nIter, nChunks, stage, f, X,
             [&](int, int) __attribute__((always_inline)) { return In0{}; },
             [&](int c, int i, const In0&, const auto& mid) __attribute__((always_inline)) {
                 fricNoise = noise_uniform(noiseSt) + 0.75 * fricNoise;
                 noiseSt = noise_step2(noiseSt, ninc2);
-                const double fric = fricNoise * 0.3 * f.cur[0];
-                const double y = (fric * f.cur[1]) * 0.5;
+                const double fric = fricNoise * 0.3 * f.gv[0].x;
+                const double y = (fric * f.gv[0].y) * 0.5;
                 double par = 0;
-                double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
-                par += (w - y) * f.cur[2];
-                w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
-                par += (w - y) * f.cur[3];
+                double w = resonate<MODE>(f.z1[0], f.z2[0], f.a(0), f.b(0), f.c(0), y);
+                par += (w - y) * f.gv[1].x;
+                w = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), y);
+                par += (w - y) * f.gv[1].y;
                 PIPE(pipeY, c, i) = y; PIPE(pipeP, c, i) = par;
                 mid(par);
             },
             noChunk);
-    } else if (stage == 6 && (KLATT_DIRECT_STAGES & 16)) {
+    } else if (stage == 6 && (ONLY & 16)) {
         // ================= T6: parallel 3, 4 (the sum continues in the reference's order; y travels on) =================
-        using DD = DirectDesc<6, LAY>; // cur: pa3, pa4
+        using DD = DirectDesc<6, LAY>; // gains: (pa3, pa4)
         const DirectCtx X = ctx(std::integral_constant<int, 6>{});
-        DirectState<DD> f;
-        direct_init<DD>(f, live, d, rec0, X);
-        direct_loop<DD, MODE, CH>(4, nIter, nChunks, stage, f, X,
+        DirectState<DD, MODE, LEAN> f;
+        direct_init(f, live, d, rec0, X);
+        direct_loop<DD, MODE, CH, LEAN>(4, nIter, nChunks, stage, f, X,
             [&](int c, int i) __attribute__((always_inline)) { return In2{PIPE(pipeY, c, i), PIPE(pipeP, c, i)}; },
             [&](int c, int i, const In2& in, const auto& mid) __attribute__((always_inline)) {
                 const double y = in.a;
                 double par = in.b;
-                double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
-                par += (w - y) * f.cur[0];
-                w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
-                par += (w - y) * f.cur[1];
+                double w = resonate<MODE>(f.z1[0], f.z2[0], f.a(0), f.b(0), f.c(0), y);
+                par += (w - y) * f.gv[0].x;
+                w = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), y);
+                par += (w - y) * f.gv[0].y;
                 PIPE(pipeY2, c, i) = y; PIPE(pipeP2, c, i) = par;
                 mid(par);
             },
             noChunk);
-    } else if (stage == FINAL && (KLATT_DIRECT_STAGES & 32)) {
+    } else if (stage == FINAL && (ONLY & 32)) {
         // ================= T7: parallel 5, 6, bypass | cascade + parallel, gain, clip, int16 -> PCM =================
-        using DD = DirectDesc<7, LAY>; // cur: pa5, pa6, parallelBypass, outputGain
+        using DD = DirectDesc<7, LAY>; // gains: (pa5, pa6) (parallelBypass, outputGain)
         const DirectCtx X = ctx(std::integral_constant<int, 7>{});
-        DirectState<DD> f;
-        direct_init<DD>(f, live, d, rec0, X);
+        DirectState<DD, MODE, LEAN> f;
+        direct_init(f, live, d, rec0, X);
         int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
         uint32_t it = 0;
-        auto flush_tile = [&](uint32_t tileStart, uint32_t validTo) __attribute__((always_inline)) {
-            rowCount[lane] = f.produced;
+        // the tile leaves as 16 bytes per lane: lane -> (row, 8-sample piece), four pieces per 32-sample row, sixteen rows per pass.
+        // PASSES rows' worth of LDS reads in flight at a time: all eight with 256 registers, two with the lean stages' 128.
+        auto flush_tile = [&](uint32_t tileStart, uint32_t validTo, uint32_t produced) __attribute__((always_inline)) {
+            rowCount[lane] = produced;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // this wave alone owns the tile: wave-level ordering is enough
             constexpr int kChunksPerRow = kTile / 8;
             constexpr int kRowsPerPass = kLanes / kChunksPerRow;
             constexpr int kPasses = kLanes / kRowsPerPass;
+            constexpr int kGroup = LEAN ? 2 : kPasses;
             const int chunk = lane % kChunksPerRow;
             const uint32_t first = tileStart + (uint32_t)chunk * 8u;
-            uint2 lo[kPasses], hi[kPasses];
-            uint32_t cnt[kPasses];
-            long long base[kPasses];
 #pragma unroll
-            for (int p = 0; p < kPasses; ++p) {
-                const int row = p * kRowsPerPass + lane / kChunksPerRow;
-                const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
-                lo[p] = src[0]; hi[p] = src[1];
-                cnt[p] = rowCount[row];
-                base[p] = rowBase[row];
-            }
+            for (int p0 = 0; p0 < kPasses; p0 += kGroup) {
+                uint2 lo[kGroup], hi[kGroup];
+                uint32_t cnt[kGroup];
+                long long base[kGroup];
 #pragma unroll
-            for (int p = 0; p < kPasses; ++p) {
-                if (cnt[p] > first && first < validTo) {
-                    uint4* dst = reinterpret_cast<uint4*>(A.pcm + base[p] + first);
-                    *dst = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+                for (int p = 0; p < kGroup; ++p) {
+                    const int row = (p0 + p) * kRowsPerPass + lane / kChunksPerRow;
+                    const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
+                    lo[p] = src[0]; hi[p] = src[1];
+                    cnt[p] = rowCount[row];
+                    base[p] = rowBase[row];
                 }
+#pragma unroll
+                for (int p = 0; p < kGroup; ++p) {
+                    if (cnt[p] > first && first < validTo) {
+                        uint4* dst = reinterpret_cast<uint4*>(A.pcm + base[p] + first);
+                        *dst = make_uint4(lo[p].x, lo[p].y, hi[p].x, hi[p].y);
+                    }
+                }
+                if (LEAN) asm volatile("" ::: "memory");      // (one group's loads and stores before the next group's: the compiler would batch all eight again)
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         };
-        direct_loop<DD, MODE, CH>(5, nIter, nChunks, stage, f, X,
+        direct_loop<DD, MODE, CH, LEAN>(5, nIter, nChunks, stage, f, X,
             [&](int c, int i) __attribute__((always_inline)) { return In3{PIPE(pipeO, c, i), PIPE(pipeY2, c, i), PIPE(pipeP2, c, i)}; },
             [&](int c, int i, const In3& in, const auto& mid) __attribute__((always_inline)) {
                 const double o = in.a;
                 const double y = in.b;
                 double par = in.c;
-                double w = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], y);
-                par += (w - y) * f.cur[0];
-                w = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], y);
-                par += (w - y) * f.cur[1];
-                par = fade_value(par, y, f.cur[2]);
+                double w = resonate<MODE>(f.z1[0], f.z2[0], f.a(0), f.b(0), f.c(0), y);
+                par += (w - y) * f.gv[0].x;
+                w = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), y);
+                par += (w - y) * f.gv[0].y;
+                par = fade_value(par, y, f.gv[1].x);
                 const double mix = o + par;
-                const double v = (mix * f.cur[3]) * 4000.0;
+                const double v = (mix * f.gv[1].y) * 4000.0;
                 const double lo = (v < 32000.0) ? v : 32000.0;       // windows.h min(): NaN -> 32000
                 const double cl = (lo > -32000.0) ? lo : -32000.0;
                 myRow[(it % kTile) + i] = (int16_t)(uint32_t)(int)cl;   // (int) truncates toward zero (reference :208)
                 mid(cl);
             },
-            [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); });
-        if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
+            [&](uint32_t end) __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it, f.length < end ? f.length : end); });
+        if ((it % kTile) != 0) flush_tile(it - (it % kTile), it, f.length);
     } else {
-        // (register census builds, KLATT_DIRECT_STAGES: a stage left out still takes part in every barrier)
+        // (register census builds, ONLY: a stage left out still takes part in every barrier)
         for (int iter = 0; iter < nIter; ++iter) __syncthreads();
     }
 #undef PIPE

@@ -220,16 +220,13 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     return 0;
 }
 
-// the direct stages (klatt_direct.h): eight wavefronts per workgroup, one workgroup per CU (152 KB of pipes)
-int launch_direct(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
+// the direct stages (klatt_direct.h): eight wavefronts per workgroup; `lean`: two workgroups per CU (8-sample hand-overs, 77 KB of pipes,
+// 128 registers per stage), else one (16-sample hand-overs, 152 KB, 256 registers)
+constexpr int kDirectChunk = 16, kDirectLeanChunk = 8;
+template <int CH, int WPE>
+int launch_direct_as(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
-    if (nGroups <= 0) return 0;
-    if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-#ifndef KLATT_DIRECT_CH
-#define KLATT_DIRECT_CH 16      // hand-over size / wavefronts per SIMD of the direct kernel: 16 / 2 (one workgroup per CU); 8 / 4: two per CU, 128 VGPRs (spills: A/B only)
-#define KLATT_DIRECT_WPE 2
-#endif
-    constexpr int ldsBytes = DirectLds<KLATT_DIRECT_CH>::kBytes;
+    constexpr int ldsBytes = DirectLds<CH>::kBytes;
     auto go = [&](auto kernel) -> int {
         if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kDirectStages), ldsBytes, stream, a);
@@ -237,13 +234,19 @@ int launch_direct(const KernelArgs& a, int mode, long long nGroups, hipStream_t 
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_direct<MODE_EXACT, KLATT_DIRECT_CH, KLATT_DIRECT_WPE>); break;
-    case MODE_FAST: rc = go(klatt_direct<MODE_FAST, KLATT_DIRECT_CH, KLATT_DIRECT_WPE>); break;
+    case MODE_EXACT: rc = go(klatt_direct<MODE_EXACT, CH, WPE>); break;
+    case MODE_FAST: rc = go(klatt_direct<MODE_FAST, CH, WPE>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
     HIP_TRY(hipGetLastError());
     return 0;
+}
+int launch_direct(const KernelArgs& a, int mode, bool lean, long long nGroups, hipStream_t stream)
+{
+    if (nGroups <= 0) return 0;
+    if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
+    return lean ? launch_direct_as<kDirectLeanChunk, 4>(a, mode, nGroups, stream) : launch_direct_as<kDirectChunk, 2>(a, mode, nGroups, stream);
 }
 
 #ifndef KLATT_LP_CH
@@ -353,6 +356,7 @@ struct Batch {
     long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with tracks (slots: utterances + padding)
     long long nTrackedUtt = 0;             // the utterances among them
     long long nJobs = 0, trackEntries = 0; // distinct tracks of the batch, their entries (16 B each)
+    int directLean = -1;                   // the direct stages' residency: 1 two workgroups per CU (the lean stages), 0 one, -1 the engine's choice (direct_lean())
     int direct = 1;                        // noisy utterances with finite, bounded parameters and no tracks: 1 the direct stages (klatt_direct.h) unless their
                                            // lanes are time-aligned and the mode is MODE_EXACT (setUtterances), 2 the direct stages always, 0 the stages with the frame state machine
     long long nDirect = 0;                 // order[nQuiet + nTracked .. + nDirect) = such utterances (slots)
@@ -728,7 +732,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
 
 // Timing-only experiment switches (KLATT_EXP & 1 / & 4 in klatt_systolic.h, KLATT_LP_EXP in klatt_systolic.h / klatt_lanepipe.h) build a
 // library with the same ABI whose PCM is garbage: such a build refuses to hand PCM out, it only times.
-#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0) || ((KLATT_DIRECT_EXP & 3) != 0) || (KLATT_DIRECT_STAGES != 0x7F)
+#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0)
 constexpr bool kTimingOnlyBuild = true;
 #else
 constexpr bool kTimingOnlyBuild = false;
@@ -783,6 +787,9 @@ template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
 // (setUtterances only forms the direct group under the stage-parallel layouts)
 long long direct_count(const Batch* b) { return b->nDirect; }
+// The direct stages' residency for a launch of nGroups workgroups (option "direct_lean").  The engine's choice: two workgroups per CU
+// (the lean stages) once the launch has more workgroups than CUs -- below that a second resident workgroup has nothing to run.
+bool direct_lean(const Batch* b, long long nGroups) { return b->directLean < 0 ? nGroups > b->cus : b->directLean != 0; }
 
 int batch_launch(Batch* b)
 {
@@ -876,7 +883,7 @@ int batch_launch(Batch* b)
         a.directHdr = b->dDirectHdr.ptr; a.directRec = b->dDirectRec.ptr; a.directFirst = b->dDirectFirst.ptr; a.nDirect = (uint32_t)b->nDirectFrames;
         a.sourceRef = b->dSourceRef.ptr;
         const long long g = (nDir + kLanes - 1) / kLanes;
-        if (launch_direct(a, b->mode, g, st)) return -1;
+        if (launch_direct(a, b->mode, direct_lean(b, g), g, st)) return -1;
         a.directHdr = nullptr; a.directRec = nullptr; a.directFirst = nullptr; a.nDirect = 0; a.sourceRef = nullptr;
     }
     for (int half = 0; half < 2; ++half) {
@@ -1558,6 +1565,7 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
               hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess;
     { const char* e = getenv("SPEECHPLAYER_TRACKS"); if (e) b->tracks = atoi(e) ? 1 : 0; }
     { const char* e = getenv("SPEECHPLAYER_DIRECT"); if (e) b->direct = std::min(2, std::max(0, atoi(e))); }
+    { const char* e = getenv("SPEECHPLAYER_DIRECT_LEAN"); if (e) b->directLean = std::min(1, std::max(-1, atoi(e))); }
     for (int i = 0; i < 6 && ok; ++i)
         ok = hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&b->join[i], hipEventDisableTiming) == hipSuccess;
@@ -1604,6 +1612,8 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     if (!strcmp(name, "track_budget_mb")) { b->trackBudgetMB = value < 0 ? 0 : value; return 0; }
     // direct: read by setUtterances (set the option before it); 0 never, 1 unless the lanes are time-aligned (default), 2 always
     if (!strcmp(name, "direct")) { b->direct = value < 0 ? 0 : (value > 2 ? 2 : value); return 0; }
+    // direct_lean: the direct stages two workgroups to a CU (1), one (0), or the engine's choice (-1, default); same PCM in MODE_EXACT
+    if (!strcmp(name, "direct_lean")) { b->directLean = value < 0 ? -1 : (value ? 1 : 0); return 0; }
     set_error("unknown option %s", name);
     return -1;
 }
@@ -2451,8 +2461,13 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
         wavesPerGroup = kStages;
         groups = g;
     } else if (directG) {
-        fn = fast ? (const void*)klatt_direct<MODE_FAST, KLATT_DIRECT_CH, KLATT_DIRECT_WPE> : (const void*)klatt_direct<MODE_EXACT, KLATT_DIRECT_CH, KLATT_DIRECT_WPE>;
-        ldsBytes = DirectLds<KLATT_DIRECT_CH>::kBytes; chunk = KLATT_DIRECT_CH;
+        if (direct_lean(b, (nDir + kLanes - 1) / kLanes)) {
+            fn = fast ? (const void*)klatt_direct<MODE_FAST, kDirectLeanChunk, 4> : (const void*)klatt_direct<MODE_EXACT, kDirectLeanChunk, 4>;
+            ldsBytes = DirectLds<kDirectLeanChunk>::kBytes; chunk = kDirectLeanChunk;
+        } else {
+            fn = fast ? (const void*)klatt_direct<MODE_FAST, kDirectChunk, 2> : (const void*)klatt_direct<MODE_EXACT, kDirectChunk, 2>;
+            ldsBytes = DirectLds<kDirectChunk>::kBytes; chunk = kDirectChunk;
+        }
         wavesPerGroup = kDirectStages;
     } else if (tracked) {
         if (pl.chunk == 8) { fn = fast ? (const void*)klatt_systolic<MODE_FAST, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true> : (const void*)klatt_systolic<MODE_EXACT, true, KLATT_FLAT_CH, KLATT_FLAT_WPS, true, false, true>; ldsBytes = SysLds<true, KLATT_FLAT_CH, true>::kBytes; chunk = KLATT_FLAT_CH; }

@@ -9,4 +9,7 @@
 #ifndef CENSUS_WPE
 #define CENSUS_WPE 2
 #endif
-template __global__ void klatt::klatt_direct<CENSUS_MODE, CENSUS_CH, CENSUS_WPE>(const klatt::KernelArgs);
+#ifndef CENSUS_ONLY
+#define CENSUS_ONLY 0x7F
+#endif
+template __global__ void klatt::klatt_direct<CENSUS_MODE, CENSUS_CH, CENSUS_WPE, CENSUS_ONLY>(const klatt::KernelArgs);

@@ -14,11 +14,12 @@ from nvspeechplayer_amd import BatchPlayer, workloads
 from mixed_probe import jitter, distinct
 
 
-def run(b, tracks, direct, mode=0, launches=0, sort=1):
+def run(b, tracks, direct, mode=0, launches=0, sort=1, lean=-1):
     bp = BatchPlayer(b["sr"] if "sr" in b else 22050, mode=mode)
     bp.setOption("sort", sort)
     bp.setOption("tracks", tracks)
     bp.setOption("direct", direct)
+    bp.setOption("direct_lean", lean)
     t0 = time.time()
     bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
     host = time.time() - t0
@@ -44,9 +45,10 @@ def check():
         exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
         for mode in (0, 1):
             legacy = run(batch, 0, 0, mode)
-            direct = run(batch, 0, 2, mode)
+            direct = run(batch, 0, 2, mode, lean=0)
+            lean = run(batch, 0, 2, mode, lean=1)
             both = run(batch, 1, 2, mode)
-            for name, r in (("legacy", legacy), ("direct", direct), ("tracked+direct", both)):
+            for name, r in (("legacy", legacy), ("direct", direct), ("direct lean", lean), ("tracked+direct", both)):
                 d = r[0].astype(np.int32) - exp.astype(np.int32)
                 print("seed %d wild %s mode %d %-15s: %d samples, %d differ from the oracle (max %d), direct utterances %d, tracked %d; equal to legacy: %s" % (
                     seed, wild, mode, name, total, int(np.count_nonzero(d)), int(np.abs(d).max()), r[2]["direct_utterances"], r[2]["tracked_utterances"],
@@ -62,10 +64,12 @@ def timing(n):
             continue
         for mode in (0, 1):
             row = []
-            for label, tracks, direct in (("tracked", 1, 2), ("direct", 0, 2), ("legacy", 0, 0), ("auto", 1, 1)):
+            for label, tracks, direct, lean in (("tracked", 1, 2, -1), ("direct", 0, 2, 0), ("lean", 0, 2, 1), ("legacy", 0, 0, -1), ("auto", 1, 1, -1)):
                 if label in ("legacy", "auto") and "+legacy" not in sys.argv:
                     continue
-                ms, dg, host, info = run(b, tracks, direct, mode, launches=5)
+                if label == "tracked" and "-tracked" in sys.argv:
+                    continue
+                ms, dg, host, info = run(b, tracks, direct, mode, launches=5, lean=lean)
                 row.append("%s %7.2f ms (%016x; direct %d, tracked %d utt; set %.2f s)" % (label, ms, dg, info["direct_utterances"], info["tracked_utterances"], host))
             print("%-14s mode %d: %s" % (name, mode, " | ".join(row)), flush=True)
 

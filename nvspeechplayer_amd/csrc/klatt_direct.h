@@ -73,10 +73,10 @@ namespace klatt {
 #define KLATT_DIRECT_STEADY_UNROLL 16
 #endif
 #ifndef KLATT_DIRECT_LEAN_UNROLL
-#define KLATT_DIRECT_LEAN_UNROLL 1       // MODE_EXACT, two workgroups per CU
+#define KLATT_DIRECT_LEAN_UNROLL 2       // MODE_EXACT, two workgroups per CU (1: 38.8 instead of 37.8 ms; the source stage goes sample by sample)
 #endif
 #ifndef KLATT_DIRECT_LEAN_UNROLL_FAST
-#define KLATT_DIRECT_LEAN_UNROLL_FAST 2  // MODE_FAST, two workgroups per CU
+#define KLATT_DIRECT_LEAN_UNROLL_FAST 4  // MODE_FAST, two workgroups per CU (2: 21.1, 1: 22.1 instead of 20.2 ms)
 #endif
 #ifndef KLATT_DIRECT_LEAN_STEADY_UNROLL
 #define KLATT_DIRECT_LEAN_STEADY_UNROLL 4
@@ -271,6 +271,20 @@ struct DirectState {
     __device__ __forceinline__ double a(int r) const { return keepsA(r) ? ra[r] : (1.0 - bc[r].x) - bc[r].y; }      // reference src/speechWaveGenerator.cpp:119
     __device__ __forceinline__ double b(int r) const { return (FASTANTI && r == 0) ? n0b : bc[r].x; }
     __device__ __forceinline__ double c(int r) const { return (FASTANTI && r == 0) ? n0c : bc[r].y; }
+    // One sample of resonator r (reference src/speechWaveGenerator.cpp:128-135).  MODE_EXACT: ((a in) + (b z1)) + (c z2), each operation
+    // rounded by itself.  The lean stages of MODE_FAST, whose a IS 1 - b - c, take in + b (z1 - in) + c (z2 - in): the same value with
+    // four operations instead of five (two for a), and no product with a, the small difference of large terms.
+#ifndef KLATT_DIRECT_FAST_DOT
+#define KLATT_DIRECT_FAST_DOT 1
+#endif
+    __device__ __forceinline__ double step(int r, double in)
+    {
+        double y;
+        if (KLATT_DIRECT_FAST_DOT && MODE == MODE_FAST && !keepsA(r)) y = __builtin_fma(bc[r].y, z2[r] - in, __builtin_fma(bc[r].x, z1[r] - in, in));
+        else y = dot3<MODE>(a(r), in, b(r), z1[r], c(r), z2[r]);
+        z2[r] = z1[r]; z1[r] = y;
+        return y;
+    }
 };
 struct DirectCtx {
     const KernelArgs& A;
@@ -552,7 +566,8 @@ __device__ __forceinline__ void direct_source_stage(const KernelArgs& A, const U
                                                     int nIter, int nChunks, double* pipeOut, uint32_t nkey, uint32_t ninc, uint32_t ninc2)
 {
 #define SRC_PIPE(c, i) pipeOut[(((c) & 1) * CH + (i)) * kLanes + lane]
-    constexpr int kMixedUnroll = DirectUnroll<MODE, LEAN>::kMixed, kSteadyUnroll = DirectUnroll<MODE, LEAN>::kSteady;
+    // (the lean source stage of MODE_EXACT -- four gain kinds, the pitch, the phases -- goes sample by sample: two per trip spill)
+    constexpr int kMixedUnroll = (LEAN && MODE != MODE_FAST) ? 1 : DirectUnroll<MODE, LEAN>::kMixed, kSteadyUnroll = DirectUnroll<MODE, LEAN>::kSteady;
     DirectState<DD, MODE, LEAN> f;
     direct_init(f, live, d, rec0, X);
     const SourceRef* const mySrc = A.sourceRef + d.frameStart;
@@ -737,6 +752,22 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int stage = wave;
+#ifndef KLATT_DIRECT_PAIRING
+#define KLATT_DIRECT_PAIRING 1
+#endif
+#ifndef KLATT_DIRECT_PAIRS_SEL
+#define KLATT_DIRECT_PAIRS_SEL 1
+#endif
+#if KLATT_DIRECT_PAIRS_SEL == 1
+#define KLATT_DIRECT_PAIRS_FAST1 {2, 1, 0, 6, 7, 3, 5, 4}
+#elif KLATT_DIRECT_PAIRS_SEL == 4
+#define KLATT_DIRECT_PAIRS_FAST1 {2, 1, 7, 6, 5, 3, 0, 4}
+#elif KLATT_DIRECT_PAIRS_SEL == 5
+#define KLATT_DIRECT_PAIRS_FAST1 {2, 6, 7, 1, 5, 4, 0, 3}
+#else
+#define KLATT_DIRECT_PAIRS_FAST1 {7, 1, 5, 2, 6, 0, 3, 4}
+#endif
+#if KLATT_DIRECT_PAIRING
     {
         const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
         const uint32_t simd = (hw >> 4) & 3u;
@@ -747,13 +778,14 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         const bool two = simdCount[0] == 2u && simdCount[1] == 2u && simdCount[2] == 2u && simdCount[3] == 2u;
         // heavy with light: MODE_EXACT T5 + T3 | T7 + T4 | T0 + T2 | T6 + T1;
         // MODE_FAST (layout 1): final + glottal | parallel 1, 2 + nasal pair | parallel 3, 4 + phase | the two cascade stages
-        constexpr int kPairsExact[8] = {5, 3, 7, 4, 0, 2, 6, 1}, kPairsFast0[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsFast1[8] = {7, 1, 5, 2, 6, 0, 3, 4};
+        constexpr int kPairsExact[8] = {5, 3, 7, 4, 0, 2, 6, 1}, kPairsFast0[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsFast1[8] = KLATT_DIRECT_PAIRS_FAST1;
         const int key = (int)(simd * 2u + (rank & 1u));
         int pick = wave;
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (key == k) pick = MODE != MODE_FAST ? kPairsExact[k] : (LAY == 1 ? kPairsFast1[k] : kPairsFast0[k]);
         stage = __builtin_amdgcn_readfirstlane(two ? pick : wave);
     }
+#endif
     if (wave == 0) atomicMax(maxLenP, d.length);
     __syncthreads();
     if (stage == FINAL) { rowBase[lane] = d.outStart; rowCount[lane] = 0; }   // read by this wave only
@@ -817,7 +849,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 const double x = in.a;
                 const double n0 = dot3<MODE>(f.a(0), x, f.b(0), f.z1[0], f.c(0), f.z2[0]);
                 f.z2[0] = f.z1[0]; f.z1[0] = x;                              // the anti-resonator remembers its INPUT (reference :133)
-                const double np = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), n0);
+                const double np = f.step(1, n0);
                 const double o = fade_value(x, np, f.gv[0].x);
                 PIPE(pout, c, i) = o;
                 mid(o);      // the next sample's values: every coefficient and gain of this one has been used
@@ -836,7 +868,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
                     double o = in.a;
 #pragma unroll
-                    for (int r = 0; r < DD::NRES; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.a(r), f.b(r), f.c(r), o);
+                    for (int r = 0; r < DD::NRES; ++r) o = f.step(r, o);
                     PIPE(pout, c, i) = o;
                     mid(o);
                 },
@@ -861,9 +893,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 const double fric = fricNoise * 0.3 * f.gv[0].x;
                 const double y = (fric * f.gv[0].y) * 0.5;
                 double par = 0;
-                double w = resonate<MODE>(f.z1[0], f.z2[0], f.a(0), f.b(0), f.c(0), y);
+                double w = f.step(0, y);
                 par += (w - y) * f.gv[1].x;
-                w = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), y);
+                w = f.step(1, y);
                 par += (w - y) * f.gv[1].y;
                 PIPE(pipeY, c, i) = y; PIPE(pipeP, c, i) = par;
                 mid(par);
@@ -880,9 +912,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             [&](int c, int i, const In2& in, const auto& mid) __attribute__((always_inline)) {
                 const double y = in.a;
                 double par = in.b;
-                double w = resonate<MODE>(f.z1[0], f.z2[0], f.a(0), f.b(0), f.c(0), y);
+                double w = f.step(0, y);
                 par += (w - y) * f.gv[0].x;
-                w = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), y);
+                w = f.step(1, y);
                 par += (w - y) * f.gv[0].y;
                 PIPE(pipeY2, c, i) = y; PIPE(pipeP2, c, i) = par;
                 mid(par);
@@ -905,7 +937,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             constexpr int kRowsPerPass = kLanes / kChunksPerRow;
             constexpr int kPasses = kLanes / kRowsPerPass;
             constexpr int kGroup = LEAN ? 2 : kPasses;
-            const int chunk = lane % kChunksPerRow;
+            int ln = lane;
+            if (LEAN) asm volatile("" : "+v"(ln));      // (the lane's row and piece are derived HERE: hoisted out of the loops they are registers held, or spilled, for the whole launch)
+            const int chunk = ln % kChunksPerRow;
             const uint32_t first = tileStart + (uint32_t)chunk * 8u;
 #pragma unroll
             for (int p0 = 0; p0 < kPasses; p0 += kGroup) {
@@ -914,7 +948,7 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 long long base[kGroup];
 #pragma unroll
                 for (int p = 0; p < kGroup; ++p) {
-                    const int row = (p0 + p) * kRowsPerPass + lane / kChunksPerRow;
+                    const int row = (p0 + p) * kRowsPerPass + ln / kChunksPerRow;
                     const uint2* src = reinterpret_cast<const uint2*>(tile + row * kTileStride + chunk * 16);
                     lo[p] = src[0]; hi[p] = src[1];
                     cnt[p] = rowCount[row];
@@ -937,9 +971,9 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
                 const double o = in.a;
                 const double y = in.b;
                 double par = in.c;
-                double w = resonate<MODE>(f.z1[0], f.z2[0], f.a(0), f.b(0), f.c(0), y);
+                double w = f.step(0, y);
                 par += (w - y) * f.gv[0].x;
-                w = resonate<MODE>(f.z1[1], f.z2[1], f.a(1), f.b(1), f.c(1), y);
+                w = f.step(1, y);
                 par += (w - y) * f.gv[0].y;
                 par = fade_value(par, y, f.gv[1].x);
                 const double mix = o + par;

@@ -357,6 +357,7 @@ struct Batch {
     long long nTrackedUtt = 0;             // the utterances among them
     long long nJobs = 0, trackEntries = 0; // distinct tracks of the batch, their entries (16 B each)
     int directLean = -1;                   // the direct stages' residency: 1 two workgroups per CU (the lean stages), 0 one, -1 the engine's choice (direct_lean())
+    bool directAligned = false;            // setUtterances: half or more of the direct candidates sit in runs of 32 or more equally long, equally timed utterances
     int direct = 1;                        // noisy utterances with finite, bounded parameters and no tracks: 1 the direct stages (klatt_direct.h) unless their
                                            // lanes are time-aligned and the mode is MODE_EXACT (setUtterances), 2 the direct stages always, 0 the stages with the frame state machine
     long long nDirect = 0;                 // order[nQuiet + nTracked .. + nDirect) = such utterances (slots)
@@ -788,8 +789,10 @@ long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ?
 // (setUtterances only forms the direct group under the stage-parallel layouts)
 long long direct_count(const Batch* b) { return b->nDirect; }
 // The direct stages' residency for a launch of nGroups workgroups (option "direct_lean").  The engine's choice: two workgroups per CU
-// (the lean stages) once the launch has more workgroups than CUs -- below that a second resident workgroup has nothing to run.
-bool direct_lean(const Batch* b, long long nGroups) { return b->directLean < 0 ? nGroups > b->cus : b->directLean != 0; }
+// (the lean stages) once the launch has more workgroups than CUs -- below that a second resident workgroup has nothing to run -- unless
+// the lanes are time-aligned: the lean stages have no steady path of their own (an aligned batch spends most chunks there: cfg2
+// without its tracks 13.9 ms against 16.4, MODE_FAST; "distinct" 16.1 / 17.3).
+bool direct_lean(const Batch* b, long long nGroups) { return b->directLean < 0 ? (nGroups > b->cus && !b->directAligned) : b->directLean != 0; }
 
 int batch_launch(Batch* b)
 {
@@ -1840,7 +1843,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         // DESIGN.md section 4.7): "direct" = 1 decides by the share of the candidates that sit in runs of 32 or more equally long,
         // equally timed utterances; 2 takes the direct stages whatever the timing.
         bool take = true;
-        if (b->direct == 1) {
+        b->directAligned = false;
+        {
             std::unordered_map<unsigned long long, long long> runOf;
             long long candidates = 0, inRuns = 0;
             for (long long u = 0; u < nUtterances; ++u)
@@ -1849,7 +1853,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             // (without the sort by length and timing nothing is side by side; in MODE_FAST the direct stages advance coefficients by
             // recurrences and win on the aligned batches whose fades move everything too -- "distinct" 19.2 -> 15.9 ms -- while a batch
             // of few moving kinds loses 8 % there: cfg2 without its tracks 12.7 -> 13.7)
-            take = !b->sortByLength || inRuns * 2 <= candidates || b->mode == MODE_FAST;
+            b->directAligned = b->sortByLength && inRuns * 2 > candidates;
+            if (b->direct == 1) take = !b->directAligned || b->mode == MODE_FAST;
         }
         if (take)
             for (long long u = 0; u < nUtterances; ++u)

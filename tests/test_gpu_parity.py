@@ -1391,9 +1391,9 @@ def test_direct_stages_change_nothing(seed, wild):
     n_utt = len(batch["seeds"])
     exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
 
-    def run(mode, tracks, direct, sort=1):
+    def run(mode, tracks, direct, sort=1, lean=-1):
         bp = eng.BatchPlayer(22050, mode=mode)
-        bp.setOption("tracks", tracks); bp.setOption("direct", direct); bp.setOption("sort", sort)
+        bp.setOption("tracks", tracks); bp.setOption("direct", direct); bp.setOption("sort", sort); bp.setOption("direct_lean", lean)
         bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
         bp.synthesize()
         pcm, start = bp.readAll()
@@ -1407,19 +1407,21 @@ def test_direct_stages_change_nothing(seed, wild):
     for mode in (0, 1):
         legacy, info0, marks0 = run(mode, 0, 0)
         assert info0["direct_utterances"] == 0 and info0["tracked_utterances"] == 0
-        for tracks, direct, sort in ((0, 2, 1), (0, 2, 0), (0, 1, 1), (1, 2, 1)):
-            pcm, info, marks = run(mode, tracks, direct, sort)
+        # (lean: the direct stages two workgroups to a CU -- 8-sample hand-overs, 128 registers, no steady path; 0: one, 16-sample hand-overs)
+        for tracks, direct, sort, lean in ((0, 2, 1, 0), (0, 2, 1, 1), (0, 2, 0, 0), (0, 2, 0, 1), (0, 1, 1, -1), (1, 2, 1, -1)):
+            pcm, info, marks = run(mode, tracks, direct, sort, lean)
             assert marks == marks0
             if tracks == 0:
                 assert info["tracked_utterances"] == 0 and info["direct_utterances"] > n_utt // (4 if wild else 2)
                 assert info["direct_utterances"] <= n_utt - nan_utts
                 assert info["scratch_bytes"] == 0 and info["direct"]
+                assert info["stage_parallel_chunk"] == (8 if lean == 1 else 16) and info["vgprs"] <= (128 if lean == 1 else 256)
             else:
                 assert info["direct_utterances"] == 0 and info["tracked_utterances"] > 0      # every candidate got its tracks
             d = pcm.astype(np.int32) - exp.astype(np.int32)
             nbad = int(np.count_nonzero(d))
-            print("seed %d wild %s mode %d tracks %d direct %d sort %d: %d direct, %d tracked of %d utterances; %d of %d samples differ from the oracle" % (
-                seed, wild, mode, tracks, direct, sort, info["direct_utterances"], info["tracked_utterances"], n_utt, nbad, total))
+            print("seed %d wild %s mode %d tracks %d direct %d sort %d lean %d: %d direct, %d tracked of %d utterances; %d of %d samples differ from the oracle" % (
+                seed, wild, mode, tracks, direct, sort, lean, info["direct_utterances"], info["tracked_utterances"], n_utt, nbad, total))
             if mode == 0 or tracks == 1:
                 assert np.array_equal(pcm, legacy), "%d samples differ from the stages with the frame state machine" % int(np.count_nonzero(pcm != legacy))
             assert np.abs(d).max() <= 1 and nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
@@ -1440,18 +1442,21 @@ def test_batch_in_which_nothing_is_shared_and_nothing_is_aligned():
     b["index"] = np.where(np.arange(len(b["min"])) % 7 == 3, np.arange(len(b["min"]), dtype=np.int32) % 1000, -1).astype(np.int32)
     exp, exp_start, total = oracle.batch_synthesize(b["sr"], b, threads=8)
     ref_marks = oracle.batch_last_index(b["sr"], b, threads=8)
-    for mode in (0, 1):
+    for mode, lean in ((0, -1), (1, -1), (0, 1), (1, 1)):
         bp = eng.BatchPlayer(b["sr"], mode=mode)
         bp.setOption("track_budget_mb", 8)
+        bp.setOption("direct_lean", lean)
         bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
         info = bp.kernelInfo()
         assert info["direct"] and info["direct_utterances"] == 2048 and info["tracked_utterances"] == 0 and info["scratch_bytes"] == 0, info
+        # 32 workgroups: by itself the engine keeps one workgroup per CU; the lean stages (two per CU) are what a launch of more workgroups than CUs takes
+        assert info["stage_parallel_chunk"] == (8 if lean == 1 else 16), info
         bp.synthesize()
         pcm, start = bp.readAll()
         assert np.array_equal(start, exp_start)
         d = pcm.astype(np.int32) - exp.astype(np.int32)
         nbad = int(np.count_nonzero(d))
-        print("all_different x 2048, mode %d: %d samples, %d differ from the oracle (max %d)" % (mode, total, nbad, int(np.abs(d).max())))
+        print("all_different x 2048, mode %d lean %d: %d samples, %d differ from the oracle (max %d)" % (mode, lean, total, nbad, int(np.abs(d).max())))
         assert np.abs(d).max() <= 1 and nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
         assert float(np.sqrt(np.mean((d / 32768.0) ** 2))) < RMS_TOL
         # index marks (reference src/frame.cpp:69, :117-119) against the oracle's own frame state machine
@@ -1494,9 +1499,9 @@ def test_direct_stages_long_fades_hold_the_recurrence_bound(ref):
     batch = dict(frames=np.array(frames), min=np.array(mins, np.uint32), fade=np.array(fades, np.uint32), index=np.full(len(mins), -1, np.int32),
                  isnull=np.array(nul, np.uint8), frame_start=np.array(start, np.int64), seeds=np.array(seeds, np.uint32))
     exp, exp_start, total = oracle.batch_synthesize(22050, batch, threads=8)
-    for mode in (0, 1):
+    for mode, lean in ((0, 0), (1, 0), (0, 1), (1, 1)):
         bp = eng.BatchPlayer(22050, mode=mode)
-        bp.setOption("tracks", 0); bp.setOption("direct", 2)
+        bp.setOption("tracks", 0); bp.setOption("direct", 2); bp.setOption("direct_lean", lean)
         bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
         assert bp.kernelInfo()["direct_utterances"] == 24
         bp.synthesize()
@@ -1505,6 +1510,6 @@ def test_direct_stages_long_fades_hold_the_recurrence_bound(ref):
         assert np.array_equal(st, exp_start)
         d = pcm.astype(np.int32) - exp.astype(np.int32)
         nbad = int(np.count_nonzero(d))
-        print("long fades, mode %d: %d samples, %d differ from the oracle (max %d)" % (mode, total, nbad, int(np.abs(d).max())))
+        print("long fades, mode %d lean %d: %d samples, %d differ from the oracle (max %d)" % (mode, lean, total, nbad, int(np.abs(d).max())))
         assert np.abs(d).max() <= 1 and nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
         assert float(np.sqrt(np.mean((d / 32768.0) ** 2))) < RMS_TOL

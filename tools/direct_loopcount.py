@@ -1,59 +1,53 @@
 #!/usr/bin/env python3
-"""Instruction census of the direct kernel's mixed sample loop, stage by stage (compiles tools/direct_census.hip with one stage each).
-   python tools/direct_loopcount.py [mode]"""
-import os, re, subprocess, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-mode = sys.argv[1] if len(sys.argv) > 1 else "0"
-extra = sys.argv[2:]
-names = {1: "T0", 2: "T1", 4: "T2-4", 8: "T5", 16: "T6", 32: "T7"}
-for mask, name in names.items():
-    out = "/tmp/direct_lc_%d.s" % mask
-    subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "--offload-arch=gfx950", "-ffp-contract=off", "-std=c++17", "-mllvm", "-amdgpu-sched-strategy=max-memory-clause",
-                           "--cuda-device-only", "-S", "-DCENSUS_MODE=" + mode, "-DKLATT_DIRECT_STAGES=%d" % mask] + extra + [os.path.join(ROOT, "tools", "direct_census.hip"), "-o", out], stderr=subprocess.DEVNULL)
-    lines = open(out).read().split("\n")
-    # basic blocks with their loop depth comments; the mixed loop is the Depth=2 loop with the most f64 instructions
-    loops = {}
-    cur = None
-    for l in lines:
-        m = re.match(r"^(\.LBB\d+_\d+):", l)
+"""Instructions per sample of each lean direct stage's sample loop, from the census assembly (tools/direct_census.sh leaves /tmp/direct_census_MASK.s).
+
+    python tools/direct_loopcount.py MODE [samples per trip]
+For every stage mask: VALU / SALU / LDS / branch instructions in the innermost loops (Depth=2), the fade-start blocks (those with global loads) left out.
+"""
+import re
+import sys
+
+trip = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+for mask in (1, 64, 2, 4, 8, 16, 32):
+    try:
+        lines = open("/tmp/direct_census_%d.s" % mask).read().split("\n")
+    except OSError:
+        continue
+    # basic blocks
+    blocks, cur, name = [], [], "entry"
+    for ln in lines:
+        m = re.match(r"^(\.LBB\d+_\d+):(.*)", ln)
         if m:
-            cur = m.group(1)
-            hdr = re.search(r"Loop Header: Depth=(\d+)", l)
-            par = re.search(r"in Loop: Header=(BB\d+_\d+) Depth=(\d+)", l)
-            key = None
-            if hdr and hdr.group(1) == "2":
-                key = cur[2:]
-            elif par and par.group(2) == "2":
-                key = par.group(1)
-            loops.setdefault(key, [])
-            curkey = key
+            blocks.append((name, cur)); name, cur = m.group(1) + m.group(2), []
+        elif re.match(r"^; %bb\.\d+:(.*)", ln):
+            blocks.append((name, cur)); name, cur = ln, []
+        elif "This Inner Loop Header: Depth=2" in ln:
+            name += " Depth=2"
+        elif ln.startswith("\t") and not ln.startswith("\t.") and not ln.startswith("\t;"):
+            cur.append(ln.strip())
+    blocks.append((name, cur))
+    loops = {}
+    for name, ins in blocks:
+        m = re.search(r"Depth=2", name)
+        if not m:
             continue
-        if cur is None:
+        hdr = re.search(r"Header=(BB\d+_\d+)", name)
+        key = hdr.group(1) if hdr else re.match(r"\.L(BB\d+_\d+)", name).group(1)
+        if any(i.startswith("global_load") for i in ins):
             continue
-        par = re.search(r"; %bb\.\d+:\s+;\s+in Loop: Header=(BB\d+_\d+) Depth=(\d+)", l)
-        if par:
-            curkey = par.group(1) if par.group(2) == "2" else None
-            loops.setdefault(curkey, [])
-            continue
-        t = l.strip()
-        if not t or t.startswith(";") or t.startswith("."):
-            continue
-        loops.setdefault(curkey, []).append(t.split()[0])
-    best = None
-    for k, ins in loops.items():
-        if k is None:
-            continue
-        f64 = sum(1 for i in ins if i.startswith("global_load_dwordx4"))      # the mixed loop holds the switch block's loads
-        if best is None or f64 > best[1]:
-            best = (k, f64, ins)
-    k, _, ins = best
-    f64 = sum(1 for i in ins if 'f64' in i)
-    valu = sum(1 for i in ins if i.startswith("v_"))
-    salu = sum(1 for i in ins if i.startswith("s_") and not i.startswith("s_waitcnt") and not i.startswith("s_nop"))
-    lds = sum(1 for i in ins if i.startswith("ds_"))
-    vmem = sum(1 for i in ins if i.startswith("global_") or i.startswith("buffer_") or i.startswith("scratch_"))
-    cnd = sum(1 for i in ins if i.startswith("v_cndmask"))
-    mov = sum(1 for i in ins if i.startswith("v_mov"))
-    unroll = 2
-    print("%-5s loop %s: %4d instructions (per sample at unroll %d: %5.1f): VALU %d (f64 %d, cndmask %d, mov %d), SALU %d, LDS %d, VMEM %d, waitcnt %d" % (
-        name, k, len(ins), unroll, len(ins) / unroll, valu, f64, cnd, mov, salu, lds, vmem, sum(1 for i in ins if i.startswith("s_waitcnt"))))
+        c = loops.setdefault(key, {"valu": 0, "f64": 0, "salu": 0, "lds": 0, "br": 0})
+        for i in ins:
+            op = i.split()[0]
+            if op.startswith("v_"):
+                c["valu"] += 1
+                if "f64" in op:
+                    c["f64"] += 1
+            elif op.startswith("s_cbranch") or op.startswith("s_branch"):
+                c["br"] += 1
+            elif op.startswith("s_"):
+                c["salu"] += 1
+            elif op.startswith("ds_"):
+                c["lds"] += 1
+    for key, c in loops.items():
+        print("mask %3d loop %-9s per sample: VALU %5.1f (f64 %5.1f)  SALU %4.1f  LDS %4.1f  branches %4.1f" % (
+            mask, key, c["valu"] / trip, c["f64"] / trip, c["salu"] / trip, c["lds"] / trip, c["br"] / trip))

@@ -85,20 +85,25 @@ def kernel_name(info):
     return "klatt_synthesize (lane kernel)"
 
 
-def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy_out=False):
+def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy_out=False, pinned=True):
     """Sustained end-to-end throughput: `n_batches` DISTINCT cfg2-sized batches (other noise seeds, other pitches: nothing of one batch
     is reused by the next) through `players` BatchPlayers; `workers` host threads run speechPlayer_batch_setUtterances (classification,
     lane packing, track planning, uploads) of the batches to come while the GPU synthesises the current one.  PCM stays in HBM, or
-    (copy_out) is read into one reused host buffer per batch.  The frames themselves are built before the clock starts (they are the
-    caller's input: what a front-end hands over)."""
+    (copy_out) is delivered into one host buffer per player: the device puts it into dense utterance order, one copy per batch crosses
+    the link (speechPlayer_batch_readAllAsync) while the next batch is synthesised.  `pinned`: the frames and the PCM buffers are
+    page-locked memory the library handed out (speechPlayer_hostAlloc) -- what a front-end that wants the link's rate writes its frames
+    into; False: pageable numpy arrays (frames through a staging thread, PCM through bounce buffers, synchronously).  The frames
+    themselves are built before the clock starts (they are the caller's input: what a front-end hands over)."""
     import threading
     import numpy as np
-    from nvspeechplayer_amd import BatchPlayer, workloads
+    from nvspeechplayer_amd import BatchPlayer, host_array, workloads
     batches = []
     for k in range(n_batches):
         b = workloads.make("cfg2", 65536, first=k * 65536)
-        b["frames"] = b["frames"].copy()
-        b["frames"][:, 0] *= 1.0 + 0.01 * k; b["frames"][:, 46] *= 1.0 + 0.01 * k
+        fr = host_array(b["frames"].shape, np.float64) if pinned else np.empty_like(b["frames"])
+        fr[...] = b["frames"]
+        fr[:, 0] *= 1.0 + 0.01 * k; fr[:, 46] *= 1.0 + 0.01 * k
+        b["frames"] = fr
         batches.append(b)
     bps = [BatchPlayer(batches[0]["sr"], device=device, mode=mode, layout=layout) for _ in range(players)]
     ready = [threading.Event() for _ in range(n_batches)]
@@ -125,39 +130,62 @@ def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy
             err.append(e)
             for r in ready:
                 r.set()
-    out = np.empty(int(max(b.sample_counts().sum() for b in batches)), dtype=np.int16) if copy_out else None
+    outs = None
+    if copy_out:
+        n_out = int(max(b.sample_counts().sum() for b in batches))
+        outs = [host_array(n_out, np.int16) if pinned else np.empty(n_out, dtype=np.int16) for _ in range(players)]
+        for o in outs:
+            o[...] = 0
     # warm-up: one batch through every player (allocations, first launches)
     for i, bp in enumerate(bps):
         b = batches[i % n_batches]
         bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
         bp.synthesize()
         if copy_out:
-            bp.readAll(out=out)
+            bp.readAll(out=outs[i])
     total = 0
     t0 = time.perf_counter()
     ths = [threading.Thread(target=work) for _ in range(workers)]
     for th in ths:
         th.start()
     synth_s = 0.0
+    in_flight = []                     # batches launched and not yet retired: one stays in flight while the next is launched
+
+    def retire(j):
+        bpj = bps[j % players]
+        bpj.wait()
+        if copy_out and pinned:
+            bpj.readWait()
+        elif copy_out:
+            bpj.readAll(out=outs[j % players])
+        free[j % players].release()
+        return bpj.totalSamples
     for k in range(n_batches):
         ready[k].wait()
         if err:
             raise err[0]
         bp = bps[k % players]
         t = time.perf_counter()
-        bp.synthesize()
-        if copy_out:
-            bp.readAll(out=out)
+        bp.synthesize(wait=False)
+        if copy_out and pinned:
+            bp.readAllAsync(outs[k % players])
+        in_flight.append(k)
+        while len(in_flight) > 1:
+            total += retire(in_flight.pop(0))
         synth_s += time.perf_counter() - t
-        total += bp.totalSamples
-        free[k % players].release()
+    t = time.perf_counter()
+    while in_flight:
+        total += retire(in_flight.pop(0))
+    synth_s += time.perf_counter() - t
     elapsed = time.perf_counter() - t0
     for th in ths:
         th.join()
     for bp in bps:
         bp.close()
     return {"value": total / elapsed, "unit": "samples/s", "batches": n_batches, "players": players, "setter_threads": workers,
-            "pcm": "copied to one host buffer per batch (speechPlayer_batch_readAll)" if copy_out else "left in HBM",
+            "host_buffers": "page-locked (speechPlayer_hostAlloc): frames in and PCM out are one DMA each" if pinned else "pageable numpy arrays",
+            "pcm": ("one dense copy per batch into a host buffer per player (speechPlayer_batch_readAllAsync), beside the next batch's synthesis" if pinned
+                    else "copied to one host buffer per player (speechPlayer_batch_readAll)") if copy_out else "left in HBM",
             "elapsed_s": round(elapsed, 3), "set_utterances_s_mean": round(float(np.mean(set_s)), 4), "gpu_side_s_per_batch": round(synth_s / n_batches, 4),
             "samples_per_batch": total // n_batches}
 
@@ -531,7 +559,9 @@ def main():
                 # what the timed region leaves out, taken in: sustained throughput over eight distinct batches, host work overlapped
                 batch_keep = batch
                 out["pipeline"] = pipeline_extra(device, args.mode, args.layout)
-                out["pipeline"]["with_pcm_to_host"] = pipeline_extra(device, args.mode, args.layout, n_batches=4, copy_out=True)
+                out["pipeline"]["with_pcm_to_host"] = pipeline_extra(device, args.mode, args.layout, n_batches=6, copy_out=True)
+                out["pipeline"]["pageable_host_buffers"] = dict(pipeline_extra(device, args.mode, args.layout, pinned=False),
+                                                                with_pcm_to_host=pipeline_extra(device, args.mode, args.layout, n_batches=4, copy_out=True, pinned=False))
                 batch = batch_keep
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)

@@ -83,6 +83,18 @@ long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long utt
 /* Copy every utterance's PCM, concatenated in utterance order; outStart[nUtterances+1] receives
  * the offsets. Returns total samples. */
 long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart);
+/* The two large transfers of a batch -- frames in (speechPlayer_batch_setUtterances), PCM out (speechPlayer_batch_readAll) -- run
+ * as ONE DMA at the link's rate when the host side is page-locked memory: from speechPlayer_hostAlloc (freed with
+ * speechPlayer_hostFree), or memory the caller registered itself (hipHostRegister).  Pageable buffers work as before, through
+ * bounce buffers.  The PCM is put into dense utterance order ON THE DEVICE first (the pool pads utterances to 32 samples), so the
+ * bytes that cross the link are the bytes of the caller's buffer.  (Additive: the reference has one stream per handle and copies
+ * through speechPlayer_synthesize, src/speechPlayer.cpp:41-45.) */
+void* speechPlayer_hostAlloc(long long bytes);
+void speechPlayer_hostFree(void* p);
+/* speechPlayer_batch_readAll without waiting: compaction and copy are queued behind the synthesis and run beside whatever is launched
+ * next; sampleBuf must be page-locked (else -1).  Returns the samples that will have arrived when speechPlayer_batch_readWait returns. */
+long long speechPlayer_batch_readAllAsync(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart);
+int speechPlayer_batch_readWait(speechPlayer_batch_t batch);
 /* Digest of the PCM, computed on the device (for checks of batches whose PCM is too large to copy): perUtterance[u]
  * (may be NULL) = sum over utterance u's samples of mix64(position, value), *whole (may be NULL) = a digest of those in
  * utterance order.  Equal PCM <=> equal digests (up to 2^-64); the kernel is an HBM-bound read of the pool. */

@@ -36,7 +36,8 @@ EXPORTS = [
     "speechPlayer_batch_setUtterances", "speechPlayer_batch_utteranceSamples",
     "speechPlayer_batch_totalSamples", "speechPlayer_batch_totalFrames", "speechPlayer_batch_sampleRate",
     "speechPlayer_batch_synthesize", "speechPlayer_batch_wait", "speechPlayer_batch_read",
-    "speechPlayer_batch_readAll", "speechPlayer_batch_readFloat", "speechPlayer_batch_digest", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
+    "speechPlayer_batch_readAll", "speechPlayer_batch_readAllAsync", "speechPlayer_batch_readWait", "speechPlayer_hostAlloc", "speechPlayer_hostFree",
+    "speechPlayer_batch_readFloat", "speechPlayer_batch_digest", "speechPlayer_batch_getLastIndex", "speechPlayer_batch_devicePcm",
     "speechPlayer_batch_deviceOffset", "speechPlayer_batch_time", "speechPlayer_batch_kernelInfo",
     "speechPlayer_lastError", "speechPlayer_lastErrorCode", "speechPlayer_setNoiseSeed", "speechPlayer_synthesizeMany", "speechPlayer_setGlobalOption",
     "speechPlayer_synthesizeManyDevice", "speechPlayer_lastLiveKernelMs", "speechPlayer_lastLiveLaunches",
@@ -194,6 +195,14 @@ def load():
     L.speechPlayer_batch_readFloat.argtypes = [vp, i64, vp, i64]
     L.speechPlayer_batch_readAll.restype = i64
     L.speechPlayer_batch_readAll.argtypes = [vp, vp, i64, vp]
+    L.speechPlayer_batch_readAllAsync.restype = i64
+    L.speechPlayer_batch_readAllAsync.argtypes = [vp, vp, i64, vp]
+    L.speechPlayer_batch_readWait.restype = i32
+    L.speechPlayer_batch_readWait.argtypes = [vp]
+    L.speechPlayer_hostAlloc.restype = vp
+    L.speechPlayer_hostAlloc.argtypes = [i64]
+    L.speechPlayer_hostFree.restype = None
+    L.speechPlayer_hostFree.argtypes = [vp]
     L.speechPlayer_batch_digest.restype = i32
     L.speechPlayer_batch_digest.argtypes = [vp, vp, vp]
     L.speechPlayer_batch_getLastIndex.restype = i32

@@ -56,6 +56,60 @@ __global__ void __launch_bounds__(256) pcm_to_float(const int16_t* __restrict__ 
     }
 }
 
+// The PCM pool pads every utterance to a multiple of 32 samples (whole 64-byte row segments for the synthesis kernels' tile
+// flushes); a consumer wants the utterances back to back.  pcm_compact writes that DENSE order in HBM, so that what crosses the
+// link afterwards is ONE contiguous copy at the DMA engines' rate (until round 5 a host thread compacted 16-MB bounce buffers:
+// 16 GB/s of a 63 GB/s link).  A thread owns 8 dense samples (one aligned 16-byte store): it finds its utterance by bisection
+// over the dense starts, and -- when the 8 samples lie in one utterance, i.e. practically always -- reads the two aligned 16-byte
+// vectors that cover them in the pool and shifts (the dense start of an utterance is any sample, so source and destination are
+// misaligned by an even number of bytes that is the same for every thread of the utterance).  HBM-bound: 2 B read + 2 B written per sample.
+__global__ void __launch_bounds__(256) pcm_compact(const int16_t* __restrict__ pool, int16_t* __restrict__ dense, const UttDesc* __restrict__ utt,
+                                                   const long long* __restrict__ denseStart, long long nUtt, long long total)
+{
+    const long long n8 = (total + 7) / 8;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < n8; t += stride) {
+        const long long p = t * 8;
+        long long lo = 0, hi = nUtt;                     // the last utterance whose dense start is <= p
+        while (hi - lo > 1) { const long long mid = (lo + hi) >> 1; if (denseStart[mid] <= p) lo = mid; else hi = mid; }
+        long long u = lo;
+        const long long d0 = denseStart[u], d1 = denseStart[u + 1];
+        uint32_t w[4];
+        if (p + 8 <= d1) {
+            const long long src = utt[u].outStart + (p - d0);            // in samples; the pool start of an utterance is a multiple of 32
+            const int k = (int)(src & 7) * 2;                               // byte offset within the aligned 16-byte vector
+            const uint4* a = reinterpret_cast<const uint4*>(pool + (src - (src & 7)));
+            const uint4 v0 = a[0];
+            uint32_t x[8] = {v0.x, v0.y, v0.z, v0.w, 0u, 0u, 0u, 0u};
+            if (k) { const uint4 v1 = a[1]; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w; }
+            const int dw = k >> 2, half = k & 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint32_t a0 = 0, a1 = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (dw == q) { a0 = x[j + q]; a1 = x[j + q + 1 < 8 ? j + q + 1 : 7]; }
+                w[j] = half ? (a0 >> 16) | (a1 << 16) : a0;
+            }
+        } else {
+            // the 8 samples straddle utterances (or run past the end): sample by sample
+            uint32_t s16[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const long long q = p + i;
+                uint32_t v = 0;
+                if (q < total) {
+                    while (q >= denseStart[u + 1]) ++u;   // (utterances of zero samples are stepped over)
+                    v = (uint16_t)pool[utt[u].outStart + (q - denseStart[u])];
+                }
+                s16[i] = v;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = s16[2 * j] | (s16[2 * j + 1] << 16);
+        }
+        reinterpret_cast<uint4*>(dense)[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
 // 64-bit digest of every utterance's PCM, computed where the PCM lives: sum over the utterance's samples of
 // mix64(position, value).  A sum, so lanes and wavefronts may add their shares in any order; one wavefront per utterance,
 // 16 B (8 samples) per lane and step.  HBM-bound read of the pool.  (Checks of full-size configurations compare digests
@@ -141,6 +195,16 @@ struct DeviceBuffer {
         ptr = nullptr; cap = 0;
     }
 };
+
+// Is this host memory page-locked (from speechPlayer_hostAlloc, or registered by the caller with hipHostRegister)?  Copies to and
+// from such memory are one DMA transfer at the link's rate and truly asynchronous; pageable memory goes through bounce buffers.
+static bool is_pinned(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
 
 // two pinned host buffers + events for pipelined device-to-host copies
 struct PinnedPair {
@@ -386,7 +450,13 @@ struct Batch {
     DeviceBuffer<unsigned long long> dDebug;   // KLATT_STAMPS builds
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
     DeviceBuffer<unsigned long long> dDigest;  // per-utterance digests (speechPlayer_batch_digest)
-    PinnedPair bounce;                         // speechPlayer_batch_readAll
+    PinnedPair bounce;                         // speechPlayer_batch_readAll into pageable memory
+    DeviceBuffer<int16_t> dDense;              // the utterances back to back (pcm_compact): what speechPlayer_batch_readAll copies out
+    DeviceBuffer<long long> dDenseStart;       // [nUtt + 1] dense start of every utterance (prefix sum of the closed-form lengths)
+    std::vector<long long> denseStart;         // the same on the host
+    hipStream_t copyStream = nullptr;          // device-to-host copies of dDense run here, beside the next launch on `stream`
+    hipEvent_t denseReady = nullptr, copyDone = nullptr;
+    bool copyPending = false;                  // a speechPlayer_batch_readAllAsync copy is in flight (speechPlayer_batch_readWait)
     bool floatFresh = false;
 };
 
@@ -1565,7 +1635,10 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     b->device = dev;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) b->cus = prop.multiProcessorCount; }
     bool ok = hipSetDevice(dev) == hipSuccess && hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&b->forkEvent, hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithFlags(&b->copyStream, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&b->denseReady, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&b->copyDone, hipEventDisableTiming) == hipSuccess;
     { const char* e = getenv("SPEECHPLAYER_TRACKS"); if (e) b->tracks = atoi(e) ? 1 : 0; }
     { const char* e = getenv("SPEECHPLAYER_DIRECT"); if (e) b->direct = std::min(2, std::max(0, atoi(e))); }
     { const char* e = getenv("SPEECHPLAYER_DIRECT_LEAN"); if (e) b->directLean = std::min(1, std::max(-1, atoi(e))); }
@@ -1591,6 +1664,10 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
         if (b->join[i]) (void)hipEventDestroy(b->join[i]);
     }
     if (b->forkEvent) (void)hipEventDestroy(b->forkEvent);
+    if (b->copyStream) { (void)hipStreamSynchronize(b->copyStream); (void)hipStreamDestroy(b->copyStream); }
+    if (b->denseReady) (void)hipEventDestroy(b->denseReady);
+    if (b->copyDone) (void)hipEventDestroy(b->copyDone);
+    b->dDense.release(); b->dDenseStart.release();
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
     b->dFlatRef.release(); b->dSourceRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
@@ -1756,7 +1833,9 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     std::string earlyErr;
     std::thread early;
     bool earlyStarted = false;
-    if (nF > 0 && (size_t)nF * kNumParams * sizeof(double) >= (32u << 20)) {
+    // (frames in page-locked memory -- speechPlayer_hostAlloc -- need no thread: one asynchronous DMA on the copy stream, at the link's rate)
+    const bool framesPinned = nF > 0 && is_pinned(frames);
+    if (nF > 0 && (framesPinned || (size_t)nF * kNumParams * sizeof(double) >= (32u << 20))) {
         if (b->dFrames.reserve((size_t)nF * kNumParams)) {
             b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
             b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
@@ -1767,6 +1846,10 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
         b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
         b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
+        if (framesPinned) {
+            HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->copyStream));
+            earlyStarted = true;
+        } else
         try {
             early = std::thread([&, dev = b->device, dst = b->dFrames.ptr]() {
                 hipError_t e = hipSetDevice(dev);
@@ -1785,6 +1868,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         pool += ((long long)lens[u] + kTile - 1) / kTile * kTile;
     }
     outStart[nUtterances] = pool;
+    std::vector<long long> denseStart((size_t)nUtterances + 1);      // the utterances back to back: what speechPlayer_batch_readAll hands out
+    { long long at = 0; for (long long u = 0; u < nUtterances; ++u) { denseStart[u] = at; at += (long long)lens[u]; } denseStart[nUtterances] = at; }
     lap("meta, lengths, classification");
     // An utterance's TIMING: a hash of its sequence of frame durations, fades and silences -- the same text at the same speed, whatever
     // the pitch, the voice or the noise seed.  Lanes with one timing dequeue and fade on the same samples (lane packing, below).
@@ -2005,7 +2090,12 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             HIP_TRY(hipMemcpyAsync(b->dOrder.ptr, order.data(), (size_t)nSlotsAll * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nUtterances * sizeof(UttResult), b->stream));
         }
+        if (nUtterances) {
+            if (b->dDenseStart.reserve((size_t)nUtterances + 1)) return -1;
+            HIP_TRY(hipMemcpyAsync(b->dDenseStart.ptr, denseStart.data(), ((size_t)nUtterances + 1) * sizeof(long long), hipMemcpyHostToDevice, b->stream));
+        }
         HIP_TRY(hipStreamSynchronize(b->stream));
+        if (framesPinned) HIP_TRY(hipStreamSynchronize(b->copyStream));
         if (early.joinable()) early.join();
         if (earlyRc) { set_error_code(SPEECHPLAYER_ERR_HIP); set_error("setUtterances: uploading the frames failed: %s", earlyErr.c_str()); return -1; }
         return 0;
@@ -2025,7 +2115,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     b->nJobs = nTrackedUtt > 0 ? (long long)jobs.size() : 0; b->trackEntries = nTrackedUtt > 0 ? (long long)trackEntries : 0;
     b->nDirect = nDirectUtt > 0 ? nDirectSlots : 0; b->nDirectUtt = nDirectUtt; b->nDirectFrames = (long long)directJobs.size();
     b->totalSamples = total; b->poolSamples = pool;
-    b->lens.swap(lens); b->outStart.swap(outStart);
+    b->lens.swap(lens); b->outStart.swap(outStart); b->denseStart.swap(denseStart);
     b->results.clear();
     b->resultsFresh = false;
     b->floatFresh = false;
@@ -2084,24 +2174,32 @@ long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long u, sampl
     return n;
 }
 
-long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart)
+// The utterances back to back in HBM (pcm_compact), queued on the batch's stream behind the synthesis; `denseReady` marks the end.
+static int dense_prepare(Batch* b)
 {
-    begin_call();
-    if (refuse_timing_only("speechPlayer_batch_readAll")) return -1;
-    Batch* b = static_cast<Batch*>(batch);
-    if (!b || !sampleBuf) return -1;
-    HIP_TRY(hipSetDevice(b->device));
-    HIP_TRY(hipStreamSynchronize(b->stream));
-    if (fetch_results(b)) return -1;
-    // compact positions first (the device pool pads every utterance to a multiple of 32 samples)
+    const long long total = b->totalSamples;
+    if (b->dDense.reserve((size_t)((total + 7) / 8 * 8 + 8))) return -1;
+    if (b->copyPending) { HIP_TRY(hipEventSynchronize(b->copyDone)); b->copyPending = false; }      // the previous copy still reads dDense
+    const long long n8 = (total + 7) / 8;
+    if (n8 > 0) {
+        const unsigned grid = (unsigned)std::min<long long>((n8 + 255) / 256, 1 << 16);
+        hipLaunchKernelGGL(pcm_compact, dim3(grid), dim3(256), 0, b->stream, b->dPcm.ptr, b->dDense.ptr, b->dUtt.ptr, b->dDenseStart.ptr, b->nUtt, total);
+        HIP_TRY(hipGetLastError());
+    }
+    HIP_TRY(hipEventRecord(b->denseReady, b->stream));
+    return 0;
+}
+
+// Before round 5 (and still, for a batch that has not been synthesised to the end: produced != length somewhere): the padded pool comes
+// over in 16 MB pieces through two pinned buffers and one host thread compacts them into the caller's buffer.
+static long long read_all_padded(Batch* b, sample* sampleBuf, long long capacity, long long* outStart)
+{
     std::vector<long long> dstStart((size_t)b->nUtt + 1);
     long long pos = 0;
     for (long long u = 0; u < b->nUtt; ++u) { dstStart[u] = pos; pos += b->results[u].produced; }
     dstStart[b->nUtt] = pos;
     if (pos > capacity) { set_error("readAll: capacity %lld too small for %lld samples", capacity, pos); return -1; }
     if (outStart) memcpy(outStart, dstStart.data(), sizeof(long long) * ((size_t)b->nUtt + 1));
-    // The pool comes over in 16 MB pieces through two pinned buffers: piece k + 1 is in flight while piece k is
-    // compacted into the caller's buffer (pageable memory would cap the copy at a few GB/s).
     constexpr long long kPiece = 8ll << 20;   // samples
     if (b->bounce.ensure((size_t)kPiece * sizeof(int16_t))) return -1;
     const long long nPieces = (b->poolSamples + kPiece - 1) / kPiece;
@@ -2129,6 +2227,107 @@ long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleB
         }
     }
     return pos;
+}
+
+long long speechPlayer_batch_readAll(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart)
+{
+    begin_call();
+    if (refuse_timing_only("speechPlayer_batch_readAll")) return -1;
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || !sampleBuf) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    HIP_TRY(hipStreamSynchronize(b->stream));
+    if (fetch_results(b)) return -1;
+    bool whole = true;      // every utterance synthesised to its end (a batch launch always does; a batch never launched has produced nothing)
+    for (long long u = 0; u < b->nUtt && whole; ++u) whole = b->results[u].produced == b->lens[u];
+    if (!whole) return read_all_padded(b, sampleBuf, capacity, outStart);
+    const long long total = b->totalSamples;
+    if (total > capacity) { set_error("readAll: capacity %lld too small for %lld samples", capacity, total); return -1; }
+    if (outStart) memcpy(outStart, b->denseStart.data(), sizeof(long long) * ((size_t)b->nUtt + 1));
+    if (total == 0) return 0;
+    // dense order on the device first; then the bytes cross the link as they will lie in the caller's buffer
+    if (dense_prepare(b)) return -1;
+    HIP_TRY(hipStreamWaitEvent(b->copyStream, b->denseReady, 0));
+    if (is_pinned(sampleBuf)) {
+        HIP_TRY(hipMemcpyAsync(sampleBuf, b->dDense.ptr, (size_t)total * sizeof(int16_t), hipMemcpyDeviceToHost, b->copyStream));
+        HIP_TRY(hipStreamSynchronize(b->copyStream));
+        return total;
+    }
+    // pageable destination: 32 MB pieces through two pinned buffers, piece k + 1 in flight while piece k is copied out (a plain memcpy now)
+    constexpr long long kPiece = 16ll << 20;   // samples
+    if (b->bounce.ensure((size_t)kPiece * sizeof(int16_t))) return -1;
+    const long long nPieces = (total + kPiece - 1) / kPiece;
+    auto issue = [&](long long k) -> int {
+        const long long off = k * kPiece, n = std::min(kPiece, total - off);
+        HIP_TRY(hipMemcpyAsync(b->bounce.buf[k & 1], b->dDense.ptr + off, (size_t)n * sizeof(int16_t), hipMemcpyDeviceToHost, b->copyStream));
+        HIP_TRY(hipEventRecord(b->bounce.ev[k & 1], b->copyStream));
+        return 0;
+    };
+    if (issue(0)) return -1;
+    int16_t* const dst = reinterpret_cast<int16_t*>(sampleBuf);
+    for (long long k = 0; k < nPieces; ++k) {
+        HIP_TRY(hipEventSynchronize(b->bounce.ev[k & 1]));
+        const long long off = k * kPiece, n = std::min(kPiece, total - off);
+        // (the other buffer's copy is issued only after this one has been emptied two pieces ago: buffers alternate)
+        if (k + 1 < nPieces && issue(k + 1)) return -1;
+        const int16_t* const src = static_cast<const int16_t*>(b->bounce.buf[k & 1]);
+        parallel_ranges(n, 1 << 21, [&](long long a, long long e) { memcpy(dst + off + a, src + a, (size_t)(e - a) * sizeof(int16_t)); });
+    }
+    return total;
+}
+
+// readAll without waiting: the compaction and ONE copy into page-locked memory (speechPlayer_hostAlloc, or registered by the caller) are
+// queued behind the synthesis and the call returns; the copy runs on a stream of its own, beside whatever is launched next (another
+// batch's synthesis, this batch's next launch: the pool is free again as soon as the compaction has run).  speechPlayer_batch_readWait
+// waits for it.  Returns the number of samples that will arrive, -1 when the buffer is not page-locked or too small.
+long long speechPlayer_batch_readAllAsync(speechPlayer_batch_t batch, sample* sampleBuf, long long capacity, long long* outStart)
+{
+    begin_call();
+    if (refuse_timing_only("speechPlayer_batch_readAllAsync")) return -1;
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || !sampleBuf) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    if (!is_pinned(sampleBuf)) { set_error("readAllAsync: the buffer is not page-locked (speechPlayer_hostAlloc)"); return -1; }
+    const long long total = b->totalSamples;
+    if (total > capacity) { set_error("readAllAsync: capacity %lld too small for %lld samples", capacity, total); return -1; }
+    if (outStart) memcpy(outStart, b->denseStart.data(), sizeof(long long) * ((size_t)b->nUtt + 1));
+    if (total == 0) return 0;
+    if (dense_prepare(b)) return -1;
+    HIP_TRY(hipStreamWaitEvent(b->copyStream, b->denseReady, 0));
+    HIP_TRY(hipMemcpyAsync(sampleBuf, b->dDense.ptr, (size_t)total * sizeof(int16_t), hipMemcpyDeviceToHost, b->copyStream));
+    HIP_TRY(hipEventRecord(b->copyDone, b->copyStream));
+    b->copyPending = true;
+    return total;
+}
+
+int speechPlayer_batch_readWait(speechPlayer_batch_t batch)
+{
+    begin_call();
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b) return -1;
+    HIP_TRY(hipSetDevice(b->device));
+    if (b->copyPending) { HIP_TRY(hipEventSynchronize(b->copyDone)); b->copyPending = false; }
+    return 0;
+}
+
+// Page-locked host memory for the two large transfers of a batch -- frames in (speechPlayer_batch_setUtterances), PCM out
+// (speechPlayer_batch_readAll / readAllAsync): a buffer from here travels as one DMA at the link's rate.  NULL when it cannot be had.
+void* speechPlayer_hostAlloc(long long bytes)
+{
+    begin_call();
+    if (bytes <= 0) return nullptr;
+    void* p = nullptr;
+    if (hipHostMalloc(&p, (size_t)bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        set_error_code(SPEECHPLAYER_ERR_HIP);
+        set_error("hostAlloc: cannot page-lock %lld bytes", bytes);
+        return nullptr;
+    }
+    return p;
+}
+void speechPlayer_hostFree(void* p)
+{
+    if (p) (void)hipHostFree(p);
 }
 
 long long speechPlayer_batch_readFloat(speechPlayer_batch_t batch, long long u, float* sampleBuf, long long capacity)

@@ -203,6 +203,35 @@ def pcm_digest(pcm):
         return int(x.sum(dtype=np.uint64))
 
 
+class _HostBlock(object):
+    """Owner of one speechPlayer_hostAlloc block: frees it when the last array view is gone."""
+    def __init__(self, dll, nbytes):
+        self._dll, self.ptr = dll, dll.speechPlayer_hostAlloc(nbytes)
+        if not self.ptr:
+            raise MemoryError("speechPlayer_hostAlloc(%d): %s" % (nbytes, _native.last_error()))
+
+    def __del__(self):
+        try:
+            if self.ptr:
+                self._dll.speechPlayer_hostFree(self.ptr)
+                self.ptr = None
+        except Exception:
+            pass
+
+
+def host_array(shape, dtype):
+    """A numpy array in page-locked host memory (speechPlayer_hostAlloc): frames handed to setUtterances from such an array, and PCM
+    read into one (readAll / readAllAsync), cross the link as one DMA at its full rate.  Freed with the array."""
+    import ctypes
+    dt = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+    n = int(np.prod(shape)) if len(shape) else 1
+    block = _HostBlock(_native.load(), max(n * dt.itemsize, 1))
+    raw = (ctypes.c_char * max(n * dt.itemsize, 1)).from_address(block.ptr)
+    raw._block = block      # the array's base is `raw`: the block lives as long as any view of the array
+    return np.frombuffer(raw, dtype=dt, count=n).reshape(shape)
+
+
 class BatchPlayer(object):
     """N independent utterances per launch (include/speechPlayer_batch.h)."""
 
@@ -328,6 +357,20 @@ class BatchPlayer(object):
         starts = np.zeros(self.nUtterances + 1, dtype=np.int64)
         got = self._check(self._dll.speechPlayer_batch_readAll(self._h, buf.ctypes.data, total, starts.ctypes.data))
         return buf[:got], starts
+
+    def readAllAsync(self, out):
+        """readAll without waiting (speechPlayer_batch_readAllAsync): `out` must be page-locked (nvspeechplayer_amd.host_array); the
+        compaction and the copy are queued behind the synthesis and run beside whatever is launched next.  Returns (view of `out`, starts);
+        the samples are there after readWait()."""
+        total = self.totalSamples
+        if out.dtype != np.int16 or not out.flags["C_CONTIGUOUS"] or out.size < total:
+            raise ValueError("readAllAsync: out must be a contiguous int16 array of at least %d samples" % total)
+        starts = np.zeros(self.nUtterances + 1, dtype=np.int64)
+        got = self._check(self._dll.speechPlayer_batch_readAllAsync(self._h, out.ctypes.data, out.size, starts.ctypes.data))
+        return out[:got], starts
+
+    def readWait(self):
+        self._check(self._dll.speechPlayer_batch_readWait(self._h))
 
     def digest(self, per_utterance=False):
         """Digest of the whole PCM pool, computed on the device (speechPlayer_batch_digest); with per_utterance also the

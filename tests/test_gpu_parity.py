@@ -1513,3 +1513,53 @@ def test_direct_stages_long_fades_hold_the_recurrence_bound(ref):
         print("long fades, mode %d lean %d: %d samples, %d differ from the oracle (max %d)" % (mode, lean, total, nbad, int(np.abs(d).max())))
         assert np.abs(d).max() <= 1 and nbad <= max(2, MAX_FLIPS_PER_M * total // 1000000 + 1)
         assert float(np.sqrt(np.mean((d / 32768.0) ** 2))) < RMS_TOL
+
+
+@pytest.mark.gpu
+def test_pcm_delivery_paths_agree():
+    """The ways PCM leaves a batch give the same bytes: per utterance (speechPlayer_batch_read, straight out of the padded pool), readAll
+    into pageable memory (dense order made on the device by pcm_compact, bounce buffers), readAll into page-locked memory
+    (speechPlayer_hostAlloc: one DMA), readAllAsync + readWait with another launch queued behind it -- on a ragged batch with utterances
+    of zero frames, of one sample, of odd lengths (dense starts at every alignment), with the frames themselves handed over in
+    page-locked memory; and a batch that was never launched still reads as nothing."""
+    import nvspeechplayer_amd as eng
+    rng = np.random.default_rng(77)
+    batch = random_batch(rng, 500, quiet_fraction=0.2)
+    # utterances without frames in between (length 0), and a tail of very short ones
+    fs = batch["frame_start"].tolist()
+    fs = fs[:100] + [fs[100]] * 3 + fs[100:]            # three empty utterances after the 100th
+    seeds = np.concatenate([batch["seeds"][:100], np.array([1, 2, 3], np.uint32), batch["seeds"][100:]])
+    n_utt = len(fs) - 1
+    frames_pinned = eng.host_array(batch["frames"].shape, np.float64)
+    frames_pinned[...] = batch["frames"]
+    bp = eng.BatchPlayer(22050)
+    bp.setUtterances(fs, frames_pinned, batch["min"], batch["fade"], batch["index"], batch["isnull"], seeds)
+    total = bp.totalSamples
+    lens = np.array([bp.utteranceSamples(u) for u in range(n_utt)])
+    assert (lens == 0).sum() >= 3 and (lens % 2 == 1).any() and (lens % 8 != 0).any()
+    never, st0 = bp.readAll()
+    assert len(never) == 0                                # nothing synthesised yet
+    bp.synthesize()
+    pageable, starts = bp.readAll()
+    assert len(pageable) == total and np.array_equal(np.diff(starts), lens)
+    for u in list(range(0, n_utt, 7)) + [100, 101, 102, n_utt - 1]:
+        assert np.array_equal(bp.read(u), pageable[starts[u]:starts[u + 1]]), u
+    pinned = eng.host_array(total + 5, np.int16)
+    pinned[...] = 0x5555
+    got, starts2 = bp.readAll(out=pinned)
+    assert np.array_equal(starts2, starts) and np.array_equal(got, pageable) and (pinned[total:] == 0x5555).all()
+    # asynchronously, with the next launch of the same batch queued right behind the read (the pool is rewritten with the same bytes)
+    pinned[...] = 0
+    got, starts3 = bp.readAllAsync(pinned)
+    bp.synthesize(wait=False)
+    bp.readWait()
+    bp.wait()
+    assert np.array_equal(starts3, starts) and np.array_equal(got, pageable)
+    # the same frames from pageable memory: the same batch
+    bq = eng.BatchPlayer(22050)
+    bq.setUtterances(fs, batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], seeds)
+    bq.synthesize()
+    assert bq.digest() == bp.digest()
+    with pytest.raises(RuntimeError):
+        bq.readAllAsync(np.zeros(total, np.int16))        # not page-locked
+    bq.close(); bp.close()

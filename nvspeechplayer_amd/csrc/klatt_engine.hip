@@ -14,6 +14,7 @@
 #include "klatt_lanepipe.h"
 #include "klatt_tracks.h"
 #include "klatt_direct.h"
+#include "klatt_plan.h"
 
 #include <algorithm>
 #include <cmath>
@@ -107,6 +108,26 @@ __global__ void __launch_bounds__(256) pcm_compact(const int16_t* __restrict__ p
             for (int j = 0; j < 4; ++j) w[j] = s16[2 * j] | (s16[2 * j + 1] << 16);
         }
         reinterpret_cast<uint4*>(dense)[t] = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+}
+
+// SourceRef of every frame (klatt_device.h): what a flat or direct source stage reads when the frame is dequeued.  The division is
+// the reference's (endVoicePitch - voicePitch) / minFrameDuration (src/frame.cpp:98), an IEEE double division here as there; a NULL
+// frame carries no pitch of its own.
+__global__ void __launch_bounds__(256) klatt_source_refs(const double* __restrict__ frames, const FrameMeta* __restrict__ meta, SourceRef* __restrict__ out, long long nFrames)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nFrames; k += stride) {
+        const FrameMeta m = meta[k];
+        const bool isNullFrame = (m.flags & FRAME_NULL) != 0;
+        const double g0 = isNullFrame ? 0.0 : frames[k * kNumParams], g46 = isNullFrame ? 0.0 : frames[k * kNumParams + 46];
+        SourceRef r;
+        r.pitch = g0;
+        r.pitchInc = isNullFrame ? 0.0 : __ddiv_rn(g46 - g0, (double)m.minSamples);
+        r.invFade = __ddiv_rn(1.0, (double)m.fadeSamples);
+        r.userIndex = m.userIndex;
+        r.flags = m.flags & FRAME_NULL;
+        out[k] = r;
     }
 }
 
@@ -205,6 +226,25 @@ static bool is_pinned(const void* p)
     if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
     return a.type == hipMemoryTypeHost;
 }
+
+// one page-locked host block, grown on demand
+struct PinnedBlock {
+    void* ptr = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes)
+    {
+        if (bytes <= cap) return 0;
+        release();
+        HIP_TRY(hipHostMalloc(&ptr, bytes + bytes / 8, hipHostMallocDefault));
+        cap = bytes + bytes / 8;
+        return 0;
+    }
+    void release()
+    {
+        if (ptr) (void)hipHostFree(ptr);
+        ptr = nullptr; cap = 0;
+    }
+};
 
 // two pinned host buffers + events for pipelined device-to-host copies
 struct PinnedPair {
@@ -451,6 +491,8 @@ struct Batch {
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
     DeviceBuffer<unsigned long long> dDigest;  // per-utterance digests (speechPlayer_batch_digest)
     PinnedPair bounce;                         // speechPlayer_batch_readAll into pageable memory
+    DeviceBuffer<FrameFacts> dFacts;           // klatt_frame_facts' output (frames that arrived by DMA are classified and hashed on the device)
+    PinnedBlock hFacts;                        // ... and where it lands on the host
     DeviceBuffer<int16_t> dDense;              // the utterances back to back (pcm_compact): what speechPlayer_batch_readAll copies out
     DeviceBuffer<long long> dDenseStart;       // [nUtt + 1] dense start of every utterance (prefix sum of the closed-form lengths)
     std::vector<long long> denseStart;         // the same on the host
@@ -520,7 +562,9 @@ struct TrackPlan {
 // planned in one pass (its fades are shared by few utterances, if at all: the parts would each make most of the tracks again, or
 // fill the budget with 400 MB of shapes and map nodes only for the one pass to find that nothing fits -- 0.4 s for 65 536
 // utterances with nothing in common, which is what such a batch costs without the parts).
-void plan_tracks_pass(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameMeta* meta,
+// `facts`: klatt_plan.h's 128-bit hash of every frame's shape values (indexed like `frames`): a frame seen before is recognised by
+// it, without gathering, hashing or comparing its 45 values again.
+void plan_tracks_pass(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameFacts* facts, const FrameMeta* meta,
                       const unsigned char* eligible, long long budgetMB, bool whole, std::atomic<unsigned long long>* sum, TrackPlan& out)
 {
     const long long frame0 = frameStart[0], nF = frameStart[nUtterances] - frame0;
@@ -558,6 +602,24 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
     };
     Shape zero; memset(&zero, 0, sizeof zero);
     shape_id(zero);
+    // frames seen before, by their hash: the id of their shape and (once somebody needed it) of the same values with the gain gated off
+    struct Key128 { unsigned long long a, b; bool operator==(const Key128& o) const { return a == o.a && b == o.b; } };
+    struct Key128Hash { size_t operator()(const Key128& k) const { return (size_t)k.a; } };
+    struct FrameIds { uint32_t plain, gated; };
+    std::unordered_map<Key128, FrameIds, Key128Hash> seen;
+    std::vector<uint32_t> gatedOf;          // shape id -> the id of its values with the gain gated off (0xFFFFFFFF: not asked for yet)
+    auto gated_id = [&](uint32_t id) -> uint32_t {
+        if (gatedOf.size() <= id) gatedOf.resize((size_t)id + 64, 0xFFFFFFFFu);
+        if (gatedOf[id] == 0xFFFFFFFFu) {
+            Shape g;
+            memcpy(g.v, &out.shapes[(size_t)id * kShapeStride], sizeof g.v);
+            g.v[kShapePreGain] = 0.0;
+            const uint32_t gid = shape_id(g);
+            if (gatedOf.size() <= id) gatedOf.resize((size_t)id + 64, 0xFFFFFFFFu);
+            gatedOf[id] = gid;
+        }
+        return gatedOf[id];
+    };
     // (the flat stages address the tracks with 32-bit byte offsets: below 4 GB, 2^28 entries)
     const unsigned long long budget = std::min((unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2), (1ull << 28) - (1ull << 21) - kTrackPad);
     std::vector<Fade> added;
@@ -593,17 +655,23 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
         for (long long k = frameStart[u]; k < frameStart[u + 1] && fits; ++k) {
             uint32_t fromId = prevId, toId;
             const uint32_t lastTo = prevId;
-            Shape to;
             if (meta[k].flags & FRAME_NULL) {
-                memcpy(to.v, &out.shapes[(size_t)prevId * kShapeStride], sizeof to.v);
-                to.v[kShapePreGain] = 0.0;                     // silence: the old values, the gain gated off (:59-63)
-                toId = shape_id(to);
+                toId = gated_id(prevId);                       // silence: the old values, the gain gated off (:59-63)
                 prevNull = true;
             } else {
-                const double* p = reinterpret_cast<const double*>(frames + k);
-                for (int i = 0; i < kShapeValues; ++i) to.v[i] = p[shape_param(i)];
-                toId = shape_id(to);
-                if (prevNull) { to.v[kShapePreGain] = 0.0; fromId = shape_id(to); }   // out of silence: the new values, from gain 0 (:64-67)
+                const Key128 fk{facts[k].h0, facts[k].h1};
+                auto it = seen.find(fk);
+                if (it == seen.end()) {
+                    Shape to;
+                    const double* p = reinterpret_cast<const double*>(frames + k);
+                    for (int i = 0; i < kShapeValues; ++i) to.v[i] = p[shape_param(i)];
+                    it = seen.emplace(fk, FrameIds{shape_id(to), 0xFFFFFFFFu}).first;
+                }
+                toId = it->second.plain;
+                if (prevNull) {                                // out of silence: the new values, from gain 0 (:64-67)
+                    if (it->second.gated == 0xFFFFFFFFu) it->second.gated = gated_id(toId);
+                    fromId = it->second.gated;
+                }
                 prevNull = false;
             }
             prevId = toId;
@@ -676,7 +744,7 @@ void parallel_ranges(long long n, long long grain, F fn)
 // look-ups per frame: 0.2 s for BASELINE configs[2] on one thread), and the parts' shapes and fades merged: equal fades of
 // different parts end up with one track.  If the merged tracks fit the budget that is the plan; if not -- or if the parts gave
 // up (plan_tracks_pass) -- the batch is planned again in one pass, whose order decides which utterances stay in.
-void plan_tracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameMeta* meta,
+void plan_tracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameFacts* facts, const FrameMeta* meta,
                  const unsigned char* eligible, long long budgetMB, TrackPlan& out)
 {
     const long long nF = frameStart[nUtterances];
@@ -687,7 +755,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     };
     const unsigned nThreads = host_threads();
     if (nThreads < 2 || nF < 200000 || nUtterances < (long long)nThreads * 64) {
-        plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
+        plan_tracks_pass(nUtterances, frameStart, frames, facts, meta, eligible, budgetMB, true, nullptr, out);
         return;
     }
     // A look at the first 128th of the batch before the threads start (the look-outs of plan_tracks_pass, whole = true): a batch
@@ -697,9 +765,9 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
         // (never past the batch: the threaded path is entered with as few as 2 x 64 utterances -- ADVICE r3)
         const long long nProbe = std::min<long long>(nUtterances, std::max<long long>(nUtterances / 128, 256));
         std::vector<unsigned char> none;
-        plan_tracks_pass(nProbe, frameStart, frames, meta, eligible, budgetMB, false, nullptr, probe);
+        plan_tracks_pass(nProbe, frameStart, frames, facts, meta, eligible, budgetMB, false, nullptr, probe);
         TrackPlan half;
-        plan_tracks_pass(nProbe / 2, frameStart, frames, meta, eligible, budgetMB, false, nullptr, half);
+        plan_tracks_pass(nProbe / 2, frameStart, frames, facts, meta, eligible, budgetMB, false, nullptr, half);
         const unsigned long long cap = std::min((unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2), (1ull << 28) - (1ull << 21) - kTrackPad);
         if (trace) fprintf(stderr, "[speechPlayer/plan] look: %llu entries after %lld utterances, %llu after %lld; budget %llu\n", half.entries, nProbe / 2, probe.entries, nProbe, cap);
         const long double scale = (long double)nUtterances / (long double)nProbe;
@@ -727,7 +795,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     std::vector<TrackPlan> part(nThreads);
     std::atomic<unsigned long long> sum{0};
     run_parts(nThreads, [&](unsigned t) {
-        plan_tracks_pass(cut[t + 1] - cut[t], frameStart + cut[t], frames, meta, eligible + cut[t], budgetMB, false, &sum, part[t]);
+        plan_tracks_pass(cut[t + 1] - cut[t], frameStart + cut[t], frames, facts, meta, eligible + cut[t], budgetMB, false, &sum, part[t]);
     });
     lap("parts planned");
     // merge: shapes by value, fades by (from, to, length)
@@ -740,7 +808,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     for (const TrackPlan& p : part) { eligibleAll += p.eligible; missedSize += p.missedSize; missedBudget += p.missedBudget; nShapesUpper += p.shapes.size() / kShapeStride; }
     if (missedBudget > 0) {
         part.clear();
-        plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
+        plan_tracks_pass(nUtterances, frameStart, frames, facts, meta, eligible, budgetMB, true, nullptr, out);
         return;
     }
     out.shapes.clear();
@@ -776,7 +844,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     }
     const unsigned long long budget = std::min((unsigned long long)std::max(budgetMB, 0ll) * (1ull << 20) / sizeof(double2), (1ull << 28) - (1ull << 21) - kTrackPad);
     if (out.entries > budget) {
-        plan_tracks_pass(nUtterances, frameStart, frames, meta, eligible, budgetMB, true, nullptr, out);
+        plan_tracks_pass(nUtterances, frameStart, frames, facts, meta, eligible, budgetMB, true, nullptr, out);
         return;
     }
     out.eligible = eligibleAll; out.missedSize = missedSize; out.missedBudget = 0;
@@ -1667,7 +1735,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (b->copyStream) { (void)hipStreamSynchronize(b->copyStream); (void)hipStreamDestroy(b->copyStream); }
     if (b->denseReady) (void)hipEventDestroy(b->denseReady);
     if (b->copyDone) (void)hipEventDestroy(b->copyDone);
-    b->dDense.release(); b->dDenseStart.release();
+    b->dDense.release(); b->dDenseStart.release(); b->dFacts.release(); b->hFacts.release();
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
     b->dFlatRef.release(); b->dSourceRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
@@ -1751,12 +1819,13 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     static thread_local RawVector<FlatRef> flatRefScratch;
     static thread_local RawVector<SourceRef> sourceRefScratch;
     static thread_local RawVector<DirectJob> directJobsScratch;
+    static thread_local RawVector<FrameFacts> factsScratch;
     struct ScratchRelease {
         long long nF;
         ~ScratchRelease()
         {
             if (nF > kScratchKeepFrames) {
-                RawVector<FrameMeta>().swap(metaScratch); RawVector<FlatRef>().swap(flatRefScratch);
+                RawVector<FrameMeta>().swap(metaScratch); RawVector<FlatRef>().swap(flatRefScratch); RawVector<FrameFacts>().swap(factsScratch);
                 RawVector<SourceRef>().swap(sourceRefScratch); RawVector<DirectJob>().swap(directJobsScratch);
             }
         }
@@ -1772,48 +1841,15 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         }
     });
     std::vector<UttDesc> utt((size_t)nUtterances);
-    // per utterance, ONE pass over its frames (on several host threads: the utterances are independent): its length, whether it needs
-    // its noise sources, whether it may skip the nasal pair, and -- for the tracks and the direct stages below -- whether all its
-    // parameters are finite (bit 0 of `shape`) and within the range of klatt_math.h (bit 1)
-    std::vector<unsigned char> shape((size_t)nUtterances, 0);
+    // per utterance, from the durations alone: its length (closed form, reference src/frame.cpp:41-80)
     std::atomic<long long> tooLong{-1};
-    const double maxBwDirect = 690.0 * b->sampleRate / M_PI, maxFDirect = 9900.0 * b->sampleRate / (2.0 * M_PI);
-    parallel_ranges(nUtterances, 512, [&](long long ua, long long ue) {
+    parallel_ranges(nUtterances, 4096, [&](long long ua, long long ue) {
         for (long long u = ua; u < ue; ++u) {
             unsigned long long len = 0;
-            // Noise sources and the parallel bank can be skipped for an utterance only if every frame has
-            // all three noise gains exactly zero (voiceTurbulenceAmplitude, aspirationAmplitude,
-            // fricationAmplitude) and no non-finite parameter that could turn 0*x into NaN.
-            // The skipped parallel bank contributes exactly 0 only while its coefficients are finite (a * 0 with a = inf
-            // is NaN, which the reference clips to 32000): a negative bandwidth makes exp(-pi bw / sr) grow without
-            // bound, so the bandwidths must be in [0, 1e6] and the frequencies bounded (reference :112-127).
-            // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152).
-            // With caNP == 0 in every frame that is x + (np - x) * 0 == x as long as np stays finite, and nothing else
-            // reads N0's or NP's memories: such an utterance may skip the pair.  np stays finite when the source is
-            // bounded (gains <= 1e30), N0's zero pair is not degenerate (bandwidth >= 1 Hz keeps 1 - b - c away from 0,
-            // reference :122) and NP does not grow (bandwidth >= 0).  Frequencies and bandwidths are bounded so that
-            // the coefficients stay finite.
-            bool needsNoise = false, noNasal = true, finite = true, bounded = true;
             for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
                 const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
-                len += std::max(m, f + 1) + 1;   // samples one request spans (follows from reference src/frame.cpp:41-80)
-                if (meta[k].flags & FRAME_NULL) continue;
-                const double* p = reinterpret_cast<const double*>(frames + k);
-                if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) needsNoise = true;
-                for (int i = 0; i < kNumParams; ++i)
-                    if (!std::isfinite(p[i])) finite = false;
-                for (int i = 25; i <= 30; ++i)
-                    if (!(std::fabs(p[i]) <= 1e6) || !(p[i + 6] >= 0.0) || !(p[i + 6] <= 1e6)) needsNoise = true;
-                if (p[23] != 0.0 || !(p[21] >= 1.0) || !(p[22] >= 0.0) || !(p[21] <= 1e6) || !(p[22] <= 1e6) ||
-                    !(std::fabs(p[13]) <= 1e6) || !(std::fabs(p[14]) <= 1e6) || !(std::fabs(p[5]) <= 1e30) || !(std::fabs(p[44]) <= 1e30) ||
-                    !(std::fabs(p[0]) <= 1e30) || !(std::fabs(p[46]) <= 1e30))
-                    noNasal = false;
-                // the direct stages evaluate exp / cos with klatt_math.h alone, whose range is |arg| <= 700 / 1e4: the frequencies and
-                // bandwidths of their utterances are bounded accordingly (no frame a speech front-end produces comes near)
-                for (int r = 0; r < kNumRes; ++r)
-                    if (!(std::fabs(p[shape_param(2 * r)]) <= maxFDirect) || !(std::fabs(p[shape_param(2 * r + 1)]) <= maxBwDirect)) bounded = false;
+                len += std::max(m, f + 1) + 1;   // samples one request spans
             }
-            if (!finite) needsNoise = true;
             if (len >= 0xFFFFFFFFull) { long long none = -1; tooLong.compare_exchange_strong(none, u); len = 0; }
             lens[u] = (uint32_t)len;
             memset(&utt[u], 0, sizeof(UttDesc));
@@ -1821,8 +1857,6 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             utt[u].nFrames = (uint32_t)(frameStart[u + 1] - frameStart[u]);
             utt[u].seed = noiseSeed ? noiseSeed[u] : (uint32_t)u;
             utt[u].length = (uint32_t)len;
-            utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : (noNasal ? UTT_NO_NASAL : 0u);
-            shape[u] = finite ? (bounded ? 3 : 1) : 0;
         }
     });
     if (tooLong.load() >= 0) { set_error("utterance %lld too long (4294967295 samples or more)", tooLong.load()); return -1; }
@@ -1860,6 +1894,28 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         } catch (const std::system_error&) {}
     }
     struct JoinEarly { std::thread& t; ~JoinEarly() { if (t.joinable()) t.join(); } } joinEarly{early};
+    // What the planning needs to know of every frame (klatt_plan.h: a word of flags, a 128-bit hash of its shape values), in ONE pass over
+    // the frames.  Frames that are on their way to the device as a DMA (page-locked memory) are looked at THERE, behind the copy on the
+    // same stream, and 24 bytes per frame come back: the host never reads them.  Pageable frames are read here, by the host's threads,
+    // while the staging thread copies them.
+    const double maxBwDirect = 690.0 * b->sampleRate / M_PI, maxFDirect = 9900.0 * b->sampleRate / (2.0 * M_PI);
+    const FrameFacts* facts = nullptr;
+    const bool factsOnDevice = framesPinned && earlyStarted;
+    if (factsOnDevice) {
+        if (b->dFacts.reserve((size_t)nF) || b->hFacts.ensure((size_t)nF * sizeof(FrameFacts))) { (void)hipStreamSynchronize(b->copyStream); return -1; }      // (the DMA reads the caller's frames: not while we return)
+        const unsigned grid = (unsigned)std::min<long long>((nF + 255) / 256, 1 << 16);
+        hipLaunchKernelGGL(klatt_frame_facts, dim3(grid), dim3(256), 0, b->copyStream, b->dFrames.ptr, b->dFacts.ptr, nF, maxFDirect, maxBwDirect);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(b->hFacts.ptr, b->dFacts.ptr, (size_t)nF * sizeof(FrameFacts), hipMemcpyDeviceToHost, b->copyStream));
+        facts = static_cast<const FrameFacts*>(b->hFacts.ptr);
+    } else if (nF > 0) {
+        RawVector<FrameFacts>& fv = factsScratch;      // (a reference: the worker threads must write the CALLER's scratch, not their own thread_local one)
+        fv.resize((size_t)nF);
+        parallel_ranges(nF, 1 << 13, [&](long long a, long long e) {
+            for (long long k = a; k < e; ++k) fv[k] = frame_facts(reinterpret_cast<const double*>(frames + k), maxFDirect, maxBwDirect);
+        });
+        facts = fv.data();
+    }
     long long total = 0, pool = 0;
     for (long long u = 0; u < nUtterances; ++u) {
         outStart[u] = pool;
@@ -1870,7 +1926,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     outStart[nUtterances] = pool;
     std::vector<long long> denseStart((size_t)nUtterances + 1);      // the utterances back to back: what speechPlayer_batch_readAll hands out
     { long long at = 0; for (long long u = 0; u < nUtterances; ++u) { denseStart[u] = at; at += (long long)lens[u]; } denseStart[nUtterances] = at; }
-    lap("meta, lengths, classification");
+    lap("meta, lengths, frame facts started");
     // An utterance's TIMING: a hash of its sequence of frame durations, fades and silences -- the same text at the same speed, whatever
     // the pitch, the voice or the noise seed.  Lanes with one timing dequeue and fade on the same samples (lane packing, below).
     std::vector<unsigned long long> timing((size_t)nUtterances);
@@ -1884,6 +1940,22 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             timing[u] = h;
         }
     });
+    // the facts are back (device path): per utterance, whether it needs its noise sources, whether it may skip the nasal pair, and -- for
+    // the tracks and the direct stages below -- whether all its parameters are finite (bit 0 of `shape`) and within the range of
+    // klatt_math.h (bit 1).  NULL frames carry no parameters of their own.
+    if (factsOnDevice) HIP_TRY(hipStreamSynchronize(b->copyStream));
+    std::vector<unsigned char> shape((size_t)nUtterances, 0);
+    parallel_ranges(nUtterances, 4096, [&](long long ua, long long ue) {
+        for (long long u = ua; u < ue; ++u) {
+            uint32_t fl = 0;
+            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k)
+                if (!(meta[k].flags & FRAME_NULL)) fl |= facts[k].flags;
+            const bool finite = !(fl & FACT_NONFINITE), needsNoise = (fl & FACT_NOISE) || !finite;
+            utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : (!(fl & FACT_NASAL) ? UTT_NO_NASAL : 0u);
+            shape[u] = finite ? (!(fl & FACT_UNBOUNDED) ? 3 : 1) : 0;
+        }
+    });
+    lap("classification");
     // A quiet utterance whose timing too few others share cannot fill a wavefront of the quiet kernels with lanes that fade together:
     // its wavefront would run every chunk sample by sample, evaluating exp / cos for whichever lane is fading (a few workgroups that
     // take longer than the whole flat launch: 24 ms for the 8192 quiet utterances of a batch with 65 536 different timings).  Such an
@@ -1916,7 +1988,7 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     }
     lap("eligibility");
     if (b->tracks && nF > 0) {
-        plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible.data(), b->trackBudgetMB, plan);
+        plan_tracks(nUtterances, frameStart, frames, facts, meta.data(), eligible.data(), b->trackBudgetMB, plan);
         lap("tracks planned");
         for (long long u = 0; u < nUtterances; ++u)
             if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED | (plan.kinds[u] << kUttKindShift);
@@ -1966,19 +2038,13 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     }
     RawVector<FlatRef>& flatRef = flatRefScratch;
     RawVector<SourceRef>& sourceRef = sourceRefScratch;
-    if (!plan.jobs.empty() || nDirectUtt > 0) {
-        if (!plan.jobs.empty()) flatRef.resize((size_t)nF);
-        sourceRef.resize((size_t)nF);
+    (void)sourceRef;      // (the source references are built on the device since round 5: klatt_source_refs, from the frames and durations there)
+    if (!plan.jobs.empty()) {
+        flatRef.resize((size_t)nF);
         parallel_ranges(nF, 1 << 16, [&](long long ka, long long ke) {
         for (long long k = ka; k < ke; ++k) {
             const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
-            if (!plan.jobs.empty()) flatRef[k] = FlatRef{(uint32_t)plan.ref[k].off, plan.ref[k].mask, meta[k].fadeSamples, (uint32_t)std::min<unsigned long long>(std::max(m, f + 1) + 1, 0xFFFFFFFFull)};
-            const bool isNullFrame = (meta[k].flags & FRAME_NULL) != 0;
-            const double* p = reinterpret_cast<const double*>(frames + k);
-            const double g0 = isNullFrame ? 0.0 : p[0], g46 = isNullFrame ? 0.0 : p[46];
-            // (volatile: the divisions are IEEE double divisions at run time, like the kernels' -- nothing folded, nothing reassociated)
-            volatile double num = g46 - g0, den = (double)meta[k].minSamples, one = 1.0, fd = (double)meta[k].fadeSamples;
-            sourceRef[k] = SourceRef{g0, isNullFrame ? 0.0 : num / den, one / fd, meta[k].userIndex, meta[k].flags & FRAME_NULL};
+            flatRef[k] = FlatRef{(uint32_t)plan.ref[k].off, plan.ref[k].mask, meta[k].fadeSamples, (uint32_t)std::min<unsigned long long>(std::max(m, f + 1) + 1, 0xFFFFFFFFull)};
         }
         });
     }
@@ -2072,7 +2138,6 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         }
         if (nTrackedUtt > 0 || nDirectUtt > 0) {
             if (b->dSourceRef.reserve((size_t)nF)) return -1;
-            HIP_TRY(hipMemcpyAsync(b->dSourceRef.ptr, sourceRef.data(), (size_t)nF * sizeof(SourceRef), hipMemcpyHostToDevice, b->stream));
         }
         if (nDirectUtt > 0) {
             const size_t nD = directJobs.size();
@@ -2098,6 +2163,14 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         if (framesPinned) HIP_TRY(hipStreamSynchronize(b->copyStream));
         if (early.joinable()) early.join();
         if (earlyRc) { set_error_code(SPEECHPLAYER_ERR_HIP); set_error("setUtterances: uploading the frames failed: %s", earlyErr.c_str()); return -1; }
+        if (nTrackedUtt > 0 || nDirectUtt > 0) {
+            // what the flat and direct source stages read at a dequeue (SourceRef: pitch, pitch increment, 1 / fade, index mark), from the
+            // frames and durations now resident: 32 bytes per frame that no longer cross the link, and no third pass of the host over the frames
+            const unsigned grid = (unsigned)std::min<long long>((nF + 255) / 256, 1 << 16);
+            hipLaunchKernelGGL(klatt_source_refs, dim3(grid), dim3(256), 0, b->stream, b->dFrames.ptr, b->dMeta.ptr, b->dSourceRef.ptr, nF);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipStreamSynchronize(b->stream));
+        }
         return 0;
     };
     if (upload()) {
@@ -2737,7 +2810,9 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
     std::vector<unsigned char> all;
     if (!eligible) { all.assign((size_t)nUtterances, 1); eligible = all.data(); }
     TrackPlan plan;
-    plan_tracks(nUtterances, frameStart, frames, meta.data(), eligible, budgetMB, plan);
+    std::vector<FrameFacts> facts((size_t)nF);
+    parallel_ranges(nF, 1 << 14, [&](long long a, long long e) { for (long long k = a; k < e; ++k) facts[k] = frame_facts(reinterpret_cast<const double*>(frames + k), 1e300, 1e300); });
+    plan_tracks(nUtterances, frameStart, frames, facts.data(), meta.data(), eligible, budgetMB, plan);
     for (long long k = 0; k < nF; ++k) {
         if (trackOff) trackOff[k] = plan.ref[k].off;
         if (trackMask) trackMask[k] = plan.ref[k].mask;

@@ -1,0 +1,118 @@
+// klatt_plan.h -- what speechPlayer_batch_setUtterances needs to know about a FRAME before it can plan a batch, as one function of
+// the frame's 47 values that runs on either side of the link.
+//
+// Planning a batch (klatt_engine.hip: classification of the utterances, plan_tracks) looked at every frame's 376 bytes twice on
+// the host: once to classify (does the utterance need its noise sources, may it skip the nasal pair, are its parameters finite and
+// within the range of klatt_math.h) and once to hash the 45 values a track depends on -- 0.6 GB per pass for BASELINE configs[2],
+// most of the call's CPU time.  frame_facts() is both in ONE pass: a word of flags and a 128-bit hash of the shape values.  The
+// host planner then works on 24 bytes per frame; when the frames arrive in page-locked memory (speechPlayer_hostAlloc) they cross
+// the link first and klatt_frame_facts evaluates the same function where they land (HBM-bound: the frames are read once at the
+// device's rate), so that the host never reads them at all.
+// The hash stands for the values: two frames with the same 128 bits are taken to hold the same 45 values (2^-128 per pair; the
+// planner used to compare the values themselves on every look-up, which is what reading the frames a second time was for).
+#pragma once
+
+#include <stdint.h>
+#include <string.h>
+
+#include "klatt_device.h"
+
+namespace klatt {
+
+struct FrameFacts {          // 24 B per frame
+    unsigned long long h0, h1;   // hash of the 45 shape values (klatt_device.h, shape_param), bit patterns
+    uint32_t flags;              // FACT_*
+    uint32_t pad;
+};
+constexpr uint32_t FACT_NOISE = 1u;        // a noise gain is non-zero, or the parallel bank's coefficients may not be finite
+constexpr uint32_t FACT_NONFINITE = 2u;    // some parameter is NaN or infinite
+constexpr uint32_t FACT_NASAL = 4u;        // the nasal pair is coupled in, or could not be skipped safely
+constexpr uint32_t FACT_UNBOUNDED = 8u;    // a frequency or bandwidth outside the range of klatt_math.h (the direct stages)
+
+__host__ __device__ inline bool fact_finite(double v)
+{
+    unsigned long long w;
+    memcpy(&w, &v, 8);
+    return (w & 0x7FF0000000000000ull) != 0x7FF0000000000000ull;
+}
+__host__ __device__ inline double fact_abs(double v) { return v < 0 ? -v : v; }      // (NaN stays NaN: every test below is written to fail on it)
+// key n of the hash (splitmix64 of n: a constant wherever n is one)
+__host__ __device__ constexpr unsigned long long fact_key(int n)
+{
+    unsigned long long z = (unsigned long long)(n + 1) * 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// high ^ low half of the 128-bit product
+__host__ __device__ inline unsigned long long fact_fold(unsigned long long a, unsigned long long c)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul64hi(a, c) ^ (a * c);
+#else
+    const unsigned __int128 m = (unsigned __int128)a * c;
+    return (unsigned long long)(m >> 64) ^ (unsigned long long)m;
+#endif
+}
+
+// p: the frame's 47 parameters (include/speechPlayer.h); maxF / maxBw: the direct stages' bounds for this sample rate
+__host__ __device__ inline FrameFacts frame_facts(const double* p, double maxF, double maxBw)
+{
+    FrameFacts o;
+    uint32_t fl = 0;
+    // Noise sources and the parallel bank can be skipped for an utterance only if every frame has all three noise gains exactly zero
+    // (voiceTurbulenceAmplitude, aspirationAmplitude, fricationAmplitude) and no non-finite parameter that could turn 0 * x into NaN.
+    if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) fl |= FACT_NOISE;
+    bool finite = true;
+    for (int i = 0; i < kNumParams; ++i) finite = finite && fact_finite(p[i]);
+    if (!finite) fl |= FACT_NONFINITE;
+    // The skipped parallel bank contributes exactly 0 only while its coefficients are finite (a * 0 with a = inf is NaN, which the
+    // reference clips to 32000): bandwidths in [0, 1e6], bounded frequencies (reference src/speechWaveGenerator.cpp:112-127).
+    for (int i = 25; i <= 30; ++i)
+        if (!(fact_abs(p[i]) <= 1e6) || !(p[i + 6] >= 0.0) || !(p[i + 6] <= 1e6)) fl |= FACT_NOISE;
+    // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152): with caNP == 0 in
+    // every frame that is x as long as np stays finite -- bounded source, N0's zero pair not degenerate, NP not growing.
+    if (p[23] != 0.0 || !(p[21] >= 1.0) || !(p[22] >= 0.0) || !(p[21] <= 1e6) || !(p[22] <= 1e6) ||
+        !(fact_abs(p[13]) <= 1e6) || !(fact_abs(p[14]) <= 1e6) || !(fact_abs(p[5]) <= 1e30) || !(fact_abs(p[44]) <= 1e30) ||
+        !(fact_abs(p[0]) <= 1e30) || !(fact_abs(p[46]) <= 1e30))
+        fl |= FACT_NASAL;
+    // the direct stages evaluate exp / cos with klatt_math.h alone, whose range is |arg| <= 700 / 1e4: frequencies (parameters 7..14,
+    // 25..30) and bandwidths (15..22, 31..36) bounded accordingly
+    bool inRange = true;
+    for (int i = 7; i <= 14; ++i) inRange = inRange && (fact_abs(p[i]) <= maxF) && (fact_abs(p[i + 8]) <= maxBw);
+    for (int i = 25; i <= 30; ++i) inRange = inRange && (fact_abs(p[i]) <= maxF) && (fact_abs(p[i + 6]) <= maxBw);
+    if (!inRange) fl |= FACT_UNBOUNDED;
+    // The 45 shape values are parameters 1..45 (klatt_device.h, shape_param: every parameter but the two pitches).  Two independently
+    // keyed multiply-fold sums over them, a pair of values per 64 x 64 -> 128-bit product (every position has keys of its own: the
+    // same values in other places are another frame), each then avalanched: ~23 multiplies per word instead of a chain of 45.
+    unsigned long long x = 0x9E3779B97F4A7C15ull, y = 0xC2B2AE3D27D4EB4Full;
+#pragma unroll
+    for (int i = 0; i < 46; i += 2) {      // (unrolled: the keys are literals)
+        unsigned long long w0, w1 = 0;
+        memcpy(&w0, &p[1 + i], 8);
+        if (i + 1 < kShapeValues) memcpy(&w1, &p[2 + i], 8);
+        x ^= fact_fold(w0 ^ fact_key(2 * i), w1 ^ fact_key(2 * i + 1));
+        y ^= fact_fold(w0 ^ fact_key(2 * i + 100), w1 ^ fact_key(2 * i + 101));
+    }
+    x ^= x >> 32; x *= 0xD6E8FEB86659FD93ull; x ^= x >> 32;
+    y ^= y >> 31; y *= 0xBF58476D1CE4E5B9ull; y ^= y >> 29;
+    o.h0 = x; o.h1 = y; o.flags = fl; o.pad = 0;
+    return o;
+}
+
+#if defined(__HIPCC__)
+// one thread per frame: 376 bytes in, 24 out (HBM-bound; a wavefront's loads cover 24 KB of consecutive frames)
+__global__ void __launch_bounds__(256) klatt_frame_facts(const double* __restrict__ frames, FrameFacts* __restrict__ out, long long nFrames, double maxF, double maxBw)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nFrames; k += stride) {
+        double p[kNumParams];
+        const double* src = frames + k * kNumParams;
+#pragma unroll
+        for (int i = 0; i < kNumParams; ++i) p[i] = src[i];
+        out[k] = frame_facts(p, maxF, maxBw);
+    }
+}
+#endif
+
+}  // namespace klatt

@@ -1560,6 +1560,9 @@ def test_pcm_delivery_paths_agree():
     bq.setUtterances(fs, batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], seeds)
     bq.synthesize()
     assert bq.digest() == bp.digest()
+    # ... and the same PLAN: page-locked frames are classified and hashed on the device (klatt_frame_facts), pageable ones by the host's
+    # threads (klatt_plan.h, the same function): groups, tracks and direct utterances must come out alike
+    assert bq.kernelInfo() == bp.kernelInfo()
     with pytest.raises(RuntimeError):
         bq.readAllAsync(np.zeros(total, np.int16))        # not page-locked
     bq.close(); bp.close()

@@ -486,6 +486,20 @@ class NodePlayer(object):
     def getLastIndex(self, u):
         return self._dll.speechPlayer_node_getLastIndex(self._h, u)
 
+    def digests(self):
+        """Per-utterance digests of the PCM in the node batch's utterance order, computed where each shard's PCM lives
+        (speechPlayer_batch_digest on the shards: nothing is copied but 8 bytes per utterance)."""
+        import ctypes
+        out = np.zeros(max(self.nUtterances, 1), dtype=np.uint64)
+        for d, (first, count, _, _) in enumerate(self.shards()):
+            part = self._dll.speechPlayer_node_part(self._h, d)
+            if not part:
+                raise RuntimeError("speechPlayer_node_part(%d) failed: %s" % (d, _native.last_error()))
+            per = np.zeros(max(count, 1), dtype=np.uint64)
+            self._check(self._dll.speechPlayer_batch_digest(part, per.ctypes.data, None))
+            out[first:first + count] = per[:count]
+        return out[:self.nUtterances]
+
     def time(self, launches):
         ms = np.zeros(launches, dtype=np.float32)
         self._check(self._dll.speechPlayer_node_time(self._h, launches, ms.ctypes.data))

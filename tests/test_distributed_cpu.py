@@ -97,3 +97,45 @@ def test_bench_starts_its_own_ranks(tmp_path):
         assert b[0] == 0 and b[2] == 2 * per_gpu
         assert abs(int(counts[:b[1]].sum()) - int(counts[b[1]:].sum())) <= 2 * int(counts.max())
         assert e["value"] is None and e["launches"] == 5
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_dry_run(tmp_path):
+    """The run the driver makes on a whole node -- `bench.py --gpus 8` -- with everything but the GPU launches (--dry-run): eight rank
+    processes rendezvous, the node's batch (8 x 65 536 utterances) is dealt into eight contiguous shards whose SAMPLE counts agree
+    within 0.1 %, every rank builds its own shard, the reductions give the node's totals; BASELINE configs[3] (10^6 utterances) and
+    configs[4] (256 variants x 16 384) are dealt at their node sizes the same way.  No rank may need more than 4 GB of host memory
+    (eight of them share a node's RAM, and the driver's box has a quota)."""
+    import json
+    import resource
+    import subprocess
+    from nvspeechplayer_amd import workloads
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    before = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2", "--warmup", "0"],
+                                  env=env, cwd=str(tmp_path), timeout=850)
+    peak_kb = resource.getrusage(resource.RUSAGE_CHILDREN).ru_maxrss      # the largest of the processes waited for: bench.py's ranks among them
+    lines = [l for l in out.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    c = d["config"]
+    assert d["n_gpus"] == 8 and d["dry_run"] is True and d["scaling"] == "weak" and c["world_size"] == 8 and c["process_group"] == "gloo"
+    assert c["node_utterances"] == 8 * 65536
+
+    def balanced(bounds, counts, what):
+        assert len(bounds) == 9 and bounds[0] == 0 and bounds[-1] == len(counts) and all(b1 > b0 for b0, b1 in zip(bounds, bounds[1:]))
+        csum = np.concatenate([[0], np.cumsum(counts, dtype=np.int64)])
+        shares = np.diff(csum[np.asarray(bounds)])
+        assert int(shares.sum()) == int(counts.sum())
+        spread = float(shares.max() - shares.min()) / float(shares.mean())
+        assert spread < 1e-3, "%s: shards differ by %.3f %% of their samples" % (what, 100 * spread)
+        return shares
+    counts = workloads.sample_counts("cfg2", 8 * 65536)
+    shares = balanced(c["shard_bounds"], counts, "cfg2 x 8")
+    assert c["node_samples"] == int(counts.sum()) == int(d["total_samples_all_ranks"]) and c["samples_per_gpu"] == int(shares[0])
+    for key, per_gpu, wl in (("cfg3_node", 125000, "cfg3"), ("cfg4_node", 32 * 16384, "cfg4")):
+        e = d[key]
+        counts = workloads.sample_counts(wl, 8 * per_gpu)
+        assert e["node_utterances"] == 8 * per_gpu and e["node_samples"] == int(counts.sum()) == int(e["total_samples_all_ranks"])
+        balanced(e["shard_bounds"], counts, key)
+    assert peak_kb < 4 * 1024 * 1024 or peak_kb == before, "a rank's peak RSS was %.1f GB" % (peak_kb / 1048576.0)

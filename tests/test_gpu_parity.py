@@ -1566,3 +1566,37 @@ def test_pcm_delivery_paths_agree():
     with pytest.raises(RuntimeError):
         bq.readAllAsync(np.zeros(total, np.int16))        # not page-locked
     bq.close(); bp.close()
+
+
+@pytest.mark.gpu
+def test_eight_shards_of_a_node_sized_share():
+    """What the driver's 8-GPU run does to BASELINE configs[3], rehearsed on one device: the per-GPU share (125 000 short utterances)
+    as ONE batch and as a NodePlayer of EIGHT shards (eight Batch objects, eight streams, eight planning threads on device 0): the
+    deal is the Python helper's, balanced within 0.1 % of the samples, and every utterance's PCM digest and a strided sample of the
+    index marks equal the single batch's.  (Nothing above three shards had ever run before round 5.)"""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    from nvspeechplayer_amd.sharding import shard_bounds
+    b = workloads.make("cfg3", 125000)
+    n = b.n_utt
+    b["index"] = np.where(np.arange(len(b["min"])) % 5 == 2, np.arange(len(b["min"]), dtype=np.int32) % 997, -1).astype(np.int32)
+    one = eng.BatchPlayer(b["sr"])
+    one.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+    one.synthesize()
+    _, ref = one.digest(per_utterance=True)
+    node = eng.NodePlayer(b["sr"], [0] * 8)
+    node.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+    assert node.totalSamples == one.totalSamples
+    sh = node.shards()
+    lens = b.sample_counts()
+    assert len(sh) == 8 and [a for a, _, _, _ in sh] + [n] == list(shard_bounds(lens, 8))
+    shares = np.array([s for _, _, s, _ in sh], dtype=np.float64)
+    assert shares.sum() == lens.sum() and (shares.max() - shares.min()) / shares.mean() < 1e-3
+    node.synthesize()
+    got = node.digests()
+    assert np.array_equal(got, ref), "%d utterances differ" % int(np.count_nonzero(got != ref))
+    for u in range(0, n, 1237):
+        assert node.getLastIndex(u) == one.getLastIndex(u), u
+    for u in (0, sh[3][0], sh[3][0] - 1, n - 1):          # across a shard boundary: the PCM itself
+        assert np.array_equal(node.read(u), one.read(u)), u
+    node.close(); one.close()

@@ -35,10 +35,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-# f64 VALU issue: 256 CUs x 4 SIMDs at 2.4 GHz; a wave64 f64 instruction occupies a SIMD for 4 cycles by the datasheet
-# (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop x 2.4 GHz) and for 4.8 measured (profiles/r1_ubench_issue_rates.txt)
-SIMDS, CLOCK_HZ, F64_CYCLES_SPEC, F64_CYCLES_MEASURED = 1024, 2.4e9, 4.0, 4.8
-PMC_FILE = os.path.join(ROOT, "profiles", "r4_pmc.json")
+# VALU issue: 256 CUs x 4 SIMDs; a wave64 f64 instruction occupies its SIMD for 4 cycles (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop
+# x 2.4 GHz), any other VALU instruction for 2 (profiles/r1_ubench_issue_rates.txt: ~2.0 / ~1.1 ns at the clock the chip holds under
+# this load, 2.06-2.07 GHz -- GRBM_GUI_ACTIVE / 8 XCDs / duration, profiles/r5_pmc.json "held_clock_hz")
+SIMDS, F64_ISSUE_CYCLES, OTHER_ISSUE_CYCLES, CLOCK_HZ_HELD_DEFAULT = 1024, 4.0, 2.0, 2.07e9
+PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc.json")
 
 
 def parse(argv=None):
@@ -342,6 +343,7 @@ def main():
     samples = int(batch.sample_counts().sum())
     bp = None
     t_set = t_set_again = 0.0
+    t_set_pinned = None
     if not dry:
         bp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
         t_set = time.perf_counter()
@@ -355,6 +357,17 @@ def main():
         bp.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"],
                          batch["isnull"], batch["seeds"])
         t_set_again = time.perf_counter() - t_set_again
+        t_set_pinned = None
+        if world == 1 and not args.no_extras:
+            # and with the frames in page-locked memory the library handed out (speechPlayer_hostAlloc): one DMA, classified and hashed on the device
+            from nvspeechplayer_amd import host_array
+            fr = host_array(batch["frames"].shape, np.float64)
+            fr[...] = batch["frames"]
+            for _ in range(2):
+                t_set_pinned = time.perf_counter()
+                bp.setUtterances(batch["frame_start"], fr, batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
+                t_set_pinned = time.perf_counter() - t_set_pinned
+            del fr
 
     def barrier():
         if not dry:
@@ -446,6 +459,7 @@ def main():
                        "world_size": 1 if dist is None else dist.get_world_size(),
                        "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else None,
                        "host": {"build_batch_s": round(t_build, 3), "set_utterances_s": round(t_set, 3), "set_utterances_again_s": round(t_set_again, 3),
+                                "set_utterances_page_locked_frames_s": None if t_set_pinned is None else round(t_set_pinned, 3),
                                 "note": "outside the timed region: the frame producer (build) and speechPlayer_batch_setUtterances (classification, "
                                         "lane packing, track planning, uploads); a batch is set once and synthesised many times"},
                        "parallelism": "node batch cut into %d contiguous shards of near-equal sample count, one process per GPU, no collective on the data path" % world},
@@ -462,8 +476,9 @@ def main():
                     "kernel": kernel_name(info), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
                     "wavefronts": info["wavefronts"], "vgprs": info["vgprs"], "lds_bytes": info["lds_bytes"], "scratch_bytes": info["scratch_bytes"],
                     "note": "declared bound: HBM (2 B per sample + 388 B per frame). What binds is f64 VALU issue with two barrier-coupled waves per SIMD: "
-                            "~138 VALU instructions per 64-sample row (of which ~100 f64), issued 72 % of the cycles at the held clock of 2.06 GHz "
-                            "(profiles/r4_cfg2_exact_summary.txt) -- see `valu` and DESIGN.md section 4, Roofline"}
+                            "see `valu` (ONE figure: issue cycles of the VALU instructions executed / issue cycles the 1024 SIMDs had at the held clock) "
+                            "and DESIGN.md section 4, Roofline.  The headline leans on the benchmark's duplicates (8 sentences x 64 pitches share 105 tracks): "
+                            "`headline_without_tracks` and `general_case` on this line are the same sample count without that help"}
             # HBM bytes and VALU instructions per launch come from the PMC passes of tools/profile.sh (bench.py cannot run rocprofv3 on
             # itself); the file names the engine sources it was collected from, and is ignored when they have changed since
             try:
@@ -472,22 +487,29 @@ def main():
                 if ent and not args.utterances and world == 1 and args.mode == 0 and args.layout == -1:
                     if pj.get("engine_sources_sha") == engine_source_digest():
                         roof["traffic"] = ent["hbm_bytes_per_launch"]
-                        roof["traffic_source"] = "profiles/r4_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
+                        roof["traffic_source"] = "profiles/r5_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
                         insts = ent["valu_insts_per_launch"]
-                        peak = SIMDS * CLOCK_HZ / F64_CYCLES_MEASURED
-                        roof["valu"] = {"insts_per_launch": insts, "achieved": insts / (k_ms * 1e-3), "peak": peak,
-                                        "unit": "wave64 VALU instructions/s", "frac": insts / (k_ms * 1e-3) / peak,
-                                        "peak_spec": SIMDS * CLOCK_HZ / F64_CYCLES_SPEC,
-                                        "insts_per_64_samples": insts * 64.0 / samples,
-                                        "source": "profiles/r4_pmc.json SQ_INSTS_VALU; peak = 1024 SIMDs x 2.4 GHz / 4.8 cycles per f64 wave instruction "
-                                                  "(measured; 4 by the datasheet = peak_spec); instructions that are not f64 (a quarter to a third of them) issue in about half that, so frac is an upper bound on issue-slot use"}
+                        f64i = ent.get("valu_f64_insts_per_launch")
+                        clock = ent.get("held_clock_hz") or CLOCK_HZ_HELD_DEFAULT
+                        if f64i is None:
+                            f64i = insts        # (no f64 pass in the file: every instruction billed as f64 -- an upper bound)
+                        cycles = F64_ISSUE_CYCLES * f64i + OTHER_ISSUE_CYCLES * (insts - f64i)
+                        avail = SIMDS * clock * (k_ms * 1e-3)
+                        roof["valu"] = {"insts_per_launch": insts, "f64_insts_per_launch": f64i, "issue_cycles_per_launch": cycles,
+                                        "held_clock_hz": clock, "frac": cycles / avail, "frac_if_every_instruction_were_f64": F64_ISSUE_CYCLES * insts / avail,
+                                        "unit": "VALU issue cycles used / available", "insts_per_64_samples": insts * 64.0 / samples,
+                                        "formula": "(4 x f64 wave-instructions + 2 x other VALU wave-instructions) / (1024 SIMDs x held clock x kernel_ms); "
+                                                   "counts: SQ_INSTS_VALU and SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 per launch (separate rocprofv3 --pmc passes), "
+                                                   "clock: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration -- all from profiles/r5_pmc.json, collected on these kernel sources"}
                     else:
-                        roof["traffic_source"] = "profiles/r4_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
+                        roof["traffic_source"] = "profiles/r5_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
             except Exception:
                 pass
             out["roofline"] = roof
             if world == 1 and args.mode == 0 and not args.no_extras:
-                # same batch in MODE_FAST (fused multiply-adds; identical PCM on every test so far, not guaranteed bit-exact)
+                # same batch in MODE_FAST (fused multiply-adds; held to <= 1 LSB and <= 5 one-LSB differences per million samples against the
+                # oracle, not bit-exact: the tracked stages measured 0 differences on the test corpus, the direct stages' pole recurrences 36 in
+                # 8.5 M samples of 350 000-sample fades)
                 bp.setOption("mode", 1)
                 bp.time(1)
                 fast_ms = float(np.mean(bp.time(max(20, args.steps))))
@@ -539,6 +561,11 @@ def main():
                 out["distinct"] = dict(timed_mode(dst, 0, 1), mode_fast=timed_mode(dst, 1, 1), direct_forced=timed_mode(dst, 0, 2), direct_forced_fast=timed_mode(dst, 1, 2))
                 out["jittered_durations"]["mode_fast"] = timed_mode(jit, 1, 1)
                 out["jittered_durations"]["direct_fast"] = timed_mode(jit, 1, 2, tracks=0)
+                # the three numbers that belong together: the headline, the same batch without its tracks, the general case
+                out["headline_without_tracks"] = dict(out["tracks_off"], what="the benchmarked batch with `tracks` off: every stage interpolates and evaluates exp / cos itself")
+                out["general_case"] = dict({k: v for k, v in out["all_different"].items() if k != "legacy"},
+                                           what="nothing shared, nothing aligned (workloads.all_different: every frame's duration, fade and formants scaled by factors of its own): "
+                                                "the direct stages, two workgroups per CU; mode_fast: pole recurrences instead of polynomials")
             if world == 1 and not args.utterances and not args.no_extras:
                 # the other single-GPU configuration (BASELINE configs[1], 4096 steady vowels) and its recipe at 65 536 utterances
                 bp.close()

@@ -78,9 +78,6 @@ namespace klatt {
 #ifndef KLATT_DIRECT_LEAN_UNROLL_FAST
 #define KLATT_DIRECT_LEAN_UNROLL_FAST 4  // MODE_FAST, two workgroups per CU (2: 21.1, 1: 22.1 instead of 20.2 ms)
 #endif
-#ifndef KLATT_DIRECT_LEAN_STEADY_UNROLL
-#define KLATT_DIRECT_LEAN_STEADY_UNROLL 4
-#endif
 
 // A pair of doubles in two adjacent register pairs: the unit a record entry is loaded in (global_load_dwordx4 into the state itself)
 typedef double dpair __attribute__((ext_vector_type(2)));
@@ -274,13 +271,10 @@ struct DirectState {
     // One sample of resonator r (reference src/speechWaveGenerator.cpp:128-135).  MODE_EXACT: ((a in) + (b z1)) + (c z2), each operation
     // rounded by itself.  The lean stages of MODE_FAST, whose a IS 1 - b - c, take in + b (z1 - in) + c (z2 - in): the same value with
     // four operations instead of five (two for a), and no product with a, the small difference of large terms.
-#ifndef KLATT_DIRECT_FAST_DOT
-#define KLATT_DIRECT_FAST_DOT 1
-#endif
     __device__ __forceinline__ double step(int r, double in)
     {
         double y;
-        if (KLATT_DIRECT_FAST_DOT && MODE == MODE_FAST && !keepsA(r)) y = __builtin_fma(bc[r].y, z2[r] - in, __builtin_fma(bc[r].x, z1[r] - in, in));
+        if (MODE == MODE_FAST && !keepsA(r)) y = __builtin_fma(bc[r].y, z2[r] - in, __builtin_fma(bc[r].x, z1[r] - in, in));
         else y = dot3<MODE>(a(r), in, b(r), z1[r], c(r), z2[r]);
         z2[r] = z1[r]; z1[r] = y;
         return y;
@@ -478,7 +472,7 @@ struct In2 { double a, b; };
 struct In3 { double a, b, c; };
 template <int MODE, bool LEAN> struct DirectUnroll {
     static constexpr int kMixed = LEAN ? (MODE == MODE_FAST ? KLATT_DIRECT_LEAN_UNROLL_FAST : KLATT_DIRECT_LEAN_UNROLL) : (MODE == MODE_FAST ? KLATT_DIRECT_UNROLL_FAST : KLATT_DIRECT_UNROLL);
-    static constexpr int kSteady = LEAN ? KLATT_DIRECT_LEAN_STEADY_UNROLL : KLATT_DIRECT_STEADY_UNROLL;
+    static constexpr int kSteady = KLATT_DIRECT_STEADY_UNROLL;      // (the lean stages have no steady loop of their own)
 };
 template <class DD, int MODE, int CH, bool LEAN, class FLoad, class FBody, class FChunk>
 __device__ __forceinline__ void direct_loop(int depth, int nIter, int nChunks, int stampSlot, DirectState<DD, MODE, LEAN>& f, const DirectCtx& X, FLoad load, FBody body, FChunk perChunk)
@@ -752,22 +746,6 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     int stage = wave;
-#ifndef KLATT_DIRECT_PAIRING
-#define KLATT_DIRECT_PAIRING 1
-#endif
-#ifndef KLATT_DIRECT_PAIRS_SEL
-#define KLATT_DIRECT_PAIRS_SEL 1
-#endif
-#if KLATT_DIRECT_PAIRS_SEL == 1
-#define KLATT_DIRECT_PAIRS_FAST1 {2, 1, 0, 6, 7, 3, 5, 4}
-#elif KLATT_DIRECT_PAIRS_SEL == 4
-#define KLATT_DIRECT_PAIRS_FAST1 {2, 1, 7, 6, 5, 3, 0, 4}
-#elif KLATT_DIRECT_PAIRS_SEL == 5
-#define KLATT_DIRECT_PAIRS_FAST1 {2, 6, 7, 1, 5, 4, 0, 3}
-#else
-#define KLATT_DIRECT_PAIRS_FAST1 {7, 1, 5, 2, 6, 0, 3, 4}
-#endif
-#if KLATT_DIRECT_PAIRING
     {
         const uint32_t hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID: wave slot [3:0], SIMD [5:4]
         const uint32_t simd = (hw >> 4) & 3u;
@@ -776,16 +754,16 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
         rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
         __syncthreads();
         const bool two = simdCount[0] == 2u && simdCount[1] == 2u && simdCount[2] == 2u && simdCount[3] == 2u;
-        // heavy with light: MODE_EXACT T5 + T3 | T7 + T4 | T0 + T2 | T6 + T1;
-        // MODE_FAST (layout 1): final + glottal | parallel 1, 2 + nasal pair | parallel 3, 4 + phase | the two cascade stages
-        constexpr int kPairsExact[8] = {5, 3, 7, 4, 0, 2, 6, 1}, kPairsFast0[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsFast1[8] = KLATT_DIRECT_PAIRS_FAST1;
+        // heavy with light (same-run A/B of the candidates at two workgroups per CU: profiles/r5_direct_ab.txt):
+        // MODE_EXACT T5 + T3 | T7 + T4 | T0 + T2 | T6 + T1;  MODE_FAST (layout 1): nasal pair + glottal | phase + parallel 3, 4 |
+        // final + first cascade stage | parallel 1, 2 + second cascade stage
+        constexpr int kPairsExact[8] = {5, 3, 7, 4, 0, 2, 6, 1}, kPairsFast0[8] = {1, 2, 0, 3, 5, 4, 7, 6}, kPairsFast1[8] = {2, 1, 0, 6, 7, 3, 5, 4};
         const int key = (int)(simd * 2u + (rank & 1u));
         int pick = wave;
 #pragma unroll
         for (int k = 0; k < 8; ++k) if (key == k) pick = MODE != MODE_FAST ? kPairsExact[k] : (LAY == 1 ? kPairsFast1[k] : kPairsFast0[k]);
         stage = __builtin_amdgcn_readfirstlane(two ? pick : wave);
     }
-#endif
     if (wave == 0) atomicMax(maxLenP, d.length);
     __syncthreads();
     if (stage == FINAL) { rowBase[lane] = d.outStart; rowCount[lane] = 0; }   // read by this wave only

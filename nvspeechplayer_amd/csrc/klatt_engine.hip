@@ -869,9 +869,9 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     lap("merged");
 }
 
-// Timing-only experiment switches (KLATT_EXP & 1 / & 4 in klatt_systolic.h, KLATT_LP_EXP in klatt_systolic.h / klatt_lanepipe.h) build a
-// library with the same ABI whose PCM is garbage: such a build refuses to hand PCM out, it only times.
-#if (KLATT_LP_EXP != 0) || ((KLATT_EXP & ~8) != 0)
+// (Timing-only experiment builds -- wrong PCM, kept as a patch under tools/variants/ since round 5 -- define KLATT_TIMING_ONLY_BUILD: such a
+// library refuses to hand PCM out, it only times.  ADVICE r3.)
+#ifdef KLATT_TIMING_ONLY_BUILD
 constexpr bool kTimingOnlyBuild = true;
 #else
 constexpr bool kTimingOnlyBuild = false;
@@ -880,7 +880,7 @@ bool refuse_timing_only(const char* what)
 {
     if (!kTimingOnlyBuild || getenv("SPEECHPLAYER_ALLOW_TIMING_ONLY_PCM")) return false;
     set_error_code(SPEECHPLAYER_ERR_ARGUMENT);
-    set_error("%s: this library was built with a timing-only experiment switch (KLATT_EXP / KLATT_LP_EXP); its PCM is not valid", what);
+    set_error("%s: this library was built with a timing-only experiment switch; its PCM is not valid", what);
     return true;
 }
 

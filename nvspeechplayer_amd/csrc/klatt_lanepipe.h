@@ -243,18 +243,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_lanepipe(const Ke
                 const double in = lp_hand_over(out, pre);
                 out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);
                 keep[i] = out;
-                if (i == CH - 1 && last && !(KLATT_LP_EXP & 2)) {
-                    if (KLATT_LP_EXP & 4) {      // timing only: 16-byte stores, half as many
+                if (i == CH - 1 && last) {
 #pragma unroll
-                        for (int j = 0; j < CH; j += 2)
-                            *reinterpret_cast<double2*>(reinterpret_cast<uintptr_t>(&LP_Y(c * CH + j)) & ~(uintptr_t)15) = make_double2(keep[j], keep[j + 1]);
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < CH; ++j) LP_Y(c * CH + j) = keep[j];
-                    }
+                    for (int j = 0; j < CH; ++j) LP_Y(c * CH + j) = keep[j];
                 }
             },
-            [&](int c, int i) { return (KLATT_LP_EXP & 8) ? 0.25 : LP_X(c, i); },      // & 8, timing only: no input loads
+            [&](int c, int i) { return LP_X(c, i); },
             [&](int c, int i, bool, double) {
                 const double in = lp_hand_over(out, LP_X(c, i));
                 out = resonate<MODE>(f.z1[0], f.z2[0], f.ra[0], f.rb[0], f.rc[0], in);

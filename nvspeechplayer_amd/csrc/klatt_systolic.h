@@ -59,19 +59,10 @@ namespace klatt {
 #define KLATT_STR2(x) #x
 #define KLATT_STR(x) KLATT_STR2(x)
 
-#ifndef KLATT_EXP
-#define KLATT_EXP 0             // timing experiments of the flat stages (wrong PCM): 1 rows without loads, 4 no fade ever starts, 16 one load per row; (same PCM) 8 every chunk a mixed one
-#endif
 #ifndef KLATT_FLAT_EXHAUSTIVE
 #define KLATT_FLAT_EXHAUSTIVE 1 // flat launches: the final stage is the chain's unconditional last branch, so that the compiler sees that a flat launch
                                 // runs none of the untracked stages (it cannot tell that a stage number is 0..3): the kernel is half the code, 245
                                 // VGPRs instead of 256 and NO scratch instead of 128 bytes per lane (0: the test `stage == 2`, as before)
-#endif
-#ifndef KLATT_FLAT_BUFS
-#define KLATT_FLAT_BUFS 2       // buffers per pipe of the flat stages (more than 2 only with KLATT_FLAT_FREE: the barrier keeps the stages within one chunk)
-#endif
-#ifndef KLATT_FLAT_XBUFS
-#define KLATT_FLAT_XBUFS KLATT_FLAT_BUFS
 #endif
 constexpr int kStages = 4;
 #ifndef KLATT_FLAT_SOURCE
@@ -82,8 +73,8 @@ constexpr int kStages = 4;
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
 template <bool NOISE, int CH, bool FLAT = false>
 struct SysLds {
-    static constexpr int kBufs = FLAT ? KLATT_FLAT_BUFS : 2;               // buffers of a pipe
-    static constexpr int kBufsX = FLAT ? KLATT_FLAT_XBUFS : 2;             // ... of pipe X (S0 -> S1), the first in memory
+    static constexpr int kBufs = 2;                                        // buffers of a pipe (the barrier keeps the stages within one chunk of each other)
+    static constexpr int kBufsX = 2;                                       // ... of pipe X (S0 -> S1), the first in memory
     static constexpr int kBufBytes = CH * kLanes * (FLAT ? (int)sizeof(sig_t) : 8);
     static constexpr int kPipeBytes = kBufs * kBufBytes;
     static constexpr int kNumPipes = NOISE ? 4 : 3;
@@ -92,7 +83,7 @@ struct SysLds {
     static constexpr int kRowBase = kTileOff + kLanes * kTileStride;
     static constexpr int kRowCount = kRowBase + kLanes * 8;
     static constexpr int kMaxLen = kRowCount + kLanes * 4;
-    static constexpr int kSync = kMaxLen + 16;         // FLAT, KLATT_FLAT_FREE: {produced, consumed} of the pipes X, O, A + B; a give-up flag
+    static constexpr int kSync = kMaxLen + 16;         // eight words the waves use while they pick their stages
     static constexpr int kFrames = kSync + 32;
     // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
     // flat launches (FLAT): the stages take everything from the tracks and keep no fade end points: 0, 0, 0, 0
@@ -509,11 +500,7 @@ struct Stamps {
 // the event steps need the state machine sample by sample; the run length comes from a bisection with ballots.  (Off for
 // the noisy kernels: the extra code costs them more than the runs save, cfg2 15.8 -> 16.8 ms.)  DELAY: lanes start `delay`
 // steps late (the lane-pipelined kernel's skew).  STREAM: the launch runs exactly A.maxSamples steps (live handles).
-// timing experiments (results are garbage): KLATT_LP_EXP & 1: the chunk loop without its barriers; & 2: the lane-pipelined filter waves store nothing
-#ifndef KLATT_LP_EXP
-#define KLATT_LP_EXP 0
-#endif
-#define STAGE_SYNC() do { if (!(KLATT_LP_EXP & 1)) __syncthreads(); } while (0)
+#define STAGE_SYNC() __syncthreads()
 template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_>
 struct LoopKnobs {
     static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_;
@@ -722,66 +709,21 @@ struct FlatDesc {
     static constexpr uint32_t USUAL = USUAL_, USUAL2 = USUAL2_;
 };
 
-// ---- hand-overs of the flat stages: the workgroup barrier, or counters per pipe (KLATT_FLAT_FREE) ---------------------------------
-// With the barrier every stage waits, in every iteration, for the slowest stage OF THAT ITERATION -- and which one that is changes
-// from chunk to chunk (a stage in a mixed chunk beside three in steady ones): the stamps show four stages within 15 % of each other
-// in work and each waiting 23-34 % of its time (profiles/r4_stage_balance.txt).  KLATT_FLAT_FREE = 1 replaces the barrier by two
-// counters per pipe in LDS -- chunks written by its producer, chunks read by its consumer -- so that a stage starts chunk c as soon as
-// ITS inputs are there (produced > c) and ITS output buffer is free (c - consumed < buffers), whatever the other stages are doing.
-// A release store after the chunk's LDS traffic (s_waitcnt lgkmcnt(0) first), an acquire load in the wait; every wait gives up
-// after 2^22 polls (the launch then ends with wrong PCM and UttResult.drained = 2 instead of hanging the GPU -- no test has seen it).
-#ifndef KLATT_FLAT_FREE
-#define KLATT_FLAT_FREE 0
-#endif
+// ---- hand-overs of the flat stages: one workgroup barrier per chunk ------------------------------------------------------------------
+// (Round 4 measured the alternative -- two counters per pipe in LDS, every stage starting a chunk as soon as ITS inputs are there and
+// ITS output buffer is free, more than two buffers per pipe: bit-identical and not faster, cfg2 8.59 -> 8.64 ms, profiles/
+// r4_handover_variants.txt.  A stage that "waits at the barrier" is not idle hardware: its SIMD runs the other workgroup's wave.  The
+// variant lives on as a patch, tools/variants/.)  The loops are written against this interface:
 struct BarrierSync {
     __device__ __forceinline__ void begin(int) const {}
     __device__ __forceinline__ void end(int) const { __syncthreads(); }
     __device__ __forceinline__ void idle() const { __syncthreads(); }
 };
-typedef __attribute__((address_space(3))) uint32_t lds_u32;
-template <int NBUF, int NIN, int NOUT>
-struct PipeSync {
-    // (counts, not null pointers: the null of the LDS address space is -1 where a generic pointer is cast and 0 where an LDS pointer
-    // is tested -- a "null" input was waited for, at LDS address 0xFFFFFFFF, in the first build)
-    lds_u32* in[2];       // {produced, consumed} of the NIN pipes this stage reads
-    lds_u32* out[1];      // ... of the NOUT pipes it writes
-    lds_u32* gaveUp;
-    static __device__ __forceinline__ uint32_t peek(lds_u32* p)
-    {
-        return (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(p, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
-    }
-    __device__ __forceinline__ void wait_until(lds_u32* p, uint32_t atLeast) const
-    {
-        uint32_t polls = 0;
-        while (peek(p) < atLeast) {
-            __builtin_amdgcn_s_sleep(1);
-            if (++polls > (1u << 22)) { *gaveUp = 1u; break; }
-        }
-    }
-    __device__ __forceinline__ void begin(int c) const
-    {
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) wait_until(in[k], (uint32_t)c + 1u);                       // produced > c
-#pragma unroll
-        for (int k = 0; k < NOUT; ++k) wait_until(out[k] + 1, (uint32_t)(c + 1 > NBUF ? c + 1 - NBUF : 0));      // c - consumed < NBUF
-    }
-    __device__ __forceinline__ void end(int c) const
-    {
-        // the chunk's LDS writes have landed and its reads have returned: lgkmcnt alone (a release fence would also wait for the final
-        // stage's PCM stores to reach memory, once per chunk)
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int k = 0; k < NOUT; ++k) __hip_atomic_store(out[k], (uint32_t)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#pragma unroll
-        for (int k = 0; k < NIN; ++k) __hip_atomic_store(in[k] + 1, (uint32_t)c + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    }
-    __device__ __forceinline__ void idle() const {}
-};
 
 // ---- flat filter stages, second form (round 3): rows loaded one sample ahead, straight into the coefficients ---------------------
 // The sample-by-sample path above pays, on every sample in which ANY lane fades: two ballots and two divergent blocks, the row's
 // loads, their full latency (a wait right behind them, ~900 cycles with the tracks beyond the L2) and then the filters, in a
-// rolled loop that keeps every sample's operations apart.  Measured with the loads taken out (wrong PCM, -DKLATT_EXP=3): the
+// rolled loop that keeps every sample's operations apart.  Measured with the loads taken out (a timing-only build, tools/variants/): the
 // all-different batch 32.6 -> 24.7 ms against 9.2 for the aligned one -- the structure costs more than the latency.  This form
 // has ONE kind of chunk besides the steady one:
 //   * a lane's fade state is a row counter (`left`) and an entry index + stride per kind; with the track layout of klatt_device.h
@@ -892,29 +834,12 @@ struct FlatMid {
     {
         using R = typename FD::R;
         (flat_pin(firstHalf), ...);
-#if KLATT_EXP & 1      // timing experiment (wrong PCM): rows cost no memory access
         if (ALLROWS || has) {
-#pragma unroll
-            for (int e = 0; e < FD::NE; ++e) if (SET & (1u << e)) f.idx[e] += f.stride[e];
-        }
-        return;
-#endif
-        if (ALLROWS || has) {
-#if KLATT_EXP & 16     // timing experiment (wrong PCM): ONE 16-byte load per row and stage, its value given to every kind
-            flat_d2 first = {0.0, 0.0};
-            bool haveFirst = false;
-#endif
 #pragma unroll
             for (int e = 0; e < FD::NE; ++e) {
                 if (!(SET & (1u << e))) continue;
                 const uint32_t off = f.idx[e];
-#if KLATT_EXP & 16
-                if (!haveFirst) { first = __builtin_bit_cast(flat_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0)); haveFirst = true; }
-                const flat_d2 v = first;
-                if (FD::STAGE == 0 && e == 3) { f.idx[e] = off + f.stride[e]; continue; }      // (the source stage's vibrato stays off: garbage there would switch the sine on)
-#else
                 const flat_d2 v = __builtin_bit_cast(flat_d2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0));
-#endif
                 if (e < FD::NRES) {
                     f.rb[e < FD::NRES ? e : 0] = (R)v.x; f.rc[e < FD::NRES ? e : 0] = (R)v.y;
                     if (FD::ANTI0 && e == 0) f.ra[0] = (R)__builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, off + 16u, 0, 0));
@@ -972,7 +897,7 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
             const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
             if (f.length <= t0) f.live = false;                               // this lane has emitted its last sample
             // a chunk is steady when no lane loads a row in it: none pending, no fade whose first row applies to t0 + 1 .. t1
-            const bool busy = (KLATT_EXP & 8) || f.left > 0u || f.startAt <= t1;      // (timing experiment 8: every chunk a mixed one)
+            const bool busy = f.left > 0u || f.startAt <= t1;
             if (!__any(busy)) {
                 if (staleG) {
 #pragma unroll
@@ -1031,12 +956,10 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
                 staleG |= SET;
 #pragma unroll KLATT_MIX_UNROLL
                 for (int i = 0; i < CH; ++i) {
-#if !(KLATT_EXP & 4)      // (timing experiment 4, wrong PCM: no fade ever starts)
                     if (!ALLROWS) {
                         const uint32_t tn = t0 + (uint32_t)i + 1u;            // the sample whose rows this one loads
                         if (tn == f.startAt) flat2_switch<FD>(f, X, GE);
                     }
-#endif
                     const bool has = ALLROWS || f.left > 0u;
                     body(c, i, setTag, FlatMid<FD, SET, ALLROWS>{f, rsrc, has});
                     if (!ALLROWS && has) f.left--;
@@ -1165,13 +1088,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     auto nothing = [&](int) __attribute__((always_inline)) {};
     auto noChunk = [&]() __attribute__((always_inline)) {};
 
-    // hand-overs of the flat stages (BarrierSync / PipeSync above): pipe X = S0 -> S1, O = S1 -> final, A and B = S3 -> final
-    constexpr bool kFree = FLAT && KLATT_FLAT_FREE && KLATT_FLAT_SOURCE && KLATT_FLAT_LAYOUT == 2 && KLATT_FLAT_EXHAUSTIVE;
-    lds_u32* const syncL = (lds_u32*)syncP;
-    auto make_sync = [&](auto nBuf, auto nIn, auto nOut, int in0, int in1, int out0) __attribute__((always_inline)) {      // nBuf: buffers of the pipe written
-        if constexpr (kFree) return PipeSync<decltype(nBuf)::value, decltype(nIn)::value, decltype(nOut)::value>{{syncL + in0, syncL + in1}, {syncL + out0}, syncL + 6};
-        else return BarrierSync{};
-    };
+    // hand-overs of the flat stages (BarrierSync above): pipe X = S0 -> S1, O = S1 -> final, A and B = S3 -> final
+    auto make_sync = [&](auto, auto, auto, int, int, int) __attribute__((always_inline)) { return BarrierSync{}; };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
     if (FLAT && KLATT_FLAT_SOURCE && stage == 0) {
         // ================= flat S0, second form: the source stage with its rows loaded one sample ahead (see flat2_loop) =================
@@ -1261,7 +1179,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                     lastChunk = c;
                     const uint32_t t0 = (uint32_t)c * (uint32_t)CH, t1 = t0 + (uint32_t)CH;
                     if (f.length <= t0) f.live = false;
-                    const bool busy = (KLATT_EXP & 8) || f.left > 0u || f.startAt <= t1 || cntF < nfU || fadeEndAt < t1 || vib_live();
+                    const bool busy = f.left > 0u || f.startAt <= t1 || cntF < nfU || fadeEndAt < t1 || vib_live();
                     STAMP_KIND(__any(busy) ? -1 : 0);
                     if (!__any(busy)) {
                         // steady stretch, decided once (as in flat2_loop): the pitch glides, nothing else changes
@@ -1295,7 +1213,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                         for (int i = 0; i < CH; ++i) {
                             const uint32_t t = t0 + (uint32_t)i;
                             const bool deq = !ALLFADE && t + 1u == f.startAt;
-                            if (!ALLFADE && !(KLATT_EXP & 4) && __any(deq)) {
+                            if (!ALLFADE && __any(deq)) {
                                 if (deq) {   // reference src/frame.cpp:55-72 (stage_event restates it); the sample itself is emitted as it is
                                     const SourceRef m = nextSrc;
                                     const uint32_t nf = f.nextRef.fadeSamples;
@@ -1660,7 +1578,6 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
                 [&]() __attribute__((always_inline)) { it += kChunk; if ((it % kTile) == 0) flush_tile(it - kTile, it); },
                 make_sync(std::integral_constant<int, L::kBufs>{}, I2{}, I0{}, 2, 4, 0));
             if ((it % kTile) != 0) flush_tile(it - (it % kTile), it);
-            if (kFree && live && syncP[6] != 0u) A.result[u].drained = 2u;      // some wait of the workgroup gave up: the PCM is not valid
         }
     } else if (!NOISE && !NASAL && (stage == 1 || stage == 2)) {
         // ================= quiet, nasal-free S1: r6, r5, r4 and S2: r3, r2, r1 =================

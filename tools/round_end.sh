@@ -5,8 +5,10 @@
 #   b: the bench lines
 #   c: the probes (tracks, mixed, steady, direct stages with a kernel trace of the all-different batch), the live-handle bench
 # Everything lands under gpurun_out/; the summaries are then copied into profiles/ (see profiles/README.md).
-R=r4
+R=r5
 mkdir -p gpurun_out
+# (A/B variant libraries and their objects are scratch: they would travel with every snapshot -- 131 MB at the end of round 4)
+rm -f nvspeechplayer_amd/build_tmp/libspeechPlayer_*.o nvspeechplayer_amd/lib/variants/*.so
 case "${1:-a}" in
 a)
 timeout -k 10 1100 python -m pytest tests -m gpu -x -q > gpurun_out/${R}_gputests.log 2>&1; tail -3 gpurun_out/${R}_gputests.log
@@ -26,7 +28,7 @@ timeout -k 10 400 python bench.py --workload cfg3 --steps 30 --no-extras --no-cp
 timeout -k 10 600 python bench.py --workload cfg4 --steps 5 --warmup 1 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_cfg4.json 2> /dev/null
 python - <<'PY'
 import json
-for f in ("r4_bench", "r4_bench_steps20", "r4_bench_fast", "r4_bench_cfg1", "r4_bench_cfg3", "r4_bench_cfg4"):
+for f in ("r5_bench", "r5_bench_steps20", "r5_bench_fast", "r5_bench_cfg1", "r5_bench_cfg3", "r5_bench_cfg4"):
     try:
         d = json.loads([l for l in open("gpurun_out/%s.json" % f) if l.startswith("{")][-1])
     except Exception as e:
@@ -56,6 +58,7 @@ for f in glob.glob("/tmp/ad_trace/**/*kernel_stats.csv", recursive=True):
             print("%-60s calls=%s avg_us=%.1f min_us=%.1f" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
 PY
 ) > gpurun_out/${R}_all_different_trace.txt 2>&1
+timeout -k 10 400 bash tools/direct_pmc.sh all_different > gpurun_out/${R}_direct_pmc.txt 2>&1
 R=${R} bash tools/live_round3.sh > /dev/null 2>&1
 timeout -k 10 300 python tools/live_large.py > gpurun_out/${R}_live_large.txt 2>&1
 cat gpurun_out/${R}_steady_probe.txt gpurun_out/${R}_mixed_probe.txt gpurun_out/${R}_track_probe.txt gpurun_out/${R}_direct_probe.txt gpurun_out/${R}_all_different_trace.txt

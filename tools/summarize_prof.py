@@ -25,12 +25,25 @@ def pmc_entry(outdir):
                     acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
         return {k: sum(v) / len(v) for k, v in acc.items()}
     valu, fetch, write = per_kernel("pmc_insts", "SQ_INSTS_VALU"), per_kernel("pmc_fetch", "FETCH_SIZE"), per_kernel("pmc_write", "WRITE_SIZE")
+    # the f64 share of the VALU instructions (their own pass: tools/profile.sh pmc_f64) and the clock the chip held (GRBM_GUI_ACTIVE is
+    # summed over the 8 XCDs; divided by the kernel-trace duration of the same kernel)
+    f64 = {}
+    for c in ("SQ_INSTS_VALU_ADD_F64", "SQ_INSTS_VALU_MUL_F64", "SQ_INSTS_VALU_FMA_F64", "SQ_INSTS_VALU_TRANS_F64"):
+        for k, v in per_kernel("pmc_f64", c).items():
+            f64[k] = f64.get(k, 0.0) + v
+    gui = per_kernel("pmc_insts", "GRBM_GUI_ACTIVE")
     ent = {"kernels": sorted(valu), "valu_insts_per_launch": sum(valu.values()), "valu_insts_by_kernel": valu,
+           "valu_f64_insts_per_launch": sum(f64.values()) if f64 else None, "valu_f64_insts_by_kernel": f64 or None,
+           "grbm_gui_active_by_kernel": gui or None,
            "fetch_size_kb": sum(fetch.values()), "write_size_kb": sum(write.values()),
            "hbm_bytes_per_launch": int((2.0 * sum(fetch.values()) + sum(write.values())) * 1024)}
     st = find(outdir, "trace", "kernel_stats.csv")
     if st:
         ent["kernel_avg_ns"] = {row["Name"]: float(row["AverageNs"]) for row in csv.DictReader(open(st)) if "klatt" in row["Name"]}
+        if gui:
+            k = max(ent["kernel_avg_ns"], key=ent["kernel_avg_ns"].get)      # the dominant kernel
+            if k in gui:
+                ent["held_clock_hz"] = gui[k] / 8.0 / (ent["kernel_avg_ns"][k] * 1e-9)
     bj = os.path.join(outdir, "bench_trace.json")
     if os.path.exists(bj):
         for line in open(bj):
@@ -53,7 +66,7 @@ def merge_json(outdir, key, path):
         if data.get("engine_sources_sha") != sha:
             data = {}                      # entries measured on other kernels do not mix with this one
     data["engine_sources_sha"] = sha
-    data["_source"] = "tools/profile.sh: rocprofv3 --pmc passes (SQ_INSTS_VALU; FETCH_SIZE; WRITE_SIZE, each in its own run) + --kernel-trace --stats"
+    data["_source"] = "tools/profile.sh: rocprofv3 --pmc passes (SQ_INSTS_VALU + GRBM_GUI_ACTIVE; SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64; FETCH_SIZE; WRITE_SIZE, each in its own run) + --kernel-trace --stats"
     data["_correction"] = "FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B, MI355X_MICROARCH.md HBM section); counters are in KB"
     data[key] = pmc_entry(outdir)
     with open(path, "w") as f:
@@ -91,7 +104,7 @@ def main(outdir):
             print("dispatch: grid=%s wg=%s lds=%s scratch=%s vgpr=%s agpr=%s sgpr=%s" % (
                 r["Grid_Size_X"], r["Workgroup_Size_X"], r["LDS_Block_Size"], r["Scratch_Size"], r["VGPR_Count"],
                 r["Accum_VGPR_Count"], r["SGPR_Count"]))
-    for sub in ("pmc_insts", "pmc_waits", "pmc_fetch", "pmc_write"):
+    for sub in ("pmc_insts", "pmc_f64", "pmc_waits", "pmc_fetch", "pmc_write"):
         f = find(outdir, sub, "counter_collection.csv")
         if not f:
             print("\n## %s: no counter file" % sub)

@@ -1990,8 +1990,24 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     if (b->tracks && nF > 0) {
         plan_tracks(nUtterances, frameStart, frames, facts, meta.data(), eligible.data(), b->trackBudgetMB, plan);
         lap("tracks planned");
-        for (long long u = 0; u < nUtterances; ++u)
-            if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED | (plan.kinds[u] << kUttKindShift);
+        // MODE_FAST, lanes that fade at unrelated times, tracks far beyond the caches (every fading lane streams through a track of its
+        // own: the jittered batch's 445 MB): the lean direct stages, whose pole recurrences compute what the tracks would deliver, are
+        // faster than the flat stages waiting for rows -- 18.4 against 21.8 ms (bench.py, jittered_durations) -- so such a batch is
+        // not tracked.  (MODE_EXACT keeps its tracks: the polynomials cost more than the rows' latency, 22 ms against ~35.)
+        bool useTracks = true;
+        if (wantDirect && b->direct == 1 && b->mode == MODE_FAST && plan.entries * sizeof(double2) > (128ull << 20)) {
+            std::unordered_map<unsigned long long, long long> runOf;
+            long long tracked = 0, direct = 0, inRuns = 0;
+            for (long long u = 0; u < nUtterances; ++u)
+                if (plan.tracked[u]) { ++tracked; direct += (eligible[u] & 2) ? 1 : 0; ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)]; }
+            for (const auto& kv : runOf) if (kv.second >= 32) inRuns += kv.second;
+            const long long groups = (tracked + kLanes - 1) / kLanes;
+            if (b->sortByLength && inRuns * 2 <= tracked && direct == tracked && groups > b->cus) useTracks = false;
+        }
+        if (useTracks)
+            for (long long u = 0; u < nUtterances; ++u)
+                if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED | (plan.kinds[u] << kUttKindShift);
+        if (!useTracks) { plan.jobs.clear(); plan.entries = 0; plan.tracked.assign((size_t)nUtterances, 0); }
     }
     if (wantDirect) {
         // The direct stages are for lanes that fade at unrelated times.  A group whose wavefronts hold equally timed utterances (the

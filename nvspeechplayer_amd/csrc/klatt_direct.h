@@ -76,7 +76,7 @@ namespace klatt {
 #define KLATT_DIRECT_LEAN_UNROLL 2       // MODE_EXACT, two workgroups per CU (1: 38.8 instead of 37.8 ms; the source stage goes sample by sample)
 #endif
 #ifndef KLATT_DIRECT_LEAN_UNROLL_FAST
-#define KLATT_DIRECT_LEAN_UNROLL_FAST 4  // MODE_FAST, two workgroups per CU (2: 21.1, 1: 22.1 instead of 20.2 ms)
+#define KLATT_DIRECT_LEAN_UNROLL_FAST 8  // MODE_FAST, two workgroups per CU: a whole hand-over (4: 18.3 instead of 18.0 ms; before the stage pairs were re-balanced 2: 21.1, 1: 22.1, 4: 20.2)
 #endif
 
 // A pair of doubles in two adjacent register pairs: the unit a record entry is loaded in (global_load_dwordx4 into the state itself)
@@ -835,26 +835,29 @@ __global__ void __launch_bounds__(kLanes * 8, WPE) klatt_direct(const KernelArgs
             noChunk);
     } else if (stage >= (LAY == 1 ? 3 : 2) && stage <= 4 && (ONLY & 4)) {
         // ================= the cascade: layout 0 T2, T3, T4 two resonators each (r6 r5 | r4 r3 | r2 r1); layout 1 T3, T4 three each =================
-        auto part = [&](auto stageTag, double* pin, double* pout) __attribute__((always_inline)) {
-            constexpr int ST = decltype(stageTag)::value;
-            using DD = DirectDesc<ST, LAY>;
-            const DirectCtx X = ctx(stageTag);
-            DirectState<DD, MODE, LEAN> f;
-            direct_init(f, live, d, rec0, X);
-            direct_loop<DD, MODE, CH, LEAN>(ST, nIter, nChunks, stage, f, X,
-                [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pin, c, i)}; },
-                [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
-                    double o = in.a;
+        // The cascade stages run the SAME program on different pipes and records: ONE copy of it, with the stage's pipes, records and depth
+        // as run-time values (three instantiations were 25 KB of the MODE_EXACT kernel's ~69 KB of loops, all hot on a CU at once, against
+        // a 64 KB instruction cache shared by two CUs).
+        constexpr int ST = 4;                             // (any of them: same resonator and gain counts; the stage number only names the records)
+        using DD = DirectDesc<ST, LAY>;
+        static_assert(LAY == 1 || (direct_stage_res(2, LAY) == direct_stage_res(4, LAY) && direct_stage_gains(2, LAY) == direct_stage_gains(4, LAY)), "the cascade stages are alike");
+        static_assert(direct_stage_res(3, LAY) == direct_stage_res(4, LAY) && direct_stage_gains(3, LAY) == direct_stage_gains(4, LAY), "the cascade stages are alike");
+        double* const pin = stage == 2 ? pipeX1 : (stage == 3 ? pipeX2 : pipeX3);
+        double* const pout = stage == 2 ? pipeX2 : (stage == 3 ? pipeX3 : pipeO);
+        const int kFirst = stage == 2 ? direct_stage_first(2, LAY) : (stage == 3 ? direct_stage_first(3, LAY) : direct_stage_first(4, LAY));
+        const DirectCtx X{A, A.directHdr + (size_t)stage * A.nDirect, reinterpret_cast<const dpair*>(A.directRec) + (size_t)kFirst * A.nDirect};
+        DirectState<DD, MODE, LEAN> f;
+        direct_init(f, live, d, rec0, X);
+        direct_loop<DD, MODE, CH, LEAN>(stage, nIter, nChunks, stage, f, X,
+            [&](int c, int i) __attribute__((always_inline)) { return In1{PIPE(pin, c, i)}; },
+            [&](int c, int i, const In1& in, const auto& mid) __attribute__((always_inline)) {
+                double o = in.a;
 #pragma unroll
-                    for (int r = 0; r < DD::NRES; ++r) o = f.step(r, o);
-                    PIPE(pout, c, i) = o;
-                    mid(o);
-                },
-                noChunk);
-        };
-        if constexpr (LAY == 0) { if (stage == 2) part(std::integral_constant<int, 2>{}, pipeX1, pipeX2); }
-        if (stage == 3) part(std::integral_constant<int, 3>{}, pipeX2, pipeX3);
-        else if (stage == 4) part(std::integral_constant<int, 4>{}, pipeX3, pipeO);
+                for (int r = 0; r < DD::NRES; ++r) o = f.step(r, o);
+                PIPE(pout, c, i) = o;
+                mid(o);
+            },
+            noChunk);
     } else if (stage == 5 && (ONLY & 8)) {
         // ================= T5: frication noise, parallel 1, 2 =================
         using DD = DirectDesc<5, LAY>; // gains: (fricationAmplitude, preFormantGain) (pa1, pa2)

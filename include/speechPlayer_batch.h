@@ -134,6 +134,13 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
  * Returns the number of frames; -1 on bad arguments. */
 long long speechPlayer_planDirect(long long nUtterances, const long long* frameStart, const unsigned char* isNull,
                                   unsigned int* from, unsigned int* to, unsigned int* flags);
+/* What speechPlayer_batch_setUtterances learns of every frame before it plans a batch (tests, tools): per frame 24 bytes --
+ * {u64 h0, u64 h1: a 128-bit hash of the 45 values a track depends on (every parameter but the two pitches), u32 flags, u32 0};
+ * flags: 1 a noise gain is set or the parallel bank's coefficients may not be finite, 2 a parameter is NaN or infinite, 4 the nasal
+ * pair is coupled in (or could not be skipped safely), 8 a frequency or bandwidth outside the direct stages' range.  onDevice = 0: the
+ * host's evaluation (touches no device); 1: the device's (klatt_frame_facts: what frames arriving from page-locked memory get) -- the
+ * same function (csrc/klatt_plan.h), the same bytes.  Returns nFrames, -1 on error. */
+long long speechPlayer_frameFacts(const speechPlayer_frame_t* frames, long long nFrames, int sampleRate, int onDevice, void* facts24);
 
 /*
  * One batch over the GPUs of a node.  Utterances are independent (the reference's only cross-handle coupling

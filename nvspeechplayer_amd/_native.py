@@ -48,7 +48,7 @@ EXPORTS = [
     "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
     "speechPlayer_node_setUtterances", "speechPlayer_node_synthesize", "speechPlayer_node_wait", "speechPlayer_node_totalSamples",
     "speechPlayer_node_read", "speechPlayer_node_getLastIndex", "speechPlayer_node_shardInfo", "speechPlayer_node_part",
-    "speechPlayer_node_time", "speechPlayer_planTracks", "speechPlayer_planDirect",
+    "speechPlayer_node_time", "speechPlayer_planTracks", "speechPlayer_planDirect", "speechPlayer_frameFacts",
 ]
 
 
@@ -279,6 +279,8 @@ def load():
     L.speechPlayer_ipa_phoneme.argtypes = [i32, vp, i32, vp, vp, vp]
     L.speechPlayer_planTracks.restype = i64
     L.speechPlayer_planTracks.argtypes = [i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp]
+    L.speechPlayer_frameFacts.restype = i64
+    L.speechPlayer_frameFacts.argtypes = [vp, i64, i32, i32, vp]
     L.speechPlayer_planDirect.restype = i64
     L.speechPlayer_planDirect.argtypes = [i64, vp, vp, vp, vp, vp]
     _lib = L

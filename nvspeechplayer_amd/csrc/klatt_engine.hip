@@ -2843,6 +2843,29 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
     return (long long)plan.jobs.size();
 }
 
+long long speechPlayer_frameFacts(const speechPlayer_frame_t* frames, long long nFrames, int sampleRate, int onDevice, void* facts24)
+{
+    begin_call();
+    if (nFrames < 0 || (nFrames > 0 && (!frames || !facts24)) || sampleRate <= 0) { set_error("frameFacts: bad arguments"); return -1; }
+    const double maxBw = 690.0 * sampleRate / M_PI, maxF = 9900.0 * sampleRate / (2.0 * M_PI);
+    FrameFacts* const out = static_cast<FrameFacts*>(facts24);
+    if (!onDevice) {
+        parallel_ranges(nFrames, 1 << 13, [&](long long a, long long e) { for (long long k = a; k < e; ++k) out[k] = frame_facts(reinterpret_cast<const double*>(frames + k), maxF, maxBw); });
+        return nFrames;
+    }
+    if (nFrames == 0) return 0;
+    DeviceBuffer<double> dF;
+    DeviceBuffer<FrameFacts> dO;
+    struct Release { DeviceBuffer<double>& a; DeviceBuffer<FrameFacts>& b; ~Release() { a.release(); b.release(); } } release{dF, dO};
+    if (dF.reserve((size_t)nFrames * kNumParams) || dO.reserve((size_t)nFrames)) return -1;
+    HIP_TRY(hipMemcpy(dF.ptr, frames, (size_t)nFrames * kNumParams * sizeof(double), hipMemcpyHostToDevice));
+    const unsigned grid = (unsigned)std::min<long long>((nFrames + 255) / 256, 1 << 16);
+    hipLaunchKernelGGL(klatt_frame_facts, dim3(grid), dim3(256), 0, nullptr, dF.ptr, dO.ptr, nFrames, maxF, maxBw);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(out, dO.ptr, (size_t)nFrames * sizeof(FrameFacts), hipMemcpyDeviceToHost));
+    return nFrames;
+}
+
 // Host-only view of what speechPlayer_batch_setUtterances hands klatt_seeds for the utterances it sends to the direct stages
 // (tests; touches no device): per frame the frames its fade starts from and ends on (0xFFFFFFFF: none -- all zero) and the flags
 // (bit 0: the start's preFormantGain is gated off, bit 1: the end's).  Returns the number of frames; -1 on bad arguments.

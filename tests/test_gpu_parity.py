@@ -1600,3 +1600,14 @@ def test_eight_shards_of_a_node_sized_share():
     for u in (0, sh[3][0], sh[3][0] - 1, n - 1):          # across a shard boundary: the PCM itself
         assert np.array_equal(node.read(u), one.read(u)), u
     node.close(); one.close()
+
+
+@pytest.mark.gpu
+def test_frame_facts_device_equals_host():
+    """klatt_frame_facts (what frames that arrive by DMA from page-locked memory are classified and hashed by) against the host's
+    evaluation of the same function (csrc/klatt_plan.h) on frames with every kind of trouble: the same 24 bytes per frame."""
+    from tests.test_track_planning import facts_frames, frame_facts
+    f = facts_frames(np.random.default_rng(10), 50000)
+    for sr in (22050, 8000):
+        host, dev = frame_facts(f, sr, 0), frame_facts(f, sr, 1)
+        assert np.array_equal(host["flags"], dev["flags"]) and np.array_equal(host["h0"], dev["h0"]) and np.array_equal(host["h1"], dev["h1"])

@@ -194,3 +194,79 @@ def test_probe_of_a_short_batch_of_long_utterances(monkeypatch):
         out[threads] = (n, int(entries.value), off.copy(), mask.copy(), tracked.copy())
     assert out["1"][:2] == out["2"][:2] and all(np.array_equal(a, b) for a, b in zip(out["1"][2:], out["2"][2:]))
     assert out["1"][4].all()
+
+
+FACTS = np.dtype([("h0", "<u8"), ("h1", "<u8"), ("flags", "<u4"), ("pad", "<u4")])
+
+
+def frame_facts(frames, sr=22050, on_device=0):
+    L = _native.load()
+    frames = np.ascontiguousarray(frames, np.float64).reshape(-1, 47)
+    out = np.zeros(len(frames), FACTS)
+    n = L.speechPlayer_frameFacts(frames.ctypes.data, len(frames), sr, on_device, out.ctypes.data)
+    assert n == len(frames), _native.last_error()
+    return out
+
+
+def facts_frames(rng, n):
+    """Frames that exercise every flag: plain speech-like ones, noise gains, NaN / inf anywhere, negative bandwidths, coupled nasal
+    pairs, out-of-range formants, negative zeros."""
+    f = np.zeros((n, 47))
+    f[:, 0] = rng.uniform(60, 300, n); f[:, 46] = f[:, 0] * rng.uniform(0.8, 1.2, n); f[:, 5] = rng.uniform(0, 1, n)
+    f[:, 7:13] = np.sort(rng.uniform(200, 5000, (n, 6)), axis=1); f[:, 13] = rng.uniform(200, 500, n); f[:, 14] = rng.uniform(200, 500, n)
+    f[:, 15:23] = rng.uniform(40, 900, (n, 8)); f[:, 25:31] = np.sort(rng.uniform(200, 5000, (n, 6)), axis=1); f[:, 31:37] = rng.uniform(40, 900, (n, 6))
+    f[:, 37:43] = rng.uniform(0, 1, (n, 6)); f[:, 43] = rng.uniform(0, 1, n); f[:, 44] = 1.0; f[:, 45] = 2.0
+    pick = lambda p: rng.random(n) < p
+    for col in (3, 6, 24):
+        f[pick(0.2), col] = rng.uniform(0.01, 1)
+    f[pick(0.1), 23] = 0.5
+    f[pick(0.03), rng.integers(0, 47)] = np.nan
+    f[pick(0.02), rng.integers(0, 47)] = np.inf
+    f[pick(0.03), 31 + rng.integers(0, 6)] = -5.0
+    f[pick(0.03), 7 + rng.integers(0, 6)] = 3e8
+    f[pick(0.03), 21] = 0.5
+    f[pick(0.05), 4] = -0.0
+    return f
+
+
+def expected_flags(f, sr=22050):
+    max_bw, max_f = 690.0 * sr / np.pi, 9900.0 * sr / (2 * np.pi)
+    with np.errstate(invalid="ignore"):
+        noise = (f[:, 3] != 0) | (f[:, 6] != 0) | (f[:, 24] != 0)
+        noise |= (~(np.abs(f[:, 25:31]) <= 1e6) | ~(f[:, 31:37] >= 0) | ~(f[:, 31:37] <= 1e6)).any(axis=1)
+        nonfinite = ~np.isfinite(f).all(axis=1)
+        nasal = (f[:, 23] != 0) | ~(f[:, 21] >= 1) | ~(f[:, 22] >= 0) | ~(f[:, 21] <= 1e6) | ~(f[:, 22] <= 1e6) | ~(np.abs(f[:, 13]) <= 1e6) | \
+                ~(np.abs(f[:, 14]) <= 1e6) | ~(np.abs(f[:, 5]) <= 1e30) | ~(np.abs(f[:, 44]) <= 1e30) | ~(np.abs(f[:, 0]) <= 1e30) | ~(np.abs(f[:, 46]) <= 1e30)
+        freq = np.concatenate([f[:, 7:15], f[:, 25:31]], axis=1); bw = np.concatenate([f[:, 15:23], f[:, 31:37]], axis=1)
+        unbounded = (~(np.abs(freq) <= max_f)).any(axis=1) | (~(np.abs(bw) <= max_bw)).any(axis=1)
+    return noise * 1 + nonfinite * 2 + nasal * 4 + unbounded * 8
+
+
+def test_frame_facts_flags_and_hash():
+    """klatt_plan.h on the host (speechPlayer_frameFacts, onDevice = 0): the flags against a numpy restatement of the rules
+    speechPlayer_batch_setUtterances classifies by; the 128-bit hash stands for the 45 shape values -- equal for frames that differ
+    in their pitches only, different for a change of any one other parameter (a sign of zero included), and for the same values in
+    other places."""
+    rng = np.random.default_rng(9)
+    f = facts_frames(rng, 6000)
+    got = frame_facts(f)
+    assert np.array_equal(got["flags"], expected_flags(f).astype(np.uint32))
+    assert set(np.unique(got["flags"])) >= {0, 1, 2, 4, 8}                     # every flag occurs, and none at all
+    g = f.copy(); g[:, 0] *= 1.5; g[:, 46] += 3.0                               # the pitches are not part of a shape
+    other = frame_facts(g)
+    assert np.array_equal(other["h0"], got["h0"]) and np.array_equal(other["h1"], got["h1"])
+    base = f[:200].copy()
+    h = frame_facts(base)
+    for p in range(1, 46):
+        g = base.copy(); g[:, p] = np.where(np.isfinite(g[:, p]), g[:, p] + 1.0, 7.0)
+        c = frame_facts(g)
+        assert not (c["h0"] == h["h0"]).any() and not (c["h1"] == h["h1"]).any(), p
+    g = base.copy(); g[:, [7, 8]] = g[:, [8, 7]]                               # two formants exchanged: other places, other hash
+    c = frame_facts(g)
+    assert not ((c["h0"] == h["h0"]) & (c["h1"] == h["h1"])).any()
+    z = np.zeros((2, 47)); z[1, 4] = -0.0
+    c = frame_facts(z)
+    assert c["h0"][0] != c["h0"][1]                                              # bit patterns, as the planner's memcmp compared them
+    pairs = np.stack([got["h0"], got["h1"]], axis=1)
+    shape_rows = np.ascontiguousarray(f[:, 1:46]).view(np.uint64)
+    assert len(np.unique(pairs, axis=0)) == len(np.unique(shape_rows, axis=0))  # as many distinct hashes as distinct shapes

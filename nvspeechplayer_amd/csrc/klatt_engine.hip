@@ -926,11 +926,19 @@ template <class T> using RawVector = std::vector<T, NoInitAlloc<T>>;
 long long tracked_count(const Batch* b) { return (b->tracks && b->layout != 0) ? b->nTracked : 0; }
 // (setUtterances only forms the direct group under the stage-parallel layouts)
 long long direct_count(const Batch* b) { return b->nDirect; }
-// The direct stages' residency for a launch of nGroups workgroups (option "direct_lean").  The engine's choice: two workgroups per CU
-// (the lean stages) once the launch has more workgroups than CUs -- below that a second resident workgroup has nothing to run -- unless
+// The direct stages' residency for a launch of nGroups workgroups (option "direct_lean").  The engine's choice (tools/direct_size_probe.py,
+// all-different batches of 8192 .. 65 536 utterances): MODE_FAST takes the lean stages -- two workgroups per CU -- at every size (12.4
+// against 12.8 ms at 128 workgroups, 13.4 / 14.5 at 512, 18.1 / 27.3 at 1024); MODE_EXACT once the launch has more than TWO workgroups
+// per CU (a launch of up to 512 workgroups lasts as long as its longest utterance takes through one workgroup's pipeline, which is
+// shorter with the CU to itself: 26.4 against 27.7 ms at 512 workgroups; 31.7 / 30.0 at 576, 50.6 / 37.7 at 1024) -- and neither when
 // the lanes are time-aligned: the lean stages have no steady path of their own (an aligned batch spends most chunks there: cfg2
-// without its tracks 13.9 ms against 16.4, MODE_FAST; "distinct" 16.1 / 17.3).
-bool direct_lean(const Batch* b, long long nGroups) { return b->directLean < 0 ? (nGroups > b->cus && !b->directAligned) : b->directLean != 0; }
+// without its tracks 13.9 ms against 16.4, MODE_FAST; "distinct" 14.3 / 15.2).
+bool direct_lean(const Batch* b, long long nGroups)
+{
+    if (b->directLean >= 0) return b->directLean != 0;
+    if (b->directAligned) return false;
+    return b->mode == MODE_FAST ? true : nGroups > 2ll * b->cus;
+}
 
 int batch_launch(Batch* b)
 {

@@ -1415,7 +1415,8 @@ def test_direct_stages_change_nothing(seed, wild):
                 assert info["tracked_utterances"] == 0 and info["direct_utterances"] > n_utt // (4 if wild else 2)
                 assert info["direct_utterances"] <= n_utt - nan_utts
                 assert info["scratch_bytes"] == 0 and info["direct"]
-                assert info["stage_parallel_chunk"] == (8 if lean == 1 else 16) and info["vgprs"] <= (128 if lean == 1 else 256)
+                lean_runs = lean == 1 or (lean == -1 and mode == 1)      # (the engine's choice: MODE_FAST takes the lean stages at every size, MODE_EXACT beyond two workgroups per CU)
+                assert info["stage_parallel_chunk"] == (8 if lean_runs else 16) and info["vgprs"] <= (128 if lean_runs else 256)
             else:
                 assert info["direct_utterances"] == 0 and info["tracked_utterances"] > 0      # every candidate got its tracks
             d = pcm.astype(np.int32) - exp.astype(np.int32)
@@ -1449,8 +1450,9 @@ def test_batch_in_which_nothing_is_shared_and_nothing_is_aligned():
         bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
         info = bp.kernelInfo()
         assert info["direct"] and info["direct_utterances"] == 2048 and info["tracked_utterances"] == 0 and info["scratch_bytes"] == 0, info
-        # 32 workgroups: by itself the engine keeps one workgroup per CU; the lean stages (two per CU) are what a launch of more workgroups than CUs takes
-        assert info["stage_parallel_chunk"] == (8 if lean == 1 else 16), info
+        # 32 workgroups: by itself the engine keeps MODE_EXACT at one workgroup per CU (the lean stages -- two per CU -- are what a launch of
+        # more than two workgroups per CU takes); MODE_FAST takes the lean stages at every size
+        assert info["stage_parallel_chunk"] == (8 if (lean == 1 or mode == 1) else 16), info
         bp.synthesize()
         pcm, start = bp.readAll()
         assert np.array_equal(start, exp_start)

@@ -1472,6 +1472,17 @@ def test_batch_in_which_nothing_is_shared_and_nothing_is_aligned():
         else:
             assert bp.kernelInfo()["direct_utterances"] > 0
         bp.close()
+    # the residency the engine picks by itself (direct_lean(), klatt_engine.hip): MODE_EXACT keeps one workgroup per CU up to two
+    # workgroups' worth per CU (a launch that short lasts as long as its longest utterance takes through ONE workgroup's pipeline) and
+    # takes the lean stages beyond; planning alone is looked at here (nothing is launched)
+    big = workloads.all_different(workloads.make("cfg2", 36864))
+    for n_utt, want in ((32768, 16), (36864, 8)):
+        part = big.slice(0, n_utt)
+        bp = eng.BatchPlayer(big["sr"], mode=0)
+        bp.setUtterances(part["frame_start"], part["frames"], part["min"], part["fade"], part["index"], part["isnull"], part["seeds"])
+        info = bp.kernelInfo()
+        assert info["direct"] and info["direct_utterances"] == n_utt and info["stage_parallel_chunk"] == want, (n_utt, info)
+        bp.close()
 
 
 @pytest.mark.gpu

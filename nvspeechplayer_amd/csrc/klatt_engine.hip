@@ -28,6 +28,9 @@
 #include <system_error>
 #include <thread>
 #include <numeric>
+#include <condition_variable>
+#include <deque>
+#include <functional>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -713,15 +716,88 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
     }
 }
 
-// fn(0) .. fn(n - 1), each on a thread of its own; the last one -- and any a thread could not be started for -- on the caller's.
+// The host's worker threads.  Until round 5 every parallel section started and joined its own std::threads: eight sections of a
+// setUtterances call are ~56 thread starts, 2-4 ms of a 22 ms call on the GPU box.  Now a pool that lives as long as the process:
+// workers sleep on a condition variable, a section queues its parts and its caller works on queued parts (its own or anybody's) until
+// its own are done -- so sections of several callers (the setter threads of a pipeline, the device threads of a node) share the workers
+// without waiting for each other, and a section whose parts all queue behind others still finishes on its caller's thread.
+// Parts never start sections of their own.  The pool is never destroyed (its threads sleep at process exit).
+class WorkerPool {
+public:
+    struct Section { std::atomic<unsigned> left{0}; };
+    static WorkerPool& get() { static WorkerPool* p = new WorkerPool(); return *p; }
+    void submit(Section* sec, std::function<void()> fn)
+    {
+        { std::lock_guard<std::mutex> lg(mu_); queue_.emplace_back(sec, std::move(fn)); }
+        cv_.notify_one();
+    }
+    // run queued parts until `sec` has none left
+    void help_until_done(Section* sec)
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        while (sec->left.load(std::memory_order_acquire) != 0) {
+            if (!queue_.empty()) {
+                auto job = std::move(queue_.front());
+                queue_.pop_front();
+                lk.unlock();
+                job.second();
+                job.first->left.fetch_sub(1, std::memory_order_acq_rel);
+                done_.notify_all();
+                lk.lock();
+            } else {
+                done_.wait_for(lk, std::chrono::microseconds(200));
+            }
+        }
+    }
+    unsigned workers() const { return nWorkers_; }
+private:
+    WorkerPool()
+    {
+        // as many workers as the process may really use: CPU affinity, capped by the cgroup quota (the GPU box shows 256 hardware threads
+        // and grants 16 CPUs) and by 32
+        unsigned n = std::max(1u, std::thread::hardware_concurrency());
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64] = {0}; long long period = 0;
+            if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, atoll(q) / period));
+            fclose(f);
+        }
+        n = std::min(n, 32u);
+        for (unsigned i = 0; i + 1 < n; ++i) {
+            try { std::thread([this] { loop(); }).detach(); ++nWorkers_; } catch (const std::system_error&) { break; }
+        }
+    }
+    void loop()
+    {
+        std::unique_lock<std::mutex> lk(mu_);
+        for (;;) {
+            cv_.wait(lk, [this] { return !queue_.empty(); });
+            auto job = std::move(queue_.front());
+            queue_.pop_front();
+            lk.unlock();
+            job.second();
+            job.first->left.fetch_sub(1, std::memory_order_acq_rel);
+            done_.notify_all();
+            lk.lock();
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_, done_;
+    std::deque<std::pair<Section*, std::function<void()>>> queue_;
+    unsigned nWorkers_ = 0;
+};
+
+// fn(0) .. fn(n - 1) side by side: n - 1 of them offered to the pool, the last one on the caller's thread, which then helps until all are done.
 template <class F>
 void run_parts(unsigned n, F fn)
 {
-    std::vector<std::thread> pool;
-    unsigned started = 0;
-    try { for (; started + 1 < n; ++started) pool.emplace_back(fn, started); } catch (const std::system_error&) {}
-    for (unsigned t = started; t < n; ++t) fn(t);
-    for (auto& th : pool) th.join();
+    if (n <= 1) { if (n) fn(0u); return; }
+    WorkerPool& pool = WorkerPool::get();
+    if (pool.workers() == 0) { for (unsigned t = 0; t < n; ++t) fn(t); return; }
+    WorkerPool::Section sec;
+    sec.left.store(n - 1, std::memory_order_release);
+    for (unsigned t = 0; t + 1 < n; ++t) pool.submit(&sec, [&fn, t] { fn(t); });
+    fn(n - 1);
+    pool.help_until_done(&sec);
 }
 
 // Host threads of setUtterances (the planner's setting: SPEECHPLAYER_PLAN_THREADS, else up to 8), and a loop over [0, n) cut into

@@ -65,6 +65,40 @@ int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtte
 	const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration, const unsigned int* fadeDuration,
 	const int* userIndex, const unsigned char* isNull, const unsigned int* noiseSeed);
 
+/*
+ * The same batch in COMPACT form: frame lists that utterances SHARE, and frames as 32-byte records the device expands.
+ * The reference produces frames lazily, one utterance at a time (ipa.py:336-353), and hands each to speechPlayer_queueFrame as a
+ * 376-byte struct (src/frame.cpp:90-101).  A batch of N utterances seldom holds N different frame streams (BASELINE's configurations
+ * are 512 streams instanced), and a frame a producer emits is one of a few hundred parameter vectors plus a pitch pair and two
+ * durations.  Both entry points describe `nLists` frame lists once and say per utterance which list it speaks (listOf[u]; NULL:
+ * utterance u speaks list u, nUtterances == nLists); utterances of one list read the same frames in HBM and differ in their noise
+ * seed alone.  Everything else is as in speechPlayer_batch_setUtterances (each utterance a fresh handle with the list's frames queued).
+ *   speechPlayer_batch_setUtterancesShared   the lists as full frames (listStart[nLists+1] into frames / durations / ...)
+ *   speechPlayer_batch_setRecords            the lists as records: record k stands for the frame whose parameters 1..45 are
+ *                                            shapes[records[k].shape] and whose voicePitch / endVoicePitch are the record's own
+ *                                            (shape SPEECHPLAYER_RECORD_SILENCE: framePtr == NULL).  32 bytes per frame cross the
+ *                                            link, the 376-byte frames are built in HBM (klatt_expand_frames), and the planner
+ *                                            recognises equal frames by their shape number -- exactly, nothing is hashed.
+ */
+#define SPEECHPLAYER_RECORD_SILENCE 0xFFFFFFFFu
+typedef struct {
+	double voicePitch, endVoicePitch;             /* parameters 0 and 46 of the frame */
+	unsigned int shape;                           /* row of the call's shape table, or SPEECHPLAYER_RECORD_SILENCE */
+	unsigned int minFrameDuration, fadeDuration;  /* samples, as in speechPlayer_queueFrame */
+	int userIndex;                                /* -1: none */
+} speechPlayer_frameRecord_t;                     /* 32 bytes */
+int speechPlayer_batch_setUtterancesShared(speechPlayer_batch_t batch, long long nLists, const long long* listStart,
+	const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration, const unsigned int* fadeDuration,
+	const int* userIndex, const unsigned char* isNull, long long nUtterances, const unsigned int* listOf, const unsigned int* noiseSeed);
+int speechPlayer_batch_setRecords(speechPlayer_batch_t batch, long long nShapes, const speechPlayer_frame_t* shapes,
+	long long nLists, const long long* listStart, const speechPlayer_frameRecord_t* records,
+	long long nUtterances, const unsigned int* listOf, const unsigned int* noiseSeed);
+/* The frames of utterance u as they are resident in HBM (downloaded; after any of the set calls): what each speechPlayer_queueFrame
+ * call of that utterance would have been given.  Returns the utterance's number of frames; fills the arrays (each may be NULL)
+ * when it is <= capacity.  fadeDuration comes back as the engine uses it (>= 1: reference src/speechPlayer.cpp:36). */
+long long speechPlayer_batch_frames(speechPlayer_batch_t batch, long long utterance, speechPlayer_frame_t* frames,
+	unsigned int* minFrameDuration, unsigned int* fadeDuration, int* userIndex, unsigned char* isNull, long long capacity);
+
 /* Number of samples utterance u produces: sum over its frames of max(M, F+1)+1. */
 long long speechPlayer_batch_utteranceSamples(speechPlayer_batch_t batch, long long utterance);
 long long speechPlayer_batch_totalSamples(speechPlayer_batch_t batch);
@@ -128,6 +162,14 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
 	const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible, long long budgetMB,
 	unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked, unsigned long long* nEntries);
 
+/* The same with the per-frame facts GIVEN (facts24: nFrames x 24 bytes as speechPlayer_frameFacts writes them; NULL: computed) and with
+ * the check the engine makes of every frame the planner recognised by its 128-bit hash: its 45 shape values compared with those of the
+ * first frame that carried the hash (on the device in speechPlayer_batch_setUtterances -- klatt_verify_shared --, here on the host).
+ * Returns -2 and the frame in *collisionAt when two frames share a hash and differ (a test forges such facts; the engine then plans
+ * the batch again without tracks and leaves a message in speechPlayer_lastError with the call succeeding). */
+long long speechPlayer_planTracksFacts(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,
+	const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible, long long budgetMB, const void* facts24,
+	unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked, unsigned long long* nEntries, long long* collisionAt);
 /* Host-only view of the fade end points speechPlayer_batch_setUtterances derives for the utterances it sends to the direct stages
  * (tests; touches no device; follows reference src/frame.cpp:55-72): per frame the frames its fade starts from and ends on
  * (0xFFFFFFFF: none -- all values zero) and flags (bit 0: the start's preFormantGain is gated off -- silence --, bit 1: the end's).
@@ -228,10 +270,29 @@ long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* co
 	double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
 	long long* frameStart, speechPlayer_frame_t* frames, unsigned int* minFrameDuration, unsigned int* fadeDuration,
 	unsigned char* isNull, long long frameCapacity);
-/* Text in, batch resident in HBM: speechPlayer_ipa_pack at the batch's sample rate + speechPlayer_batch_setUtterances. */
+/* Text in, batch resident in HBM: the producer's compact form (distinct (text, clause, base pitch, voice) combinations built once, as
+ * lists of 32-byte records over a table of (voice, phoneme) shapes) handed to speechPlayer_batch_setRecords. */
 int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
 	const double* basePitch, double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
 	const unsigned int* noiseSeed);
+/* The same with a voice PER TEXT: voiceOf[i] = index of text i's voice (0 .. speechPlayer_voiceCount()-1; -1 none); NULL: none.
+ * BASELINE configs[4] -- 256 voice-parameter variants x 16 384 utterances -- is this call with 256 defined voices. */
+int speechPlayer_batch_setIpaVoices(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
+	const double* basePitch, double inflection, const char* clauseTypes, const int* voiceOf, double trailingSilenceMs,
+	const unsigned int* noiseSeed);
+/* The compact form itself, for callers that keep a batch's description (and for the tests): an object that owns the arrays
+ * speechPlayer_batch_setRecords takes.  NULL on bad arguments. */
+typedef void* speechPlayer_records_t;
+typedef struct {
+	long long nShapes; const speechPlayer_frame_t* shapes;
+	long long nLists; const long long* listStart;
+	long long nRecords; const speechPlayer_frameRecord_t* records;
+	long long nUtterances; const unsigned int* listOf;
+} speechPlayer_recordsView_t;
+speechPlayer_records_t speechPlayer_ipa_records(int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed, const double* basePitch,
+	double inflection, const char* clauseTypes, const int* voiceOf, const char* voiceName, double trailingSilenceMs);
+int speechPlayer_records_view(speechPlayer_records_t records, speechPlayer_recordsView_t* view);
+void speechPlayer_records_free(speechPlayer_records_t records);
 /*
  * Optional text front-end: what the NVDA driver does before the frame producer (reference
  * nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:189-234), with eSpeak NG loaded at run time (dlopen of libespeak-ng.so.1, or of
@@ -261,8 +322,15 @@ int speechPlayer_batch_setText(speechPlayer_batch_t batch, long long nTexts, con
 int speechPlayer_ipa_phonemeCount(void);
 int speechPlayer_ipa_phoneme(int index, char* symbolUtf8, int symbolCapacity, double* values, unsigned long long* fieldMask, unsigned int* classBits);
 /* The voice presets of the NVDA driver (reference __init__.py:86-116), by index and by name. */
-int speechPlayer_voiceCount(void);
+int speechPlayer_voiceCount(void);          /* presets, then the voices defined with speechPlayer_voiceDefine */
+int speechPlayer_voicePresetCount(void);    /* the driver's presets alone: indices 0 .. this - 1 */
 const char* speechPlayer_voiceName(int index);
+/* Index of a voice by name (-1: none such), and a voice of the caller's own in the presets' form (reference __init__.py:86-116: per
+ * parameter an absolute value, a multiplier, or both -- absolute first): entry e sets parameter param[e] (0..46) to absValue[e] unless
+ * that is NaN (or absValue NULL), then multiplies it by multiplier[e] unless that is NaN (or multiplier NULL).  Defining a name again
+ * replaces its entries; built-in names cannot be redefined.  Returns the voice's index, -1 on bad arguments. */
+int speechPlayer_voiceIndex(const char* voiceName);
+int speechPlayer_voiceDefine(const char* voiceName, int nEntries, const int* param, const double* absValue, const double* multiplier);
 /* reference __init__.py:118-125.  0, or -1 for an unknown voice. */
 int speechPlayer_applyVoiceToFrame(speechPlayer_frame_t* frame, const char* voiceName);
 

@@ -48,7 +48,9 @@ EXPORTS = [
     "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
     "speechPlayer_node_setUtterances", "speechPlayer_node_synthesize", "speechPlayer_node_wait", "speechPlayer_node_totalSamples",
     "speechPlayer_node_read", "speechPlayer_node_getLastIndex", "speechPlayer_node_shardInfo", "speechPlayer_node_part",
-    "speechPlayer_node_time", "speechPlayer_planTracks", "speechPlayer_planDirect", "speechPlayer_frameFacts",
+    "speechPlayer_node_time", "speechPlayer_planTracks", "speechPlayer_planDirect", "speechPlayer_frameFacts", "speechPlayer_planTracksFacts",
+    "speechPlayer_batch_setUtterancesShared", "speechPlayer_batch_setRecords", "speechPlayer_batch_frames", "speechPlayer_batch_setIpaVoices",
+    "speechPlayer_ipa_records", "speechPlayer_records_view", "speechPlayer_records_free", "speechPlayer_voiceIndex", "speechPlayer_voiceDefine", "speechPlayer_voicePresetCount",
 ]
 
 
@@ -283,6 +285,28 @@ def load():
     L.speechPlayer_frameFacts.argtypes = [vp, i64, i32, i32, vp]
     L.speechPlayer_planDirect.restype = i64
     L.speechPlayer_planDirect.argtypes = [i64, vp, vp, vp, vp, vp]
+    L.speechPlayer_planTracksFacts.restype = i64
+    L.speechPlayer_planTracksFacts.argtypes = [i64, vp, vp, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp]
+    L.speechPlayer_batch_setUtterancesShared.restype = i32
+    L.speechPlayer_batch_setUtterancesShared.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp]
+    L.speechPlayer_batch_setRecords.restype = i32
+    L.speechPlayer_batch_setRecords.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp]
+    L.speechPlayer_batch_frames.restype = i64
+    L.speechPlayer_batch_frames.argtypes = [vp, i64, vp, vp, vp, vp, vp, i64]
+    L.speechPlayer_batch_setIpaVoices.restype = i32
+    L.speechPlayer_batch_setIpaVoices.argtypes = [vp, i64, vp, f64, vp, f64, ctypes.c_char_p, vp, f64, vp]
+    L.speechPlayer_ipa_records.restype = vp
+    L.speechPlayer_ipa_records.argtypes = [i32, i64, vp, f64, vp, f64, ctypes.c_char_p, vp, ctypes.c_char_p, f64]
+    L.speechPlayer_records_view.restype = i32
+    L.speechPlayer_records_view.argtypes = [vp, vp]
+    L.speechPlayer_records_free.restype = None
+    L.speechPlayer_records_free.argtypes = [vp]
+    L.speechPlayer_voicePresetCount.restype = i32
+    L.speechPlayer_voicePresetCount.argtypes = []
+    L.speechPlayer_voiceIndex.restype = i32
+    L.speechPlayer_voiceIndex.argtypes = [ctypes.c_char_p]
+    L.speechPlayer_voiceDefine.restype = i32
+    L.speechPlayer_voiceDefine.argtypes = [ctypes.c_char_p, i32, vp, vp, vp]
     _lib = L
     return L
 

@@ -24,6 +24,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -96,27 +97,59 @@ int row_of_h()
 }
 
 // ---- an utterance as flat records --------------------------------------------------------------
-enum : uint16_t { S_TIED_TO = 1, S_TIED_FROM = 2, S_LONG = 4, S_WORD_START = 8, S_SYLLABLE_START = 16, S_GAP = 32, S_PUFF = 64, S_HAS_PITCH = 128 };
+enum : uint16_t { S_TIED_TO = 1, S_TIED_FROM = 2, S_LONG = 4, S_WORD_START = 8, S_SYLLABLE_START = 16, S_GAP = 32, S_PUFF = 64 };
 
 struct Segment {
     int row;             // table row; -1 for a pre-stop gap (silence)
+    int comp;            // the segment's values: the row itself, or the row with the fields it took over from a neighbour (Composites)
     uint8_t cls;
     uint8_t stress;      // 0, 1 primary, 2 secondary; meaningful on syllable heads
     uint16_t pros;       // S_* bits
-    int borrowed;        // index into Utterance::extra of the fields taken over from a neighbour, or -1
-    double duration, fade, pitch, endPitch;
+    double duration, fade;
 };
-struct Borrowed { uint64_t mask; double value[kParams]; };
+struct Utterance { std::vector<Segment> seg; };
 
-struct Utterance {
-    std::vector<Segment> seg;
-    std::vector<Borrowed> extra;
-    uint64_t mask_of(const Segment& s) const { return (s.row < 0 ? 0 : kPhonemeRows[s.row].mask) | (s.borrowed < 0 ? 0 : extra[s.borrowed].mask); }
-    double field(const Segment& s, int k) const
+// A COMPOSITE is what a segment's parameter values are before pitch and voice: a table row, or a copy-adjacent row completed with
+// the fields of a neighbour's composite (reference ipa.py:121-133).  Composites are identified exactly -- id below kNumPhonemes: the
+// row; above: (base composite, donor composite), a pure function of the two -- so a frame's 45 non-pitch values are known by a small
+// integer, and everything behind the producer (the device's frame expansion, the track planner) recognises equal frames by that
+// integer instead of by comparing or hashing 376 bytes.
+struct Composite { uint64_t mask; double value[kParams]; };
+class Composites {
+public:
+    int count()
     {
-        if (s.row >= 0 && (kPhonemeRows[s.row].mask >> k & 1)) return kPhonemeRows[s.row].value[k];
-        return extra[s.borrowed].value[k];
+        std::lock_guard<std::mutex> g(mu_);
+        return kNumPhonemes + (int)extra_.size();
     }
+    void get(int id, Composite& out)
+    {
+        if (id < kNumPhonemes) { out.mask = kPhonemeRows[id].mask; memcpy(out.value, kPhonemeRows[id].value, sizeof out.value); return; }
+        std::lock_guard<std::mutex> g(mu_);
+        out = extra_[(size_t)(id - kNumPhonemes)];
+    }
+    // `base` with every field it lacks taken from `donor`; `base` itself when the donor adds nothing
+    int combine(int base, int donor)
+    {
+        Composite b, d;
+        get(base, b); get(donor, d);
+        const uint64_t take = d.mask & ~b.mask;
+        if (!take) return base;
+        const uint64_t key = (uint64_t)(uint32_t)base << 32 | (uint32_t)donor;
+        std::lock_guard<std::mutex> g(mu_);
+        auto it = byKey_.find(key);
+        if (it != byKey_.end()) return it->second;
+        for (int k = 0; k < kParams; ++k) if (take >> k & 1) b.value[k] = d.value[k];
+        b.mask |= take;
+        extra_.push_back(b);
+        const int id = kNumPhonemes + (int)extra_.size() - 1;
+        byKey_.emplace(key, id);
+        return id;
+    }
+private:
+    std::mutex mu_;
+    std::vector<Composite> extra_;
+    std::unordered_map<uint64_t, int> byKey_;
 };
 
 void decode_utf8(const char* text, std::vector<uint32_t>& out)
@@ -138,8 +171,8 @@ void decode_utf8(const char* text, std::vector<uint32_t>& out)
 Segment make_segment(int row)
 {
     Segment s;
-    s.row = row; s.cls = row < 0 ? 0 : kPhonemeRows[row].cls; s.stress = 0; s.pros = 0; s.borrowed = -1;
-    s.duration = s.fade = s.pitch = s.endPitch = 0.0;
+    s.row = row; s.comp = row; s.cls = row < 0 ? 0 : kPhonemeRows[row].cls; s.stress = 0; s.pros = 0;
+    s.duration = s.fade = 0.0;
     return s;
 }
 
@@ -149,7 +182,7 @@ Segment make_segment(int row)
 // does not carry the stress mark itself goes a gap.
 void lex(const std::vector<uint32_t>& cp, Utterance& u)
 {
-    u.seg.clear(); u.extra.clear();
+    u.seg.clear();
     const SymbolIndex& sym = symbols();
     const size_t n = cp.size();
     int waitingStress = 0;
@@ -213,28 +246,15 @@ void lex(const std::vector<uint32_t>& cp, Utterance& u)
 
 // A segment of the copy-adjacent class takes every field it lacks from the segment after it -- or, when that is a gap or
 // the end, from the one before -- as that neighbour stands at this point of a left-to-right pass.
-void colour(Utterance& u)
+void colour(Utterance& u, Composites& comps)
 {
     const int n = (int)u.seg.size();
     for (int i = 0; i < n; ++i) {
         Segment& s = u.seg[i];
         if (!(s.cls & C_COPY_ADJACENT)) continue;
-        int from = (i + 1 < n && !(u.seg[i + 1].pros & S_GAP)) ? i + 1 : i - 1;
-        if (from < 0) continue;
-        const Segment& d = u.seg[from];
-        const uint64_t take = u.mask_of(d) & ~u.mask_of(s);
-        if (!take) continue;
-        Borrowed b;
-        b.mask = take;
-        for (int k = 0; k < kParams; ++k) b.value[k] = (take >> k & 1) ? u.field(d, k) : 0.0;
-        if (s.borrowed >= 0) {      // (cannot happen in one pass; kept so that a second pass would merge)
-            Borrowed& old = u.extra[s.borrowed];
-            for (int k = 0; k < kParams; ++k) if (take >> k & 1) old.value[k] = b.value[k];
-            old.mask |= take;
-        } else {
-            u.extra.push_back(b);
-            s.borrowed = (int)u.extra.size() - 1;
-        }
+        const int from = (i + 1 < n && !(u.seg[i + 1].pros & S_GAP)) ? i + 1 : i - 1;
+        if (from < 0 || u.seg[from].row < 0) continue;                  // (a gap has no fields to give)
+        s.comp = comps.combine(s.comp, u.seg[from].comp);
     }
 }
 
@@ -336,8 +356,15 @@ void contour_spans(const Utterance& u, int clause, std::vector<Span>& spans)
     }
 }
 
-void apply_spans(Utterance& u, const std::vector<Span>& spans, double basePitch, double inflection)
+// the pitch pair of every segment a span covers (a later span overwrites an earlier one, as in the reference's loop)
+struct Pitches {
+    std::vector<double> pitch, endPitch;
+    std::vector<unsigned char> has;
+    void reset(size_t n) { pitch.assign(n, 0.0); endPitch.assign(n, 0.0); has.assign(n, 0); }
+};
+void apply_spans(const Utterance& u, const std::vector<Span>& spans, double basePitch, double inflection, Pitches& out)
 {
+    out.reset(u.seg.size());
     for (const Span& sp : spans) {
         const double p0 = basePitch * std::pow(2.0, ((sp.from - 50) / 50.0) * inflection);
         const double p1 = basePitch * std::pow(2.0, ((sp.to - 50) / 50.0) * inflection);
@@ -346,114 +373,76 @@ void apply_spans(Utterance& u, const std::vector<Span>& spans, double basePitch,
         const double delta = p1 - p0;
         double done = 0.0, cur = p0;
         for (int i = sp.a; i < sp.b; ++i) {
-            Segment& s = u.seg[i];
-            s.pitch = cur;
+            const Segment& s = u.seg[i];
+            out.pitch[i] = cur;
             if (s.cls & C_VOICED) {
                 done += s.duration;
                 cur = p0 + (delta * (done / voiced));
             }
-            s.endPitch = cur;
-            s.pros |= S_HAS_PITCH;
+            out.endPitch[i] = cur;
+            out.has[i] = 1;
         }
     }
 }
 
-const VoiceRow* find_voice(const char* name)
+// ---- voices: the driver's presets (frame_tables.inc) and the ones a caller defines -------------------------------
+struct VoiceDef { std::string name; std::vector<VoiceEntry> entries; };
+std::mutex g_voiceMutex;
+std::vector<std::unique_ptr<VoiceDef>> g_definedVoices;       // indices kNumVoices .. ; never shrinks: names handed out stay valid
+
+// index of a voice by name, -1 if there is none.  (The reference's table has one key with a trailing blank, "Caleb ": the name
+// without it is accepted too.)
+int voice_index(const char* name)
 {
-    if (!name || !*name) return nullptr;
-    for (const VoiceRow& v : kVoiceRows)
-        if (!strcmp(v.name, name)) return &v;
-    // the reference's table has one key with a trailing blank ("Caleb "): accept the name without it too
+    if (!name || !*name) return -1;
+    for (int i = 0; i < kNumVoices; ++i)
+        if (!strcmp(kVoiceRows[i].name, name)) return i;
     const size_t len = strlen(name);
-    for (const VoiceRow& v : kVoiceRows)
-        if (strlen(v.name) == len + 1 && !strncmp(v.name, name, len) && v.name[len] == ' ') return &v;
-    return nullptr;
+    for (int i = 0; i < kNumVoices; ++i) {
+        const char* v = kVoiceRows[i].name;
+        if (strlen(v) == len + 1 && !strncmp(v, name, len) && v[len] == ' ') return i;
+    }
+    std::lock_guard<std::mutex> g(g_voiceMutex);
+    for (size_t i = 0; i < g_definedVoices.size(); ++i)
+        if (g_definedVoices[i]->name == name) return kNumVoices + (int)i;
+    return -1;
+}
+int voice_count()
+{
+    std::lock_guard<std::mutex> g(g_voiceMutex);
+    return kNumVoices + (int)g_definedVoices.size();
+}
+// the entries of voice `index` (a copy: a producer call works on what the voice was when the call started); false if out of range
+bool voice_entries(int index, std::vector<VoiceEntry>& out)
+{
+    out.clear();
+    if (index < 0) return false;
+    if (index < kNumVoices) { out.assign(kVoiceRows[index].entries, kVoiceRows[index].entries + kVoiceRows[index].nEntries); return true; }
+    std::lock_guard<std::mutex> g(g_voiceMutex);
+    const size_t i = (size_t)(index - kNumVoices);
+    if (i >= g_definedVoices.size()) return false;
+    out = g_definedVoices[i]->entries;
+    return true;
 }
 
-// absolute value first, then the multiplier, parameter by parameter in frame order (entries are stored in that order)
-void apply_voice(double* frame, const VoiceRow& v)
+// absolute value first, then the multiplier, parameter by parameter in the entries' order (reference __init__.py:118-125)
+void apply_voice(double* frame, const std::vector<VoiceEntry>& v)
 {
-    for (int e = 0; e < v.nEntries; ++e) {
-        const VoiceEntry& x = v.entries[e];
+    for (const VoiceEntry& x : v) {
         if (x.hasAbs) frame[x.param] = x.abs;
         if (x.hasMul) frame[x.param] = frame[x.param] * x.mul;
     }
 }
-
-// one finished stream: what the reference's generator yields, as arrays
-struct Stream {
-    std::vector<double> frames;          // [n][47]; zeros for silence
-    std::vector<unsigned char> isNull;
-    std::vector<double> durationMs, fadeMs;
-    size_t size() const { return isNull.size(); }
-};
-
-void emit(const Utterance& u, const VoiceRow* voice, Stream& out)
+// the same for ONE parameter whose value is `value` before the voice (an entry touches nothing but its own parameter)
+double apply_voice_param(const std::vector<VoiceEntry>& v, int param, double value)
 {
-    const size_t n = u.seg.size();
-    out.frames.assign(n * kParams, 0.0);
-    out.isNull.assign(n, 0);
-    out.durationMs.resize(n); out.fadeMs.resize(n);
-    for (size_t i = 0; i < n; ++i) {
-        const Segment& s = u.seg[i];
-        out.durationMs[i] = s.duration; out.fadeMs[i] = s.fade;
-        if (s.pros & S_GAP) { out.isNull[i] = 1; continue; }
-        double* f = &out.frames[i * kParams];
-        f[P_PREGAIN] = 1.0;                 // reference ipa.py:349-351
-        f[P_OUTGAIN] = 2.0;
-        const uint64_t m = u.mask_of(s);
-        for (int k = 0; k < kParams; ++k) if (m >> k & 1) f[k] = u.field(s, k);
-        if (s.pros & S_HAS_PITCH) { f[P_VOICEPITCH] = s.pitch; f[P_ENDPITCH] = s.endPitch; }
-        if (voice) apply_voice(f, *voice);
+    for (const VoiceEntry& x : v) {
+        if (x.param != param) continue;
+        if (x.hasAbs) value = x.abs;
+        if (x.hasMul) value = value * x.mul;
     }
+    return value;
 }
-
-// Builder with the per-call memo: segments + timing per text, finished streams per (text, clause, base pitch).
-class Producer {
-public:
-    Producer(double speed, double inflection, const VoiceRow* voice) : speed_(speed), inflection_(inflection), voice_(voice) {}
-
-    const Stream& stream(const char* text, int clause, double basePitch)
-    {
-        std::string key(text ? text : "");
-        key.push_back('\0'); key.push_back((char)clause);
-        uint64_t bits; memcpy(&bits, &basePitch, 8);
-        key.append(reinterpret_cast<const char*>(&bits), 8);
-        auto it = done_.find(key);
-        if (it != done_.end()) return it->second;
-        const Timed& t = timed(text);
-        Utterance u = t.u;                         // pitches are per (clause, base pitch): work on a copy
-        std::vector<Span>& spans = spansScratch_;
-        if (!u.seg.empty()) {
-            contour_spans(u, clause, spans);
-            apply_spans(u, spans, basePitch, inflection_);
-        }
-        Stream& s = done_[key];
-        emit(u, voice_, s);
-        return s;
-    }
-
-private:
-    struct Timed { Utterance u; };
-    const Timed& timed(const char* text)
-    {
-        std::string key(text ? text : "");
-        auto it = timed_.find(key);
-        if (it != timed_.end()) return it->second;
-        Timed& t = timed_[key];
-        decode_utf8(text, cpScratch_);
-        lex(cpScratch_, t.u);
-        colour(t.u);
-        time_segments(t.u, speed_);
-        return t;
-    }
-    double speed_, inflection_;
-    const VoiceRow* voice_;
-    std::unordered_map<std::string, Timed> timed_;
-    std::unordered_map<std::string, Stream> done_;
-    std::vector<uint32_t> cpScratch_;
-    std::vector<Span> spansScratch_;
-};
 
 // milliseconds -> samples as the reference wrapper converts them (reference speechPlayer.py:53): int(ms * (sr / 1000.0))
 unsigned int ms_to_samples(double ms, int sampleRate)
@@ -465,26 +454,277 @@ unsigned int ms_to_samples(double ms, int sampleRate)
 }  // namespace
 
 extern "C" {
+// klatt_engine.hip: fn(ctx, a, e) over [0, n) cut into ranges, on the engine's worker threads (the caller's thread takes part)
+void speechPlayer_internal_parallel(long long n, long long grain, void (*fn)(void* ctx, long long a, long long e), void* ctx);
+}
 
-int speechPlayer_voiceCount(void) { return kNumVoices; }
+namespace {
 
-const char* speechPlayer_voiceName(int i) { return (i >= 0 && i < kNumVoices) ? kVoiceRows[i].name : nullptr; }
-
-int speechPlayer_applyVoiceToFrame(speechPlayer_frame_t* frame, const char* voiceName)
+template <class F>
+void parallel_for(long long n, long long grain, F body)
 {
-    const VoiceRow* v = find_voice(voiceName);
-    if (!frame || !v) return -1;
-    apply_voice(reinterpret_cast<double*>(frame), *v);
+    speechPlayer_internal_parallel(n, grain, [](void* ctx, long long a, long long e) { (*static_cast<F*>(ctx))(a, e); }, &body);
+}
+
+// ---- a batch in compact form ----------------------------------------------------------------------------------------
+// What the reference's generator yields frame by frame (ipa.py:336-353: a 47-field Frame, a duration, a fade), a batch call yields as
+//   shapes   [nVoices x nComposites] frames: every (voice, composite) pair's 45 non-pitch values, voice applied (a few hundred rows)
+//   records  32 bytes per frame: the two pitches (voice applied), the shape's row, the durations in samples
+//   lists    one per DISTINCT (text, clause, base pitch, voice); listOf[u]: the list utterance u speaks
+// -- include/speechPlayer_batch.h, speechPlayer_batch_setRecords: the device builds the 376-byte frames from it (klatt_expand_frames),
+// and utterances that speak the same list share its frames in HBM.
+struct PackArgs {
+    int sampleRate = 22050;
+    long long nTexts = 0;
+    const char* const* texts = nullptr;
+    double speed = 1.0;
+    const double* basePitch = nullptr;       // [nTexts] or NULL (100 Hz)
+    double inflection = 0.5;
+    const char* clauseTypes = nullptr;       // [nTexts] or NULL (none)
+    const int* voiceOf = nullptr;            // [nTexts] voice index per text (-1: none), or NULL: voiceAll
+    int voiceAll = -1;
+    double tailMs = -1.0;                    // silence after every utterance (negative: none)
+};
+struct Compact {
+    long long nComposites = 0;
+    int nVoices = 0;
+    std::vector<speechPlayer_frame_t> shapes;
+    std::vector<long long> listStart;
+    std::vector<speechPlayer_frameRecord_t> records;
+    std::vector<uint32_t> listOf;
+    std::vector<double> durationMs, fadeMs;          // per record (keepMs)
+    long long frames_of(long long u) const { const uint32_t l = listOf[(size_t)u]; return listStart[l + 1] - listStart[l]; }
+};
+
+struct Timed {                                        // a text, lexed, coloured and timed: everything that does not depend on pitch or voice
+    Utterance u;
+    std::vector<unsigned int> minSamples, fadeSamples;
+};
+
+struct ListKey {
+    int text, clause, slot;
+    uint64_t pitchBits;
+    bool operator==(const ListKey& o) const { return text == o.text && clause == o.clause && slot == o.slot && pitchBits == o.pitchBits; }
+};
+struct ListKeyHash {
+    size_t operator()(const ListKey& k) const
+    {
+        uint64_t h = k.pitchBits * 0x9E3779B97F4A7C15ull;
+        h ^= h >> 29;
+        h += (uint64_t)(uint32_t)k.text * 0xC2B2AE3D27D4EB4Full + (uint64_t)(uint32_t)k.clause * 0x165667B19E3779F9ull + (uint64_t)(uint32_t)k.slot;
+        h *= 0xFF51AFD7ED558CCDull;
+        return (size_t)(h ^ (h >> 32));
+    }
+};
+
+// 0, or -1 (bad voice index).  sizeOnly: listOf and listStart alone (no shapes, no records).
+int build_compact(const PackArgs& a, bool sizeOnly, bool keepMs, Compact& out)
+{
+    const long long n = a.nTexts;
+    const bool tail = a.tailMs >= 0.0;
+    // ---- every utterance's list: distinct texts (by pointer first: a batch repeats its strings), distinct (text, clause, pitch, voice) ----
+    std::vector<const char*> textPtr;                 // text id -> the string
+    std::unordered_map<const char*, int> textByPtr;
+    std::unordered_map<std::string, int> textByContent;
+    std::vector<int> voiceOfSlot;                     // slot -> voice index (-1: none)
+    std::unordered_map<int, int> slotOfVoice;
+    std::vector<ListKey> lists;
+    std::unordered_map<ListKey, uint32_t, ListKeyHash> listByKey;
+    out.listOf.resize((size_t)n);
+    const int nVoicesKnown = voice_count();
+    const char* lastPtr = nullptr; int lastText = -1;
+    for (long long i = 0; i < n; ++i) {
+        const char* t = a.texts[i] ? a.texts[i] : "";
+        int text;
+        if (t == lastPtr) text = lastText;
+        else {
+            auto ip = textByPtr.find(t);
+            if (ip != textByPtr.end()) text = ip->second;
+            else {
+                auto ic = textByContent.find(t);
+                if (ic == textByContent.end()) { ic = textByContent.emplace(t, (int)textPtr.size()).first; textPtr.push_back(t); }
+                text = ic->second;
+                textByPtr.emplace(t, text);
+            }
+            lastPtr = t; lastText = text;
+        }
+        const int voice = a.voiceOf ? a.voiceOf[i] : a.voiceAll;
+        if (voice < -1 || voice >= nVoicesKnown) return -1;
+        auto is = slotOfVoice.find(voice);
+        if (is == slotOfVoice.end()) { is = slotOfVoice.emplace(voice, (int)voiceOfSlot.size()).first; voiceOfSlot.push_back(voice); }
+        const double pitch = a.basePitch ? a.basePitch[i] : 100.0;
+        ListKey key{text, a.clauseTypes ? (int)(unsigned char)a.clauseTypes[i] : 0, is->second, 0};
+        memcpy(&key.pitchBits, &pitch, 8);
+        auto il = listByKey.find(key);
+        if (il == listByKey.end()) { il = listByKey.emplace(key, (uint32_t)lists.size()).first; lists.push_back(key); }
+        out.listOf[(size_t)i] = il->second;
+    }
+    // ---- every distinct text: segments, colours, durations (in parallel: nothing here depends on another text but the composite ids) ----
+    Composites comps;
+    std::vector<Timed> timed(textPtr.size());
+    parallel_for((long long)textPtr.size(), 64, [&](long long ta, long long te) {
+        std::vector<uint32_t> cp;
+        for (long long t = ta; t < te; ++t) {
+            Timed& x = timed[(size_t)t];
+            decode_utf8(textPtr[(size_t)t], cp);
+            lex(cp, x.u);
+            colour(x.u, comps);
+            time_segments(x.u, a.speed);
+            const size_t ns = x.u.seg.size();
+            x.minSamples.resize(ns); x.fadeSamples.resize(ns);
+            for (size_t k = 0; k < ns; ++k) {
+                x.minSamples[k] = ms_to_samples(x.u.seg[k].duration, a.sampleRate);
+                x.fadeSamples[k] = ms_to_samples(x.u.seg[k].fade, a.sampleRate);
+            }
+        }
+    });
+    const size_t nLists = lists.size();
+    out.listStart.assign(nLists + 1, 0);
+    for (size_t l = 0; l < nLists; ++l) out.listStart[l + 1] = out.listStart[l] + (long long)timed[(size_t)lists[l].text].u.seg.size() + (tail ? 1 : 0);
+    if (sizeOnly) return 0;
+    // ---- the shape table: one row per (voice, composite) ----
+    const int C = comps.count(), V = (int)voiceOfSlot.size();
+    out.nComposites = C; out.nVoices = V;
+    std::vector<std::vector<VoiceEntry>> voices((size_t)V);
+    for (int s = 0; s < V; ++s)
+        if (voiceOfSlot[(size_t)s] >= 0 && !voice_entries(voiceOfSlot[(size_t)s], voices[(size_t)s])) return -1;
+    out.shapes.resize((size_t)C * (size_t)std::max(V, 0));
+    for (int s = 0; s < V; ++s)
+        for (int c = 0; c < C; ++c) {
+            double* f = reinterpret_cast<double*>(&out.shapes[(size_t)s * C + c]);
+            Composite co;
+            comps.get(c, co);
+            for (int k = 0; k < kParams; ++k) f[k] = 0.0;
+            f[P_PREGAIN] = 1.0;                 // reference ipa.py:349-351
+            f[P_OUTGAIN] = 2.0;
+            for (int k = 0; k < kParams; ++k) if (co.mask >> k & 1) f[k] = co.value[k];
+            apply_voice(f, voices[(size_t)s]);  // (parameters 0 and 46 of a row serve the segments no span covers)
+        }
+    // ---- the records, list by list ----
+    const size_t nRec = (size_t)out.listStart[nLists];
+    out.records.resize(nRec);
+    if (keepMs) { out.durationMs.assign(nRec, 0.0); out.fadeMs.assign(nRec, 0.0); }
+    const unsigned int tailSamples = tail ? ms_to_samples(a.tailMs, a.sampleRate) : 0u;
+    parallel_for((long long)nLists, 16, [&](long long la, long long le) {
+        std::vector<Span> spans;
+        Pitches pt;
+        for (long long l = la; l < le; ++l) {
+            const ListKey& key = lists[(size_t)l];
+            const Timed& x = timed[(size_t)key.text];
+            const std::vector<VoiceEntry>& voice = voices[(size_t)key.slot];
+            double basePitch;
+            memcpy(&basePitch, &key.pitchBits, 8);
+            const size_t ns = x.u.seg.size();
+            if (ns) {
+                contour_spans(x.u, key.clause, spans);
+                apply_spans(x.u, spans, basePitch, a.inflection, pt);
+            }
+            speechPlayer_frameRecord_t* r = out.records.data() + out.listStart[(size_t)l];
+            for (size_t k = 0; k < ns; ++k) {
+                const Segment& s = x.u.seg[k];
+                r[k].minFrameDuration = x.minSamples[k]; r[k].fadeDuration = x.fadeSamples[k]; r[k].userIndex = -1;
+                if (keepMs) { out.durationMs[(size_t)out.listStart[(size_t)l] + k] = s.duration; out.fadeMs[(size_t)out.listStart[(size_t)l] + k] = s.fade; }
+                if (s.pros & S_GAP) { r[k].shape = SPEECHPLAYER_RECORD_SILENCE; r[k].voicePitch = 0.0; r[k].endVoicePitch = 0.0; continue; }
+                const uint32_t shape = (uint32_t)((size_t)key.slot * C + s.comp);
+                r[k].shape = shape;
+                const double* row = reinterpret_cast<const double*>(out.shapes.data() + shape);
+                r[k].voicePitch = pt.has[k] ? apply_voice_param(voice, P_VOICEPITCH, pt.pitch[k]) : row[P_VOICEPITCH];
+                r[k].endVoicePitch = pt.has[k] ? apply_voice_param(voice, P_ENDPITCH, pt.endPitch[k]) : row[P_ENDPITCH];
+            }
+            if (tail) {                      // silence after the utterance, as reference test_speakIpa.py:27 queues it
+                speechPlayer_frameRecord_t& t = r[ns];
+                t.shape = SPEECHPLAYER_RECORD_SILENCE; t.voicePitch = 0.0; t.endVoicePitch = 0.0;
+                t.minFrameDuration = tailSamples; t.fadeDuration = 0; t.userIndex = -1;
+                if (keepMs) { out.durationMs[(size_t)out.listStart[(size_t)l] + ns] = a.tailMs; out.fadeMs[(size_t)out.listStart[(size_t)l] + ns] = 0.0; }
+            }
+        }
+    });
     return 0;
 }
 
+// record -> the 47-value frame it stands for (what klatt_expand_frames does on the device); silence: zeros
+void expand_record(const Compact& c, const speechPlayer_frameRecord_t& r, speechPlayer_frame_t* out, unsigned char* isNull)
+{
+    if (r.shape == SPEECHPLAYER_RECORD_SILENCE) { memset(out, 0, sizeof *out); *isNull = 1; return; }
+    *out = c.shapes[r.shape];
+    out->voicePitch = r.voicePitch;
+    out->endVoicePitch = r.endVoicePitch;
+    *isNull = 0;
+}
+
 // the clause types the intonation table knows (reference ipa.py:207-276; the reference raises KeyError for any other), and 0: none
-static bool clause_known(int clause)
+bool clause_known(int clause)
 {
     if (clause == 0) return true;
     for (const IntonationRow& r : kIntonationRows)
         if (r.clause == clause) return true;
     return false;
+}
+
+void set_producer_error(const char* msg);
+
+// nothing a host allocation throws crosses the C ABI
+template <class R, class F>
+R producer_call(const char* what, R fail, F body)
+{
+    try {
+        return body();
+    } catch (const std::exception& e) {
+        set_producer_error((std::string(what) + ": " + e.what()).c_str());
+        return fail;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+void speechPlayer_internal_setError(int code, const char* message);      // klatt_engine.hip
+
+int speechPlayer_voiceCount(void) { return voice_count(); }
+
+int speechPlayer_voicePresetCount(void) { return kNumVoices; }
+
+const char* speechPlayer_voiceName(int i)
+{
+    if (i < 0) return nullptr;
+    if (i < kNumVoices) return kVoiceRows[i].name;
+    std::lock_guard<std::mutex> g(g_voiceMutex);
+    const size_t k = (size_t)(i - kNumVoices);
+    return k < g_definedVoices.size() ? g_definedVoices[k]->name.c_str() : nullptr;
+}
+
+int speechPlayer_voiceIndex(const char* voiceName) { return voice_index(voiceName); }
+
+int speechPlayer_voiceDefine(const char* voiceName, int nEntries, const int* param, const double* absValue, const double* multiplier)
+{
+    return producer_call<int>("speechPlayer_voiceDefine", -1, [&]() -> int {
+        if (!voiceName || !*voiceName || nEntries < 0 || (nEntries > 0 && !param)) { set_producer_error("speechPlayer_voiceDefine: bad arguments"); return -1; }
+        std::vector<VoiceEntry> entries;
+        for (int e = 0; e < nEntries; ++e) {
+            if (param[e] < 0 || param[e] >= kParams) { set_producer_error("speechPlayer_voiceDefine: parameter index out of range"); return -1; }
+            VoiceEntry x;
+            x.param = param[e];
+            x.hasAbs = absValue && !std::isnan(absValue[e]); x.abs = x.hasAbs ? absValue[e] : 0.0;
+            x.hasMul = multiplier && !std::isnan(multiplier[e]); x.mul = x.hasMul ? multiplier[e] : 1.0;
+            entries.push_back(x);
+        }
+        for (int i = 0; i < kNumVoices; ++i)
+            if (!strcmp(kVoiceRows[i].name, voiceName)) { set_producer_error("speechPlayer_voiceDefine: the name of a built-in preset"); return -1; }
+        std::lock_guard<std::mutex> g(g_voiceMutex);
+        for (size_t i = 0; i < g_definedVoices.size(); ++i)
+            if (g_definedVoices[i]->name == voiceName) { g_definedVoices[i]->entries.swap(entries); return kNumVoices + (int)i; }
+        g_definedVoices.emplace_back(new VoiceDef{voiceName, std::move(entries)});
+        return kNumVoices + (int)g_definedVoices.size() - 1;
+    });
+}
+
+int speechPlayer_applyVoiceToFrame(speechPlayer_frame_t* frame, const char* voiceName)
+{
+    std::vector<VoiceEntry> v;
+    if (!frame || !voice_entries(voice_index(voiceName), v)) return -1;
+    apply_voice(reinterpret_cast<double*>(frame), v);
+    return 0;
 }
 
 int speechPlayer_ipa_phonemeCount(void) { return kNumPhonemes; }
@@ -515,94 +755,139 @@ long long speechPlayer_ipa_frames(const char* ipaUtf8, double speed, double base
                                   const char* voiceName, speechPlayer_frame_t* frames, unsigned char* isNull,
                                   double* durationMs, double* fadeMs, long long capacity)
 {
-    const VoiceRow* voice = find_voice(voiceName);
-    if (voiceName && *voiceName && !voice) return -1;
-    if (!clause_known(clauseType)) return -2;
-    Producer p(speed, inflection, voice);
-    const Stream& s = p.stream(ipaUtf8, clauseType, basePitch);
-    const long long n = (long long)s.size();
-    if (n <= capacity) {
-        if (n && frames) memcpy(frames, s.frames.data(), (size_t)n * sizeof(speechPlayer_frame_t));
-        if (n && isNull) memcpy(isNull, s.isNull.data(), (size_t)n);
-        if (n && durationMs) memcpy(durationMs, s.durationMs.data(), (size_t)n * sizeof(double));
-        if (n && fadeMs) memcpy(fadeMs, s.fadeMs.data(), (size_t)n * sizeof(double));
-    }
-    return n;
+    return producer_call<long long>("speechPlayer_ipa_frames", -1, [&]() -> long long {
+        const int voice = voice_index(voiceName);
+        if (voiceName && *voiceName && voice < 0) return -1;
+        if (!clause_known(clauseType)) return -2;
+        PackArgs a;
+        const char clause = (char)clauseType;
+        a.nTexts = 1; a.texts = &ipaUtf8; a.speed = speed; a.basePitch = &basePitch; a.inflection = inflection;
+        a.clauseTypes = &clause; a.voiceAll = voice; a.tailMs = -1.0;
+        Compact c;
+        if (build_compact(a, false, true, c)) return -1;
+        const long long n = (long long)c.records.size();
+        if (n <= capacity) {
+            for (long long k = 0; k < n; ++k) {
+                speechPlayer_frame_t f; unsigned char nul;
+                expand_record(c, c.records[(size_t)k], &f, &nul);
+                if (frames) frames[k] = f;
+                if (isNull) isNull[k] = nul;
+                if (durationMs) durationMs[k] = c.durationMs[(size_t)k];
+                if (fadeMs) fadeMs[k] = c.fadeMs[(size_t)k];
+            }
+        }
+        return n;
+    });
 }
 
-// one pass over the texts with a producer (and its memo) the caller keeps: sizes when the arrays are absent, else fills them
-static long long pack_with(Producer& p, int sampleRate, long long nTexts, const char* const* ipaUtf8, const double* basePitch,
-                           const char* clauseTypes, double trailingSilenceMs, long long* frameStart, speechPlayer_frame_t* frames,
-                           unsigned int* minFrameDuration, unsigned int* fadeDuration, unsigned char* isNull, long long frameCapacity);
+static int check_pack_args(long long nTexts, const char* const* ipaUtf8, const char* clauseTypes, const int* voiceOf, const char* voiceName, int* voiceAll)
+{
+    if (nTexts < 0 || (nTexts > 0 && !ipaUtf8)) return -1;
+    *voiceAll = voice_index(voiceName);
+    if (!voiceOf && voiceName && *voiceName && *voiceAll < 0) return -1;
+    for (long long i = 0; clauseTypes && i < nTexts; ++i)
+        if (!clause_known((int)(unsigned char)clauseTypes[i])) return -2;
+    return 0;
+}
 
 long long speechPlayer_ipa_pack(int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed, const double* basePitch,
                                 double inflection, const char* clauseTypes, const char* voiceName, double trailingSilenceMs,
                                 long long* frameStart, speechPlayer_frame_t* frames, unsigned int* minFrameDuration,
                                 unsigned int* fadeDuration, unsigned char* isNull, long long frameCapacity)
 {
-    if (nTexts < 0 || (nTexts > 0 && !ipaUtf8)) return -1;
-    const VoiceRow* voice = find_voice(voiceName);
-    if (voiceName && *voiceName && !voice) return -1;
-    for (long long i = 0; clauseTypes && i < nTexts; ++i)
-        if (!clause_known((int)(unsigned char)clauseTypes[i])) return -2;
-    Producer p(speed, inflection, voice);
-    return pack_with(p, sampleRate, nTexts, ipaUtf8, basePitch, clauseTypes, trailingSilenceMs, frameStart, frames, minFrameDuration, fadeDuration, isNull, frameCapacity);
+    return producer_call<long long>("speechPlayer_ipa_pack", -1, [&]() -> long long {
+        PackArgs a;
+        if (int rc = check_pack_args(nTexts, ipaUtf8, clauseTypes, nullptr, voiceName, &a.voiceAll)) return rc;
+        a.sampleRate = sampleRate; a.nTexts = nTexts; a.texts = ipaUtf8; a.speed = speed; a.basePitch = basePitch; a.inflection = inflection;
+        a.clauseTypes = clauseTypes; a.tailMs = trailingSilenceMs;
+        const bool store = frames && minFrameDuration && fadeDuration && isNull;
+        Compact c;
+        if (build_compact(a, !store, false, c)) return -1;
+        long long pos = 0;
+        std::vector<long long> start((size_t)nTexts + 1);
+        for (long long i = 0; i < nTexts; ++i) { start[(size_t)i] = pos; pos += c.frames_of(i); }
+        start[(size_t)nTexts] = pos;
+        if (frameStart) memcpy(frameStart, start.data(), sizeof(long long) * ((size_t)nTexts + 1));
+        if (store && pos <= frameCapacity) {
+            parallel_for(nTexts, 256, [&](long long ua, long long ue) {
+                for (long long i = ua; i < ue; ++i) {
+                    const speechPlayer_frameRecord_t* r = c.records.data() + c.listStart[c.listOf[(size_t)i]];
+                    const long long n = c.frames_of(i), at = start[(size_t)i];
+                    for (long long k = 0; k < n; ++k) {
+                        expand_record(c, r[k], &frames[at + k], &isNull[at + k]);
+                        minFrameDuration[at + k] = r[k].minFrameDuration;
+                        fadeDuration[at + k] = r[k].fadeDuration;
+                    }
+                }
+            });
+        }
+        return pos;
+    });
 }
 
-static long long pack_with(Producer& p, int sampleRate, long long nTexts, const char* const* ipaUtf8, const double* basePitch,
-                           const char* clauseTypes, double trailingSilenceMs, long long* frameStart, speechPlayer_frame_t* frames,
-                           unsigned int* minFrameDuration, unsigned int* fadeDuration, unsigned char* isNull, long long frameCapacity)
+// ---- the compact form handed out (tests, callers that keep a batch's description) ---------------------------------------
+struct speechPlayer_recordsObject { Compact c; };
+
+speechPlayer_records_t speechPlayer_ipa_records(int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed, const double* basePitch,
+                                                double inflection, const char* clauseTypes, const int* voiceOf, const char* voiceName,
+                                                double trailingSilenceMs)
 {
-    const bool tail = trailingSilenceMs >= 0.0;
-    const bool store = frames && minFrameDuration && fadeDuration && isNull;
-    long long pos = 0;
-    for (long long i = 0; i < nTexts; ++i) {
-        const Stream& s = p.stream(ipaUtf8[i], clauseTypes ? (int)(unsigned char)clauseTypes[i] : 0, basePitch ? basePitch[i] : 100.0);
-        const long long n = (long long)s.size();
-        if (frameStart) frameStart[i] = pos;
-        if (store && pos + n + (tail ? 1 : 0) <= frameCapacity) {
-            if (n) {
-                memcpy(frames + pos, s.frames.data(), (size_t)n * sizeof(speechPlayer_frame_t));
-                memcpy(isNull + pos, s.isNull.data(), (size_t)n);
-            }
-            for (long long k = 0; k < n; ++k) {
-                minFrameDuration[pos + k] = ms_to_samples(s.durationMs[k], sampleRate);
-                fadeDuration[pos + k] = ms_to_samples(s.fadeMs[k], sampleRate);
-            }
-            if (tail) {                      // silence after the utterance, as reference test_speakIpa.py:27 queues it
-                memset(frames + pos + n, 0, sizeof(speechPlayer_frame_t));
-                isNull[pos + n] = 1;
-                minFrameDuration[pos + n] = ms_to_samples(trailingSilenceMs, sampleRate);
-                fadeDuration[pos + n] = 0;
-            }
+    return producer_call<speechPlayer_records_t>("speechPlayer_ipa_records", nullptr, [&]() -> speechPlayer_records_t {
+        PackArgs a;
+        if (check_pack_args(nTexts, ipaUtf8, clauseTypes, voiceOf, voiceName, &a.voiceAll)) { set_producer_error("speechPlayer_ipa_records: bad arguments, unknown voice or clause type"); return nullptr; }
+        a.sampleRate = sampleRate; a.nTexts = nTexts; a.texts = ipaUtf8; a.speed = speed; a.basePitch = basePitch; a.inflection = inflection;
+        a.clauseTypes = clauseTypes; a.voiceOf = voiceOf; a.tailMs = trailingSilenceMs;
+        std::unique_ptr<speechPlayer_recordsObject> o(new speechPlayer_recordsObject);
+        if (build_compact(a, false, false, o->c)) { set_producer_error("speechPlayer_ipa_records: voice index out of range"); return nullptr; }
+        return o.release();
+    });
+}
+
+int speechPlayer_records_view(speechPlayer_records_t records, speechPlayer_recordsView_t* view)
+{
+    if (!records || !view) return -1;
+    const Compact& c = static_cast<speechPlayer_recordsObject*>(records)->c;
+    view->nShapes = (long long)c.shapes.size(); view->shapes = c.shapes.data();
+    view->nLists = (long long)c.listStart.size() - 1; view->listStart = c.listStart.data();
+    view->nRecords = (long long)c.records.size(); view->records = c.records.data();
+    view->nUtterances = (long long)c.listOf.size(); view->listOf = c.listOf.data();
+    return 0;
+}
+
+void speechPlayer_records_free(speechPlayer_records_t records) { delete static_cast<speechPlayer_recordsObject*>(records); }
+
+static int set_ipa(const char* what, speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
+                   const double* basePitch, double inflection, const char* clauseTypes, const int* voiceOf, const char* voiceName,
+                   double trailingSilenceMs, const unsigned int* noiseSeed)
+{
+    return producer_call<int>(what, -1, [&]() -> int {
+        const int rate = speechPlayer_batch_sampleRate(batch);
+        PackArgs a;
+        if (rate <= 0 || check_pack_args(nTexts, ipaUtf8, clauseTypes, voiceOf, voiceName, &a.voiceAll)) {
+            set_producer_error((std::string(what) + ": bad batch, text array, voice or clause type").c_str());
+            return -1;
         }
-        pos += n + (tail ? 1 : 0);
-    }
-    if (frameStart) frameStart[nTexts] = pos;
-    return pos;
+        a.sampleRate = rate; a.nTexts = nTexts; a.texts = ipaUtf8; a.speed = speed; a.basePitch = basePitch; a.inflection = inflection;
+        a.clauseTypes = clauseTypes; a.voiceOf = voiceOf; a.tailMs = trailingSilenceMs;
+        Compact c;
+        if (build_compact(a, false, false, c)) { set_producer_error((std::string(what) + ": voice index out of range").c_str()); return -1; }
+        return speechPlayer_batch_setRecords(batch, (long long)c.shapes.size(), c.shapes.data(), (long long)c.listStart.size() - 1, c.listStart.data(),
+                                             c.records.data(), nTexts, c.listOf.data(), noiseSeed);
+    });
 }
 
 int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
                               const double* basePitch, double inflection, const char* clauseTypes, const char* voiceName,
                               double trailingSilenceMs, const unsigned int* noiseSeed)
 {
-    int rate = speechPlayer_batch_sampleRate(batch);
-    if (rate <= 0 || nTexts < 0 || (nTexts > 0 && !ipaUtf8)) return -1;
-    const VoiceRow* voice = find_voice(voiceName);
-    if (voiceName && *voiceName && !voice) return -1;
-    for (long long i = 0; clauseTypes && i < nTexts; ++i)
-        if (!clause_known((int)(unsigned char)clauseTypes[i])) return -1;
-    // ONE producer for the sizing pass and the filling pass: the second finds every stream in the first's memo
-    Producer p(speed, inflection, voice);
-    std::vector<long long> start((size_t)nTexts + 1, 0);
-    const long long total = pack_with(p, rate, nTexts, ipaUtf8, basePitch, clauseTypes, trailingSilenceMs, start.data(), nullptr, nullptr, nullptr, nullptr, 0);
-    if (total < 0) return -1;
-    std::vector<speechPlayer_frame_t> frames((size_t)total);
-    std::vector<unsigned int> mins((size_t)total), fades((size_t)total);
-    std::vector<unsigned char> nul((size_t)total);
-    if (pack_with(p, rate, nTexts, ipaUtf8, basePitch, clauseTypes, trailingSilenceMs, start.data(), frames.data(), mins.data(), fades.data(), nul.data(), total) != total)
-        return -1;
-    return speechPlayer_batch_setUtterances(batch, nTexts, start.data(), frames.data(), mins.data(), fades.data(), nullptr, nul.data(), noiseSeed);
+    return set_ipa("speechPlayer_batch_setIpa", batch, nTexts, ipaUtf8, speed, basePitch, inflection, clauseTypes, nullptr, voiceName, trailingSilenceMs, noiseSeed);
+}
+
+int speechPlayer_batch_setIpaVoices(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
+                                    const double* basePitch, double inflection, const char* clauseTypes, const int* voiceOf,
+                                    double trailingSilenceMs, const unsigned int* noiseSeed)
+{
+    return set_ipa("speechPlayer_batch_setIpaVoices", batch, nTexts, ipaUtf8, speed, basePitch, inflection, clauseTypes, voiceOf, nullptr, trailingSilenceMs, noiseSeed);
 }
 
 }  // extern "C"
@@ -775,6 +1060,7 @@ void speechPlayer_internal_setError(int code, const char* message);      // klat
 namespace {
 void set_text_error(const char* msg) { speechPlayer_internal_setError(SPEECHPLAYER_ERR_TEXT_FRONTEND, msg); }
 void set_arg_error(const char* msg) { speechPlayer_internal_setError(SPEECHPLAYER_ERR_ARGUMENT, msg); }
+void set_producer_error(const char* msg) { speechPlayer_internal_setError(SPEECHPLAYER_ERR_ARGUMENT, msg); }
 // Every text entry point runs through this: the error code of an earlier call is cleared, and nothing a host allocation throws
 // (std::bad_alloc, std::length_error) crosses the C ABI -- the caller gets `fail` and a message instead.
 template <class R, class F>
@@ -844,24 +1130,24 @@ int speechPlayer_batch_setText(speechPlayer_batch_t batch, long long nTexts, con
     return text_call<int>("speechPlayer_batch_setText", -1, [&]() -> int {
         const int rate = speechPlayer_batch_sampleRate(batch);
         if (rate <= 0 || nTexts < 0 || (nTexts > 0 && !textUtf8) || !(speed > 0.0)) { set_arg_error("speechPlayer_batch_setText: bad batch, text array or speed"); return -1; }
-        const VoiceRow* voice = find_voice(voiceName);
-        if (voiceName && *voiceName && !voice) { set_arg_error("speechPlayer_batch_setText: unknown voice preset"); return -1; }
-        Producer p(speed, inflection, voice);
-        std::vector<long long> start((size_t)nTexts + 1, 0);
-        std::vector<speechPlayer_frame_t> frames;
-        std::vector<unsigned int> mins, fades;
-        std::vector<unsigned char> nul;
+        const int voice = voice_index(voiceName);
+        if (voiceName && *voiceName && voice < 0) { set_arg_error("speechPlayer_batch_setText: unknown voice preset"); return -1; }
+        // every clause of every text becomes one ITEM of a single producer call (its IPA, its clause type, its text's base pitch)
         std::vector<Clause> cl;
         std::unordered_map<std::string, std::string> ipaOf;       // clause text -> IPA: a batch repeats its sentences
+        std::vector<const std::string*> itemIpa;
+        std::string itemClause;
+        std::vector<double> itemPitch;
+        std::vector<size_t> firstItem((size_t)nTexts + 1, 0);
+        std::vector<double> endPauseOf((size_t)nTexts, 20.0);     // reference __init__.py:182: not divided by the rate unless a clause sets it (:204)
         {
             std::lock_guard<std::mutex> g(g_espeakMutex);
             for (long long i = 0; i < nTexts; ++i) {
-                start[(size_t)i] = (long long)nul.size();
+                firstItem[(size_t)i] = itemIpa.size();
                 if (!textUtf8[i]) { set_arg_error("speechPlayer_batch_setText: NULL text"); return -1; }
                 split_clauses(textUtf8[i], cl);
-                double endPause = 20.0;                           // reference __init__.py:182: not divided by the rate unless a clause sets it (:204)
                 for (const Clause& c : cl) {
-                    endPause = c.endPauseMs / speed;
+                    endPauseOf[(size_t)i] = c.endPauseMs / speed;
                     const std::string key(textUtf8[i] + c.begin, c.end - c.begin);
                     auto it = ipaOf.find(key);
                     if (it == ipaOf.end()) {
@@ -870,28 +1156,38 @@ int speechPlayer_batch_setText(speechPlayer_batch_t batch, long long nTexts, con
                         it = ipaOf.emplace(key, ipa).first;
                     }
                     if (it->second.empty()) continue;             // :219
-                    const Stream& s = p.stream(it->second.c_str(), (int)(unsigned char)c.type, basePitch ? basePitch[i] : 100.0);
-                    const size_t n = s.size(), at = nul.size();
-                    frames.resize(at + n); mins.resize(at + n); fades.resize(at + n); nul.resize(at + n);
-                    if (n) {
-                        memcpy(&frames[at], s.frames.data(), n * sizeof(speechPlayer_frame_t));
-                        memcpy(&nul[at], s.isNull.data(), n);
-                    }
-                    for (size_t k = 0; k < n; ++k) {
-                        mins[at + k] = ms_to_samples(s.durationMs[k], rate);
-                        fades[at + k] = ms_to_samples(s.fadeMs[k], rate);
-                    }
+                    itemIpa.push_back(&it->second);               // (nodes of an unordered_map stay where they are)
+                    itemClause.push_back(c.type);
+                    itemPitch.push_back(basePitch ? basePitch[i] : 100.0);
                 }
-                // silence after the last clause (:234): queueFrame(None, endPause / rate, max(10, 10 / rate))
-                speechPlayer_frame_t zero;
-                memset(&zero, 0, sizeof zero);
-                frames.push_back(zero); nul.push_back(1);
-                mins.push_back(ms_to_samples(endPause, rate));
-                fades.push_back(ms_to_samples(std::max(10.0, 10.0 / speed), rate));
             }
-            start[(size_t)nTexts] = (long long)nul.size();
+            firstItem[(size_t)nTexts] = itemIpa.size();
         }
-        return speechPlayer_batch_setUtterances(batch, nTexts, start.data(), frames.data(), mins.data(), fades.data(), nullptr, nul.data(), noiseSeed);
+        std::vector<const char*> itemPtr(itemIpa.size());
+        for (size_t k = 0; k < itemIpa.size(); ++k) itemPtr[k] = itemIpa[k]->c_str();
+        PackArgs a;
+        a.sampleRate = rate; a.nTexts = (long long)itemPtr.size(); a.texts = itemPtr.data(); a.speed = speed; a.basePitch = itemPitch.data();
+        a.inflection = inflection; a.clauseTypes = itemClause.c_str(); a.voiceAll = voice; a.tailMs = -1.0;
+        Compact c;
+        if (build_compact(a, false, false, c)) { set_arg_error("speechPlayer_batch_setText: voice index out of range"); return -1; }
+        // an utterance: its clauses' records one after the other, then silence after the last clause (:234):
+        // queueFrame(None, endPause / rate, max(10, 10 / rate))
+        std::vector<long long> start((size_t)nTexts + 1, 0);
+        std::vector<speechPlayer_frameRecord_t> recs;
+        for (long long i = 0; i < nTexts; ++i) {
+            start[(size_t)i] = (long long)recs.size();
+            for (size_t k = firstItem[(size_t)i]; k < firstItem[(size_t)i + 1]; ++k) {
+                const uint32_t l = c.listOf[k];
+                recs.insert(recs.end(), c.records.begin() + c.listStart[l], c.records.begin() + c.listStart[l + 1]);
+            }
+            speechPlayer_frameRecord_t t;
+            t.shape = SPEECHPLAYER_RECORD_SILENCE; t.voicePitch = 0.0; t.endVoicePitch = 0.0; t.userIndex = -1;
+            t.minFrameDuration = ms_to_samples(endPauseOf[(size_t)i], rate);
+            t.fadeDuration = ms_to_samples(std::max(10.0, 10.0 / speed), rate);
+            recs.push_back(t);
+        }
+        start[(size_t)nTexts] = (long long)recs.size();
+        return speechPlayer_batch_setRecords(batch, (long long)c.shapes.size(), c.shapes.data(), nTexts, start.data(), recs.data(), nTexts, nullptr, noiseSeed);
     });
 }
 

@@ -30,6 +30,7 @@
 #include <numeric>
 #include <condition_variable>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <string>
 #include <unordered_map>
@@ -458,7 +459,11 @@ struct Batch {
     long long trackBudgetMB = 4096;        // the tracks of a batch may take this much device memory (at most 4 GB: the flat stages address them with 32-bit byte offsets); utterances beyond it run untracked
     hipStream_t side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
     hipEvent_t forkEvent = nullptr, join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    long long nUtt = 0, nFrames = 0, nSlots = 0;
+    long long nUtt = 0, nFrames = 0, nSlots = 0;   // nFrames: frames resident in HBM (the lists')
+    long long nLists = 0, nFramesSpoken = 0;       // frame lists of the batch; frames the utterances queue (sum over utterances of their list's)
+    std::vector<long long> uttFrameStart;          // [nUtt] first frame of the utterance's list
+    std::vector<uint32_t> uttFrames;               // [nUtt] its number of frames
+    bool launched = false;                         // a synthesis launch has been queued since the batch was set
     long long nQuiet = 0;                  // order[0..nQuiet) = utterances without noise, the rest with
     long long nTracked = 0;                // order[nQuiet..nQuiet + nTracked) = noisy utterances with tracks (slots: utterances + padding)
     long long nTrackedUtt = 0;             // the utterances among them
@@ -494,6 +499,10 @@ struct Batch {
     DeviceBuffer<float> dFloat;                // float copy of the PCM pool (speechPlayer_batch_readFloat)
     DeviceBuffer<unsigned long long> dDigest;  // per-utterance digests (speechPlayer_batch_digest)
     PinnedPair bounce;                         // speechPlayer_batch_readAll into pageable memory
+    DeviceBuffer<FrameRecord> dRecords;        // speechPlayer_batch_setRecords: the records as they crossed the link (klatt_expand_frames reads them)
+    DeviceBuffer<double> dShapeTable;          // ... and the call's shape table
+    DeviceBuffer<uint32_t> dRep;               // klatt_verify_shared: per frame the frame the planner took its shape values from
+    DeviceBuffer<unsigned long long> dMismatch;
     DeviceBuffer<FrameFacts> dFacts;           // klatt_frame_facts' output (frames that arrived by DMA are classified and hashed on the device)
     PinnedBlock hFacts;                        // ... and where it lands on the host
     DeviceBuffer<int16_t> dDense;              // the utterances back to back (pcm_compact): what speechPlayer_batch_readAll copies out
@@ -550,8 +559,18 @@ inline unsigned long long hash_shape(const double* v)
     return x;
 }
 
+// where a frame's parameter values are on the host: in the caller's frames, or -- records -- in the row of the shape table a record names
+// (the planner reads parameters 1..45 only: a record's own pitches are not among them)
+struct FrameSource {
+    const speechPlayer_frame_t* frames;
+    const speechPlayer_frameRecord_t* records;
+    const speechPlayer_frame_t* shapes;
+    const double* values(long long k) const { return reinterpret_cast<const double*>(records ? shapes + records[k].shape : frames + k); }
+};
+unsigned long long g_planHashMask[2] = {~0ull, ~0ull};      // speechPlayer_setGlobalOption("plan_hash_bits")
 struct TrackPlan {
     std::vector<TrackRef> ref;              // [nFrames]
+    std::vector<uint32_t> rep;              // [nFrames] the frame whose shape values stand for this frame's (the first one seen with its hash); 0xFFFFFFFF: itself / none
     std::vector<TrackJob> jobs;             // one per distinct track
     std::vector<double> shapes;             // [nShapes][kShapeStride]
     std::vector<unsigned char> tracked;     // [nUtterances]
@@ -567,11 +586,13 @@ struct TrackPlan {
 // utterances with nothing in common, which is what such a batch costs without the parts).
 // `facts`: klatt_plan.h's 128-bit hash of every frame's shape values (indexed like `frames`): a frame seen before is recognised by
 // it, without gathering, hashing or comparing its 45 values again.
-void plan_tracks_pass(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameFacts* facts, const FrameMeta* meta,
+void plan_tracks_pass(long long nUtterances, const long long* frameStart, const FrameSource& frames, const FrameFacts* facts, const FrameMeta* meta,
                       const unsigned char* eligible, long long budgetMB, bool whole, std::atomic<unsigned long long>* sum, TrackPlan& out)
 {
     const long long frame0 = frameStart[0], nF = frameStart[nUtterances] - frame0;
     out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
+    const bool wantRep = frameStart[nUtterances] < 0xFFFFFFFFll;
+    out.rep.assign(wantRep ? (size_t)nF : 0, 0xFFFFFFFFu);
     out.jobs.clear();
     out.shapes.clear();
     out.tracked.assign((size_t)nUtterances, 0);
@@ -608,7 +629,7 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
     // frames seen before, by their hash: the id of their shape and (once somebody needed it) of the same values with the gain gated off
     struct Key128 { unsigned long long a, b; bool operator==(const Key128& o) const { return a == o.a && b == o.b; } };
     struct Key128Hash { size_t operator()(const Key128& k) const { return (size_t)k.a; } };
-    struct FrameIds { uint32_t plain, gated; };
+    struct FrameIds { uint32_t plain, gated; long long first; };
     std::unordered_map<Key128, FrameIds, Key128Hash> seen;
     std::vector<uint32_t> gatedOf;          // shape id -> the id of its values with the gain gated off (0xFFFFFFFF: not asked for yet)
     auto gated_id = [&](uint32_t id) -> uint32_t {
@@ -662,13 +683,16 @@ void plan_tracks_pass(long long nUtterances, const long long* frameStart, const 
                 toId = gated_id(prevId);                       // silence: the old values, the gain gated off (:59-63)
                 prevNull = true;
             } else {
-                const Key128 fk{facts[k].h0, facts[k].h1};
+                // (records: the key is the shape's number, exact -- never masked)
+                const Key128 fk = frames.records ? Key128{facts[k].h0, facts[k].h1} : Key128{facts[k].h0 & g_planHashMask[0], facts[k].h1 & g_planHashMask[1]};
                 auto it = seen.find(fk);
                 if (it == seen.end()) {
                     Shape to;
-                    const double* p = reinterpret_cast<const double*>(frames + k);
+                    const double* p = frames.values(k);
                     for (int i = 0; i < kShapeValues; ++i) to.v[i] = p[shape_param(i)];
-                    it = seen.emplace(fk, FrameIds{shape_id(to), 0xFFFFFFFFu}).first;
+                    it = seen.emplace(fk, FrameIds{shape_id(to), 0xFFFFFFFFu, k}).first;
+                } else if (wantRep) {
+                    out.rep[k - frame0] = (uint32_t)it->second.first;      // taken on trust here; compared where the frames are (klatt_verify_shared)
                 }
                 toId = it->second.plain;
                 if (prevNull) {                                // out of silence: the new values, from gain 0 (:64-67)
@@ -793,11 +817,20 @@ void run_parts(unsigned n, F fn)
     if (n <= 1) { if (n) fn(0u); return; }
     WorkerPool& pool = WorkerPool::get();
     if (pool.workers() == 0) { for (unsigned t = 0; t < n; ++t) fn(t); return; }
+    // A part that throws (std::bad_alloc in a planner's maps) must neither unwind this frame while queued parts still point at it nor
+    // leave the section's count standing: every part runs under a guard that keeps the first exception, the caller helps until all
+    // parts are done, and only then is the exception thrown on -- on the caller's thread.
     WorkerPool::Section sec;
+    std::mutex emu;
+    std::exception_ptr first;
+    auto guarded = [&](unsigned t) {
+        try { fn(t); } catch (...) { std::lock_guard<std::mutex> g(emu); if (!first) first = std::current_exception(); }
+    };
     sec.left.store(n - 1, std::memory_order_release);
-    for (unsigned t = 0; t + 1 < n; ++t) pool.submit(&sec, [&fn, t] { fn(t); });
-    fn(n - 1);
+    for (unsigned t = 0; t + 1 < n; ++t) pool.submit(&sec, [&guarded, t] { guarded(t); });
+    guarded(n - 1);
     pool.help_until_done(&sec);
+    if (first) std::rethrow_exception(first);
 }
 
 // Host threads of setUtterances (the planner's setting: SPEECHPLAYER_PLAN_THREADS, else up to 8), and a loop over [0, n) cut into
@@ -820,7 +853,7 @@ void parallel_ranges(long long n, long long grain, F fn)
 // look-ups per frame: 0.2 s for BASELINE configs[2] on one thread), and the parts' shapes and fades merged: equal fades of
 // different parts end up with one track.  If the merged tracks fit the budget that is the plan; if not -- or if the parts gave
 // up (plan_tracks_pass) -- the batch is planned again in one pass, whose order decides which utterances stay in.
-void plan_tracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames, const FrameFacts* facts, const FrameMeta* meta,
+void plan_tracks(long long nUtterances, const long long* frameStart, const FrameSource& frames, const FrameFacts* facts, const FrameMeta* meta,
                  const unsigned char* eligible, long long budgetMB, TrackPlan& out)
 {
     const long long nF = frameStart[nUtterances];
@@ -852,6 +885,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
         if (half.entries > 0 && probe.missedBudget == 0 && probe.entries - half.entries >= half.entries - half.entries / 8 &&
             (long double)probe.entries * scale * 0.9L > (long double)cap) {
             out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
+            out.rep.clear();
             out.jobs.clear(); out.shapes.clear(); out.entries = 0;
             out.tracked.assign((size_t)nUtterances, 0);
             out.kinds.assign((size_t)nUtterances, 0);
@@ -925,6 +959,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
     }
     out.eligible = eligibleAll; out.missedSize = missedSize; out.missedBudget = 0;
     out.ref.assign((size_t)nF, TrackRef{0, 0, 0});
+    out.rep.assign(nF < 0xFFFFFFFFll ? (size_t)nF : 0, 0xFFFFFFFFu);
     out.tracked.assign((size_t)nUtterances, 0);
     out.kinds.assign((size_t)nUtterances, 0);
     if (missedSize * 10 > eligibleAll) { out.jobs.clear(); out.entries = 0; return; }   // all or nothing
@@ -939,6 +974,7 @@ void plan_tracks(long long nUtterances, const long long* frameStart, const speec
                 TrackRef r = p.ref[k - f0];
                 r.off = offOf[t].find(r.off)->second;
                 out.ref[k] = r;
+                if (!out.rep.empty() && !p.rep.empty()) out.rep[k] = p.rep[k - f0];
             }
         }
     });
@@ -1023,6 +1059,7 @@ int batch_launch(Batch* b)
     a.pcm = b->dPcm.ptr; a.result = b->dResult.ptr; a.state = nullptr; a.control = nullptr;
     b->resultsFresh = false;
     b->floatFresh = false;
+    b->launched = true;
 #ifdef KLATT_STAMPS
     if (b->dDebug.reserve((size_t)(b->nSlots / kLpUPG + 2) * 32 * 2)) return -1;
     HIP_TRY(hipMemsetAsync(b->dDebug.ptr, 0, b->dDebug.cap * 8, b->stream));
@@ -1705,6 +1742,15 @@ int speechPlayer_setGlobalOption(const char* name, int value)
     // takes the two-workgroups-per-CU instantiation of the stream kernel -- on a 256-CU device from 16 385 handles on; a small value
     // lets a test (or a small device) reach that kernel with a few hundred handles.
     if (name && !strcmp(name, "live_cus")) { g_liveCus = value < 0 ? 0 : value; g_liveCusForced = value > 0; return 0; }
+    // "plan_hash_bits" (tests): the track planner looks at this many bits of a frame's 128-bit shape hash (default 128).  With few bits
+    // different frames collide for certain, which is how the tests reach the verification of hashed shapes (klatt_verify_shared) and the
+    // fall-back behind it; the PCM must not change.
+    if (name && !strcmp(name, "plan_hash_bits")) {
+        const int bits = value < 0 ? 0 : (value > 128 ? 128 : value);
+        g_planHashMask[0] = bits >= 64 ? ~0ull : (bits == 0 ? 0ull : ((1ull << bits) - 1ull));
+        g_planHashMask[1] = bits >= 128 ? ~0ull : (bits <= 64 ? 0ull : ((1ull << (bits - 64)) - 1ull));
+        return 0;
+    }
     set_error("unknown global option %s", name ? name : "(null)");
     return -1;
 }
@@ -1820,6 +1866,7 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch)
     if (b->denseReady) (void)hipEventDestroy(b->denseReady);
     if (b->copyDone) (void)hipEventDestroy(b->copyDone);
     b->dDense.release(); b->dDenseStart.release(); b->dFacts.release(); b->hFacts.release();
+    b->dRecords.release(); b->dShapeTable.release(); b->dRep.release(); b->dMismatch.release();
     b->dFrames.release(); b->dMeta.release(); b->dUtt.release(); b->dOrder.release(); b->dPcm.release(); b->dResult.release();
     b->dFloat.release(); b->dDebug.release(); b->dDigest.release(); b->bounce.release();
     b->dFlatRef.release(); b->dSourceRef.release(); b->dJobs.release(); b->dShapes.release(); b->dTrack.release();
@@ -1850,50 +1897,123 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
     return -1;
 }
 
-static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
-                                const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
-                                const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
-                                const unsigned int* noiseSeed);
+// What a set call describes: `nLists` frame lists -- as full frames (frames, durations, marks, silences) or as records over a shape table
+// -- and `nUtt` utterances, each speaking one list (listOf == nullptr: utterance u speaks list u).  speechPlayer_batch_setUtterances is
+// the case "every utterance its own list, full frames".
+struct SetInput {
+    long long nLists = 0;
+    const long long* listStart = nullptr;
+    const speechPlayer_frame_t* frames = nullptr;
+    const unsigned int* minDur = nullptr;
+    const unsigned int* fadeDur = nullptr;
+    const int* userIndex = nullptr;
+    const unsigned char* isNull = nullptr;
+    const speechPlayer_frameRecord_t* records = nullptr;
+    long long nShapes = 0;
+    const speechPlayer_frame_t* shapes = nullptr;
+    long long nUtt = 0;
+    const unsigned int* listOf = nullptr;
+    const unsigned int* seeds = nullptr;
+    bool noTracks = false;       // the second attempt of a batch whose shared shapes failed their verification
+};
+static_assert(sizeof(speechPlayer_frameRecord_t) == sizeof(FrameRecord), "record layout");
+
+static void batch_clear(Batch* b)
+{
+    b->nUtt = 0; b->nFrames = 0; b->nFramesSpoken = 0; b->nLists = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
+    b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
+    b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
+    b->uttFrameStart.clear(); b->uttFrames.clear();
+}
+
+static int batch_set(Batch* b, const SetInput& in);
+
+static int batch_set_guarded(const char* what, speechPlayer_batch_t batch, const SetInput& in)
+{
+    begin_call();
+    try {       // nothing may throw across the C ABI (host allocations of a large batch; the planning threads)
+        return batch_set(static_cast<Batch*>(batch), in);
+    } catch (const std::exception& e) {
+        set_error("%s: %s", what, e.what());
+        return -1;
+    }
+}
+
 int speechPlayer_batch_setUtterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
                                      const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
                                      const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
                                      const unsigned int* noiseSeed)
 {
-    begin_call();
-    try {       // nothing may throw across the C ABI (host allocations of a large batch; the planning threads)
-        return batch_set_utterances(batch, nUtterances, frameStart, frames, minFrameDuration, fadeDuration, userIndex, isNull, noiseSeed);
-    } catch (const std::exception& e) {
-        set_error("setUtterances: %s", e.what());
-        return -1;
-    }
+    SetInput in;
+    in.nLists = nUtterances; in.listStart = frameStart; in.frames = frames; in.minDur = minFrameDuration; in.fadeDur = fadeDuration;
+    in.userIndex = userIndex; in.isNull = isNull; in.nUtt = nUtterances; in.seeds = noiseSeed;
+    return batch_set_guarded("setUtterances", batch, in);
 }
-static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterances, const long long* frameStart,
-                                const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
-                                const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
-                                const unsigned int* noiseSeed)
+
+int speechPlayer_batch_setUtterancesShared(speechPlayer_batch_t batch, long long nLists, const long long* listStart,
+                                           const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration, const unsigned int* fadeDuration,
+                                           const int* userIndex, const unsigned char* isNull, long long nUtterances, const unsigned int* listOf,
+                                           const unsigned int* noiseSeed)
 {
-    Batch* b = static_cast<Batch*>(batch);
-    if (!b || nUtterances < 0 || !frameStart) { set_error("setUtterances: bad arguments"); return -1; }
-    if (nUtterances >= 0xFFFFFFFFll) { set_error("setUtterances: too many utterances"); return -1; }
+    SetInput in;
+    in.nLists = nLists; in.listStart = listStart; in.frames = frames; in.minDur = minFrameDuration; in.fadeDur = fadeDuration;
+    in.userIndex = userIndex; in.isNull = isNull; in.nUtt = nUtterances; in.listOf = listOf; in.seeds = noiseSeed;
+    return batch_set_guarded("setUtterancesShared", batch, in);
+}
+
+int speechPlayer_batch_setRecords(speechPlayer_batch_t batch, long long nShapes, const speechPlayer_frame_t* shapes,
+                                  long long nLists, const long long* listStart, const speechPlayer_frameRecord_t* records,
+                                  long long nUtterances, const unsigned int* listOf, const unsigned int* noiseSeed)
+{
+    SetInput in;
+    in.nLists = nLists; in.listStart = listStart; in.records = records; in.nShapes = nShapes; in.shapes = shapes;
+    in.nUtt = nUtterances; in.listOf = listOf; in.seeds = noiseSeed;
+    if (nShapes < 0 || (nShapes > 0 && !shapes)) { begin_call(); set_error("setRecords: bad shape table"); return -1; }
+    if (!records && nLists > 0 && listStart && listStart[nLists] > 0) { begin_call(); set_error("setRecords: no records"); return -1; }
+    static const speechPlayer_frameRecord_t none = {0.0, 0.0, SPEECHPLAYER_RECORD_SILENCE, 0u, 0u, -1};
+    if (!in.records) in.records = &none;      // (an empty batch: the record path all the same)
+    return batch_set_guarded("setRecords", batch, in);
+}
+
+static int batch_set(Batch* b, const SetInput& in)
+{
+    const long long nL = in.nLists, nU = in.nUtt;
+    const long long* const listStart = in.listStart;
+    const unsigned int* const listOf = in.listOf;
+    const bool byRecords = in.records != nullptr;
+    if (!b || nL < 0 || nU < 0 || !listStart) { set_error("set: bad arguments"); return -1; }
+    if (nU >= 0xFFFFFFFFll || nL >= 0xFFFFFFFFll) { set_error("set: too many utterances"); return -1; }
+    if (!listOf && nU != nL) { set_error("set: %lld utterances for %lld lists and no listOf", nU, nL); return -1; }
     static const bool setTrace = getenv("SPEECHPLAYER_SET_TRACE") != nullptr;      // where the call's time goes, on stderr
     const auto tSet = std::chrono::steady_clock::now();
     auto lap = [&](const char* what) {
         if (setTrace) fprintf(stderr, "[speechPlayer/set] %s: %.1f ms since the start\n", what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tSet).count());
     };
     HIP_TRY(hipSetDevice(b->device));
-    // validate the index array before anything reads through it
-    if (frameStart[0] != 0) { set_error("setUtterances: frameStart[0] must be 0"); return -1; }
-    for (long long u = 0; u < nUtterances; ++u)
-        if (frameStart[u + 1] < frameStart[u]) { set_error("setUtterances: frameStart not monotone at %lld", u); return -1; }
-    const long long nF = frameStart[nUtterances];
-    if (nF > 0 && (!frames || !minFrameDuration || !fadeDuration)) {
-        set_error("setUtterances: bad frame arrays");
-        return -1;
+    // validate the index arrays before anything reads through them
+    if (listStart[0] != 0) { set_error("set: frameStart[0] must be 0"); return -1; }
+    for (long long l = 0; l < nL; ++l)
+        if (listStart[l + 1] < listStart[l]) { set_error("set: frameStart not monotone at %lld", l); return -1; }
+    const long long nF = listStart[nL];
+    if (nF > 0 && !byRecords && (!in.frames || !in.minDur || !in.fadeDur)) { set_error("set: bad frame arrays"); return -1; }
+    if (listOf) {
+        std::atomic<long long> bad{-1};
+        parallel_ranges(nU, 1 << 16, [&](long long a, long long e) {
+            for (long long u = a; u < e; ++u) if ((long long)listOf[u] >= nL) { long long none = -1; bad.compare_exchange_strong(none, u); }
+        });
+        if (bad.load() >= 0) { set_error("set: listOf[%lld] is not a list", bad.load()); return -1; }
     }
+    if (byRecords) {
+        std::atomic<long long> bad{-1};
+        parallel_ranges(nF, 1 << 16, [&](long long a, long long e) {
+            for (long long k = a; k < e; ++k)
+                if (in.records[k].shape != SPEECHPLAYER_RECORD_SILENCE && (long long)in.records[k].shape >= in.nShapes) { long long none = -1; bad.compare_exchange_strong(none, k); }
+        });
+        if (bad.load() >= 0) { set_error("setRecords: record %lld names shape %u of %lld", bad.load(), in.records[bad.load()].shape, in.nShapes); return -1; }
+    }
+    auto list_of = [&](long long u) -> long long { return listOf ? (long long)listOf[u] : u; };
     // everything below is built in locals and committed to the Batch only after the uploads succeeded: a call that fails
     // validation leaves the previous batch in place, one that fails while uploading leaves an empty batch
-    std::vector<uint32_t> lens((size_t)nUtterances, 0);
-    std::vector<long long> outStart((size_t)nUtterances + 1, 0);
     // Per-frame work arrays are kept between calls (per calling thread): a fresh 25-50 MB vector costs its page faults on first touch
     // and its unmapping on release -- together ~15 ms of a 65 ms call for BASELINE configs[2].  Every element is written below before it
     // is read.  (Released again when a batch was very large: kScratchKeepFrames.)
@@ -1901,7 +2021,6 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     // (RawVector: resize() leaves new elements uninitialised, so a fresh array is first touched by the threads that fill it)
     static thread_local RawVector<FrameMeta> metaScratch;
     static thread_local RawVector<FlatRef> flatRefScratch;
-    static thread_local RawVector<SourceRef> sourceRefScratch;
     static thread_local RawVector<DirectJob> directJobsScratch;
     static thread_local RawVector<FrameFacts> factsScratch;
     struct ScratchRelease {
@@ -1910,83 +2029,111 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         {
             if (nF > kScratchKeepFrames) {
                 RawVector<FrameMeta>().swap(metaScratch); RawVector<FlatRef>().swap(flatRefScratch); RawVector<FrameFacts>().swap(factsScratch);
-                RawVector<SourceRef>().swap(sourceRefScratch); RawVector<DirectJob>().swap(directJobsScratch);
+                RawVector<DirectJob>().swap(directJobsScratch);
             }
         }
     } scratchRelease{nF};
     RawVector<FrameMeta>& meta = metaScratch;
     meta.resize((size_t)nF);
     parallel_ranges(nF, 1 << 16, [&](long long a, long long e) {
-        for (long long k = a; k < e; ++k) {
-            meta[k].minSamples = minFrameDuration[k];
-            meta[k].fadeSamples = std::max(fadeDuration[k], 1u);   // reference src/speechPlayer.cpp:36
-            meta[k].userIndex = userIndex ? userIndex[k] : -1;
-            meta[k].flags = (isNull && isNull[k]) ? FRAME_NULL : 0u;
-        }
+        if (byRecords)
+            for (long long k = a; k < e; ++k) {
+                const speechPlayer_frameRecord_t& r = in.records[k];
+                meta[k].minSamples = r.minFrameDuration;
+                meta[k].fadeSamples = std::max(r.fadeDuration, 1u);      // reference src/speechPlayer.cpp:36
+                meta[k].userIndex = r.userIndex;
+                meta[k].flags = r.shape == SPEECHPLAYER_RECORD_SILENCE ? FRAME_NULL : 0u;
+            }
+        else
+            for (long long k = a; k < e; ++k) {
+                meta[k].minSamples = in.minDur[k];
+                meta[k].fadeSamples = std::max(in.fadeDur[k], 1u);       // reference src/speechPlayer.cpp:36
+                meta[k].userIndex = in.userIndex ? in.userIndex[k] : -1;
+                meta[k].flags = (in.isNull && in.isNull[k]) ? FRAME_NULL : 0u;
+            }
     });
-    std::vector<UttDesc> utt((size_t)nUtterances);
-    // per utterance, from the durations alone: its length (closed form, reference src/frame.cpp:41-80)
+    // per list, from the durations alone: its length (closed form, reference src/frame.cpp:41-80)
+    std::vector<uint32_t> lensL((size_t)nL, 0);
     std::atomic<long long> tooLong{-1};
-    parallel_ranges(nUtterances, 4096, [&](long long ua, long long ue) {
-        for (long long u = ua; u < ue; ++u) {
+    parallel_ranges(nL, 4096, [&](long long la, long long le) {
+        for (long long l = la; l < le; ++l) {
             unsigned long long len = 0;
-            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+            for (long long k = listStart[l]; k < listStart[l + 1]; ++k) {
                 const unsigned long long m = meta[k].minSamples, f = meta[k].fadeSamples;
                 len += std::max(m, f + 1) + 1;   // samples one request spans
             }
-            if (len >= 0xFFFFFFFFull) { long long none = -1; tooLong.compare_exchange_strong(none, u); len = 0; }
-            lens[u] = (uint32_t)len;
-            memset(&utt[u], 0, sizeof(UttDesc));
-            utt[u].frameStart = frameStart[u];
-            utt[u].nFrames = (uint32_t)(frameStart[u + 1] - frameStart[u]);
-            utt[u].seed = noiseSeed ? noiseSeed[u] : (uint32_t)u;
-            utt[u].length = (uint32_t)len;
+            if (len >= 0xFFFFFFFFull) { long long none = -1; tooLong.compare_exchange_strong(none, l); len = 0; }
+            lensL[l] = (uint32_t)len;
         }
     });
-    if (tooLong.load() >= 0) { set_error("utterance %lld too long (4294967295 samples or more)", tooLong.load()); return -1; }
-    // From here on nothing but an allocation or a copy can fail (which leaves an empty batch): the frames -- by far the largest upload,
-    // 0.6 GB for BASELINE configs[2] -- start on their way now, on a thread of their own (a copy from pageable memory keeps its caller
-    // until it is done), beside the planning below.
+    if (tooLong.load() >= 0) { set_error("utterance (frame list %lld) too long (4294967295 samples or more)", tooLong.load()); return -1; }
+    // From here on nothing but an allocation or a copy can fail (which leaves an empty batch).  The frames -- by far the largest upload
+    // of a batch of full frames, 0.6 GB for BASELINE configs[2] -- start on their way now: on a thread of their own from pageable memory
+    // (such a copy keeps its caller until it is done), as one asynchronous DMA from page-locked memory (speechPlayer_hostAlloc); records
+    // travel the same way (32 bytes per frame) with their shape table, and klatt_expand_frames builds frames and meta words behind them.
     int earlyRc = 0;
     std::string earlyErr;
     std::thread early;
     bool earlyStarted = false;
-    // (frames in page-locked memory -- speechPlayer_hostAlloc -- need no thread: one asynchronous DMA on the copy stream, at the link's rate)
-    const bool framesPinned = nF > 0 && is_pinned(frames);
-    if (nF > 0 && (framesPinned || (size_t)nF * kNumParams * sizeof(double) >= (32u << 20))) {
-        if (b->dFrames.reserve((size_t)nF * kNumParams)) {
-            b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
-            b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
-            b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
-            return -1;
+    // while a DMA reads the caller's arrays no exit may leave it running: every return below passes this guard
+    struct CopyGuard { Batch* b; bool armed = false; ~CopyGuard() { if (armed) (void)hipStreamSynchronize(b->copyStream); } } copyGuard{b};
+    const bool framesPinned = !byRecords && nF > 0 && is_pinned(in.frames);
+    if (byRecords) {
+        if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>((size_t)nF, 1)) ||
+            b->dRecords.reserve(std::max<size_t>((size_t)nF, 1)) || b->dShapeTable.reserve(std::max<size_t>((size_t)in.nShapes * kNumParams, 1))) { batch_clear(b); return -1; }
+        batch_clear(b);      // the batch on the device is the old frames with the new ones over them from now on: it no longer exists
+        copyGuard.armed = true;
+        if (in.nShapes) HIP_TRY(hipMemcpyAsync(b->dShapeTable.ptr, in.shapes, (size_t)in.nShapes * sizeof(speechPlayer_frame_t), hipMemcpyHostToDevice, b->copyStream));
+        if (nF) {
+            HIP_TRY(hipMemcpyAsync(b->dRecords.ptr, in.records, (size_t)nF * sizeof(FrameRecord), hipMemcpyHostToDevice, b->copyStream));
+            const unsigned grid = (unsigned)std::min<long long>((nF * kNumParams + 255) / 256, 1 << 16);
+            hipLaunchKernelGGL(klatt_expand_frames, dim3(grid), dim3(256), 0, b->copyStream, b->dRecords.ptr, b->dShapeTable.ptr, b->dFrames.ptr, b->dMeta.ptr, nF);
+            HIP_TRY(hipGetLastError());
         }
-        // the batch on the device is the old frames with the new ones over them from now on: it no longer exists
-        b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
-        b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
-        b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
+        earlyStarted = true;
+    } else if (nF > 0 && (framesPinned || (size_t)nF * kNumParams * sizeof(double) >= (32u << 20))) {
+        if (b->dFrames.reserve((size_t)nF * kNumParams)) { batch_clear(b); return -1; }
+        batch_clear(b);
         if (framesPinned) {
-            HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->copyStream));
+            copyGuard.armed = true;
+            HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, in.frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->copyStream));
             earlyStarted = true;
         } else
         try {
             early = std::thread([&, dev = b->device, dst = b->dFrames.ptr]() {
                 hipError_t e = hipSetDevice(dev);
-                if (e == hipSuccess) e = hipMemcpy(dst, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice);
+                if (e == hipSuccess) e = hipMemcpy(dst, in.frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice);
                 if (e != hipSuccess) { earlyRc = -1; earlyErr = hipGetErrorString(e); }
             });
             earlyStarted = true;
         } catch (const std::system_error&) {}
     }
     struct JoinEarly { std::thread& t; ~JoinEarly() { if (t.joinable()) t.join(); } } joinEarly{early};
-    // What the planning needs to know of every frame (klatt_plan.h: a word of flags, a 128-bit hash of its shape values), in ONE pass over
-    // the frames.  Frames that are on their way to the device as a DMA (page-locked memory) are looked at THERE, behind the copy on the
-    // same stream, and 24 bytes per frame come back: the host never reads them.  Pageable frames are read here, by the host's threads,
-    // while the staging thread copies them.
+    // What the planning needs to know of every frame (klatt_plan.h: a word of flags, and something that stands for its 45 shape values),
+    // in ONE pass.  Records: the flags of their shape (evaluated once per row of the table) and of their pitches; the shape's number
+    // stands for the values, exactly.  Frames on their way to the device as a DMA (page-locked memory) are looked at THERE, behind the
+    // copy on the same stream, and 24 bytes per frame come back: the host never reads them.  Pageable frames are read here, by the
+    // host's threads, while the staging thread copies them.
     const double maxBwDirect = 690.0 * b->sampleRate / M_PI, maxFDirect = 9900.0 * b->sampleRate / (2.0 * M_PI);
     const FrameFacts* facts = nullptr;
     const bool factsOnDevice = framesPinned && earlyStarted;
-    if (factsOnDevice) {
-        if (b->dFacts.reserve((size_t)nF) || b->hFacts.ensure((size_t)nF * sizeof(FrameFacts))) { (void)hipStreamSynchronize(b->copyStream); return -1; }      // (the DMA reads the caller's frames: not while we return)
+    if (byRecords) {
+        std::vector<uint32_t> shapeFl((size_t)in.nShapes);
+        for (long long s = 0; s < in.nShapes; ++s) shapeFl[(size_t)s] = shape_flags(reinterpret_cast<const double*>(in.shapes + s), maxFDirect, maxBwDirect);
+        RawVector<FrameFacts>& fv = factsScratch;
+        fv.resize((size_t)nF);
+        parallel_ranges(nF, 1 << 15, [&](long long a, long long e) {
+            for (long long k = a; k < e; ++k) {
+                const speechPlayer_frameRecord_t& r = in.records[k];
+                FrameFacts f;
+                f.h0 = r.shape; f.h1 = ~0ull; f.pad = 0;
+                f.flags = r.shape == SPEECHPLAYER_RECORD_SILENCE ? 0u : (shapeFl[r.shape] | pitch_flags(r.voicePitch, r.endVoicePitch));
+                fv[k] = f;
+            }
+        });
+        facts = fv.data();
+    } else if (factsOnDevice) {
+        if (b->dFacts.reserve((size_t)nF) || b->hFacts.ensure((size_t)nF * sizeof(FrameFacts))) return -1;
         const unsigned grid = (unsigned)std::min<long long>((nF + 255) / 256, 1 << 16);
         hipLaunchKernelGGL(klatt_frame_facts, dim3(grid), dim3(256), 0, b->copyStream, b->dFrames.ptr, b->dFacts.ptr, nF, maxFDirect, maxBwDirect);
         HIP_TRY(hipGetLastError());
@@ -1996,83 +2143,97 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         RawVector<FrameFacts>& fv = factsScratch;      // (a reference: the worker threads must write the CALLER's scratch, not their own thread_local one)
         fv.resize((size_t)nF);
         parallel_ranges(nF, 1 << 13, [&](long long a, long long e) {
-            for (long long k = a; k < e; ++k) fv[k] = frame_facts(reinterpret_cast<const double*>(frames + k), maxFDirect, maxBwDirect);
+            for (long long k = a; k < e; ++k) fv[k] = frame_facts(reinterpret_cast<const double*>(in.frames + k), maxFDirect, maxBwDirect);
         });
         facts = fv.data();
     }
-    long long total = 0, pool = 0;
-    for (long long u = 0; u < nUtterances; ++u) {
+    // per utterance: its length, where its PCM goes
+    std::vector<uint32_t> lens((size_t)nU, 0);
+    std::vector<long long> outStart((size_t)nU + 1, 0);
+    std::vector<long long> denseStart((size_t)nU + 1);      // the utterances back to back: what speechPlayer_batch_readAll hands out
+    long long total = 0, pool = 0, spoken = 0;
+    for (long long u = 0; u < nU; ++u) {
+        const long long l = list_of(u);
+        lens[u] = lensL[l];
         outStart[u] = pool;
-        utt[u].outStart = pool;
+        denseStart[u] = total;
         total += (long long)lens[u];
         pool += ((long long)lens[u] + kTile - 1) / kTile * kTile;
+        spoken += listStart[l + 1] - listStart[l];
     }
-    outStart[nUtterances] = pool;
-    std::vector<long long> denseStart((size_t)nUtterances + 1);      // the utterances back to back: what speechPlayer_batch_readAll hands out
-    { long long at = 0; for (long long u = 0; u < nUtterances; ++u) { denseStart[u] = at; at += (long long)lens[u]; } denseStart[nUtterances] = at; }
+    outStart[nU] = pool;
+    denseStart[nU] = total;
+    // how many utterances speak each list
+    std::vector<uint32_t> weight((size_t)nL, listOf ? 0u : 1u);
+    if (listOf) for (long long u = 0; u < nU; ++u) ++weight[listOf[u]];
     lap("meta, lengths, frame facts started");
-    // An utterance's TIMING: a hash of its sequence of frame durations, fades and silences -- the same text at the same speed, whatever
+    // A list's TIMING: a hash of its sequence of frame durations, fades and silences -- the same text at the same speed, whatever
     // the pitch, the voice or the noise seed.  Lanes with one timing dequeue and fade on the same samples (lane packing, below).
-    std::vector<unsigned long long> timing((size_t)nUtterances);
-    parallel_ranges(nUtterances, 4096, [&](long long ua, long long ue) {
-        for (long long u = ua; u < ue; ++u) {
-            unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(frameStart[u + 1] - frameStart[u]);
-            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+    std::vector<unsigned long long> timingL((size_t)nL);
+    parallel_ranges(nL, 4096, [&](long long la, long long le) {
+        for (long long l = la; l < le; ++l) {
+            unsigned long long h = 0x9E3779B97F4A7C15ull ^ (unsigned long long)(listStart[l + 1] - listStart[l]);
+            for (long long k = listStart[l]; k < listStart[l + 1]; ++k) {
                 h ^= ((unsigned long long)meta[k].minSamples << 32) ^ meta[k].fadeSamples ^ ((unsigned long long)(meta[k].flags & FRAME_NULL) << 63);
                 h *= 0xFF51AFD7ED558CCDull; h ^= h >> 29;
             }
-            timing[u] = h;
+            timingL[l] = h;
         }
     });
-    // the facts are back (device path): per utterance, whether it needs its noise sources, whether it may skip the nasal pair, and -- for
+    // the facts are back (device path): per list, whether it needs its noise sources, whether it may skip the nasal pair, and -- for
     // the tracks and the direct stages below -- whether all its parameters are finite (bit 0 of `shape`) and within the range of
     // klatt_math.h (bit 1).  NULL frames carry no parameters of their own.
     if (factsOnDevice) HIP_TRY(hipStreamSynchronize(b->copyStream));
-    std::vector<unsigned char> shape((size_t)nUtterances, 0);
-    parallel_ranges(nUtterances, 4096, [&](long long ua, long long ue) {
-        for (long long u = ua; u < ue; ++u) {
+    std::vector<unsigned char> shapeL((size_t)nL, 0);
+    std::vector<uint32_t> flagsL((size_t)nL, 0);
+    parallel_ranges(nL, 4096, [&](long long la, long long le) {
+        for (long long l = la; l < le; ++l) {
             uint32_t fl = 0;
-            for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k)
+            for (long long k = listStart[l]; k < listStart[l + 1]; ++k)
                 if (!(meta[k].flags & FRAME_NULL)) fl |= facts[k].flags;
             const bool finite = !(fl & FACT_NONFINITE), needsNoise = (fl & FACT_NOISE) || !finite;
-            utt[u].flags = needsNoise ? UTT_NEEDS_NOISE : (!(fl & FACT_NASAL) ? UTT_NO_NASAL : 0u);
-            shape[u] = finite ? (!(fl & FACT_UNBOUNDED) ? 3 : 1) : 0;
+            flagsL[l] = needsNoise ? UTT_NEEDS_NOISE : (!(fl & FACT_NASAL) ? UTT_NO_NASAL : 0u);
+            shapeL[l] = finite ? (!(fl & FACT_UNBOUNDED) ? 3 : 1) : 0;
         }
     });
     lap("classification");
+    // how many utterances have a given (timing, length): lanes of such a run fade together
+    auto run_key = [&](long long l) { return timingL[l] ^ ((unsigned long long)lensL[l] * 0x9E3779B97F4A7C15ull); };
     // A quiet utterance whose timing too few others share cannot fill a wavefront of the quiet kernels with lanes that fade together:
     // its wavefront would run every chunk sample by sample, evaluating exp / cos for whichever lane is fading (a few workgroups that
     // take longer than the whole flat launch: 24 ms for the 8192 quiet utterances of a batch with 65 536 different timings).  Such an
     // utterance goes with the noisy ones instead -- same PCM (its noise gains are zero: the sources add exactly 0), flat stages.
     constexpr long long kQuietRunMin = 32;
-    std::vector<std::pair<long long, uint32_t>> rerouted;      // (utterance, its flags as a quiet one): back to the quiet kernels if it gets no tracks
+    std::vector<std::pair<long long, uint32_t>> rerouted;      // (list, its flags as a quiet one): back to the quiet kernels if it gets no tracks
+    const bool wantTracks = b->tracks && !in.noTracks;
     const bool wantDirect = b->direct && b->layout != 0 && nF > 0 && nF < 0xFFFFFFFFll;
-    if ((b->tracks || wantDirect) && nF > 0 && b->layout == -1) {      // (an explicit layout is taken at its word)
+    if ((wantTracks || wantDirect) && nF > 0 && b->layout == -1) {      // (an explicit layout is taken at its word)
         std::unordered_map<unsigned long long, long long> runOf;
-        for (long long u = 0; u < nUtterances; ++u)
-            if (!(utt[u].flags & UTT_NEEDS_NOISE)) ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)];
-        for (long long u = 0; u < nUtterances; ++u)
-            if (!(utt[u].flags & UTT_NEEDS_NOISE) && runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)] < kQuietRunMin) {
-                rerouted.emplace_back(u, utt[u].flags);
-                utt[u].flags = (utt[u].flags | UTT_NEEDS_NOISE) & ~UTT_NO_NASAL;
+        for (long long l = 0; l < nL; ++l)
+            if (!(flagsL[l] & UTT_NEEDS_NOISE)) runOf[run_key(l)] += weight[l];
+        for (long long l = 0; l < nL; ++l)
+            if (!(flagsL[l] & UTT_NEEDS_NOISE) && runOf[run_key(l)] < kQuietRunMin) {
+                rerouted.emplace_back(l, flagsL[l]);
+                flagsL[l] = (flagsL[l] | UTT_NEEDS_NOISE) & ~UTT_NO_NASAL;
             }
     }
     lap("timing hashes, quiet runs");
-    // ---- tracks (klatt_tracks.h) for the noisy utterances whose parameters are all finite: plan_tracks -----
+    // ---- tracks (klatt_tracks.h) for the noisy lists whose parameters are all finite: plan_tracks ---------
     // ---- and the direct stages (klatt_direct.h) for those among them that get none ------------------------
     TrackPlan plan;
     std::vector<unsigned char> eligible;
-    if ((b->tracks || wantDirect) && nF > 0) {
+    if ((wantTracks || wantDirect) && nF > 0) {
         // A NaN anywhere ("hold" targets, reference src/utils.h:21) or an infinite parameter keeps an utterance with the untracked kernel.
         // Finite parameters whose COEFFICIENTS overflow (a huge bandwidth or frequency) are tracked all the same: klatt_tracks evaluates
         // the same expressions as the kernels' own coefficient code, so the track holds the same inf / NaN the kernel would have computed.
-        eligible.assign((size_t)nUtterances, 0);
-        for (long long u = 0; u < nUtterances; ++u)
-            if (utt[u].flags & UTT_NEEDS_NOISE) eligible[u] = shape[u];
+        eligible.assign((size_t)nL, 0);
+        for (long long l = 0; l < nL; ++l)
+            if ((flagsL[l] & UTT_NEEDS_NOISE) && weight[l]) eligible[l] = shapeL[l];
     }
     lap("eligibility");
-    if (b->tracks && nF > 0) {
-        plan_tracks(nUtterances, frameStart, frames, facts, meta.data(), eligible.data(), b->trackBudgetMB, plan);
+    const FrameSource source{in.frames, in.records, in.shapes};
+    if (wantTracks && nF > 0) {
+        plan_tracks(nL, listStart, source, facts, meta.data(), eligible.data(), b->trackBudgetMB, plan);
         lap("tracks planned");
         // MODE_FAST, lanes that fade at unrelated times, tracks far beyond the caches (every fading lane streams through a track of its
         // own: the jittered batch's 445 MB): the lean direct stages, whose pole recurrences compute what the tracks would deliver, are
@@ -2082,16 +2243,16 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         if (wantDirect && b->direct == 1 && b->mode == MODE_FAST && plan.entries * sizeof(double2) > (128ull << 20)) {
             std::unordered_map<unsigned long long, long long> runOf;
             long long tracked = 0, direct = 0, inRuns = 0;
-            for (long long u = 0; u < nUtterances; ++u)
-                if (plan.tracked[u]) { ++tracked; direct += (eligible[u] & 2) ? 1 : 0; ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)]; }
+            for (long long l = 0; l < nL; ++l)
+                if (plan.tracked[l]) { tracked += weight[l]; direct += (eligible[l] & 2) ? weight[l] : 0; runOf[run_key(l)] += weight[l]; }
             for (const auto& kv : runOf) if (kv.second >= 32) inRuns += kv.second;
             const long long groups = (tracked + kLanes - 1) / kLanes;
             if (b->sortByLength && inRuns * 2 <= tracked && direct == tracked && groups > b->cus) useTracks = false;
         }
         if (useTracks)
-            for (long long u = 0; u < nUtterances; ++u)
-                if (plan.tracked[u]) utt[u].flags |= UTT_TRACKED | (plan.kinds[u] << kUttKindShift);
-        if (!useTracks) { plan.jobs.clear(); plan.entries = 0; plan.tracked.assign((size_t)nUtterances, 0); }
+            for (long long l = 0; l < nL; ++l)
+                if (plan.tracked[l]) flagsL[l] |= UTT_TRACKED | (plan.kinds[l] << kUttKindShift);
+        if (!useTracks) { plan.jobs.clear(); plan.entries = 0; plan.tracked.assign((size_t)nL, 0); }
     }
     if (wantDirect) {
         // The direct stages are for lanes that fade at unrelated times.  A group whose wavefronts hold equally timed utterances (the
@@ -2104,8 +2265,8 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         {
             std::unordered_map<unsigned long long, long long> runOf;
             long long candidates = 0, inRuns = 0;
-            for (long long u = 0; u < nUtterances; ++u)
-                if ((eligible[u] & 2) && !(utt[u].flags & UTT_TRACKED)) { ++candidates; ++runOf[timing[u] ^ ((unsigned long long)lens[u] * 0x9E3779B97F4A7C15ull)]; }
+            for (long long l = 0; l < nL; ++l)
+                if ((eligible[l] & 2) && !(flagsL[l] & UTT_TRACKED)) { candidates += weight[l]; runOf[run_key(l)] += weight[l]; }
             for (const auto& kv : runOf) if (kv.second >= 32) inRuns += kv.second;
             // (without the sort by length and timing nothing is side by side; in MODE_FAST the direct stages advance coefficients by
             // recurrences and win on the aligned batches whose fades move everything too -- "distinct" 19.2 -> 15.9 ms -- while a batch
@@ -2114,31 +2275,31 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
             if (b->direct == 1) take = !b->directAligned || b->mode == MODE_FAST;
         }
         if (take)
-            for (long long u = 0; u < nUtterances; ++u)
-                if ((eligible[u] & 2) && !(utt[u].flags & UTT_TRACKED)) utt[u].flags |= UTT_DIRECT;
+            for (long long l = 0; l < nL; ++l)
+                if ((eligible[l] & 2) && !(flagsL[l] & UTT_TRACKED)) flagsL[l] |= UTT_DIRECT;
     }
-    // (a re-routed quiet utterance that got neither tracks nor the direct stages goes back to the quiet kernels)
+    // (a re-routed quiet list that got neither tracks nor the direct stages goes back to the quiet kernels)
     for (const auto& r : rerouted)
-        if (!(utt[r.first].flags & (UTT_TRACKED | UTT_DIRECT))) utt[r.first].flags = r.second;
-    // the direct utterances' fades: per frame where its fade starts from and ends on (reference src/frame.cpp:55-72: silence keeps
+        if (!(flagsL[r.first] & (UTT_TRACKED | UTT_DIRECT))) flagsL[r.first] = r.second;
+    // the direct lists' fades: per frame where its fade starts from and ends on (reference src/frame.cpp:55-72: silence keeps
     // the previous request's values with the gain gated off; the first frame after silence starts from its own values with the gain
     // gated off; any other frame fades from the previous request's values) -- klatt_seeds reads the values themselves on the device
     RawVector<DirectJob>& directJobs = directJobsScratch;
     directJobs.clear();
-    std::vector<uint32_t> directFirst;
+    std::vector<uint32_t> directFirstL, directFirst;
     long long nDirectUtt = 0;
     if (wantDirect) {
-        directFirst.assign((size_t)nUtterances, 0u);
-        for (long long u = 0; u < nUtterances; ++u) {
-            if (!(utt[u].flags & UTT_DIRECT)) continue;
-            ++nDirectUtt;
-            directFirst[u] = (uint32_t)directJobs.size();
-            walk_fade_ends(frameStart[u], frameStart[u + 1], meta.data(), directJobs);
+        directFirstL.assign((size_t)nL, 0u);
+        for (long long l = 0; l < nL; ++l) {
+            if (!(flagsL[l] & UTT_DIRECT)) continue;
+            nDirectUtt += weight[l];
+            directFirstL[l] = (uint32_t)directJobs.size();
+            walk_fade_ends(listStart[l], listStart[l + 1], meta.data(), directJobs);
         }
+        directFirst.resize((size_t)nU);
+        parallel_ranges(nU, 1 << 16, [&](long long a, long long e) { for (long long u = a; u < e; ++u) directFirst[u] = directFirstL[list_of(u)]; });
     }
     RawVector<FlatRef>& flatRef = flatRefScratch;
-    RawVector<SourceRef>& sourceRef = sourceRefScratch;
-    (void)sourceRef;      // (the source references are built on the device since round 5: klatt_source_refs, from the frames and durations there)
     if (!plan.jobs.empty()) {
         flatRef.resize((size_t)nF);
         parallel_ranges(nF, 1 << 16, [&](long long ka, long long ke) {
@@ -2149,11 +2310,32 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         });
     }
     lap("direct jobs, flat / source references");
+    // the utterances, each with its list's frames, flags and length
+    std::vector<UttDesc> utt((size_t)nU);
+    std::vector<long long> uttFrameStart((size_t)nU);
+    std::vector<uint32_t> uttFrames((size_t)nU);
+    parallel_ranges(nU, 1 << 15, [&](long long a, long long e) {
+        for (long long u = a; u < e; ++u) {
+            const long long l = list_of(u);
+            UttDesc d;
+            d.frameStart = listStart[l];
+            d.outStart = outStart[u];
+            d.nFrames = (uint32_t)(listStart[l + 1] - listStart[l]);
+            d.seed = in.seeds ? in.seeds[u] : (uint32_t)u;
+            d.flags = flagsL[l];
+            d.length = lensL[l];
+            utt[u] = d;
+            uttFrameStart[u] = d.frameStart; uttFrames[u] = d.nFrames;
+        }
+    });
     std::vector<TrackJob>& jobs = plan.jobs;
     const unsigned long long trackEntries = plan.entries;
     // lane packing: similar lengths share a wavefront (longest first), so lanes finish together
     // (within the quiet group and within the noisy group, which are launched as separate kernels)
-    std::vector<uint32_t> order((size_t)nUtterances);
+    std::vector<unsigned long long> timing;      // per utterance (its list's)
+    if (listOf) { timing.resize((size_t)nU); for (long long u = 0; u < nU; ++u) timing[u] = timingL[listOf[u]]; }
+    else timing.swap(timingL);
+    std::vector<uint32_t> order((size_t)nU);
     std::iota(order.begin(), order.end(), 0u);
     auto quietEnd = std::stable_partition(order.begin(), order.end(), [&](uint32_t x) { return !(utt[x].flags & UTT_NEEDS_NOISE); });
     const long long nQuiet = quietEnd - order.begin();
@@ -2224,10 +2406,15 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
     const long long nSlotsAll = (long long)order.size();
     lap("lane packing");
 
+    // Frames the planner recognised by their HASH are compared with the frame that first carried it, where the frames are (records
+    // need none of this: a shape number IS the values).  The verdict comes back with the upload's last synchronisation.
+    const bool verify = !byRecords && nTrackedUtt > 0 && !plan.rep.empty();
+    unsigned long long mismatchAt = ~0ull;
+
     auto upload = [&]() -> int {
         if (b->dFrames.reserve(std::max<size_t>((size_t)nF * kNumParams, 1)) || b->dMeta.reserve(std::max<size_t>(nF, 1)) ||
-            b->dUtt.reserve(std::max<size_t>(nUtterances, 1)) || b->dOrder.reserve(std::max<size_t>(nSlotsAll, 1)) ||
-            b->dResult.reserve(std::max<size_t>(nUtterances, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
+            b->dUtt.reserve(std::max<size_t>(nU, 1)) || b->dOrder.reserve(std::max<size_t>(nSlotsAll, 1)) ||
+            b->dResult.reserve(std::max<size_t>(nU, 1)) || b->dPcm.reserve(std::max<size_t>(pool, 1)))
             return -1;
         if (nTrackedUtt > 0) {
             if (b->dFlatRef.reserve((size_t)nF) || b->dJobs.reserve(jobs.size()) || b->dShapes.reserve(plan.shapes.size()) ||
@@ -2241,58 +2428,103 @@ static int batch_set_utterances(speechPlayer_batch_t batch, long long nUtterance
         }
         if (nDirectUtt > 0) {
             const size_t nD = directJobs.size();
-            if (b->dDirectJobs.reserve(nD) || b->dDirectFirst.reserve((size_t)nUtterances) || b->dDirectHdr.reserve((size_t)kDirectStages * nD) ||
+            if (b->dDirectJobs.reserve(nD) || b->dDirectFirst.reserve((size_t)nU) || b->dDirectHdr.reserve((size_t)kDirectStages * nD) ||
                 b->dDirectRec.reserve((size_t)kDirectEntries * nD)) return -1;
             HIP_TRY(hipMemcpyAsync(b->dDirectJobs.ptr, directJobs.data(), nD * sizeof(DirectJob), hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->dDirectFirst.ptr, directFirst.data(), (size_t)nUtterances * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemcpyAsync(b->dDirectFirst.ptr, directFirst.data(), (size_t)nU * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
         }
         if (nF) {
-            if (!earlyStarted) HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipMemcpyAsync(b->dMeta.ptr, meta.data(), (size_t)nF * sizeof(FrameMeta), hipMemcpyHostToDevice, b->stream));
+            if (!earlyStarted) HIP_TRY(hipMemcpyAsync(b->dFrames.ptr, in.frames, (size_t)nF * kNumParams * sizeof(double), hipMemcpyHostToDevice, b->stream));
+            if (!byRecords) HIP_TRY(hipMemcpyAsync(b->dMeta.ptr, meta.data(), (size_t)nF * sizeof(FrameMeta), hipMemcpyHostToDevice, b->stream));
         }
-        if (nUtterances) {
-            HIP_TRY(hipMemcpyAsync(b->dUtt.ptr, utt.data(), (size_t)nUtterances * sizeof(UttDesc), hipMemcpyHostToDevice, b->stream));
+        if (nU) {
+            HIP_TRY(hipMemcpyAsync(b->dUtt.ptr, utt.data(), (size_t)nU * sizeof(UttDesc), hipMemcpyHostToDevice, b->stream));
             HIP_TRY(hipMemcpyAsync(b->dOrder.ptr, order.data(), (size_t)nSlotsAll * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
-            HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nUtterances * sizeof(UttResult), b->stream));
+            HIP_TRY(hipMemsetAsync(b->dResult.ptr, 0, (size_t)nU * sizeof(UttResult), b->stream));
+            if (b->dDenseStart.reserve((size_t)nU + 1)) return -1;
+            HIP_TRY(hipMemcpyAsync(b->dDenseStart.ptr, denseStart.data(), ((size_t)nU + 1) * sizeof(long long), hipMemcpyHostToDevice, b->stream));
         }
-        if (nUtterances) {
-            if (b->dDenseStart.reserve((size_t)nUtterances + 1)) return -1;
-            HIP_TRY(hipMemcpyAsync(b->dDenseStart.ptr, denseStart.data(), ((size_t)nUtterances + 1) * sizeof(long long), hipMemcpyHostToDevice, b->stream));
+        if (verify) {
+            if (b->dRep.reserve((size_t)nF) || b->dMismatch.reserve(1)) return -1;
+            HIP_TRY(hipMemcpyAsync(b->dRep.ptr, plan.rep.data(), (size_t)nF * sizeof(uint32_t), hipMemcpyHostToDevice, b->stream));
+            HIP_TRY(hipMemsetAsync(b->dMismatch.ptr, 0xFF, sizeof(unsigned long long), b->stream));
         }
         HIP_TRY(hipStreamSynchronize(b->stream));
-        if (framesPinned) HIP_TRY(hipStreamSynchronize(b->copyStream));
+        if (copyGuard.armed) { HIP_TRY(hipStreamSynchronize(b->copyStream)); copyGuard.armed = false; }
         if (early.joinable()) early.join();
-        if (earlyRc) { set_error_code(SPEECHPLAYER_ERR_HIP); set_error("setUtterances: uploading the frames failed: %s", earlyErr.c_str()); return -1; }
+        if (earlyRc) { set_error_code(SPEECHPLAYER_ERR_HIP); set_error("set: uploading the frames failed: %s", earlyErr.c_str()); return -1; }
+        const unsigned grid = (unsigned)std::min<long long>((nF + 255) / 256, 1 << 16);
+        if (verify) {
+            hipLaunchKernelGGL(klatt_verify_shared, dim3(grid), dim3(256), 0, b->stream, b->dFrames.ptr, b->dRep.ptr, nF, b->dMismatch.ptr);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(&mismatchAt, b->dMismatch.ptr, sizeof mismatchAt, hipMemcpyDeviceToHost, b->stream));
+        }
         if (nTrackedUtt > 0 || nDirectUtt > 0) {
             // what the flat and direct source stages read at a dequeue (SourceRef: pitch, pitch increment, 1 / fade, index mark), from the
             // frames and durations now resident: 32 bytes per frame that no longer cross the link, and no third pass of the host over the frames
-            const unsigned grid = (unsigned)std::min<long long>((nF + 255) / 256, 1 << 16);
             hipLaunchKernelGGL(klatt_source_refs, dim3(grid), dim3(256), 0, b->stream, b->dFrames.ptr, b->dMeta.ptr, b->dSourceRef.ptr, nF);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipStreamSynchronize(b->stream));
         }
+        if (verify || nTrackedUtt > 0 || nDirectUtt > 0) HIP_TRY(hipStreamSynchronize(b->stream));
         return 0;
     };
     if (upload()) {
         // the device buffers may hold a mix of the old and the new batch now: the object becomes an empty batch
-        b->nUtt = 0; b->nFrames = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
-        b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0;
-        b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
-        b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
+        batch_clear(b);
         return -1;
     }
     lap("uploads");
-    b->nUtt = nUtterances; b->nFrames = nF; b->nSlots = nSlotsAll;
+    if (verify && mismatchAt != ~0ull) {
+        // two frames with one hash and different values: the plan built on their equality is void.  The batch is planned again
+        // without tracks (nothing else rests on the hash) and the caller is told -- the call succeeds, the message stays.
+        const unsigned long long k = mismatchAt;
+        if (early.joinable()) early.join();
+        SetInput again = in;
+        again.noTracks = true;
+        const uint32_t first = plan.rep[(size_t)k];
+        const int rc = batch_set(b, again);
+        if (rc == 0) {
+            set_error("set: frames %llu and %u carry one 128-bit shape hash and different values; the batch runs without tracks", k, first);
+            set_error_code(SPEECHPLAYER_OK);
+        }
+        return rc;
+    }
+    b->nUtt = nU; b->nFrames = nF; b->nFramesSpoken = spoken; b->nLists = nL; b->nSlots = nSlotsAll;
     b->nQuiet = nQuiet; b->nNoNasal = nNoNasal;
     b->nTracked = nTrackedUtt > 0 ? nTracked : 0; b->nTrackedUtt = nTrackedUtt;
     b->nJobs = nTrackedUtt > 0 ? (long long)jobs.size() : 0; b->trackEntries = nTrackedUtt > 0 ? (long long)trackEntries : 0;
     b->nDirect = nDirectUtt > 0 ? nDirectSlots : 0; b->nDirectUtt = nDirectUtt; b->nDirectFrames = (long long)directJobs.size();
     b->totalSamples = total; b->poolSamples = pool;
     b->lens.swap(lens); b->outStart.swap(outStart); b->denseStart.swap(denseStart);
+    b->uttFrameStart.swap(uttFrameStart); b->uttFrames.swap(uttFrames);
     b->results.clear();
     b->resultsFresh = false;
     b->floatFresh = false;
+    b->launched = false;
     return 0;
+}
+
+long long speechPlayer_batch_frames(speechPlayer_batch_t batch, long long u, speechPlayer_frame_t* frames, unsigned int* minFrameDuration,
+                                    unsigned int* fadeDuration, int* userIndex, unsigned char* isNull, long long capacity)
+{
+    begin_call();
+    Batch* b = static_cast<Batch*>(batch);
+    if (!b || u < 0 || u >= b->nUtt) { set_error("batch_frames: no such utterance"); return -1; }
+    HIP_TRY(hipSetDevice(b->device));
+    const long long n = b->uttFrames[(size_t)u], k0 = b->uttFrameStart[(size_t)u];
+    if (n > capacity || n == 0) return n;
+    if (frames) HIP_TRY(hipMemcpy(frames, b->dFrames.ptr + k0 * kNumParams, (size_t)n * sizeof(speechPlayer_frame_t), hipMemcpyDeviceToHost));
+    if (minFrameDuration || fadeDuration || userIndex || isNull) {
+        std::vector<FrameMeta> m((size_t)n);
+        HIP_TRY(hipMemcpy(m.data(), b->dMeta.ptr + k0, (size_t)n * sizeof(FrameMeta), hipMemcpyDeviceToHost));
+        for (long long k = 0; k < n; ++k) {
+            if (minFrameDuration) minFrameDuration[k] = m[(size_t)k].minSamples;
+            if (fadeDuration) fadeDuration[k] = m[(size_t)k].fadeSamples;
+            if (userIndex) userIndex[k] = m[(size_t)k].userIndex;
+            if (isNull) isNull[k] = (m[(size_t)k].flags & FRAME_NULL) ? 1 : 0;
+        }
+    }
+    return n;
 }
 
 long long speechPlayer_batch_utteranceSamples(speechPlayer_batch_t batch, long long u)
@@ -2302,7 +2534,7 @@ long long speechPlayer_batch_utteranceSamples(speechPlayer_batch_t batch, long l
     return b->lens[u];
 }
 long long speechPlayer_batch_totalSamples(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->totalSamples : -1; }
-long long speechPlayer_batch_totalFrames(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->nFrames : -1; }
+long long speechPlayer_batch_totalFrames(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->nFramesSpoken : -1; }
 int speechPlayer_batch_sampleRate(speechPlayer_batch_t batch) { return batch ? static_cast<Batch*>(batch)->sampleRate : -1; }
 
 int speechPlayer_batch_synthesize(speechPlayer_batch_t batch)
@@ -2351,8 +2583,8 @@ long long speechPlayer_batch_read(speechPlayer_batch_t batch, long long u, sampl
 static int dense_prepare(Batch* b)
 {
     const long long total = b->totalSamples;
+    if (b->copyPending) { HIP_TRY(hipEventSynchronize(b->copyDone)); b->copyPending = false; }      // the previous copy still reads dDense (before it may be re-allocated)
     if (b->dDense.reserve((size_t)((total + 7) / 8 * 8 + 8))) return -1;
-    if (b->copyPending) { HIP_TRY(hipEventSynchronize(b->copyDone)); b->copyPending = false; }      // the previous copy still reads dDense
     const long long n8 = (total + 7) / 8;
     if (n8 > 0) {
         const unsigned grid = (unsigned)std::min<long long>((n8 + 255) / 256, 1 << 16);
@@ -2461,6 +2693,9 @@ long long speechPlayer_batch_readAllAsync(speechPlayer_batch_t batch, sample* sa
     if (!b || !sampleBuf) return -1;
     HIP_TRY(hipSetDevice(b->device));
     if (!is_pinned(sampleBuf)) { set_error("readAllAsync: the buffer is not page-locked (speechPlayer_hostAlloc)"); return -1; }
+    // (readAll checks what every utterance produced and falls back to the padded copy; this call cannot wait for that -- it needs a launch
+    // queued since the batch was set: a batch launch always synthesises every utterance to its end.  ADVICE r5)
+    if (!b->launched && b->nUtt > 0) { set_error("readAllAsync: the batch has not been synthesised since it was set"); return -1; }
     const long long total = b->totalSamples;
     if (total > capacity) { set_error("readAllAsync: capacity %lld too small for %lld samples", capacity, total); return -1; }
     if (outStart) memcpy(outStart, b->denseStart.data(), sizeof(long long) * ((size_t)b->nUtt + 1));
@@ -2890,10 +3125,10 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
 // utterances (eligible[u] != 0: utterance u may be tracked; NULL: all).  Per frame: first entry and resonator mask of its
 // fade's track (0 / 0 in utterances that are not tracked); per utterance: tracked or not.  Returns the number of distinct
 // tracks, *nEntries the 16-byte entries they hold; -1 on bad arguments.  Touches no device.
-long long speechPlayer_planTracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,
+static long long plan_tracks_view(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,
                                   const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible,
-                                  long long budgetMB, unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked,
-                                  unsigned long long* nEntries)
+                                  long long budgetMB, const void* facts24, unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked,
+                                  unsigned long long* nEntries, long long* collisionAt)
 {
     begin_call();
     if (nUtterances < 0 || !frameStart || frameStart[0] != 0) { set_error("planTracks: bad arguments"); return -1; }
@@ -2910,9 +3145,25 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
     std::vector<unsigned char> all;
     if (!eligible) { all.assign((size_t)nUtterances, 1); eligible = all.data(); }
     TrackPlan plan;
-    std::vector<FrameFacts> facts((size_t)nF);
-    parallel_ranges(nF, 1 << 14, [&](long long a, long long e) { for (long long k = a; k < e; ++k) facts[k] = frame_facts(reinterpret_cast<const double*>(frames + k), 1e300, 1e300); });
-    plan_tracks(nUtterances, frameStart, frames, facts.data(), meta.data(), eligible, budgetMB, plan);
+    std::vector<FrameFacts> own;
+    const FrameFacts* facts = static_cast<const FrameFacts*>(facts24);
+    if (!facts) {
+        own.resize((size_t)nF);
+        parallel_ranges(nF, 1 << 14, [&](long long a, long long e) { for (long long k = a; k < e; ++k) own[k] = frame_facts(reinterpret_cast<const double*>(frames + k), 1e300, 1e300); });
+        facts = own.data();
+    }
+    plan_tracks(nUtterances, frameStart, FrameSource{frames, nullptr, nullptr}, facts, meta.data(), eligible, budgetMB, plan);
+    // what klatt_verify_shared does on the device, here on the host: every frame recognised by its hash against the frame that stood for it
+    if (collisionAt) *collisionAt = -1;
+    for (long long k = 0; k < nF && !plan.rep.empty(); ++k) {
+        const uint32_t r = plan.rep[(size_t)k];
+        if (r == 0xFFFFFFFFu || (long long)r == k) continue;
+        if (!shape_values_equal(reinterpret_cast<const double*>(frames + k), reinterpret_cast<const double*>(frames + r))) {
+            if (collisionAt) *collisionAt = k;
+            set_error("planTracks: frames %lld and %u carry one 128-bit shape hash and different values", k, r);
+            return -2;
+        }
+    }
     for (long long k = 0; k < nF; ++k) {
         if (trackOff) trackOff[k] = plan.ref[k].off;
         if (trackMask) trackMask[k] = plan.ref[k].mask;
@@ -2925,6 +3176,33 @@ long long speechPlayer_planTracks(long long nUtterances, const long long* frameS
     }
     if (nEntries) *nEntries = plan.entries;
     return (long long)plan.jobs.size();
+}
+
+long long speechPlayer_planTracks(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,
+                                  const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible,
+                                  long long budgetMB, unsigned long long* trackOff, unsigned int* trackMask, unsigned char* tracked,
+                                  unsigned long long* nEntries)
+{
+    try {
+        return plan_tracks_view(nUtterances, frameStart, frames, fadeDuration, isNull, eligible, budgetMB, nullptr, trackOff, trackMask, tracked, nEntries, nullptr);
+    } catch (const std::exception& e) { set_error("planTracks: %s", e.what()); return -1; }
+}
+
+long long speechPlayer_planTracksFacts(long long nUtterances, const long long* frameStart, const speechPlayer_frame_t* frames,
+                                       const unsigned int* fadeDuration, const unsigned char* isNull, const unsigned char* eligible,
+                                       long long budgetMB, const void* facts24, unsigned long long* trackOff, unsigned int* trackMask,
+                                       unsigned char* tracked, unsigned long long* nEntries, long long* collisionAt)
+{
+    try {
+        return plan_tracks_view(nUtterances, frameStart, frames, fadeDuration, isNull, eligible, budgetMB, facts24, trackOff, trackMask, tracked, nEntries, collisionAt);
+    } catch (const std::exception& e) { set_error("planTracksFacts: %s", e.what()); return -1; }
+}
+
+// the engine's worker threads for the other translation unit (frame_producer.cpp): fn(ctx, a, e) over [0, n) in ranges
+void speechPlayer_internal_parallel(long long n, long long grain, void (*fn)(void* ctx, long long a, long long e), void* ctx)
+{
+    if (n <= 0 || !fn) return;
+    parallel_ranges(n, grain, [&](long long a, long long e) { fn(ctx, a, e); });
 }
 
 long long speechPlayer_frameFacts(const speechPlayer_frame_t* frames, long long nFrames, int sampleRate, int onDevice, void* facts24)

@@ -8,8 +8,12 @@
 // host planner then works on 24 bytes per frame; when the frames arrive in page-locked memory (speechPlayer_hostAlloc) they cross
 // the link first and klatt_frame_facts evaluates the same function where they land (HBM-bound: the frames are read once at the
 // device's rate), so that the host never reads them at all.
-// The hash stands for the values: two frames with the same 128 bits are taken to hold the same 45 values (2^-128 per pair; the
-// planner used to compare the values themselves on every look-up, which is what reading the frames a second time was for).
+// The hash stands for the values while a batch is planned: two frames with the same 128 bits are taken to hold the same 45 values
+// (2^-128 per pair of honest frames).  It is not trusted blindly: every frame the planner recognised by its hash is compared, value
+// for value, with the first frame that carried that hash -- on the device, where the frames are (klatt_verify_shared: one more read
+// of the frames at HBM rate); a batch in which that comparison fails is planned again without tracks (klatt_engine.hip).
+// Frames that arrive as RECORDS (speechPlayer_batch_setRecords) need neither: a record names its shape by number, frames with one
+// number hold the same values by construction, and klatt_expand_frames builds the 376-byte frames in HBM from 32 bytes each.
 #pragma once
 
 #include <stdint.h>
@@ -44,44 +48,70 @@ __host__ __device__ constexpr unsigned long long fact_key(int n)
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     return z ^ (z >> 31);
 }
-// high ^ low half of the 128-bit product
+// high ^ low half of the 128-bit product, plus both operands: a zero operand (a value whose bit pattern equals its key) annihilates
+// the product, not the word -- the other operand still counts
 __host__ __device__ inline unsigned long long fact_fold(unsigned long long a, unsigned long long c)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __umul64hi(a, c) ^ (a * c);
+    return (__umul64hi(a, c) ^ (a * c)) + a + ((c << 32) | (c >> 32));
 #else
     const unsigned __int128 m = (unsigned __int128)a * c;
-    return (unsigned long long)(m >> 64) ^ (unsigned long long)m;
+    return ((unsigned long long)(m >> 64) ^ (unsigned long long)m) + a + ((c << 32) | (c >> 32));
 #endif
+}
+
+// what the two pitches (parameters 0 and 46) contribute to a frame's flags
+__host__ __device__ inline uint32_t pitch_flags(double p0, double p46)
+{
+    uint32_t fl = 0;
+    if (!fact_finite(p0) || !fact_finite(p46)) fl |= 2u;                         // FACT_NONFINITE
+    if (!(fact_abs(p0) <= 1e30) || !(fact_abs(p46) <= 1e30)) fl |= 4u;           // FACT_NASAL: the source must stay bounded
+    return fl;
+}
+// ... and what parameters 1..45 contribute (p: all 47; 0 and 46 are not looked at)
+__host__ __device__ inline uint32_t shape_flags(const double* p, double maxF, double maxBw)
+{
+    uint32_t fl = 0;
+    // Noise sources and the parallel bank can be skipped for an utterance only if every frame has all three noise gains exactly zero
+    // (voiceTurbulenceAmplitude, aspirationAmplitude, fricationAmplitude) and no non-finite parameter that could turn 0 * x into NaN.
+    if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) fl |= 1u;                    // FACT_NOISE
+    bool finite = true;
+    for (int i = 1; i < kNumParams - 1; ++i) finite = finite && fact_finite(p[i]);
+    if (!finite) fl |= 2u;
+    // The skipped parallel bank contributes exactly 0 only while its coefficients are finite (a * 0 with a = inf is NaN, which the
+    // reference clips to 32000): bandwidths in [0, 1e6], bounded frequencies (reference src/speechWaveGenerator.cpp:112-127).
+    for (int i = 25; i <= 30; ++i)
+        if (!(fact_abs(p[i]) <= 1e6) || !(p[i + 6] >= 0.0) || !(p[i + 6] <= 1e6)) fl |= 1u;
+    // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152): with caNP == 0 in
+    // every frame that is x as long as np stays finite -- bounded source, N0's zero pair not degenerate, NP not growing.
+    if (p[23] != 0.0 || !(p[21] >= 1.0) || !(p[22] >= 0.0) || !(p[21] <= 1e6) || !(p[22] <= 1e6) ||
+        !(fact_abs(p[13]) <= 1e6) || !(fact_abs(p[14]) <= 1e6) || !(fact_abs(p[5]) <= 1e30) || !(fact_abs(p[44]) <= 1e30))
+        fl |= 4u;
+    // the direct stages evaluate exp / cos with klatt_math.h alone, whose range is |arg| <= 700 / 1e4: frequencies (parameters 7..14,
+    // 25..30) and bandwidths (15..22, 31..36) bounded accordingly
+    bool inRange = true;
+    for (int i = 7; i <= 14; ++i) inRange = inRange && (fact_abs(p[i]) <= maxF) && (fact_abs(p[i + 8]) <= maxBw);
+    for (int i = 25; i <= 30; ++i) inRange = inRange && (fact_abs(p[i]) <= maxF) && (fact_abs(p[i + 6]) <= maxBw);
+    if (!inRange) fl |= 8u;                                                      // FACT_UNBOUNDED
+    return fl;
+}
+// are the 45 shape values (parameters 1..45) of two frames the same bits?
+__host__ __device__ inline bool shape_values_equal(const double* a, const double* c)
+{
+    bool same = true;
+    for (int i = 1; i < kNumParams - 1; ++i) {
+        unsigned long long x, y;
+        memcpy(&x, &a[i], 8); memcpy(&y, &c[i], 8);
+        same = same && x == y;
+    }
+    return same;
 }
 
 // p: the frame's 47 parameters (include/speechPlayer.h); maxF / maxBw: the direct stages' bounds for this sample rate
 __host__ __device__ inline FrameFacts frame_facts(const double* p, double maxF, double maxBw)
 {
     FrameFacts o;
-    uint32_t fl = 0;
-    // Noise sources and the parallel bank can be skipped for an utterance only if every frame has all three noise gains exactly zero
-    // (voiceTurbulenceAmplitude, aspirationAmplitude, fricationAmplitude) and no non-finite parameter that could turn 0 * x into NaN.
-    if (p[3] != 0.0 || p[6] != 0.0 || p[24] != 0.0) fl |= FACT_NOISE;
-    bool finite = true;
-    for (int i = 0; i < kNumParams; ++i) finite = finite && fact_finite(p[i]);
-    if (!finite) fl |= FACT_NONFINITE;
-    // The skipped parallel bank contributes exactly 0 only while its coefficients are finite (a * 0 with a = inf is NaN, which the
-    // reference clips to 32000): bandwidths in [0, 1e6], bounded frequencies (reference src/speechWaveGenerator.cpp:112-127).
-    for (int i = 25; i <= 30; ++i)
-        if (!(fact_abs(p[i]) <= 1e6) || !(p[i + 6] >= 0.0) || !(p[i + 6] <= 1e6)) fl |= FACT_NOISE;
-    // The nasal pair N0 -> NP enters the cascade as lerp(x, np, caNP) (reference src/speechWaveGenerator.cpp:151-152): with caNP == 0 in
-    // every frame that is x as long as np stays finite -- bounded source, N0's zero pair not degenerate, NP not growing.
-    if (p[23] != 0.0 || !(p[21] >= 1.0) || !(p[22] >= 0.0) || !(p[21] <= 1e6) || !(p[22] <= 1e6) ||
-        !(fact_abs(p[13]) <= 1e6) || !(fact_abs(p[14]) <= 1e6) || !(fact_abs(p[5]) <= 1e30) || !(fact_abs(p[44]) <= 1e30) ||
-        !(fact_abs(p[0]) <= 1e30) || !(fact_abs(p[46]) <= 1e30))
-        fl |= FACT_NASAL;
-    // the direct stages evaluate exp / cos with klatt_math.h alone, whose range is |arg| <= 700 / 1e4: frequencies (parameters 7..14,
-    // 25..30) and bandwidths (15..22, 31..36) bounded accordingly
-    bool inRange = true;
-    for (int i = 7; i <= 14; ++i) inRange = inRange && (fact_abs(p[i]) <= maxF) && (fact_abs(p[i + 8]) <= maxBw);
-    for (int i = 25; i <= 30; ++i) inRange = inRange && (fact_abs(p[i]) <= maxF) && (fact_abs(p[i + 6]) <= maxBw);
-    if (!inRange) fl |= FACT_UNBOUNDED;
+    const uint32_t fl = shape_flags(p, maxF, maxBw) | pitch_flags(p[0], p[46]);
     // The 45 shape values are parameters 1..45 (klatt_device.h, shape_param: every parameter but the two pitches).  Two independently
     // keyed multiply-fold sums over them, a pair of values per 64 x 64 -> 128-bit product (every position has keys of its own: the
     // same values in other places are another frame), each then avalanched: ~23 multiplies per word instead of a chain of 45.
@@ -111,6 +141,58 @@ __global__ void __launch_bounds__(256) klatt_frame_facts(const double* __restric
 #pragma unroll
         for (int i = 0; i < kNumParams; ++i) p[i] = src[i];
         out[k] = frame_facts(p, maxF, maxBw);
+    }
+}
+
+// A frame as a producer knows it (include/speechPlayer_batch.h, speechPlayer_frameRecord_t): 32 bytes
+struct FrameRecord {
+    double voicePitch, endVoicePitch;
+    uint32_t shape;              // row of the shape table; kRecordSilence: the call passed framePtr == NULL
+    uint32_t minSamples, fadeSamples;
+    int32_t userIndex;
+};
+constexpr uint32_t kRecordSilence = 0xFFFFFFFFu;
+static_assert(sizeof(FrameRecord) == 32, "FrameRecord layout");
+
+// records -> the frames and their meta words in HBM: frame k = row records[k].shape of the shape table with parameters 0 and 46 from
+// the record; silence = zeros, flagged.  One thread per DOUBLE written (consecutive threads write consecutive doubles: the 376-byte
+// frames go out as whole cache lines; the shape table is a few hundred rows and stays in L2), the thread that writes a frame's first
+// double also writes its 16-byte meta word.  HBM-bound: 32 B read, 392 B written per frame.
+__global__ void __launch_bounds__(256) klatt_expand_frames(const FrameRecord* __restrict__ records, const double* __restrict__ shapes,
+                                                           double* __restrict__ frames, FrameMeta* __restrict__ meta, long long nFrames)
+{
+    const long long n = nFrames * kNumParams;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const long long k = i / kNumParams;
+        const int j = (int)(i - k * kNumParams);
+        const FrameRecord r = records[k];
+        const bool silence = r.shape == kRecordSilence;
+        double v = 0.0;
+        if (!silence) v = j == 0 ? r.voicePitch : (j == kNumParams - 1 ? r.endVoicePitch : shapes[(long long)r.shape * kNumParams + j]);
+        frames[i] = v;
+        if (j == 0) {
+            FrameMeta m;
+            m.minSamples = r.minSamples;
+            m.fadeSamples = r.fadeSamples > 1u ? r.fadeSamples : 1u;      // reference src/speechPlayer.cpp:36
+            m.userIndex = r.userIndex;
+            m.flags = silence ? FRAME_NULL : 0u;
+            meta[k] = m;
+        }
+    }
+}
+
+// rep[k]: the frame whose 45 shape values the planner took frame k's to be (the first frame it saw with k's hash), or k itself /
+// 0xFFFFFFFF for a frame nobody stood in for.  One thread per frame; any difference sets *mismatch (and the first frame found).
+__global__ void __launch_bounds__(256) klatt_verify_shared(const double* __restrict__ frames, const uint32_t* __restrict__ rep, long long nFrames,
+                                                           unsigned long long* __restrict__ mismatch)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x; k < nFrames; k += stride) {
+        const uint32_t r = rep[k];
+        if (r == 0xFFFFFFFFu || (long long)r == k) continue;
+        if (!shape_values_equal(frames + k * kNumParams, frames + (long long)r * kNumParams))
+            atomicMin(mismatch, (unsigned long long)k);
     }
 }
 #endif

@@ -23,10 +23,11 @@ def _voice_arg(voice):
     return None if not voice else voice.encode("utf8")
 
 
-def voices():
-    """Names of the voice presets (reference __init__.py:86-116), in the driver's sorted order."""
+def voices(defined=False):
+    """Names of the voice presets (reference __init__.py:86-116), in the driver's sorted order; defined=True: followed by the voices
+    defined with defineVoice (a voice's position in that list is its index)."""
     L = _native.load()
-    return [L.speechPlayer_voiceName(i).decode("utf8") for i in range(L.speechPlayer_voiceCount())]
+    return [L.speechPlayer_voiceName(i).decode("utf8") for i in range(L.speechPlayer_voiceCount() if defined else L.speechPlayer_voicePresetCount())]
 
 
 def applyVoiceToFrame(frame, voiceName):
@@ -138,23 +139,39 @@ def generateFramesAndTiming(ipaText, speed=1, basePitch=100, inflection=0.5, cla
         yield (None if vec is None else Frame.from_array(vec)), dur, fade
 
 
+# one frame as the producer hands it to the device (include/speechPlayer_batch.h, speechPlayer_frameRecord_t): 32 bytes
+RECORD_DTYPE = np.dtype([("voicePitch", "<f8"), ("endVoicePitch", "<f8"), ("shape", "<u4"), ("min", "<u4"), ("fade", "<u4"), ("index", "<i4")])
+RECORD_SILENCE = 0xFFFFFFFF
+
+
+def _text_pointers(texts, textOf=None):
+    """char* per utterance as a uint64 array (-> array, number of utterances, what must stay alive): the strings are encoded once and
+    utterances that repeat a sentence (textOf[u]: index into texts) repeat its pointer -- the producer recognises equal pointers
+    without reading the text."""
+    enc = [ctypes.create_string_buffer(t.encode("utf8")) for t in texts]
+    addr = np.array([ctypes.addressof(b) for b in enc] or [0], dtype=np.uint64)
+    ptrs = addr[:len(enc)] if textOf is None else addr[np.asarray(textOf, dtype=np.int64)]
+    ptrs = np.ascontiguousarray(ptrs if len(ptrs) else np.zeros(1, np.uint64))
+    return ptrs, (len(enc) if textOf is None else len(textOf)), enc
+
+
+def _clauses(clauseType, n):
+    if clauseType is None or isinstance(clauseType, str):
+        return bytes([_clause_code(clauseType)]) * n + b"\0"
+    return bytes(_clause_code(c) for c in clauseType) + b"\0"
+
+
 def frames_for_batch(texts, sampleRate=22050, speed=1, basePitch=100, inflection=0.5, clauseType=None,
-                     trailing_silence_ms=150.0, voice=None):
+                     trailing_silence_ms=150.0, voice=None, textOf=None):
     """Pack many utterances for BatchPlayer.setUtterances (speechPlayer_ipa_pack).  basePitch and clauseType may be
-    sequences (one per text).  Each utterance ends with NULL(trailing_silence_ms, 0) as in reference
+    sequences (one per utterance).  Each utterance ends with NULL(trailing_silence_ms, 0) as in reference
     test_speakIpa.py:27 (None: no trailing silence).  -> dict(frame_start, frames, min, fade, isnull)."""
     L = _native.load()
-    n = len(texts)
-    enc = [t.encode("utf8") for t in texts]
-    ptrs = (ctypes.c_char_p * max(n, 1))(*enc)
+    ptrs, n, keep = _text_pointers(texts, textOf)
     pitch = np.ascontiguousarray(np.broadcast_to(np.asarray(basePitch, dtype=np.float64), (n,)))
-    if clauseType is None or isinstance(clauseType, str):
-        clauses = bytes([_clause_code(clauseType)]) * n
-    else:
-        clauses = bytes(_clause_code(c) for c in clauseType)
     tail = -1.0 if trailing_silence_ms is None else float(trailing_silence_ms)
     start = np.zeros(n + 1, np.int64)
-    head = (int(sampleRate), n, ptrs, float(speed), pitch.ctypes.data, float(inflection), clauses + b"\0", _voice_arg(voice), tail)
+    head = (int(sampleRate), n, ptrs.ctypes.data, float(speed), pitch.ctypes.data, float(inflection), _clauses(clauseType, n), _voice_arg(voice), tail)
     total = L.speechPlayer_ipa_pack(*head, start.ctypes.data, None, None, None, None, 0)
     if total == -2:
         raise KeyError("unknown clause type in %r" % (clauseType,))
@@ -163,7 +180,76 @@ def frames_for_batch(texts, sampleRate=22050, speed=1, basePitch=100, inflection
     frames = np.zeros((total, 47)); m = np.zeros(total, np.uint32); f = np.zeros(total, np.uint32); nul = np.zeros(total, np.uint8)
     got = L.speechPlayer_ipa_pack(*head, start.ctypes.data, frames.ctypes.data, m.ctypes.data, f.ctypes.data, nul.ctypes.data, total)
     assert got == total
+    del keep
     return dict(frame_start=start, frames=frames, min=m, fade=f, isnull=nul)
+
+
+class _RecordsView(ctypes.Structure):
+    _fields_ = [("nShapes", ctypes.c_longlong), ("shapes", ctypes.c_void_p), ("nLists", ctypes.c_longlong), ("listStart", ctypes.c_void_p),
+                ("nRecords", ctypes.c_longlong), ("records", ctypes.c_void_p), ("nUtterances", ctypes.c_longlong), ("listOf", ctypes.c_void_p)]
+
+
+def records_for_batch(texts, sampleRate=22050, speed=1, basePitch=100, inflection=0.5, clauseType=None,
+                      trailing_silence_ms=150.0, voice=None, textOf=None):
+    """The same batch in COMPACT form (speechPlayer_ipa_records; what BatchPlayer.setIpa hands the device): -> dict(shapes[nShapes, 47],
+    list_start[nLists + 1], records[nRecords] of RECORD_DTYPE, list_of[nUtterances]).  voice: a name, or a sequence of voice indices."""
+    L = _native.load()
+    ptrs, n, keep = _text_pointers(texts, textOf)
+    pitch = np.ascontiguousarray(np.broadcast_to(np.asarray(basePitch, dtype=np.float64), (n,)))
+    tail = -1.0 if trailing_silence_ms is None else float(trailing_silence_ms)
+    by_name = voice is None or isinstance(voice, str)
+    vo = None if by_name else np.ascontiguousarray(np.broadcast_to(np.asarray(voice, dtype=np.int32), (n,)))
+    h = L.speechPlayer_ipa_records(int(sampleRate), n, ptrs.ctypes.data, float(speed), pitch.ctypes.data, float(inflection), _clauses(clauseType, n),
+                                   None if vo is None else vo.ctypes.data, _voice_arg(voice) if by_name else None, tail)
+    del keep
+    if not h:
+        raise KeyError("speechPlayer_ipa_records: %s" % _native.last_error())
+    try:
+        v = _RecordsView()
+        assert L.speechPlayer_records_view(h, ctypes.byref(v)) == 0
+        grab = lambda ptr, count, dt: np.frombuffer(ctypes.string_at(ptr, count * np.dtype(dt).itemsize), dtype=dt).copy() if count else np.zeros(0, dt)
+        return dict(shapes=grab(v.shapes, v.nShapes * 47, np.float64).reshape(-1, 47), list_start=grab(v.listStart, v.nLists + 1, np.int64),
+                    records=grab(v.records, v.nRecords, RECORD_DTYPE), list_of=grab(v.listOf, v.nUtterances, np.uint32))
+    finally:
+        L.speechPlayer_records_free(h)
+
+
+def expand_records(pk):
+    """records_for_batch's result as full frames, utterance by utterance (numpy restatement of klatt_expand_frames, for checks):
+    -> dict(frame_start, frames, min, fade, isnull) as frames_for_batch returns it."""
+    rec, ls, lo = pk["records"], pk["list_start"], pk["list_of"]
+    n_per = (ls[1:] - ls[:-1])[lo]
+    fs = np.concatenate([[0], np.cumsum(n_per)]).astype(np.int64)
+    idx = np.concatenate([np.arange(ls[l], ls[l + 1]) for l in lo]) if len(lo) else np.zeros(0, np.int64)
+    r = rec[idx]
+    silent = r["shape"] == RECORD_SILENCE
+    frames = np.zeros((len(r), 47))
+    frames[~silent] = pk["shapes"][r["shape"][~silent]]
+    frames[~silent, 0] = r["voicePitch"][~silent]
+    frames[~silent, 46] = r["endVoicePitch"][~silent]
+    return dict(frame_start=fs, frames=frames, min=r["min"].copy(), fade=r["fade"].copy(), isnull=silent.astype(np.uint8))
+
+
+def voiceIndex(name):
+    """Index of a voice (preset or defined) by name; -1 if there is none."""
+    return _native.load().speechPlayer_voiceIndex(name.encode("utf8"))
+
+
+def defineVoice(name, entries):
+    """A voice of the caller's own in the presets' form (reference __init__.py:86-125; speechPlayer_voiceDefine): entries maps a frame
+    field (name or index 0..46) to an absolute value, or to a (absolute | None, multiplier | None) pair -- e.g. {"cf1": (None, 0.9),
+    "voicePitch": (None, 1.2)}.  -> the voice's index (usable wherever a preset's is)."""
+    names = [n for n, _ in Frame._fields_]
+    par, ab, mu = [], [], []
+    for k, v in entries.items():
+        par.append(names.index(k) if isinstance(k, str) else int(k))
+        a, m = v if isinstance(v, tuple) else (v, None)
+        ab.append(np.nan if a is None else float(a)); mu.append(np.nan if m is None else float(m))
+    par = np.asarray(par, np.int32); ab = np.asarray(ab, np.float64); mu = np.asarray(mu, np.float64)
+    i = _native.load().speechPlayer_voiceDefine(name.encode("utf8"), len(par), par.ctypes.data, ab.ctypes.data, mu.ctypes.data)
+    if i < 0:
+        raise ValueError("defineVoice(%r): %s" % (name, _native.last_error()))
+    return i
 
 
 # ---- the optional text front-end (include/speechPlayer_batch.h: speechPlayer_text_*; eSpeak NG loaded at run time) ----

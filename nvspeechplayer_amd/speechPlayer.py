@@ -270,23 +270,67 @@ class BatchPlayer(object):
         self._check(self._dll.speechPlayer_batch_setUtterances(self._h, n_utt, p(fs), p(fr), p(m), p(f), p(ix), p(nu), p(sd)))
         self.nUtterances = n_utt
 
+    def setUtterancesShared(self, listStart, frames, minSamples, fadeSamples, listOf, userIndex=None, isNull=None, noiseSeed=None):
+        """Frame lists that utterances share (speechPlayer_batch_setUtterancesShared): `listStart`/frames/... describe the lists as
+        setUtterances describes utterances; utterance u speaks list listOf[u] with noise seed noiseSeed[u]."""
+        ls = np.ascontiguousarray(listStart, dtype=np.int64)
+        fr = np.ascontiguousarray(frames, dtype=np.float64).reshape(-1, 47)
+        m = np.ascontiguousarray(minSamples, dtype=np.uint32)
+        f = np.ascontiguousarray(fadeSamples, dtype=np.uint32)
+        lo = np.ascontiguousarray(listOf, dtype=np.uint32)
+        assert ls[-1] == len(fr) == len(m) == len(f)
+        ix = None if userIndex is None else np.ascontiguousarray(userIndex, dtype=np.int32)
+        nu = None if isNull is None else np.ascontiguousarray(isNull, dtype=np.uint8)
+        sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
+        p = lambda a: None if a is None else a.ctypes.data
+        self._check(self._dll.speechPlayer_batch_setUtterancesShared(self._h, len(ls) - 1, p(ls), p(fr), p(m), p(f), p(ix), p(nu), len(lo), p(lo), p(sd)))
+        self.nUtterances = len(lo)
+
+    def setRecords(self, shapes, listStart, records, listOf=None, noiseSeed=None):
+        """The batch in compact form (speechPlayer_batch_setRecords): `shapes` [nShapes, 47] f64, `records` a structured array of
+        nvspeechplayer_amd.ipa.RECORD_DTYPE (32 bytes per frame), lists and listOf as in setUtterancesShared (None: utterance u = list u)."""
+        from .ipa import RECORD_DTYPE
+        sh = np.ascontiguousarray(shapes, dtype=np.float64).reshape(-1, 47)
+        ls = np.ascontiguousarray(listStart, dtype=np.int64)
+        rc = np.ascontiguousarray(records, dtype=RECORD_DTYPE)
+        assert ls[-1] == len(rc)
+        lo = None if listOf is None else np.ascontiguousarray(listOf, dtype=np.uint32)
+        n_utt = len(ls) - 1 if lo is None else len(lo)
+        sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
+        p = lambda a: None if a is None else a.ctypes.data
+        self._check(self._dll.speechPlayer_batch_setRecords(self._h, len(sh), p(sh), len(ls) - 1, p(ls), p(rc), n_utt, p(lo), p(sd)))
+        self.nUtterances = n_utt
+
+    def frames(self, u):
+        """The frames of utterance u as they are resident in HBM (speechPlayer_batch_frames): -> (frames[n, 47], min[n], fade[n], index[n], isnull[n])."""
+        n = self._check(self._dll.speechPlayer_batch_frames(self._h, u, None, None, None, None, None, 0))
+        fr = np.zeros((n, 47)); m = np.zeros(n, np.uint32); f = np.zeros(n, np.uint32); ix = np.zeros(n, np.int32); nu = np.zeros(n, np.uint8)
+        if n:
+            self._check(self._dll.speechPlayer_batch_frames(self._h, u, fr.ctypes.data, m.ctypes.data, f.ctypes.data, ix.ctypes.data, nu.ctypes.data, n))
+        return fr, m, f, ix, nu
+
     def setIpa(self, texts, speed=1, basePitch=100, inflection=0.5, clauseType=None, noiseSeed=None, voice=None,
-               trailing_silence_ms=150.0):
-        """Text in, batch ready (speechPlayer_batch_setIpa): every IPA string becomes one utterance through the native
+               trailing_silence_ms=150.0, textOf=None):
+        """Text in, batch ready (speechPlayer_batch_setIpa / _setIpaVoices): every IPA string becomes one utterance through the native
         frame producer followed by 150 ms of silence, as reference test_speakIpa.py:24-27 queues them.  basePitch and
-        clauseType may be sequences (one per text); voice: one of nvspeechplayer_amd.ipa.voices()."""
-        import ctypes
-        n = len(texts)
-        enc = [t.encode("utf8") for t in texts]
-        ptrs = (ctypes.c_char_p * max(n, 1))(*enc)
+        clauseType may be sequences (one per utterance); voice: one of nvspeechplayer_amd.ipa.voices() (or a voice defined with
+        ipa.defineVoice), or a sequence of voice INDICES, one per utterance (-1: none).  textOf: utterance u speaks texts[textOf[u]]
+        (a batch that repeats few sentences hands them over once)."""
+        from .ipa import _text_pointers
+        ptrs, n, keep = _text_pointers(texts, textOf)
         pitch = np.ascontiguousarray(np.broadcast_to(np.asarray(basePitch, dtype=np.float64), (n,)))
         code = lambda c: 0 if not c else ord(c[0])
         clauses = bytes([code(clauseType)]) * n if (clauseType is None or isinstance(clauseType, str)) else bytes(code(c) for c in clauseType)
         sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
-        self._check(self._dll.speechPlayer_batch_setIpa(self._h, n, ptrs, float(speed), pitch.ctypes.data, float(inflection), clauses + b"\0",
-                                                        None if not voice else voice.encode("utf8"),
-                                                        -1.0 if trailing_silence_ms is None else float(trailing_silence_ms),
-                                                        None if sd is None else sd.ctypes.data))
+        tail = -1.0 if trailing_silence_ms is None else float(trailing_silence_ms)
+        if voice is None or isinstance(voice, str):
+            self._check(self._dll.speechPlayer_batch_setIpa(self._h, n, ptrs.ctypes.data, float(speed), pitch.ctypes.data, float(inflection), clauses + b"\0",
+                                                            None if not voice else voice.encode("utf8"), tail, None if sd is None else sd.ctypes.data))
+        else:
+            vo = np.ascontiguousarray(np.broadcast_to(np.asarray(voice, dtype=np.int32), (n,)))
+            self._check(self._dll.speechPlayer_batch_setIpaVoices(self._h, n, ptrs.ctypes.data, float(speed), pitch.ctypes.data, float(inflection), clauses + b"\0",
+                                                                  vo.ctypes.data, tail, None if sd is None else sd.ctypes.data))
+        del keep
         self.nUtterances = n
 
     def setText(self, texts, speed=1, basePitch=100, inflection=0.5, noiseSeed=None, voice=None, espeakVoice="en"):

@@ -158,6 +158,57 @@ def cfg4_voice_variants(n_variants=256, utt_per_variant=16384, first_variant=0, 
                  name="cfg4: %d voice variants x %d utterances" % (n_variants, utt_per_variant), sr=sr)
 
 
+# ---- the same recipes in COMPACT form: what a caller hands BatchPlayer.setIpa (texts, pitches, voices) or setUtterancesShared ------
+CFG2_PERIOD = 512      # 8 sampleIpa lines x 64 base pitches: the distinct frame streams of configs[2] / [3] (and of one voice of configs[4])
+
+
+def cfg2_spec(n_utt=65536, first=0, sr=SR):
+    """BASELINE configs[2] as arguments of BatchPlayer.setIpa: the eight sampleIpa lines once, per utterance which line it speaks,
+    its base pitch and its noise seed.  bp.setIpa(**spec) gives the batch cfg2_ipa_utterances(n_utt, first) describes."""
+    z = _load()
+    lines = [b.decode("utf8") for b in z["ipa_lines"]][:8]
+    u = first + np.arange(n_utt, dtype=np.int64)
+    pitch_of = np.array([100.0 * 2.0 ** ((v - 32) / 64.0) for v in range(64)])
+    return dict(texts=lines, textOf=(u % 8).astype(np.int64), basePitch=pitch_of[(u // 8) % 64], speed=1.0, inflection=0.5, clauseType=".",
+                trailing_silence_ms=150.0, noiseSeed=u.astype(np.uint32))
+
+
+def cfg4_voice(v):
+    """Voice variant v of configs[4] as a defined voice (nvspeechplayer_amd.ipa.defineVoice): the multipliers cfg4_voice_variants draws."""
+    from . import ipa
+    rng = np.random.default_rng(1234 + v)
+    cf = rng.uniform(0.75, 1.05, size=3)
+    cb1 = rng.uniform(1.0, 1.3)
+    pm = rng.uniform(0.75, 1.5)
+    fr = rng.uniform(0.7, 1.0)
+    pa6 = rng.uniform(1.0, 1.3)
+    return ipa.defineVoice("cfg4-variant-%d" % v, {0: (None, pm), 7: (None, cf[0]), 8: (None, cf[1]), 9: (None, cf[2]), 15: (None, cb1),
+                                                   24: (None, fr), 42: (None, pa6), 46: (None, pm)})
+
+
+def cfg4_spec(n_utt, first=0, per=16384, sr=SR):
+    """BASELINE configs[4] as arguments of BatchPlayer.setIpa: utterance i of the flat (variant, utterance) list speaks with the defined
+    voice of variant i // per and is utterance i % per of the cfg2 generator; noise seeds as cfg4_voice_variants sets them."""
+    i = first + np.arange(n_utt, dtype=np.int64)
+    v, w = i // per, i % per
+    spec = cfg2_spec(1, 0, sr)
+    pitch_of = np.array([100.0 * 2.0 ** ((k - 32) / 64.0) for k in range(64)])
+    index_of = {int(k): cfg4_voice(int(k)) for k in np.unique(v)}
+    spec.update(textOf=(w % 8).astype(np.int64), basePitch=pitch_of[(w // 8) % 64], voice=np.array([index_of[int(k)] for k in v], np.int32),
+                noiseSeed=((w + v * per) & 0xFFFFFFFF).astype(np.uint32))
+    return spec
+
+
+def shared(workload, n_utt=None, first=0):
+    """A configuration as frame lists that utterances SHARE (BatchPlayer.setUtterancesShared): configs[2] / [3] are 512 distinct streams
+    instanced.  -> (lists: Batch of the 512 streams, list_of[n_utt], seeds[n_utt])."""
+    assert workload in ("cfg2", "cfg3")
+    n = n_utt or PER_GPU[workload]
+    lists = make(workload, CFG2_PERIOD, 0)
+    u = first + np.arange(n, dtype=np.int64)
+    return lists, (u % CFG2_PERIOD).astype(np.uint32), u.astype(np.uint32)
+
+
 # utterances per GPU of each BASELINE configuration (configs[3] is 10^6 over 8 GPUs, configs[4] 256 x 16384 over 8)
 PER_GPU = {"cfg1": 4096, "cfg2": 65536, "cfg3": 125000, "cfg4": 32 * 16384}
 CFG4_PER_VARIANT = 16384

@@ -149,3 +149,51 @@ def test_headers_are_plain_c_and_cpp(tmp_path):
     subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c++", "-I", inc, str(src)])
     subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", inc,
                            os.path.join(ROOT, "tests", "native", "c_client.c")])
+
+
+def test_forged_shape_hashes_are_refused():
+    """The track planner recognises a frame by a 128-bit hash of its 45 shape values (csrc/klatt_plan.h) and no longer compares the
+    values on a hit; what it took on trust is verified afterwards -- on the device in setUtterances (klatt_verify_shared), on the host
+    in this view (speechPlayer_planTracksFacts).  Two frames that differ in ONE value and carry the SAME facts (forged here: the real
+    hash function would need ~2^64 tries) must be refused, with the frame named; honest facts for the same frames plan fine."""
+    import numpy as np
+    from nvspeechplayer_amd import _native, workloads
+    L = _native.load()
+    b = workloads.make("cfg2", 16)
+    fs, fr = b["frame_start"], b["frames"].copy()
+    nf = len(fr)
+    facts = np.zeros(nf, dtype=[("h0", "<u8"), ("h1", "<u8"), ("flags", "<u4"), ("pad", "<u4")])
+    assert L.speechPlayer_frameFacts(fr.ctypes.data, nf, 22050, 0, facts.ctypes.data) == nf
+    fade = np.maximum(b["fade"], 1).astype(np.uint32)
+    nul = b["isnull"]
+    args = lambda f: (len(fs) - 1, fs.ctypes.data, fr.ctypes.data, fade.ctypes.data, nul.ctypes.data, None, 4096, f, None, None, None, None)
+    at = np.zeros(1, np.int64)
+    n_tracks = L.speechPlayer_planTracksFacts(*args(facts.ctypes.data), at.ctypes.data)
+    assert n_tracks > 0 and at[0] == -1
+    assert n_tracks == L.speechPlayer_planTracksFacts(*args(None), at.ctypes.data) == L.speechPlayer_planTracks(*args(None)[:6], 4096, None, None, None, None)
+    # frame k of the second utterance gets another cf2 and the facts of what it was
+    k = int(fs[1]) + 2
+    assert not nul[k]
+    fr[k, 8] += 1.0
+    honest = facts.copy()
+    assert L.speechPlayer_frameFacts(fr.ctypes.data, nf, 22050, 0, honest.ctypes.data) == nf
+    assert (honest["h0"][k], honest["h1"][k]) != (facts["h0"][k], facts["h1"][k])       # the hash sees one changed value
+    assert np.array_equal(np.delete(honest, k), np.delete(facts, k))
+    assert L.speechPlayer_planTracksFacts(*args(honest.ctypes.data), at.ctypes.data) > 0 and at[0] == -1
+    assert L.speechPlayer_planTracksFacts(*args(facts.ctypes.data), at.ctypes.data) == -2       # the forged ones
+    # (the forged frame is the first of its hash here, so the frame NAMED is a later one that really holds those values: the pair is what counts)
+    assert at[0] >= 0 and "one 128-bit shape hash and different values" in _native.last_error()
+    import re
+    pair = [int(x) for x in re.search(r"frames (\d+) and (\d+)", _native.last_error()).groups()]
+    assert k in pair and at[0] == pair[0] and not np.array_equal(fr[pair[0], 1:46], fr[pair[1], 1:46])
+    # a value whose bit pattern equals its position's key no longer hides its partner (ADVICE r5: hi ^ lo of a * c is 0 when a is)
+    one = np.zeros((2, 47)); out = np.zeros(2, dtype=facts.dtype)
+    def splitmix(n):
+        z = ((n + 1) * 0x9E3779B97F4A7C15) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2 ** 64 - 1)
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2 ** 64 - 1)
+        return z ^ (z >> 31)
+    one[:, 1] = np.array([splitmix(0)], np.uint64).view(np.float64)[0]      # parameter 1 ^ key(0) == 0 in the first chain
+    one[1, 2] = 123.0                                                        # its partner in that product
+    assert L.speechPlayer_frameFacts(one.ctypes.data, 2, 22050, 0, out.ctypes.data) == 2
+    assert out["h0"][0] != out["h0"][1] and out["h1"][0] != out["h1"][1]

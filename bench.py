@@ -86,27 +86,40 @@ def kernel_name(info):
     return "klatt_synthesize (lane kernel)"
 
 
-def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy_out=False, pinned=True):
+def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy_out=False, pinned=True, source="frames"):
     """Sustained end-to-end throughput: `n_batches` DISTINCT cfg2-sized batches (other noise seeds, other pitches: nothing of one batch
-    is reused by the next) through `players` BatchPlayers; `workers` host threads run speechPlayer_batch_setUtterances (classification,
-    lane packing, track planning, uploads) of the batches to come while the GPU synthesises the current one.  PCM stays in HBM, or
-    (copy_out) is delivered into one host buffer per player: the device puts it into dense utterance order, one copy per batch crosses
-    the link (speechPlayer_batch_readAllAsync) while the next batch is synthesised.  `pinned`: the frames and the PCM buffers are
-    page-locked memory the library handed out (speechPlayer_hostAlloc) -- what a front-end that wants the link's rate writes its frames
-    into; False: pageable numpy arrays (frames through a staging thread, PCM through bounce buffers, synchronously).  The frames
-    themselves are built before the clock starts (they are the caller's input: what a front-end hands over)."""
+    is reused by the next) through `players` BatchPlayers; `workers` host threads run the set call of the batches to come while the GPU
+    synthesises the current one.  source = "frames": the caller hands over 376-byte frames, one list per utterance
+    (speechPlayer_batch_setUtterances: classification, lane packing, track planning, 0.6 GB uploaded per batch; `pinned`: the frames are
+    in page-locked memory the library handed out, else pageable numpy arrays); source = "ipa": the caller hands over IPA text, base
+    pitches and seeds (speechPlayer_batch_setIpa: the native producer builds the distinct frame lists as 32-byte records, the device
+    expands them, utterances share their list's frames) -- the producer's work is INSIDE the clock.  PCM stays in HBM, or (copy_out) is
+    delivered into one host buffer per player: the device puts it into dense utterance order, one copy per batch crosses the link
+    (speechPlayer_batch_readAllAsync) while the next batch is synthesised."""
     import threading
     import numpy as np
     from nvspeechplayer_amd import BatchPlayer, host_array, workloads
     batches = []
     for k in range(n_batches):
+        if source == "ipa":
+            spec = workloads.cfg2_spec(65536, first=k * 65536)
+            spec["basePitch"] = spec["basePitch"] * (1.0 + 0.01 * k)
+            batches.append(spec)
+            continue
         b = workloads.make("cfg2", 65536, first=k * 65536)
         fr = host_array(b["frames"].shape, np.float64) if pinned else np.empty_like(b["frames"])
         fr[...] = b["frames"]
         fr[:, 0] *= 1.0 + 0.01 * k; fr[:, 46] *= 1.0 + 0.01 * k
         b["frames"] = fr
         batches.append(b)
-    bps = [BatchPlayer(batches[0]["sr"], device=device, mode=mode, layout=layout) for _ in range(players)]
+    sr = workloads.SR
+
+    def set_batch(bp, b):
+        if source == "ipa":
+            bp.setIpa(**b)
+        else:
+            bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+    bps = [BatchPlayer(sr, device=device, mode=mode, layout=layout) for _ in range(players)]
     ready = [threading.Event() for _ in range(n_batches)]
     free = [threading.Semaphore(1) for _ in range(players)]
     set_s = [0.0] * n_batches
@@ -122,28 +135,25 @@ def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy
                 if k >= n_batches:
                     return
                 free[k % players].acquire()          # the player's previous batch has been synthesised (and read)
-                b = batches[k]
                 t = time.perf_counter()
-                bps[k % players].setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+                set_batch(bps[k % players], batches[k])
                 set_s[k] = time.perf_counter() - t
                 ready[k].set()
         except Exception as e:      # noqa: BLE001
             err.append(e)
             for r in ready:
                 r.set()
-    outs = None
-    if copy_out:
-        n_out = int(max(b.sample_counts().sum() for b in batches))
-        outs = [host_array(n_out, np.int16) if pinned else np.empty(n_out, dtype=np.int16) for _ in range(players)]
-        for o in outs:
-            o[...] = 0
     # warm-up: one batch through every player (allocations, first launches)
     for i, bp in enumerate(bps):
-        b = batches[i % n_batches]
-        bp.setUtterances(b["frame_start"], b["frames"], b["min"], b["fade"], b["index"], b["isnull"], b["seeds"])
+        set_batch(bp, batches[i % n_batches])
         bp.synthesize()
-        if copy_out:
-            bp.readAll(out=outs[i])
+    outs = None
+    if copy_out:
+        n_out = int(max(bp.totalSamples for bp in bps) * 1.05)
+        outs = [host_array(n_out, np.int16) if pinned else np.empty(n_out, dtype=np.int16) for _ in range(players)]
+        for i, o in enumerate(outs):
+            o[...] = 0
+            bps[i].readAll(out=o)
     total = 0
     t0 = time.perf_counter()
     ths = [threading.Thread(target=work) for _ in range(workers)]
@@ -159,8 +169,9 @@ def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy
             bpj.readWait()
         elif copy_out:
             bpj.readAll(out=outs[j % players])
+        n = bpj.totalSamples
         free[j % players].release()
-        return bpj.totalSamples
+        return n
     for k in range(n_batches):
         ready[k].wait()
         if err:
@@ -184,11 +195,64 @@ def pipeline_extra(device, mode, layout, n_batches=8, players=4, workers=3, copy
     for bp in bps:
         bp.close()
     return {"value": total / elapsed, "unit": "samples/s", "batches": n_batches, "players": players, "setter_threads": workers,
+            "planner_threads_per_set_call": int(os.environ.get("SPEECHPLAYER_PLAN_THREADS", "8")), "host_cores": usable_cores(),
+            "input": ("IPA text + base pitch + seed per utterance (speechPlayer_batch_setIpa: producer inside the clock, 32-byte records, shared frame lists)"
+                      if source == "ipa" else "376-byte frames, one list per utterance (speechPlayer_batch_setUtterances)"),
             "host_buffers": "page-locked (speechPlayer_hostAlloc): frames in and PCM out are one DMA each" if pinned else "pageable numpy arrays",
             "pcm": ("one dense copy per batch into a host buffer per player (speechPlayer_batch_readAllAsync), beside the next batch's synthesis" if pinned
                     else "copied to one host buffer per player (speechPlayer_batch_readAll)") if copy_out else "left in HBM",
-            "elapsed_s": round(elapsed, 3), "set_utterances_s_mean": round(float(np.mean(set_s)), 4), "gpu_side_s_per_batch": round(synth_s / n_batches, 4),
+            "elapsed_s": round(elapsed, 3), "set_call_s_mean_under_load": round(float(np.mean(set_s)), 4), "gpu_side_s_per_batch": round(synth_s / n_batches, 4),
             "samples_per_batch": total // n_batches}
+
+
+def single_stream_extra(pulls=50, pull=8192):
+    """The reference's own use (nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:62-81): ONE handle, pulled 8192 samples at a time.
+    Median milliseconds per speechPlayer_synthesize call, beside the same pulls of the oracle on one host core."""
+    import numpy as np
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    from tests import oracle
+    b = workloads.make("cfg2", 8)
+    rows = [(b["frames"][k], int(b["min"][k]), int(b["fade"][k]), bool(b["isnull"][k])) for k in range(int(b["frame_start"][8]))]
+    need = pulls * pull + pull
+    p = eng.SpeechPlayer(22050, noiseSeed=1)
+    o = oracle.OraclePlayer(22050, seed=1)
+    queued = 0
+    while queued < need:                     # the eight sentences again and again: no pull runs dry
+        for fr, m, f, nul in rows:
+            p.queueFrameSamples(None if nul else eng.Frame.from_array(fr), m, f)
+            o.queue(None if nul else fr, m, f)
+            queued += max(m, max(f, 1) + 1) + 1
+    p.synthesize(pull); o.synthesize(pull)   # first call: allocations, first launch
+    t_gpu, t_cpu, same = [], [], True
+    for _ in range(pulls):
+        t = time.perf_counter(); buf = p.synthesize(pull); t_gpu.append(time.perf_counter() - t)
+        t = time.perf_counter(); exp = o.synthesize(pull); t_cpu.append(time.perf_counter() - t)
+        same = same and buf is not None and buf.length == pull and np.array_equal(np.frombuffer(buf, dtype=np.int16)[:pull], exp)
+    p.close()
+    return {"what": "one live handle, %d pulls of %d samples (speechPlayer_synthesize); the same pulls of the oracle on one host core" % (pulls, pull),
+            "ms_per_pull_median": float(np.median(t_gpu)) * 1e3, "ms_per_pull_min": float(np.min(t_gpu)) * 1e3,
+            "oracle_ms_per_pull_median": float(np.median(t_cpu)) * 1e3, "real_time_ms_per_pull": pull / 22050.0 * 1e3, "pcm_equal": bool(same)}
+
+
+def cfg0_cpu_extra():
+    """BASELINE configs[0]: a single steady /a/ at 120 Hz, 1 s at 22.05 kHz, on the CPU (the oracle on one core; SURVEY 8c's recipe,
+    test_playVowelchart path): samples/s and multiples of real time."""
+    import numpy as np
+    from tests import oracle, scenarios
+    ref = scenarios.Ref()
+    fr = scenarios.vowel_frame(ref, "a", 120.0)
+    best = None
+    for _ in range(20):
+        o = oracle.OraclePlayer(22050, seed=0)
+        o.queue(fr, 22050, 1102)
+        t = time.perf_counter()
+        pcm = o.synthesize(22050)
+        dt = time.perf_counter() - t
+        o.close()
+        best = dt if best is None else min(best, dt)
+    return {"workload": "BASELINE configs[0]: single steady /a/ 120 Hz, 1 s at 22.05 kHz, oracle on one host core (best of 20)",
+            "value": len(pcm) / best, "unit": "samples/s", "seconds": best, "times_real_time": len(pcm) / best / 22050.0, "cores": 1, "kind": "port"}
 
 
 def usable_cores():
@@ -344,6 +408,7 @@ def main():
     bp = None
     t_set = t_set_again = 0.0
     t_set_pinned = None
+    compact = None
     if not dry:
         bp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
         t_set = time.perf_counter()
@@ -372,6 +437,30 @@ def main():
                     bp.setUtterances(batch["frame_start"], fr, batch["min"], batch["fade"], batch["index"], batch["isnull"], batch["seeds"])
                     t_set_pinned = time.perf_counter() - t_set_pinned
                 del fr
+        if world == 1 and not args.no_extras and args.workload in ("cfg2", "cfg4"):
+            # the same batch handed over as IPA text (speechPlayer_batch_setIpa / _setIpaVoices): the producer builds the distinct frame lists
+            # as 32-byte records, the device expands them, utterances share their list's frames -- "build" is numpy writing the arguments
+            try:
+                spec_fn = workloads.cfg2_spec if args.workload == "cfg2" else workloads.cfg4_spec
+                c_spec = c_set = c_again = 0.0
+                cbp = BatchPlayer(batch["sr"], device=device, mode=args.mode, layout=args.layout)
+                for rep in range(3):
+                    t = time.perf_counter(); spec = spec_fn(shard["utterances"], first=shard["first_utterance"]); c_spec = time.perf_counter() - t
+                    t = time.perf_counter(); cbp.setIpa(**spec); dt = time.perf_counter() - t
+                    if rep == 0:
+                        c_set = dt
+                    c_again = dt
+                assert cbp.totalSamples == samples
+                cbp.synthesize(); bp.synthesize()
+                c_equal = cbp.digest() == bp.digest()
+                c_ms = float(np.mean(cbp.time(5)))
+                compact = {"arguments_s": round(c_spec, 4), "set_ipa_first_call_s": round(c_set, 4), "set_ipa_s": round(c_again, 4),
+                           "build_plus_set_s": round(c_spec + c_again, 4), "kernel_ms": c_ms, "pcm_equal_to_the_plain_batch": bool(c_equal),
+                           "resident_frames": None, "what": "speechPlayer_batch_setIpa%s on the same utterances: producer + records + device-side frame expansion + planning on the distinct lists"
+                                                           % ("" if args.workload == "cfg2" else "Voices (32 defined voices)")}
+                cbp.close()
+            except Exception as e:      # noqa: BLE001
+                compact = {"error": "%s: %s" % (type(e).__name__, e)}
 
     def barrier():
         if not dry:
@@ -464,8 +553,10 @@ def main():
                        "rccl_ranks": dist.get_world_size() if (dist is not None and dist.get_backend() == "nccl") else None,
                        "host": {"build_batch_s": round(t_build, 3), "set_utterances_s": round(t_set, 3), "set_utterances_again_s": round(t_set_again, 3),
                                 "set_utterances_page_locked_frames_s": None if t_set_pinned is None else round(t_set_pinned, 3),
+                                "from_ipa": compact,
                                 "note": "outside the timed region: the frame producer (build) and speechPlayer_batch_setUtterances (classification, "
-                                        "lane packing, track planning, uploads); a batch is set once and synthesised many times"},
+                                        "lane packing, track planning, uploads); a batch is set once and synthesised many times.  from_ipa: the same "
+                                        "utterances handed over as text, pitches and seeds (compact form)"},
                        "parallelism": "node batch cut into %d contiguous shards of near-equal sample count, one process per GPU, no collective on the data path" % world},
         }
         out.update(node_extras)
@@ -475,6 +566,8 @@ def main():
         else:
             out["realtime_factor"] = total_samples * args.steps / elapsed / head_sr
             out["config"]["host"]["first_launch_end_to_end_samples_per_s"] = samples / (t_set + k_ms * 1e-3)
+            if compact and "build_plus_set_s" in compact:
+                out["config"]["host"]["from_ipa_launch_end_to_end_samples_per_s"] = samples / (compact["build_plus_set_s"] + k_ms * 1e-3)
             achieved = alg_bytes / (k_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                     "kernel": kernel_name(info), "kernel_ms": k_ms, "algorithmic_bytes_per_launch": alg_bytes,
@@ -596,10 +689,19 @@ def main():
                         return pipeline_extra(device, args.mode, args.layout, **kw)
                     except Exception as e:      # noqa: BLE001
                         return {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
-                out["pipeline"] = extra(n_batches=16, players=6, workers=4)
-                out["pipeline"]["with_pcm_to_host"] = extra(n_batches=8, copy_out=True)
-                out["pipeline"]["pageable_host_buffers"] = dict(extra(pinned=False), with_pcm_to_host=extra(n_batches=4, copy_out=True, pinned=False))
+                same = dict(n_batches=16, players=6, workers=4)      # every variant with the same counts
+                out["pipeline_from_ipa"] = extra(source="ipa", **same)
+                out["pipeline_from_ipa"]["with_pcm_to_host"] = extra(source="ipa", copy_out=True, n_batches=8, players=6, workers=4)
+                out["pipeline"] = extra(**same)
+                out["pipeline"]["with_pcm_to_host"] = extra(copy_out=True, n_batches=8, players=6, workers=4)
+                out["pipeline"]["pageable_host_buffers"] = dict(extra(pinned=False, **same), with_pcm_to_host=extra(n_batches=8, players=6, workers=4, copy_out=True, pinned=False))
                 batch = batch_keep
+            if world == 1 and not args.no_extras:
+                for key, fn in (("single_stream", single_stream_extra), ("cfg0_cpu", cfg0_cpu_extra)):
+                    try:
+                        out[key] = fn()
+                    except Exception as e:      # noqa: BLE001
+                        out[key] = {"value": None, "error": "%s: %s" % (type(e).__name__, e)}
             if world == 1 and not args.no_cpu_baseline:
                 out["cpu_baseline"] = cpu_baseline(batch, args.cpu_seconds)
         print(json.dumps(out), flush=True)

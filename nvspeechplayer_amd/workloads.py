@@ -193,8 +193,10 @@ def cfg4_spec(n_utt, first=0, per=16384, sr=SR):
     v, w = i // per, i % per
     spec = cfg2_spec(1, 0, sr)
     pitch_of = np.array([100.0 * 2.0 ** ((k - 32) / 64.0) for k in range(64)])
-    index_of = {int(k): cfg4_voice(int(k)) for k in np.unique(v)}
-    spec.update(textOf=(w % 8).astype(np.int64), basePitch=pitch_of[(w // 8) % 64], voice=np.array([index_of[int(k)] for k in v], np.int32),
+    index_of = np.zeros(int(v.max()) + 1 if n_utt else 1, np.int32)
+    for k in np.unique(v):
+        index_of[int(k)] = cfg4_voice(int(k))
+    spec.update(textOf=(w % 8).astype(np.int64), basePitch=pitch_of[(w // 8) % 64], voice=index_of[v],
                 noiseSeed=((w + v * per) & 0xFFFFFFFF).astype(np.uint32))
     return spec
 

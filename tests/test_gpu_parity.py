@@ -242,10 +242,10 @@ def test_full_size_cfg1_properties():
     body = a.reshape(4096, 23155)
     assert np.all(np.abs(body[:, 5000:20000]).max(axis=1) > 500)
     assert np.all(np.abs(body[:, -50:]).max(axis=1) < np.abs(body[:, 5000:20000]).max(axis=1))   # faded out
-    for u in range(0, 4096, 337):
-        sub = batch.slice(u, 1)
-        exp, _, _ = oracle.batch_synthesize(22050, sub)
-        compare(body[u], exp, "cfg1 utt %d" % u)
+    from tests import whole_batch
+    n, differ = whole_batch.check_against_oracle(bp, batch, bp.digest(per_utterance=True)[1], compare, "cfg1")      # every utterance
+    print("cfg1: %d utterances against the oracle, %d with one-LSB differences" % (n, differ))
+    assert n == 4096
     bp.close()
 
 
@@ -493,7 +493,7 @@ def test_full_size_cfg2_properties():
     """BASELINE configs[2] at full size (65 536 speech utterances, 1.5e9 samples): closed-form lengths,
     idempotent relaunch, noise-free utterances are independent of their seed (line 8 is all vowels, so
     u and u + 512 -- same line, same pitch variant, different noise stream -- must be bit-identical),
-    noisy ones differ, and a strided sample of utterances equals the oracle."""
+    noisy ones differ, and EVERY utterance equals the oracle (digest and index mark)."""
     import hashlib
     import nvspeechplayer_amd as eng
     from nvspeechplayer_amd import workloads
@@ -518,10 +518,15 @@ def test_full_size_cfg2_properties():
         assert np.array_equal(a[starts[u]:starts[u + 1]], a[starts[u + 512]:starts[u + 513]])
     for u in (2, 13):                                              # noisy lines: another seed, another PCM
         assert not np.array_equal(a[starts[u]:starts[u + 1]], a[starts[u + 512]:starts[u + 513]])
-    for u in range(5, 65536, 1637):
-        exp, _, _ = oracle.batch_synthesize(22050, batch.slice(u, 1))
-        compare(a[starts[u]:starts[u + 1]], exp, "cfg2 utt %d" % u)
-        assert bp.getLastIndex(u) == int(oracle.batch_last_index(22050, batch.slice(u, 1))[0])      # reference src/frame.cpp:69, :117-119
+    # EVERY utterance against the oracle: per-utterance digests computed where the PCM lives against the same digest of the oracle's
+    # PCM (tests/whole_batch.py), index marks too; the digest kernel itself against the host's formula on what was read back
+    from tests import whole_batch
+    per = bp.digest(per_utterance=True)[1]
+    assert np.array_equal(per[:2048], whole_batch.host_digests(a[:starts[2048]], starts[:2049]))
+    del a
+    n, differ = whole_batch.check_against_oracle(bp, batch, per, compare, "cfg2")
+    print("cfg2: %d utterances against the oracle, %d with one-LSB differences" % (n, differ))
+    assert n == 65536
     bp.close()
 
 
@@ -873,6 +878,10 @@ def test_full_size_cfg3_cfg4_properties(workload, n_utt):
                 assert bp.getLastIndex(u) == int(oracle.batch_last_index(22050, batch.slice(u, 1))[0])      # reference src/frame.cpp:69, :117-119
             for u in (0, n_utt - 1):
                 assert bp.utteranceSamples(u) == counts[u] and len(bp.read(u)) == counts[u]
+            # configs[3]'s share: every utterance against the oracle; configs[4]'s (1.2e10 samples): every eighth
+            from tests import whole_batch
+            n, differ = whole_batch.check_against_oracle(bp, batch, per[(1, 0)], compare, workload, stride=1 if workload == "cfg3" else 8)
+            print("%s: %d utterances against the oracle, %d with one-LSB differences" % (workload, n, differ))
             keep = bp
             continue
         if mode == 1:

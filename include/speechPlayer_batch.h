@@ -205,8 +205,14 @@ int speechPlayer_node_wait(speechPlayer_node_t node);
 long long speechPlayer_node_totalSamples(speechPlayer_node_t node);
 long long speechPlayer_node_read(speechPlayer_node_t node, long long utterance, sample* sampleBuf, long long capacity);
 int speechPlayer_node_getLastIndex(speechPlayer_node_t node, long long utterance);
-/* Shard `shard`: its first utterance, utterance count, sample count and device (each pointer may be NULL). */
+/* Option "deal" (besides the batch options, which go to every shard): 0 (default) contiguous shards of near-equal total sample count;
+ * 1 the SORTED deal of SURVEY 8(e) -- utterances sorted by length, blocks of 64 (one wavefront) dealt round-robin -- so that every
+ * device sees the same length distribution whatever the order of the batch (the shards' frames are then gathered on the host).
+ * Shard `shard`: its first utterance (-1 under the sorted deal: its utterances are not a range), utterance count, sample count and
+ * device (each pointer may be NULL); speechPlayer_node_shardUtterances lists the shard's utterances in the shard's own order
+ * (returns their number; fills when it is <= capacity). */
 int speechPlayer_node_shardInfo(speechPlayer_node_t node, int shard, long long* firstUtterance, long long* nUtterances, long long* samples, int* device);
+long long speechPlayer_node_shardUtterances(speechPlayer_node_t node, int shard, long long* utterances, long long capacity);
 /* The shard's own batch object, for everything else (digest, float output, device pointers); utterance numbers are
  * relative to the shard's first utterance there. */
 speechPlayer_batch_t speechPlayer_node_part(speechPlayer_node_t node, int shard);

@@ -2843,7 +2843,13 @@ int speechPlayer_batch_time(speechPlayer_batch_t batch, int launches, float* msP
 struct Node {
     int sampleRate = 0;
     std::vector<Batch*> parts;
-    std::vector<long long> bounds;       // shard d = utterances bounds[d] .. bounds[d + 1] - 1
+    std::vector<long long> bounds;       // contiguous deal: shard d = utterances bounds[d] .. bounds[d + 1] - 1
+    int deal = 0;                        // option "deal": 0 contiguous shards of near-equal sample count, 1 the sorted deal
+    bool sorted = false;                 // the batch that is set was dealt sorted: shard d = members[d]
+    std::vector<std::vector<long long>> members;   // sorted deal: the utterances of every shard, in the shard's own order
+    std::vector<int> shardOf;            // sorted deal: [nUtterances]
+    std::vector<long long> localOf;      // ... and the utterance's number within its shard
+    long long nUtt = 0;
 };
 
 speechPlayer_node_t speechPlayer_node_create(int sampleRate, int nDevices, const int* devices)
@@ -2881,7 +2887,12 @@ int speechPlayer_node_setOption(speechPlayer_node_t node, const char* name, int 
 {
     begin_call();
     Node* n = static_cast<Node*>(node);
-    if (!n) return -1;
+    if (!n || !name) return -1;
+    // "deal" (read by speechPlayer_node_setUtterances): 0 contiguous shards of near-equal total sample count (default), 1 the SORTED deal
+    // of SURVEY 8(e): utterances sorted by length, blocks of 64 (one wavefront) dealt round-robin, so that every device sees the same
+    // length distribution -- a batch whose long utterances cluster gives every device its share of them.  Results are addressed by the
+    // batch's own utterance numbers either way.
+    if (!strcmp(name, "deal")) { n->deal = value ? 1 : 0; return 0; }
     for (Batch* b : n->parts)
         if (speechPlayer_batch_setOption(b, name, value)) return -1;
     return 0;
@@ -2911,6 +2922,9 @@ int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtteran
     }
     const int nd = (int)n->parts.size();
     const unsigned long long total = before[nUtterances];
+    n->nUtt = nUtterances;
+    n->sorted = n->deal == 1 && nd > 1;
+    n->members.clear(); n->shardOf.clear(); n->localOf.clear();
     n->bounds[0] = 0;
     for (int d = 1; d < nd; ++d) {
         // first utterance whose start is at or beyond d/nd of the samples (the rule of nvspeechplayer_amd.sharding.shard_bounds)
@@ -2919,6 +2933,20 @@ int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtteran
         n->bounds[d] = std::max(n->bounds[d - 1], std::min(cut, nUtterances));
     }
     n->bounds[nd] = nUtterances;
+    if (n->sorted) {
+        // longest first (ties in the batch's order), blocks of 64 dealt round-robin (nvspeechplayer_amd.sharding.shard_deal states the same rule)
+        std::vector<long long> order((size_t)nUtterances);
+        std::iota(order.begin(), order.end(), 0ll);
+        std::stable_sort(order.begin(), order.end(), [&](long long x, long long y) { return before[x + 1] - before[x] > before[y + 1] - before[y]; });
+        n->members.assign((size_t)nd, {});
+        n->shardOf.assign((size_t)nUtterances, 0); n->localOf.assign((size_t)nUtterances, 0);
+        for (long long i = 0; i < nUtterances; ++i) {
+            const int d = (int)((i / kLanes) % nd);
+            n->shardOf[(size_t)order[i]] = d;
+            n->localOf[(size_t)order[i]] = (long long)n->members[(size_t)d].size();
+            n->members[(size_t)d].push_back(order[i]);
+        }
+    }
     // one host thread per device: rebase the shard's index array, give every utterance its GLOBAL default seed, upload
     std::vector<int> rc((size_t)nd, 0), codes((size_t)nd, 0);
     std::vector<std::string> errors((size_t)nd);
@@ -2927,6 +2955,32 @@ int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtteran
     run_parts((unsigned)nd, [&](unsigned ud) {
         const int d = (int)ud;
         try {
+            if (n->sorted) {
+                // the shard's utterances are scattered over the batch: their frames are gathered (one copy on the host, 392 bytes per frame)
+                const std::vector<long long>& mem = n->members[(size_t)d];
+                std::vector<long long> fs(mem.size() + 1, 0);
+                for (size_t j = 0; j < mem.size(); ++j) fs[j + 1] = fs[j] + (frameStart[mem[j] + 1] - frameStart[mem[j]]);
+                const size_t nf = (size_t)fs[mem.size()];
+                std::vector<speechPlayer_frame_t> fr(frames ? nf : 0);
+                std::vector<unsigned int> mins(nf), fades(nf), seeds(mem.size());
+                std::vector<int> idx(userIndex ? nf : 0);
+                std::vector<unsigned char> nul(isNull ? nf : 0);
+                for (size_t j = 0; j < mem.size(); ++j) {
+                    const long long a = frameStart[mem[j]], cnt = frameStart[mem[j] + 1] - a, at = fs[j];
+                    if (cnt > 0) {
+                        if (frames) memcpy(&fr[(size_t)at], frames + a, (size_t)cnt * sizeof(speechPlayer_frame_t));
+                        memcpy(&mins[(size_t)at], minFrameDuration + a, (size_t)cnt * sizeof(unsigned int));
+                        memcpy(&fades[(size_t)at], fadeDuration + a, (size_t)cnt * sizeof(unsigned int));
+                        if (userIndex) memcpy(&idx[(size_t)at], userIndex + a, (size_t)cnt * sizeof(int));
+                        if (isNull) memcpy(&nul[(size_t)at], isNull + a, (size_t)cnt);
+                    }
+                    seeds[j] = noiseSeed ? noiseSeed[mem[j]] : (unsigned int)mem[j];
+                }
+                rc[d] = speechPlayer_batch_setUtterances(n->parts[d], (long long)mem.size(), fs.data(), frames ? fr.data() : nullptr, mins.data(), fades.data(),
+                                                         userIndex ? idx.data() : nullptr, isNull ? nul.data() : nullptr, seeds.data());
+                if (rc[d]) { errors[d] = g_lastError; codes[d] = g_lastErrorCode; }
+                return;
+            }
             const long long u0 = n->bounds[d], u1 = n->bounds[d + 1], f0 = frameStart[u0];
             std::vector<long long> fs((size_t)(u1 - u0) + 1);
             for (long long u = u0; u <= u1; ++u) fs[u - u0] = frameStart[u] - f0;
@@ -2977,8 +3031,8 @@ int speechPlayer_node_shardInfo(speechPlayer_node_t node, int shard, long long* 
 {
     Node* n = static_cast<Node*>(node);
     if (!n || shard < 0 || shard >= (int)n->parts.size()) return -1;
-    if (firstUtterance) *firstUtterance = n->bounds[shard];
-    if (nUtterances) *nUtterances = n->bounds[shard + 1] - n->bounds[shard];
+    if (firstUtterance) *firstUtterance = n->sorted ? -1 : n->bounds[shard];      // (the sorted deal's shards are not ranges: speechPlayer_node_shardUtterances)
+    if (nUtterances) *nUtterances = n->sorted ? (long long)n->members[(size_t)shard].size() : n->bounds[shard + 1] - n->bounds[shard];
     if (samples) *samples = n->parts[shard]->totalSamples;
     if (device) *device = n->parts[shard]->device;
     return 0;
@@ -2993,25 +3047,41 @@ long long speechPlayer_node_totalSamples(speechPlayer_node_t node)
     return t;
 }
 
-static int node_locate(Node* n, long long u)
+// the shard that holds utterance u and its number there
+static int node_locate(Node* n, long long u, long long* local)
 {
-    if (!n || u < 0 || u >= n->bounds.back()) return -1;
-    return (int)(std::upper_bound(n->bounds.begin(), n->bounds.end(), u) - n->bounds.begin()) - 1;
+    if (!n || u < 0 || u >= n->nUtt) return -1;
+    if (n->sorted) { *local = n->localOf[(size_t)u]; return n->shardOf[(size_t)u]; }
+    const int d = (int)(std::upper_bound(n->bounds.begin(), n->bounds.end(), u) - n->bounds.begin()) - 1;
+    *local = u - n->bounds[d];
+    return d;
+}
+
+long long speechPlayer_node_shardUtterances(speechPlayer_node_t node, int shard, long long* utterances, long long capacity)
+{
+    Node* n = static_cast<Node*>(node);
+    if (!n || shard < 0 || shard >= (int)n->parts.size()) return -1;
+    const long long cnt = n->sorted ? (long long)n->members[(size_t)shard].size() : n->bounds[shard + 1] - n->bounds[shard];
+    if (utterances && cnt <= capacity)
+        for (long long j = 0; j < cnt; ++j) utterances[j] = n->sorted ? n->members[(size_t)shard][(size_t)j] : n->bounds[shard] + j;
+    return cnt;
 }
 
 long long speechPlayer_node_read(speechPlayer_node_t node, long long u, sample* sampleBuf, long long capacity)
 {
     Node* n = static_cast<Node*>(node);
-    const int d = node_locate(n, u);
+    long long local = 0;
+    const int d = node_locate(n, u, &local);
     if (d < 0) { begin_call(); set_error("node_read: utterance %lld out of range", u); return -1; }
-    return speechPlayer_batch_read(n->parts[d], u - n->bounds[d], sampleBuf, capacity);
+    return speechPlayer_batch_read(n->parts[d], local, sampleBuf, capacity);
 }
 
 int speechPlayer_node_getLastIndex(speechPlayer_node_t node, long long u)
 {
     Node* n = static_cast<Node*>(node);
-    const int d = node_locate(n, u);
-    return d < 0 ? -1 : speechPlayer_batch_getLastIndex(n->parts[d], u - n->bounds[d]);
+    long long local = 0;
+    const int d = node_locate(n, u, &local);
+    return d < 0 ? -1 : speechPlayer_batch_getLastIndex(n->parts[d], local);
 }
 
 // `launches` passes over the node's batch, every device launched before any is waited for; wall-clock milliseconds per pass

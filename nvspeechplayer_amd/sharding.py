@@ -22,6 +22,37 @@ def shard_bounds(sample_counts, world):
     return np.maximum.accumulate(bounds)
 
 
+def shard_deal(sample_counts, world, deal="contiguous", block=64):
+    """-> list of `world` index arrays: the utterances of every rank, in the rank's own order.
+    "contiguous": shard_bounds' ranges (near-equal total sample count; what bench.py's ranks build, each from its own range of the
+    recipe).  "sorted": SURVEY 8(e) -- utterances sorted by length (longest first, ties in batch order), blocks of `block` (one
+    wavefront) dealt round-robin -- every rank sees the same length distribution, so a batch whose long utterances cluster does not
+    leave one GPU with the long tail; the engine's node object does the same under its option "deal" (speechPlayer_node_setOption)."""
+    counts = np.asarray(sample_counts, dtype=np.int64)
+    if deal == "contiguous":
+        b = shard_bounds(counts, world)
+        return [np.arange(b[r], b[r + 1], dtype=np.int64) for r in range(world)]
+    if deal != "sorted":
+        raise ValueError(deal)
+    order = np.argsort(-counts, kind="stable")
+    rank_of = (np.arange(len(order)) // block) % max(world, 1)
+    return [order[rank_of == r] for r in range(world)]
+
+
+def longest_wave(sample_counts, members, lanes=64):
+    """Samples of the longest wavefront a rank launches for the utterances `members`: the engine packs lanes by length (longest
+    first), a wavefront lasts as long as its longest lane, and a launch at least as long as its longest wavefront."""
+    c = np.asarray(sample_counts, dtype=np.int64)[np.asarray(members, dtype=np.int64)]
+    return int(c.max()) if len(c) else 0
+
+
+def wave_time(sample_counts, members, lanes=64):
+    """Sum over a rank's wavefronts (lanes packed longest first) of the wavefront's longest lane: what the rank's launch costs when
+    it has more wavefronts than the device runs at once."""
+    c = np.sort(np.asarray(sample_counts, dtype=np.int64)[np.asarray(members, dtype=np.int64)])[::-1]
+    return int(c[::lanes].sum())
+
+
 def reduce_throughput(elapsed_s, samples, dist=None, device=None):
     """(max elapsed over ranks, total samples over ranks)."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

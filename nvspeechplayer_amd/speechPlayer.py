@@ -530,18 +530,30 @@ class NodePlayer(object):
     def getLastIndex(self, u):
         return self._dll.speechPlayer_node_getLastIndex(self._h, u)
 
+    def setOption(self, name, value):
+        """Batch options go to every shard; "deal": 0 contiguous shards (default), 1 the sorted deal (blocks of 64 length-sorted
+        utterances dealt round-robin) -- set it before setUtterances."""
+        self._check(self._dll.speechPlayer_node_setOption(self._h, name.encode(), int(value)))
+
+    def shardUtterances(self, d):
+        """The utterances of shard d (numbers in the node batch), in the shard's own order."""
+        n = self._check(self._dll.speechPlayer_node_shardUtterances(self._h, d, None, 0))
+        out = np.zeros(max(n, 1), dtype=np.int64)
+        self._check(self._dll.speechPlayer_node_shardUtterances(self._h, d, out.ctypes.data, n))
+        return out[:n]
+
     def digests(self):
         """Per-utterance digests of the PCM in the node batch's utterance order, computed where each shard's PCM lives
         (speechPlayer_batch_digest on the shards: nothing is copied but 8 bytes per utterance)."""
-        import ctypes
         out = np.zeros(max(self.nUtterances, 1), dtype=np.uint64)
-        for d, (first, count, _, _) in enumerate(self.shards()):
+        for d in range(self._dll.speechPlayer_node_devices(self._h)):
+            mem = self.shardUtterances(d)
             part = self._dll.speechPlayer_node_part(self._h, d)
             if not part:
                 raise RuntimeError("speechPlayer_node_part(%d) failed: %s" % (d, _native.last_error()))
-            per = np.zeros(max(count, 1), dtype=np.uint64)
+            per = np.zeros(max(len(mem), 1), dtype=np.uint64)
             self._check(self._dll.speechPlayer_batch_digest(part, per.ctypes.data, None))
-            out[first:first + count] = per[:count]
+            out[mem] = per[:len(mem)]
         return out[:self.nUtterances]
 
     def time(self, launches):

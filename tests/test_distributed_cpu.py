@@ -139,3 +139,34 @@ def test_bench_eight_ranks_dry_run(tmp_path):
         assert e["node_utterances"] == 8 * per_gpu and e["node_samples"] == int(counts.sum()) == int(e["total_samples_all_ranks"])
         balanced(e["shard_bounds"], counts, key)
     assert peak_kb < 4 * 1024 * 1024 or peak_kb == before, "a rank's peak RSS was %.1f GB" % (peak_kb / 1048576.0)
+
+
+def test_sorted_deal_balances_a_batch_whose_long_utterances_cluster():
+    """utterances sorted by length, blocks of 64 dealt round-robin.  On a NON-periodic batch -- lengths log-uniform over
+    two decades, the long ones clustered at the front -- the contiguous deal (near-equal sample totals) gives one rank a few very long
+    utterances: its launch lasts as long as its longest wavefront, and its wavefront-time (sum over wavefronts of the longest lane) is
+    far from the others'.  Under the sorted deal every rank sees the same length distribution: longest wavefronts within 5 %, samples
+    and wavefront-times within 2 %; every utterance is dealt exactly once."""
+    from nvspeechplayer_amd.sharding import longest_wave, shard_deal, wave_time
+    rng = np.random.default_rng(11)
+    n, world = 200000, 8
+    counts = np.exp(rng.uniform(np.log(2000.0), np.log(200000.0), n)).astype(np.int64)
+    # the long ones at the front, in no particular order among themselves
+    key = -(counts // 20000) * 10.0 + rng.random(n)
+    counts = counts[np.argsort(key, kind="stable")]
+    for deal in ("contiguous", "sorted"):
+        parts = shard_deal(counts, world, deal)
+        allu = np.sort(np.concatenate(parts))
+        assert np.array_equal(allu, np.arange(n))                                           # a partition
+        longest = np.array([longest_wave(counts, m) for m in parts], dtype=np.float64)
+        samples = np.array([counts[m].sum() for m in parts], dtype=np.float64)
+        wtime = np.array([wave_time(counts, m) for m in parts], dtype=np.float64)
+        if deal == "contiguous":
+            assert samples.max() / samples.mean() < 1.01                                     # what it balances
+            assert longest.max() / longest.mean() > 1.5                                      # what it does not
+            lens0 = np.sort(counts[parts[0]]); lens7 = np.sort(counts[parts[-1]])
+            assert np.median(lens0) > 8 * np.median(lens7)                                   # rank 0: few long utterances; rank 7: many short ones
+        else:
+            assert longest.max() / longest.mean() <= 1.05
+            assert samples.max() / samples.mean() < 1.02 and wtime.max() / wtime.mean() < 1.02
+    # the engine's node object deals the same way under its option "deal" (tests/test_gpu_parity.py runs it on the GPU)

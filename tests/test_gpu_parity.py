@@ -1073,6 +1073,29 @@ def test_one_batch_over_several_devices(ref, all_scenarios):
     assert len(ms) == 2 and (ms > 0).all()
     with pytest.raises(RuntimeError, match="out of range|failed"):
         node.read(n)
+    # the SORTED deal (option "deal"): blocks of 64 length-sorted utterances dealt round-robin -- the same partition as
+    # nvspeechplayer_amd.sharding.shard_deal, every utterance's PCM and mark still found under its number in the whole batch
+    from nvspeechplayer_amd.sharding import shard_deal
+    big = make_batch(sel * 5)                                   # 5 x the corpus: several blocks of 64 per shard
+    nb = len(sel) * 5
+    one.setUtterances(big["frame_start"], big["frames"], big["min"], big["fade"], big["index"], big["isnull"], None)
+    one.synthesize()
+    node.setOption("deal", 1)
+    node.setUtterances(big["frame_start"], big["frames"], big["min"], big["fade"], big["index"], big["isnull"], None)
+    lens = np.array([one.utteranceSamples(u) for u in range(nb)])
+    want = shard_deal(lens, 3, "sorted")
+    for d in range(3):
+        assert np.array_equal(node.shardUtterances(d), want[d])
+    assert [a for a, _, _, _ in node.shards()] == [-1, -1, -1] and sum(c for _, c, _, _ in node.shards()) == nb
+    assert node.totalSamples == one.totalSamples
+    node.synthesize()
+    assert np.array_equal(node.digests(), one.digest(per_utterance=True)[1])
+    for u in range(0, nb, 7):
+        assert np.array_equal(node.read(u), one.read(u)), u
+        assert node.getLastIndex(u) == one.getLastIndex(u)
+    node.setOption("deal", 0)
+    node.setUtterances(batch["frame_start"], batch["frames"], batch["min"], batch["fade"], batch["index"], batch["isnull"], None)
+    assert [a for a, _, _, _ in node.shards()] + [n] == list(shard_bounds(np.array([lens[u] for u in range(n)]), 3))
     node.close(); one.close()
 
 

@@ -248,7 +248,10 @@ int speechPlayer_lastLiveLaunches(int device);
  * the device's CU count -- 16 384 handles on MI355X; a small value lets a test reach that kernel with a few hundred handles).
  * Memory: every live handle owns a slot of ~100 KB of HBM in a per-device arena (a ring of 256 queued frames with their durations
  * and a 240-double state block); the arena doubles when the slots run out (old and new coexist during the move: ~2.4 GB transient
- * at 16 384 slots), never shrinks, and speechPlayer_initialize fails with SPEECHPLAYER_ERR_HIP when the device cannot hold it. */
+ * at 16 384 slots), and speechPlayer_initialize fails with SPEECHPLAYER_ERR_HIP when the device cannot hold it.  It does not shrink while
+ * a handle lives; "live_trim" = 1 releases a device's arena (and the pull buffers) when the LAST handle on that device is terminated --
+ * and at once on devices where none lives; 0 (default) keeps it for the next handles.
+ * "plan_hash_bits" (tests): how many bits of a frame's 128-bit shape hash the track planner looks at (default 128). */
 int speechPlayer_setGlobalOption(const char* name, int value);
 /* Choose a handle's noise stream (default 0); see DESIGN.md "Noise". */
 int speechPlayer_setNoiseSeed(speechPlayer_handle_t playerHandle, unsigned int seed);

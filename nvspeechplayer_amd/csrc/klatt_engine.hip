@@ -1300,6 +1300,21 @@ std::vector<LiveContext*> g_live;   // per device
 int g_liveLayout = [] { const char* e = getenv("SPEECHPLAYER_LIVE_LAYOUT"); return e ? atoi(e) : 1; }();
 int g_liveCus = 0;
 bool g_liveCusForced = false;
+int g_liveReplicate = [] { const char* e = getenv("SPEECHPLAYER_LIVE_REPLICATE"); return e ? atoi(e) : 1; }();   // a lone handle fills its wavefront (streams_synthesize)
+int g_liveTrim = 0;                 // speechPlayer_setGlobalOption("live_trim"): release a device's arena when its last handle is terminated
+
+// c->mu held.  No handle lives on this device: give its arena (state blocks, rings) and the pull buffers back.  The next
+// speechPlayer_initialize starts a new arena of 64 slots.
+void arena_trim(LiveContext* c)
+{
+    if (c->slots == 0 || c->freeSlots.size() != (size_t)c->nextSlot) return;
+    (void)hipStreamSynchronize(c->stream);
+    c->dState.release(); c->dRingFrames.release(); c->dRingMeta.release();
+    c->dPcm.release(); c->dPcmJoin.release(); c->dCtl.release(); c->dResult.release(); c->dOrder.release();
+    c->orderFilled = 0;
+    c->slots = 0; c->nextSlot = 0;
+    c->freeSlots.clear();
+}
 
 LiveContext* live_context(int device)
 {
@@ -1438,8 +1453,18 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     std::lock_guard<std::mutex> g(c->mu);
     HIP_TRY(hipSetDevice(device));
     const size_t padded = ((size_t)count + kTile - 1) / kTile * kTile;
-    const size_t ctlBytes = (size_t)n * (sizeof(UttDesc) + sizeof(double*) + sizeof(uint32_t));
-    if (c->hCtl.reserve(ctlBytes) || c->dCtl.reserve(c->hCtl.cap) || c->hResult.reserve(n) || c->dResult.reserve(c->hResult.cap) ||
+    // A LONE handle -- the reference's own use (one stream pulled 8192 samples at a time, nvdaAddon/synthDrivers/nvSpeechPlayer/__init__.py:62-81)
+    // -- is advanced in ALL 64 lanes of its wavefront: every lane is given the same control entry (same state block, same ring, same PCM
+    // row) and computes the same samples; they store the same values to the same places.  A wavefront with one active lane runs the same
+    // instructions but, measured, takes 1.0 / 1.4 / 1.7 times as long from launch to launch (4.3 / 6.1 / 7.4 ms for one cfg2 utterance
+    // against a steady 4.13 ms with 16 or more lanes active: tools/lone_probe2.py); with all lanes active a pull costs what 64 handles cost:
+    // thirty 8192-sample pulls of one handle 3.05 -> 2.04 ms of kernel time on average (tools/single_stream_ab.sh).  Control bit 1 marks
+    // the entries (nothing reads it yet: evaluating the stage's coefficients side by side across the now identical lanes was built on it
+    // and lost, tools/variants/lone_coefficients.patch).
+    const bool replicate = n == 1 && g_liveLayout != 0 && g_liveReplicate;
+    const int nCtl = replicate ? kLanes : n;
+    const size_t ctlBytes = (size_t)nCtl * (sizeof(UttDesc) + sizeof(double*) + sizeof(uint32_t));
+    if (c->hCtl.reserve(ctlBytes) || c->dCtl.reserve(c->hCtl.cap) || c->hResult.reserve(nCtl) || c->dResult.reserve(c->hResult.cap) ||
         c->dPcm.reserve(padded * n))
         return -1;
     if (c->orderFilled < (size_t)n) {
@@ -1451,8 +1476,8 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         c->orderFilled = m;
     }
     UttDesc* const hUtt = reinterpret_cast<UttDesc*>(c->hCtl.ptr);
-    double** const hState = reinterpret_cast<double**>(c->hCtl.ptr + (size_t)n * sizeof(UttDesc));
-    uint32_t* const hControl = reinterpret_cast<uint32_t*>(c->hCtl.ptr + (size_t)n * (sizeof(UttDesc) + sizeof(double*)));
+    double** const hState = reinterpret_cast<double**>(c->hCtl.ptr + (size_t)nCtl * sizeof(UttDesc));
+    uint32_t* const hControl = reinterpret_cast<uint32_t*>(c->hCtl.ptr + (size_t)nCtl * (sizeof(UttDesc) + sizeof(double*)));
     if (g_liveCus == 0 && !g_liveCusForced) {
         hipDeviceProp_t prop;
         g_liveCus = (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
@@ -1461,11 +1486,11 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     KernelArgs a = base_args(rate);
     a.frames = c->dRingFrames.ptr; a.meta = c->dRingMeta.ptr; a.ringMask = kRing - 1;
     a.utt = reinterpret_cast<const UttDesc*>(c->dCtl.ptr);
-    a.statePtrs = reinterpret_cast<double* const*>(c->dCtl.ptr + (size_t)n * sizeof(UttDesc));
-    a.control = reinterpret_cast<const uint32_t*>(c->dCtl.ptr + (size_t)n * (sizeof(UttDesc) + sizeof(double*)));
+    a.statePtrs = reinterpret_cast<double* const*>(c->dCtl.ptr + (size_t)nCtl * sizeof(UttDesc));
+    a.control = reinterpret_cast<const uint32_t*>(c->dCtl.ptr + (size_t)nCtl * (sizeof(UttDesc) + sizeof(double*)));
     a.order = c->dOrder.ptr; a.pcm = c->dPcm.ptr; a.result = c->dResult.ptr; a.state = nullptr;
-    a.nSlots = n;
-    const long long groups = (n + kLanes - 1) / kLanes;
+    a.nSlots = nCtl;
+    const long long groups = (nCtl + kLanes - 1) / kLanes;
 
     c->done.assign(n, 0u);
     c->lastKernelMs = 0.0f; c->lastLaunches = 0;
@@ -1504,6 +1529,10 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
             d.length = piece;                // the stage-parallel kernel runs exactly `piece` steps (klatt_systolic.h, STREAM)
             hState[i] = c->dState.ptr + (size_t)s->slot * kStateDoubles;
             hControl[i] = s->purgePending ? 1u : 0u;
+        }
+        if (replicate) {
+            hControl[0] |= 2u;               // every lane of the wavefront advances THIS handle
+            for (int i = 1; i < nCtl; ++i) { hUtt[i] = hUtt[0]; hState[i] = hState[0]; hControl[i] = hControl[0]; }
         }
         const auto tb = now();
         tFill += ms(ta, tb);
@@ -1718,6 +1747,7 @@ void speechPlayer_terminate(speechPlayer_handle_t playerHandle)
         std::lock_guard<std::mutex> g(c->mu);
         ring_drop(c, s);                        // its entries in the log go nowhere
         c->freeSlots.push_back(s->slot);        // state block and ring are the next handle's (zeroed at its initialize, in stream order)
+        if (g_liveTrim && hipSetDevice(s->device) == hipSuccess) arena_trim(c);
     }
     delete s;
 }
@@ -1742,6 +1772,20 @@ int speechPlayer_setGlobalOption(const char* name, int value)
     // takes the two-workgroups-per-CU instantiation of the stream kernel -- on a 256-CU device from 16 385 handles on; a small value
     // lets a test (or a small device) reach that kernel with a few hundred handles.
     if (name && !strcmp(name, "live_cus")) { g_liveCus = value < 0 ? 0 : value; g_liveCusForced = value > 0; return 0; }
+    // "live_replicate": 1 (default) a handle pulled alone is advanced in all 64 lanes of its wavefront (streams_synthesize); 0: in one lane
+    if (name && !strcmp(name, "live_replicate")) { g_liveReplicate = value ? 1 : 0; return 0; }
+    // "live_trim": 1 = a device's arena of live handles (~100 KB of HBM per slot, grown by doubling) is released when the last handle on
+    // that device is terminated -- and now, on devices where none lives; 0 (default): it stays for the next handles.
+    if (name && !strcmp(name, "live_trim")) {
+        g_liveTrim = value ? 1 : 0;
+        if (g_liveTrim) {
+            std::vector<LiveContext*> all;
+            { std::lock_guard<std::mutex> g(g_liveMutex); all = g_live; }
+            for (size_t dev = 0; dev < all.size(); ++dev)
+                if (all[dev] && hipSetDevice((int)dev) == hipSuccess) { std::lock_guard<std::mutex> g(all[dev]->mu); arena_trim(all[dev]); }
+        }
+        return 0;
+    }
     // "plan_hash_bits" (tests): the track planner looks at this many bits of a frame's 128-bit shape hash (default 128).  With few bits
     // different frames collide for certain, which is how the tests reach the verification of hashed shapes (klatt_verify_shared) and the
     // fall-back behind it; the PCM must not change.
@@ -2211,7 +2255,8 @@ static int batch_set(Batch* b, const SetInput& in)
         std::unordered_map<unsigned long long, long long> runOf;
         for (long long l = 0; l < nL; ++l)
             if (!(flagsL[l] & UTT_NEEDS_NOISE)) runOf[run_key(l)] += weight[l];
-        for (long long l = 0; l < nL; ++l)
+        // (quiet utterances that ALL share one timing fade together however few they are: a single sentence, a handful of copies)
+        for (long long l = 0; l < nL && runOf.size() > 1; ++l)
             if (!(flagsL[l] & UTT_NEEDS_NOISE) && runOf[run_key(l)] < kQuietRunMin) {
                 rerouted.emplace_back(l, flagsL[l]);
                 flagsL[l] = (flagsL[l] | UTT_NEEDS_NOISE) & ~UTT_NO_NASAL;
@@ -2402,6 +2447,32 @@ static int batch_set(Batch* b, const SetInput& in)
         const size_t padT = (size_t)((kLanes - nTrackedUtt % kLanes) % kLanes);
         order.insert(order.begin() + nQuiet + nTrackedUtt, padT, 0xFFFFFFFFu);
         nTracked = nTrackedUtt + (long long)padT;
+    }
+    // A wavefront of the noisy groups with FEW live lanes takes up to 1.7 times as long as a full one for the same instructions (measured:
+    // streams_synthesize, tools/lone_probe2.py: 1 .. 8 live lanes 4.3 / 6.1 / 7.4 ms from launch to launch, 16 or more a steady 4.13).  Its
+    // empty slots are given its own utterances again: those lanes compute the same samples and store the same bytes to the same places.
+    // (What a batch of a handful of sentences -- or the tail of a large one -- costs in latency; nothing for full wavefronts.)
+    {
+        const long long noisy0 = nQuiet;
+        const bool tailNoisy = (long long)order.size() > noisy0;
+        if (tailNoisy && ((long long)order.size() - noisy0) % kLanes != 0) {
+            // the last wavefront's dead lanes become slots of the group that ends there
+            const long long ext = kLanes - ((long long)order.size() - noisy0) % kLanes;
+            const long long legacy = (long long)order.size() - nQuiet - nTracked - nDirectSlots;
+            if (legacy <= 0) { if (nDirectSlots > 0) nDirectSlots += ext; else nTracked += ext; }
+            order.insert(order.end(), (size_t)ext, 0xFFFFFFFFu);
+        }
+        for (long long w = noisy0; w + kLanes <= (long long)order.size(); w += kLanes) {
+            constexpr int kSparse = 32;      // (16 live lanes still wavered a little: 4.32 against 4.15 ms)
+            uint32_t liveU[kSparse];
+            int nLive = 0;
+            for (int i = 0; i < kLanes && nLive < kSparse; ++i)
+                if (order[(size_t)(w + i)] != 0xFFFFFFFFu) liveU[nLive++] = order[(size_t)(w + i)];
+            if (nLive == 0 || nLive >= kSparse) continue;
+            int next = 0;
+            for (int i = 0; i < kLanes; ++i)
+                if (order[(size_t)(w + i)] == 0xFFFFFFFFu) { order[(size_t)(w + i)] = liveU[next]; next = (next + 1) % nLive; }
+        }
     }
     const long long nSlotsAll = (long long)order.size();
     lap("lane packing");

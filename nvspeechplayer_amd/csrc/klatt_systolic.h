@@ -50,6 +50,9 @@ namespace klatt {
 #ifndef KLATT_NOISY_RUNS
 #define KLATT_NOISY_RUNS 0      // 1: uniform runs inside event chunks for the noisy kernels too (measured slower: cfg2 15.8 -> 16.8 ms)
 #endif
+#ifndef KLATT_LONE
+#define KLATT_LONE 1            // a live handle pulled alone: its fade chunks computed side by side across the 64 identical lanes (stage_loop)
+#endif
 #ifndef KLATT_FADE_TIGHT
 #define KLATT_FADE_TIGHT 1      // a fade's chunks run in a tight loop (what moves is fixed for the fade): cfg2 16.4 -> 15.7 ms; 0 decides chunk by chunk
 #endif
@@ -146,6 +149,7 @@ struct StageCtx {          // what every stage needs from the launch
     uint32_t ringOff, ringMask;    // frame k of the queue is myFrames[(ringOff + k) & ringMask] (frame_window, klatt_device.h)
     const FlatRef* myFlat;     // flat launches: the utterance's per-frame track references, loaded ahead by the stages (klatt_device.h)
     const SourceRef* mySrc;    // flat launches: what the source stage loads ahead
+    bool lone = false;         // live handles: every lane of the wavefront advances ONE handle (streams_synthesize's replicas); wave-uniform
 };
 
 // OR over the wavefront of the low NBITS bits of a per-lane mask, as a wave-uniform (scalar) value.
@@ -267,6 +271,14 @@ __device__ __forceinline__ uint32_t fade_classes(const SF& f, const KernelArgs& 
         bits = (bits & ~(3u << (2 * r))) | (cls << (2 * r));
     }
     return bits;
+}
+
+// value of lane `srcLane` (wave-uniform) in every lane
+__device__ __forceinline__ double lane_read(double v, int srcLane)
+{
+    const unsigned long long w = (unsigned long long)__double_as_longlong(v);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)w, srcLane), hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(w >> 32), srcLane);
+    return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
 }
 
 template <class D, int MODE, bool PLAIN = false, class SF>
@@ -584,6 +596,56 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 const uint32_t coefCls = fade_classes<D>(f, X.A, RF, RB, wRes);   // once per fade stretch
                 // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {
+                    if (K::STREAM && KLATT_LONE && X.lone) {
+                        // A handle pulled ALONE fills its wavefront with 64 identical lanes (streams_synthesize).  What a fade sample costs
+                        // beyond a steady one -- the interpolation of the stage's parameters and exp / cos per moving resonator, 1700 cycles
+                        // against 280 in the cascade and parallel stages (KLATT_STAMPS build, tools/stamps_lone.py) -- depends on the fade
+                        // position alone, not on the filter memories: lane i computes it for sample i of the chunk, all CH samples side by
+                        // side, and the recurrence then takes each sample's values out of its lane.  Same expressions on the same operands
+                        // as stage_fade, sample for sample.
+                        if (!f.done) {
+                            const int mine = (int)(threadIdx.x & (CH - 1));
+                            const double ratio = div_by((double)(f.cnt + 1u + (uint32_t)mine), (double)f.newFade, f.invFade);
+                            double pitchMine = 0.0;
+                            if (D::PITCH) pitchMine = fade_value(ps->old0, ps->new0, ratio);
+                            constexpr int NP_ = D::NPARAM > 0 ? D::NPARAM : 1, NR_ = D::NRES > 0 ? D::NRES : 1;
+                            double cv[NP_];
+#pragma unroll
+                            for (int k = 0; k < D::NPARAM; ++k) cv[k] = f.cur[k];
+                            const bool gainAlone = D::GAIN >= 0 && lerp && gainOnly;
+                            if (gainAlone) cv[GI] = fade_value(f.oldL[GI * kLanes], f.getNew(GI), ratio);
+                            else if (lerp) {
+#pragma unroll
+                                for (int k = 0; k < D::NPARAM; ++k) { const double o = f.oldL[k * kLanes], n = f.getNew(k); cv[k] = o + ((n - o) * ratio); }
+                            }
+                            double ka[NR_], kb[NR_], kc[NR_];
+#pragma unroll
+                            for (int r = 0; r < D::NRES; ++r) {
+                                ka[r] = f.ra[r]; kb[r] = f.rb[r]; kc[r] = f.rc[r];
+                                if (wRes & (1u << r)) {
+                                    const Coef k = D::INLINE_COEF
+                                        ? resonator_coefficients_inline<MODE>(cv[RF[r]], cv[RB[r]], D::ANTI0 && r == 0, X.A.negPiOverSr, X.A.twoPiOverSr, (int)((coefCls >> (2 * r)) & 3u))
+                                        : resonator_coefficients<MODE>(cv[RF[r]], cv[RB[r]], D::ANTI0 && r == 0, X.A.negPiOverSr, X.A.twoPiOverSr);
+                                    ka[r] = k.a; kb[r] = k.b; kc[r] = k.c;
+                                }
+                            }
+#pragma unroll
+                            for (int i = 0; i < CH; ++i) {
+                                f.cnt++;
+                                if (D::PITCH) ps->cur0 = lane_read(pitchMine, i);
+                                if (gainAlone) f.cur[GI] = lane_read(cv[GI], i);
+                                else if (lerp) {
+#pragma unroll
+                                    for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = lane_read(cv[k], i);
+                                }
+#pragma unroll
+                                for (int r = 0; r < D::NRES; ++r)
+                                    if (wRes & (1u << r)) { f.ra[r] = lane_read(ka[r], i); f.rb[r] = lane_read(kb[r], i); f.rc[r] = lane_read(kc[r], i); }
+                                body(c, i, false, 0.0);
+                            }
+                            fadeDone(CH);
+                        }
+                    } else
                     if (!f.done) {
                         if (!fadeAlt(c, lerp, gainOnly)) {
 #pragma unroll 2
@@ -1034,7 +1096,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     if (live) d = A.utt[u];
     const FrameWindow fw = frame_window(A, d);
     const StageCtx X{A, d, A.frames + fw.base * kNumParams, A.meta + fw.base, fw.off, fw.mask,
-                     FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr};
+                     FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr,
+                     STREAM && A.control && A.nSlots == kLanes && (A.control[0] & 2u) != 0u};      // control bit 1: 64 copies of one handle
     const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed), ninc2 = noise_inc2(ninc);
     constexpr int FINAL = NOISE ? 2 : 3;
     // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out

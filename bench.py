@@ -37,9 +37,9 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 # VALU issue: 256 CUs x 4 SIMDs; a wave64 f64 instruction occupies its SIMD for 4 cycles (78.6 TFLOP/s = 1024 SIMDs x 16 lanes x 2 flop
 # x 2.4 GHz), any other VALU instruction for 2 (profiles/r1_ubench_issue_rates.txt: ~2.0 / ~1.1 ns at the clock the chip holds under
-# this load, 2.06-2.07 GHz -- GRBM_GUI_ACTIVE / 8 XCDs / duration, profiles/r5_pmc.json "held_clock_hz")
+# this load, 2.06-2.07 GHz -- GRBM_GUI_ACTIVE / 8 XCDs / duration, profiles/r6_pmc.json "held_clock_hz")
 SIMDS, F64_ISSUE_CYCLES, OTHER_ISSUE_CYCLES, CLOCK_HZ_HELD_DEFAULT = 1024, 4.0, 2.0, 2.07e9
-PMC_FILE = os.path.join(ROOT, "profiles", "r5_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r6_pmc.json")
 
 
 def parse(argv=None):
@@ -500,15 +500,22 @@ def main():
             mine = int(counts[first:first + n].sum())
             x_ms, x_el, x_info, x_build, x_set = [0.0], 0.0, {}, 0.0, 0.0
             if not dry:
+                # the shard in compact form (tests/test_gpu_compact.py: same PCM as the plain batch): configs[3] as the 512 cut frame lists its
+                # utterances share, configs[4] as IPA text with a defined voice per variant -- megabytes per rank instead of 0.6 / 4.7 GB of frames
+                x = BatchPlayer(head_sr, device=device, mode=args.mode, layout=args.layout)
                 x_build = time.perf_counter()
-                xb = workloads.make(wl, n, first=first)
-                x_build = time.perf_counter() - x_build
-                x = BatchPlayer(xb["sr"], device=device, mode=args.mode, layout=args.layout)
-                x_set = time.perf_counter()
-                x.setUtterances(xb["frame_start"], xb["frames"], xb["min"], xb["fade"], xb["index"], xb["isnull"], xb["seeds"])
+                if wl == "cfg3":
+                    lists, list_of, seeds = workloads.shared("cfg3", n, first=first)
+                    x_build = time.perf_counter() - x_build
+                    x_set = time.perf_counter()
+                    x.setUtterancesShared(lists["frame_start"], lists["frames"], lists["min"], lists["fade"], list_of, lists["index"], lists["isnull"], seeds)
+                else:
+                    spec = workloads.cfg4_spec(n, first=first)
+                    x_build = time.perf_counter() - x_build
+                    x_set = time.perf_counter()
+                    x.setIpa(**spec)
                 x_set = time.perf_counter() - x_set
                 assert x.totalSamples == mine
-                xb = None
                 x.time(1)
                 barrier()
                 t0 = time.perf_counter()
@@ -584,7 +591,7 @@ def main():
                 if ent and not args.utterances and world == 1 and args.mode == 0 and args.layout == -1:
                     if pj.get("engine_sources_sha") == engine_source_digest():
                         roof["traffic"] = ent["hbm_bytes_per_launch"]
-                        roof["traffic_source"] = "profiles/r5_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
+                        roof["traffic_source"] = "profiles/r6_pmc.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes, bytes per launch)"
                         insts = ent["valu_insts_per_launch"]
                         f64i = ent.get("valu_f64_insts_per_launch")
                         clock = ent.get("held_clock_hz") or CLOCK_HZ_HELD_DEFAULT
@@ -597,9 +604,9 @@ def main():
                                         "unit": "VALU issue cycles used / available", "insts_per_64_samples": insts * 64.0 / samples,
                                         "formula": "(4 x f64 wave-instructions + 2 x other VALU wave-instructions) / (1024 SIMDs x held clock x kernel_ms); "
                                                    "counts: SQ_INSTS_VALU and SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F64 per launch (separate rocprofv3 --pmc passes), "
-                                                   "clock: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration -- all from profiles/r5_pmc.json, collected on these kernel sources"}
+                                                   "clock: GRBM_GUI_ACTIVE / 8 XCDs / kernel duration -- all from profiles/r6_pmc.json, collected on these kernel sources"}
                     else:
-                        roof["traffic_source"] = "profiles/r5_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
+                        roof["traffic_source"] = "profiles/r6_pmc.json is stale (kernels changed since it was collected): traffic and valu omitted"
             except Exception:
                 pass
             out["roofline"] = roof

@@ -3,9 +3,11 @@
 #   a: the GPU test suite, the rocprofv3 profiles of the single-GPU configurations in both arithmetic modes (which also write the
 #      PMC file bench.py reads)
 #   b: the bench lines
-#   c: the probes (tracks, mixed, steady, direct stages with a kernel trace of the all-different batch), the live-handle bench
+#   c: the probes (tracks, mixed, steady, direct stages with a kernel trace of the all-different batch; compact forms, sparse wavefronts),
+#      the live-handle bench
+#   d: the N > 1 path on the one GPU this box has: bench.py --gpus 2 with the node-sized extras (two ranks share the device, gloo)
 # Everything lands under gpurun_out/; the summaries are then copied into profiles/ (see profiles/README.md).
-R=r5
+R=r6
 mkdir -p gpurun_out
 # (A/B variant libraries and their objects are scratch: they would travel with every snapshot -- 131 MB at the end of round 4)
 rm -f nvspeechplayer_amd/build_tmp/libspeechPlayer_*.o nvspeechplayer_amd/lib/variants/*.so
@@ -28,7 +30,7 @@ timeout -k 10 400 python bench.py --workload cfg3 --steps 30 --no-extras --no-cp
 timeout -k 10 600 python bench.py --workload cfg4 --steps 5 --warmup 1 --no-extras --no-cpu-baseline > gpurun_out/${R}_bench_cfg4.json 2> /dev/null
 python - <<'PY'
 import json
-for f in ("r5_bench", "r5_bench_steps20", "r5_bench_fast", "r5_bench_cfg1", "r5_bench_cfg3", "r5_bench_cfg4"):
+for f in ("r6_bench", "r6_bench_steps20", "r6_bench_fast", "r6_bench_cfg1", "r6_bench_cfg3", "r6_bench_cfg4"):
     try:
         d = json.loads([l for l in open("gpurun_out/%s.json" % f) if l.startswith("{")][-1])
     except Exception as e:
@@ -37,11 +39,15 @@ for f in ("r5_bench", "r5_bench_steps20", "r5_bench_fast", "r5_bench_cfg1", "r5_
     for k, v in d.items():
         if isinstance(v, dict) and "kernel_ms" in v:
             print("    %-34s %8.3f ms" % (k, v["kernel_ms"]))
-        elif k in ("pipeline", "pipeline_with_pcm_to_host") and isinstance(v, dict):
+        elif k in ("pipeline", "pipeline_from_ipa", "single_stream", "cfg0_cpu") and isinstance(v, dict):
             print("    %-34s %s" % (k, {a: b for a, b in v.items() if not isinstance(b, (list, dict))}))
     if "config" in d and "host" in d["config"]:
         print("    host:", d["config"]["host"])
 PY
+;;
+d)
+timeout -k 10 900 python bench.py --gpus 2 --steps 5 --warmup 1 > gpurun_out/${R}_bench_2ranks_one_gpu.json 2> gpurun_out/${R}_bench_2ranks_one_gpu.err; echo rc=$?
+tail -c 3000 gpurun_out/${R}_bench_2ranks_one_gpu.json
 ;;
 c)
 timeout -k 10 300 python tools/steady_probe.py > gpurun_out/${R}_steady_probe.txt 2>&1
@@ -61,6 +67,10 @@ PY
 timeout -k 10 400 bash tools/direct_pmc.sh all_different > gpurun_out/${R}_direct_pmc.txt 2>&1
 R=${R} bash tools/live_round3.sh > /dev/null 2>&1
 timeout -k 10 300 python tools/live_large.py > gpurun_out/${R}_live_large.txt 2>&1
+timeout -k 10 300 python tools/compact_probe.py 65536 0 > gpurun_out/${R}_compact_probe.txt 2>&1
+timeout -k 10 300 python tools/lone_probe2.py > gpurun_out/${R}_sparse_wavefronts.txt 2>&1
+timeout -k 10 300 python tools/lone_probe.py > gpurun_out/${R}_one_utterance.txt 2>&1
+cat gpurun_out/${R}_compact_probe.txt gpurun_out/${R}_sparse_wavefronts.txt gpurun_out/${R}_one_utterance.txt
 cat gpurun_out/${R}_steady_probe.txt gpurun_out/${R}_mixed_probe.txt gpurun_out/${R}_track_probe.txt gpurun_out/${R}_direct_probe.txt gpurun_out/${R}_all_different_trace.txt
 grep -v "live. 1 handles" gpurun_out/${R}_live_bench.txt; cat gpurun_out/${R}_live_large.txt
 ;;

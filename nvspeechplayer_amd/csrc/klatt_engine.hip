@@ -306,7 +306,7 @@ KernelArgs base_args(int sampleRate)
     return a;
 }
 
-template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false, bool FLAT = false>
+template <bool NOISE, int CH, int WPS = 1, bool NASAL = true, bool STREAM = false, bool FLAT = false, bool LONE = false>
 int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_t stream)
 {
     if (nGroups <= 0) return 0;
@@ -319,8 +319,8 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
     };
     int rc;
     switch (mode) {
-    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM, FLAT>); break;
-    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM, FLAT>); break;
+    case MODE_EXACT: rc = go(klatt_systolic<MODE_EXACT, NOISE, CH, WPS, NASAL, STREAM, FLAT, LONE>); break;
+    case MODE_FAST: rc = go(klatt_systolic<MODE_FAST, NOISE, CH, WPS, NASAL, STREAM, FLAT, LONE>); break;
     default: set_error("unknown arithmetic mode %d", mode); return -1;
     }
     if (rc) return rc;
@@ -1458,9 +1458,9 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     // row) and computes the same samples; they store the same values to the same places.  A wavefront with one active lane runs the same
     // instructions but, measured, takes 1.0 / 1.4 / 1.7 times as long from launch to launch (4.3 / 6.1 / 7.4 ms for one cfg2 utterance
     // against a steady 4.13 ms with 16 or more lanes active: tools/lone_probe2.py); with all lanes active a pull costs what 64 handles cost:
-    // thirty 8192-sample pulls of one handle 3.05 -> 2.04 ms of kernel time on average (tools/single_stream_ab.sh).  Control bit 1 marks
-    // the entries (nothing reads it yet: evaluating the stage's coefficients side by side across the now identical lanes was built on it
-    // and lost, tools/variants/lone_coefficients.patch).
+    // thirty 8192-sample pulls of one handle 3.05 -> 2.04 ms of kernel time on average (tools/single_stream_ab.sh).  The launch then takes
+    // the kernel's LONE instantiation, whose fade chunks are computed side by side across the identical lanes (klatt_systolic.h,
+    // stage_loop: 2.04 -> 1.84 ms); control bit 1 marks the entries.
     const bool replicate = n == 1 && g_liveLayout != 0 && g_liveReplicate;
     const int nCtl = replicate ? kLanes : n;
     const size_t ctlBytes = (size_t)nCtl * (sizeof(UttDesc) + sizeof(double*) + sizeof(uint32_t));
@@ -1547,8 +1547,9 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
             if (launch<true, true>(a, mode, groups, c->stream)) return -1;
         } else {
             // one workgroup per CU while they all fit (16-sample hand-overs), else two per CU (8-sample hand-overs), as for batches
-            if (groups <= g_liveCus ? launch_systolic<true, 16, 1, true, true>(a, mode, groups, c->stream)
-                                    : launch_systolic<true, KLATT_NOISY_CH, 2, true, true>(a, mode, groups, c->stream)) return -1;
+            if (replicate ? launch_systolic<true, 16, 1, true, true, false, true>(a, mode, groups, c->stream)      // the LONE instantiation: 64 replicas of one handle
+                : (groups <= g_liveCus ? launch_systolic<true, 16, 1, true, true>(a, mode, groups, c->stream)
+                                       : launch_systolic<true, KLATT_NOISY_CH, 2, true, true>(a, mode, groups, c->stream))) return -1;
         }
         HIP_TRY(hipEventRecord(c->kernelStop, c->stream));
         HIP_TRY(hipMemcpyAsync(c->hResult.ptr, c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));

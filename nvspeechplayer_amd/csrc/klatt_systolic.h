@@ -50,9 +50,6 @@ namespace klatt {
 #ifndef KLATT_NOISY_RUNS
 #define KLATT_NOISY_RUNS 0      // 1: uniform runs inside event chunks for the noisy kernels too (measured slower: cfg2 15.8 -> 16.8 ms)
 #endif
-#ifndef KLATT_LONE
-#define KLATT_LONE 1            // a live handle pulled alone: its fade chunks computed side by side across the 64 identical lanes (stage_loop)
-#endif
 #ifndef KLATT_FADE_TIGHT
 #define KLATT_FADE_TIGHT 1      // a fade's chunks run in a tight loop (what moves is fixed for the fade): cfg2 16.4 -> 15.7 ms; 0 decides chunk by chunk
 #endif
@@ -513,9 +510,9 @@ struct Stamps {
 // the noisy kernels: the extra code costs them more than the runs save, cfg2 15.8 -> 16.8 ms.)  DELAY: lanes start `delay`
 // steps late (the lane-pipelined kernel's skew).  STREAM: the launch runs exactly A.maxSamples steps (live handles).
 #define STAGE_SYNC() __syncthreads()
-template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_>
+template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_, bool LONE_ = false>
 struct LoopKnobs {
-    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_;
+    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_, LONE = LONE_;
     static constexpr int UNROLL = UNROLL_;
 };
 
@@ -596,7 +593,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 const uint32_t coefCls = fade_classes<D>(f, X.A, RF, RB, wRes);   // once per fade stretch
                 // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {
-                    if (K::STREAM && KLATT_LONE && X.lone) {
+                    if (K::LONE) {
                         // A handle pulled ALONE fills its wavefront with 64 identical lanes (streams_synthesize).  What a fade sample costs
                         // beyond a steady one -- the interpolation of the stage's parameters and exp / cos per moving resonator, 1700 cycles
                         // against 280 in the cascade and parallel stages (KLATT_STAMPS build, tools/stamps_lone.py) -- depends on the fade
@@ -1064,9 +1061,12 @@ __device__ __forceinline__ void flat2_loop(int depth, int nIter, int nChunks, in
 // (reference src/speechWaveGenerator.cpp:39-42), and a handle that is quiet now may be given noisy frames later.
 // FLAT (noisy batch launches only): the utterances of the launch have tracks (klatt_tracks.h; host: UTT_TRACKED) and all four
 // stages are flat stages (above): no exp / cos, no interpolation, no frame state machine in the sample loop.
-template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false, bool FLAT = false>
+// LONE: the launch is ONE workgroup whose 64 lanes advance the same live handle (streams_synthesize's replicas): an instantiation of its
+// own, so that the fade chunks' side-by-side path (stage_loop) costs the other live-handle kernels neither registers nor code
+template <int MODE, bool NOISE, int CH, int WPS = KLATT_MINWAVES, bool NASAL = true, bool STREAM = false, bool FLAT = false, bool LONE = false>
 __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const KernelArgs A)
 {
+    static_assert(!LONE || STREAM, "LONE: a live handle pulled alone");
     static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
     static_assert(NOISE || !STREAM, "live handles take the noisy instantiation");
     static_assert(!FLAT || (NOISE && !STREAM), "tracks: noisy batch launches");
@@ -1096,8 +1096,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     if (live) d = A.utt[u];
     const FrameWindow fw = frame_window(A, d);
     const StageCtx X{A, d, A.frames + fw.base * kNumParams, A.meta + fw.base, fw.off, fw.mask,
-                     FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr,
-                     STREAM && A.control && A.nSlots == kLanes && (A.control[0] & 2u) != 0u};      // control bit 1: 64 copies of one handle
+                     FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr, LONE};
     const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed), ninc2 = noise_inc2(ninc);
     constexpr int FINAL = NOISE ? 2 : 3;
     // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out
@@ -1140,8 +1139,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // pipe slot of sample i of chunk c
 #define PIPE(p, c, i) (p)[(((nbuf_##p) == 2 ? ((c) & 1) : ((c) % (nbuf_##p))) * kChunk + (i)) * kLanes + lane]
     // the chunk loop's knobs: quiet launches preload a steady chunk's inputs and run uniform stretches inside event chunks
-    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;      // stages without a pipe input
-    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL>;       // stages that read a pipe
+    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, LONE>;      // stages without a pipe input
+    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, LONE>;       // stages that read a pipe
     uint32_t noDelay = 0;
     auto never = [&]() __attribute__((always_inline)) { return false; };
     auto noBegin = [&](int) __attribute__((always_inline)) { return false; };

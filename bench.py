@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py -- throughput of the Klatt hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W [--workload cfg2|cfg1|cfg3|cfg4] [--mode 0]

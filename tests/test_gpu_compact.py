@@ -275,3 +275,84 @@ def test_read_all_async_needs_a_launch():
     ref_pcm, ref_starts = bp.readAll()
     assert np.array_equal(got, ref_pcm) and np.array_equal(starts, ref_starts)
     bp.close()
+
+
+def test_a_handle_pulled_alone_fills_its_wavefront_and_changes_nothing(ref):
+    """A lone handle is advanced in all 64 lanes of its wavefront (64 identical control entries) on the kernel's LONE instantiation,
+    whose fade chunks are computed side by side across those lanes (speechPlayer_setGlobalOption("live_replicate")): the same PCM,
+    call lengths and index marks as in one lane, pull by pull -- ragged pulls through speech with fades, silences, marks and a purge
+    in the middle of a fade; and the same when the option changes between pulls of one handle."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    case = ref.ipa_case(ref.find_ipa(1)) + ref.ipa_case(ref.find_ipa(5))
+    pulls = [8192, 1, 17, 4096, 333, 8192, 64, 5000, 16, 15, 8192, 8192, 2048]
+
+    def run(policy):
+        p = eng.SpeechPlayer(22050, noiseSeed=9)
+        out, marks = [], []
+        k = 0
+        for j, (fr, m, f) in enumerate(case):
+            p.queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, userIndex=(j if j % 3 == 0 else -1))
+        for i in range(60):
+            assert L.speechPlayer_setGlobalOption(b"live_replicate", {"on": 1, "off": 0, "alternate": i % 2}[policy]) == 0
+            n = pulls[i % len(pulls)]
+            if i == 7:      # a purge inside a fade: the frame that follows cuts over from the interpolated values
+                fr, m, f = case[3]
+                p.queueFrameSamples(eng.Frame.from_array(fr), m, f, userIndex=777, purgeQueue=True)
+                for fr2, m2, f2 in case[4:]:
+                    p.queueFrameSamples(None if fr2 is None else eng.Frame.from_array(fr2), m2, f2)
+            buf = p.synthesize(n)
+            got = np.zeros(0, np.int16) if buf is None else np.frombuffer(buf, dtype=np.int16)[:buf.length].copy()
+            out.append(got); marks.append(p.getLastIndex())
+            if len(got) < n:
+                break
+        p.close()
+        return out, marks
+    try:
+        one_lane = run("off")
+        for policy in ("on", "alternate"):
+            got = run(policy)
+            assert [len(x) for x in got[0]] == [len(x) for x in one_lane[0]] and got[1] == one_lane[1], policy
+            assert all(np.array_equal(a, b) for a, b in zip(got[0], one_lane[0])), policy
+        assert sum(len(x) for x in one_lane[0]) > 60000 and 777 in one_lane[1]
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_replicate", 1)
+
+
+def test_live_trim_releases_and_rebuilds_the_arena(ref):
+    """speechPlayer_setGlobalOption("live_trim", 1): when the last live handle of a device is terminated its arena (state blocks, rings,
+    pull buffers) is released; the next handle starts a new one and synthesises what a handle always does."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    case = ref.ipa_case(ref.find_ipa(0))
+
+    def speak():
+        p = eng.SpeechPlayer(22050, noiseSeed=4)
+        for fr, m, f in case:
+            p.queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f)
+        parts = []
+        while True:
+            buf = p.synthesize(4096)
+            if buf is None:
+                break
+            parts.append(np.frombuffer(buf, dtype=np.int16)[:buf.length].copy())
+            if buf.length < 4096:
+                break
+        return p, np.concatenate(parts)
+    try:
+        a, want = speak()
+        b, same = speak()
+        assert np.array_equal(want, same)
+        assert L.speechPlayer_setGlobalOption(b"live_trim", 1) == 0      # handles live: nothing is released
+        c, again = speak()
+        assert np.array_equal(want, again)
+        for p in (a, b, c):
+            p.close()                                                    # the last one trims the arena
+        for _ in range(2):
+            d, fresh = speak()                                           # a new arena
+            assert np.array_equal(want, fresh)
+            d.close()
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_trim", 0)

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """A/B timing of alternative builds of the engine library (same ABI, other -D flags) on the GPU box.
 
     python tools/ab_probe.py build name=-DFLAG=1,-DOTHER=2 ...      (here: cross-compile variants into lib/variants/)

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Timing of library variants on the direct stages' batches (tools/ab_probe.py build NAME=-DFLAGS first).
    python tools/direct_ab.py NAME ... [+workload ...] [n=65536]"""
 import json, os, subprocess, sys

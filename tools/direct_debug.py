@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where does MODE_FAST on the direct stages leave the legacy PCM?  (debugging aid)"""
 import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Instructions per sample of each lean direct stage's sample loop, from the census assembly (tools/direct_census.sh leaves /tmp/direct_census_MASK.s).
 
     python tools/direct_loopcount.py MODE [samples per trip]

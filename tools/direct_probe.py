@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Direct stages (klatt_direct.h) against the stages with the frame state machine and the tracked flat stages: same PCM (MODE_EXACT: the
 same bytes), and how long each takes on the batches in which nothing is shared and / or nothing is aligned.
 

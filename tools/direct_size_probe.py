@@ -1,5 +1,6 @@
 import sys, os
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tools")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np
 from nvspeechplayer_amd import BatchPlayer, workloads
 for n in [int(a) for a in sys.argv[1:]] or (8192, 16384, 20480, 24576, 32768):

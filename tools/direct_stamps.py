@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic (KLATT_STAMPS build): where do the eight stage waves of the direct kernel (klatt_direct.h) spend their cycles?
 
     python tools/ab_probe.py build dst=-DKLATT_STAMPS          (here)

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Kernel time of the cfg1 recipe with its steady frame cut into k identical frames (fade of 1 sample between them):
 what one frame boundary (dequeue event + one-sample fade + fade-end event) costs a launch."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """The float experiment of DESIGN.md section 4 ("A float signal path"): a build with -DKLATT_SIGNAL_F32 (flat filter stages in float: klatt_device.h
 sig_t) against the shipped double build -- kernel time, and how far its PCM is from the double PCM, overall and on the WORST
 utterance (the tolerance north_star allows a float path is RMS < 1e-5 of full scale; an utterance over it is audibly the same

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Kernel time of the cfg1 recipe against the length of its two fades (in and out of silence): per-fade-sample cost."""
 import os
 import sys

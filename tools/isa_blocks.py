@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Per-basic-block instruction census of a gfx950 .s kernel (tools for DESIGN.md's instruction budgets)."""
 import re
 import sys

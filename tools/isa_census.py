@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Census of the loops of one kernel as compiled (device assembly of klatt_engine.hip with the build's flags): per loop, its
 instructions by kind -- the figures DESIGN.md quotes for the steady loops of the flat stages.  No GPU needed.
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Registers, scratch and LDS of every kernel in the built library's gfx950 code object (no GPU needed): the figures DESIGN.md
 quotes, and the check that no batch kernel spills.
 

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Kernel time of the cfg1 recipe against utterance length: the slope is the cost per steady sample, the intercept
 what fades, events and the launch cost.  usage: len_probe.py [layout] [n_utt]"""
 import os

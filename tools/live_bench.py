@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """How fast do N LIVE handles advance when pulled together (speechPlayer_synthesizeMany)?
 Three figures per run: the kernel alone (HIP events around the launch), the call with the PCM left in HBM
 (speechPlayer_synthesizeManyDevice: upload of the queued frames + kernel + results), and the call that hands every handle

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Large pulls of live handles: the two-workgroups-per-CU stream kernel (what a pull of more than CUs x 64 handles launches) against
 the one-per-CU instantiation run over the same handles (speechPlayer_setGlobalOption("live_cus", huge)): kernel ms per 8192-sample pull.
     python tools/live_large.py [handles ...]"""

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """How much slower is a batch whose lanes do NOT fade at the same time?  (The BASELINE recipes repeat eight
 sentences, so after the sort by length every wavefront holds 64 copies of one sentence: all lanes fade together.)
   sorted     : cfg2 as benchmarked

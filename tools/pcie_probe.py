@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Host-buffer (PCIe-inclusive) rate of the batch path: upload of the frame streams, kernel, read-back of all PCM.
 bench.py's `value` is the HBM-resident rate; this is the note DESIGN.md section 7 quotes beside it."""
 import os

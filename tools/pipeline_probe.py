@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """bench.py's `pipeline` extra alone: sustained end-to-end throughput over distinct cfg2-sized batches, host work overlapped.
     python tools/pipeline_probe.py [workers=3] [players=4] [batches=8] [pageable] [nohost]"""
 import json, os, sys

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Where does speechPlayer_batch_setUtterances spend its time?  (SPEECHPLAYER_SET_TRACE / SPEECHPLAYER_PLAN_TRACE laps on stderr.)
     python tools/set_trace.py [workload] [utterances]"""
 import os, sys, time

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Diagnostic (KLATT_STAMPS build): where do the four stage waves spend their cycles?  Not a timing run."""
 import ctypes
 import os

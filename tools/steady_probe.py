@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """How fast is the noisy kernel when nothing fades?  65 536 utterances of one steady phoneme with noise gains (1 s + the fades
 into and out of silence), against the speech mix of cfg2: separates the cost of steady samples from the cost of fades."""
 import os

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """120 000 random ragged utterances (NaN holds, vibrato, NULL frames, half of them quiet) through every kernel layout:
 the PCM pools must agree byte for byte (the lane kernel, layout 0, is the independent implementation)."""
 import sys, os, hashlib, time

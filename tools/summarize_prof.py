@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Reduce a tools/profile.sh output directory to a short text summary (the file committed under profiles/)."""
 import csv
 import glob
@@ -10,7 +9,8 @@ from collections import defaultdict
 
 def synthesis_kernel(name):
     """The kernels of a synthesis LAUNCH (what bench.py times): not the ones speechPlayer_batch_setUtterances runs once per batch."""
-    return "klatt" in name and "klatt_source_refs" not in name and "klatt_frame_facts" not in name
+    once_per_batch = ("klatt_source_refs", "klatt_frame_facts", "klatt_verify_shared", "klatt_expand_frames")
+    return "klatt" in name and not any(k in name for k in once_per_batch)
 
 
 def find(outdir, sub, suffix):

@@ -1,4 +1,3 @@
-#!/usr/bin/env python3
 """Tracks (and the flat stages they feed) on / off: kernel time and PCM digest of cfg2 as benchmarked, with rotated frame lists, with jittered
 durations and without the sort by length (tools/mixed_probe.py), plus cfg3 / cfg4 on request.  The digests of a row must agree.
 

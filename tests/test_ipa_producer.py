@@ -150,3 +150,69 @@ def test_phoneme_table_surface_of_the_reference():
         list(ipa.generateFramesAndTiming("hælou", clauseType=";"))
     with pytest.raises(KeyError):
         ipa.frames_for_batch(["hælou", "wɜːld"], clauseType=[".", ";"])
+
+
+def test_compact_form_expands_to_the_packed_frames():
+    """The producer's compact form (speechPlayer_ipa_records: a (voice, composite) shape table, 32-byte records, lists that utterances
+    share) expanded with numpy equals what speechPlayer_ipa_pack hands out as full frames, array for array -- for BASELINE configs[2] and
+    configs[4] (workloads.cfg2_spec / cfg4_spec against workloads.make, which multiplies the frames by each variant's factors itself),
+    for the captured lines with tie bars, length marks and unknown symbols, with and without the closing silence, a voice per text."""
+    from nvspeechplayer_amd import ipa, workloads
+    keys = ("frame_start", "frames", "min", "fade", "isnull")
+
+    def both(texts, **kw):
+        full = ipa.frames_for_batch(texts, **kw)
+        pk = ipa.records_for_batch(texts, **kw)
+        got = ipa.expand_records(pk)
+        for k in keys:
+            assert np.array_equal(full[k], got[k]), k
+        return pk
+    b = workloads.make("cfg2", 1536, first=700)
+    sp = workloads.cfg2_spec(1536, first=700)
+    pk = both(sp["texts"], textOf=sp["textOf"], basePitch=sp["basePitch"], clauseType=".", trailing_silence_ms=150.0)
+    e = ipa.expand_records(pk)
+    for k in keys:
+        assert np.array_equal(b[k], e[k]), k
+    assert len(pk["list_start"]) - 1 == 512 and pk["list_of"].max() == 511 and len(pk["records"]) == pk["list_start"][-1] < len(b["min"])
+    assert pk["shapes"].shape[0] == 57 and pk["records"].dtype.itemsize == 32
+    b4 = workloads.make("cfg4", 3072, first=1024)
+    sp4 = workloads.cfg4_spec(3072, first=1024, per=1024)
+    pk4 = ipa.records_for_batch(sp4["texts"], textOf=sp4["textOf"], basePitch=sp4["basePitch"], clauseType=".", voice=sp4["voice"])
+    e4 = ipa.expand_records(pk4)
+    for k in keys:
+        assert np.array_equal(b4[k], e4[k]), k
+    assert np.array_equal(b4["seeds"], sp4["noiseSeed"]) and len(np.unique(sp4["voice"])) == 3
+    golden_lines = [b.decode("utf8") for b in np.load(scenarios.GOLDEN + "/ref_frames.npz")["ipa_lines"]]
+    for tail in (None, 0.0, 150.0):
+        for voice in (None, "Adam", "Caleb"):
+            both(golden_lines + ["", "x#"], clauseType=[".", "?", "!", ",", None] * 4, basePitch=np.linspace(60, 240, 20), speed=0.6,
+                 trailing_silence_ms=tail, voice=voice)
+
+
+def test_defined_voices_behave_like_presets():
+    """speechPlayer_voiceDefine: a caller's voice in the presets' form (absolute value first, then the multiplier; reference
+    __init__.py:118-125) applied by the producer and by speechPlayer_applyVoiceToFrame; a definition can be replaced, a preset's name
+    cannot be taken, an index out of range is refused."""
+    from nvspeechplayer_amd import Frame, ipa
+    n0 = len(ipa.voices(defined=True))
+    v = ipa.defineVoice("test-voice", {"cf1": (None, 0.9), "cb1": 80.0, "voicePitch": (150.0, 1.1), 46: (None, 2.0)})
+    assert v == ipa.voiceIndex("test-voice") >= 4 and ipa.voices() == ipa.voices(defined=True)[:4]
+    plain, nul, _, _ = ipa.frame_arrays("hælou", basePitch=100.0, clauseType=".")
+    mine, nul2, _, _ = ipa.frame_arrays("hælou", basePitch=100.0, clauseType=".", voice="test-voice")
+    real = nul == 0
+    assert np.array_equal(nul, nul2)
+    assert np.array_equal(mine[real, 7], plain[real, 7] * 0.9) and (mine[real, 15] == 80.0).all()
+    assert (mine[real, 0] == 150.0 * 1.1).all() and np.array_equal(mine[real, 46], plain[real, 46] * 2.0)
+    others = [k for k in range(47) if k not in (0, 7, 15, 46)]
+    assert np.array_equal(mine[:, others], plain[:, others])
+    fr = Frame.from_array(plain[real][0])
+    ipa.applyVoiceToFrame(fr, "test-voice")
+    assert np.array_equal(np.array([getattr(fr, n) for n, _ in Frame._fields_]), mine[real][0])
+    assert ipa.defineVoice("test-voice", {"cf1": (None, 0.5)}) == v                  # replaced in place
+    again, _, _, _ = ipa.frame_arrays("hælou", basePitch=100.0, clauseType=".", voice="test-voice")
+    assert np.array_equal(again[real, 7], plain[real, 7] * 0.5) and np.array_equal(again[real, 15], plain[real, 15])
+    with pytest.raises(ValueError):
+        ipa.defineVoice("Adam", {"cf1": 1.0})
+    with pytest.raises(KeyError):
+        ipa.records_for_batch(["hælou"], voice=[len(ipa.voices(defined=True))])
+    assert len(ipa.voices(defined=True)) == max(n0, v + 1)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # The HOST side of the engine's translation unit (track and direct planning, frame facts, lane packing helpers -- everything the host-only
-# C-ABI views reach: speechPlayer_planTracks, speechPlayer_planDirect, speechPlayer_frameFacts) under AddressSanitizer + UBSan, no GPU needed:
+# C-ABI views reach: speechPlayer_planTracks / _planTracksFacts, speechPlayer_planDirect, speechPlayer_frameFacts, and the frame producer's
+# compact form on the engine's worker pool) under AddressSanitizer + UBSan, no GPU needed:
 # the device code is compiled as usual, the host code with -Xarch_host -fsanitize=address,undefined, and the planning tests run against
 # that library (GPU AddressSanitizer is not available on this pool; the frame producer has its own sanitizer test in the CPU suite).
 #   bash tools/sanitize_host.sh            (about three minutes, most of it the compile)
@@ -16,5 +17,5 @@ mkdir -p "$OUT"
 RT=$(ls /opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so | head -1)
 for threads in 8 2; do
   LD_PRELOAD=$RT ASAN_OPTIONS=detect_leaks=0 SPEECHPLAYER_PLAN_THREADS=$threads SPEECHPLAYER_LIB="$OUT/libspeechPlayer_asan.so" \
-      python -m pytest tests/test_track_planning.py tests/test_direct_planning.py -x -q
+      python -m pytest tests/test_track_planning.py tests/test_direct_planning.py tests/test_host_logic.py tests/test_ipa_producer.py -x -q -k "not sanitizers and not product_does_not"
 done

@@ -474,7 +474,8 @@ struct Batch {
                                            // lanes are time-aligned and the mode is MODE_EXACT (setUtterances), 2 the direct stages always, 0 the stages with the frame state machine
     long long nDirect = 0;                 // order[nQuiet + nTracked .. + nDirect) = such utterances (slots)
     long long nDirectUtt = 0, nDirectFrames = 0;
-    long long nNoNasal = 0;                // order[0..nNoNasal) = quiet utterances that never couple the nasal pair (UTT_NO_NASAL)
+    long long nNoNasal = 0;                // order[0..nNoNasal) = quiet utterances that never couple the nasal pair (UTT_NO_NASAL); slots
+    long long nNoNasalUtt = 0;             // the utterances among them (the rest: replicas that complete a sparse last wavefront)
     long long totalSamples = 0, poolSamples = 0;
     std::vector<uint32_t> lens;
     std::vector<long long> outStart;   // padded offsets in the device pool
@@ -1965,7 +1966,7 @@ static_assert(sizeof(speechPlayer_frameRecord_t) == sizeof(FrameRecord), "record
 
 static void batch_clear(Batch* b)
 {
-    b->nUtt = 0; b->nFrames = 0; b->nFramesSpoken = 0; b->nLists = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->totalSamples = 0; b->poolSamples = 0;
+    b->nUtt = 0; b->nFrames = 0; b->nFramesSpoken = 0; b->nLists = 0; b->nSlots = 0; b->nQuiet = 0; b->nNoNasal = 0; b->nNoNasalUtt = 0; b->totalSamples = 0; b->poolSamples = 0;
     b->nTracked = 0; b->nTrackedUtt = 0; b->nJobs = 0; b->trackEntries = 0; b->nDirect = 0; b->nDirectUtt = 0; b->nDirectFrames = 0;
     b->lens.clear(); b->outStart.assign(1, 0); b->results.clear(); b->resultsFresh = false; b->floatFresh = false;
     b->uttFrameStart.clear(); b->uttFrames.clear();
@@ -2449,22 +2450,36 @@ static int batch_set(Batch* b, const SetInput& in)
         order.insert(order.begin() + nQuiet + nTrackedUtt, padT, 0xFFFFFFFFu);
         nTracked = nTrackedUtt + (long long)padT;
     }
-    // A wavefront of the noisy groups with FEW live lanes takes up to 1.7 times as long as a full one for the same instructions (measured:
+    // A wavefront with FEW live lanes takes up to 1.7 times as long as a full one for the same instructions (measured:
     // streams_synthesize, tools/lone_probe2.py: 1 .. 8 live lanes 4.3 / 6.1 / 7.4 ms from launch to launch, 16 or more a steady 4.13).  Its
     // empty slots are given its own utterances again: those lanes compute the same samples and store the same bytes to the same places.
     // (What a batch of a handful of sentences -- or the tail of a large one -- costs in latency; nothing for full wavefronts.)
+    constexpr int kSparse = 32;      // (16 live lanes still wavered a little: 4.32 against 4.15 ms)
+    long long nQuietSlots = nQuiet, nNoNasalSlots = nNoNasal;
     {
-        const long long noisy0 = nQuiet;
+        // the two quiet groups are packed densely: only their LAST wavefront can be sparse (one vowel alone: 46 ns per sample against 31)
+        auto fill_tail = [&](long long begin, long long end) -> long long {
+            const long long n = end - begin, tail = n % kLanes;
+            if (n == 0 || tail == 0 || tail >= kSparse) return 0;
+            const long long ext = kLanes - tail;
+            std::vector<uint32_t> rep((size_t)ext);
+            for (long long j = 0; j < ext; ++j) rep[(size_t)j] = order[(size_t)(end - tail + j % tail)];
+            order.insert(order.begin() + end, rep.begin(), rep.end());
+            return ext;
+        };
+        const long long e1 = fill_tail(0, nNoNasal);
+        nNoNasalSlots += e1; nQuietSlots += e1;
+        nQuietSlots += fill_tail(nNoNasalSlots, nQuietSlots);
+        const long long noisy0 = nQuietSlots;
         const bool tailNoisy = (long long)order.size() > noisy0;
         if (tailNoisy && ((long long)order.size() - noisy0) % kLanes != 0) {
             // the last wavefront's dead lanes become slots of the group that ends there
             const long long ext = kLanes - ((long long)order.size() - noisy0) % kLanes;
-            const long long legacy = (long long)order.size() - nQuiet - nTracked - nDirectSlots;
+            const long long legacy = (long long)order.size() - nQuietSlots - nTracked - nDirectSlots;
             if (legacy <= 0) { if (nDirectSlots > 0) nDirectSlots += ext; else nTracked += ext; }
             order.insert(order.end(), (size_t)ext, 0xFFFFFFFFu);
         }
         for (long long w = noisy0; w + kLanes <= (long long)order.size(); w += kLanes) {
-            constexpr int kSparse = 32;      // (16 live lanes still wavered a little: 4.32 against 4.15 ms)
             uint32_t liveU[kSparse];
             int nLive = 0;
             for (int i = 0; i < kLanes && nLive < kSparse; ++i)
@@ -2562,7 +2577,8 @@ static int batch_set(Batch* b, const SetInput& in)
         return rc;
     }
     b->nUtt = nU; b->nFrames = nF; b->nFramesSpoken = spoken; b->nLists = nL; b->nSlots = nSlotsAll;
-    b->nQuiet = nQuiet; b->nNoNasal = nNoNasal;
+    b->nNoNasalUtt = nNoNasal;
+    b->nQuiet = nQuietSlots; b->nNoNasal = nNoNasalSlots;      // (slots: the groups' utterances and the replicas that complete their sparse last wavefronts)
     b->nTracked = nTrackedUtt > 0 ? nTracked : 0; b->nTrackedUtt = nTrackedUtt;
     b->nJobs = nTrackedUtt > 0 ? (long long)jobs.size() : 0; b->trackEntries = nTrackedUtt > 0 ? (long long)trackEntries : 0;
     b->nDirect = nDirectUtt > 0 ? nDirectSlots : 0; b->nDirectUtt = nDirectUtt; b->nDirectFrames = (long long)directJobs.size();
@@ -3248,8 +3264,9 @@ int speechPlayer_batch_kernelInfo(speechPlayer_batch_t batch, int* info, int nIn
     info[4] = (int)(prop.sharedMemPerMultiprocessor / ldsBytes);
     info[5] = (int)fa.localSizeBytes;   // scratch
     if (nInfo >= 8) { info[6] = chunk; info[7] = noisy ? 1 : 0; }
-    if (nInfo >= 10) { info[8] = lanepipe ? 1 : 0; info[9] = (int)std::min<long long>(nLp, 0x7FFFFFFF); }
-    if (nInfo >= 12) { info[10] = nasalFree ? 1 : 0; info[11] = (int)std::min<long long>(nNn, 0x7FFFFFFF); }
+    // (utterances, not slots: the lane-pipelined kernel takes all of the nasal-free group or none of it)
+    if (nInfo >= 10) { info[8] = lanepipe ? 1 : 0; info[9] = (int)std::min<long long>(nLp > 0 ? b->nNoNasalUtt : 0, 0x7FFFFFFF); }
+    if (nInfo >= 12) { info[10] = nasalFree ? 1 : 0; info[11] = (int)std::min<long long>(nNn > 0 ? b->nNoNasalUtt : 0, 0x7FFFFFFF); }
     if (nInfo >= 16) {
         info[12] = (int)std::min<long long>(nTr > 0 ? b->nTrackedUtt : 0, 0x7FFFFFFF); info[13] = (int)std::min<long long>(b->nJobs, 0x7FFFFFFF);
         info[14] = (int)std::min<long long>(b->trackEntries * (long long)sizeof(double2) >> 20, 0x7FFFFFFF); info[15] = tracked ? 1 : 0;

@@ -2132,7 +2132,7 @@ static int batch_set(Batch* b, const SetInput& in)
         if (in.nShapes) HIP_TRY(hipMemcpyAsync(b->dShapeTable.ptr, in.shapes, (size_t)in.nShapes * sizeof(speechPlayer_frame_t), hipMemcpyHostToDevice, b->copyStream));
         if (nF) {
             HIP_TRY(hipMemcpyAsync(b->dRecords.ptr, in.records, (size_t)nF * sizeof(FrameRecord), hipMemcpyHostToDevice, b->copyStream));
-            const unsigned grid = (unsigned)std::min<long long>((nF * kNumParams + 255) / 256, 1 << 16);
+            const unsigned grid = (unsigned)std::min<long long>((nF + 63) / 64, 8192);      // tiles of 64 frames
             hipLaunchKernelGGL(klatt_expand_frames, dim3(grid), dim3(256), 0, b->copyStream, b->dRecords.ptr, b->dShapeTable.ptr, b->dFrames.ptr, b->dMeta.ptr, nF);
             HIP_TRY(hipGetLastError());
         }

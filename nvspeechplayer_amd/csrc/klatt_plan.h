@@ -155,29 +155,45 @@ constexpr uint32_t kRecordSilence = 0xFFFFFFFFu;
 static_assert(sizeof(FrameRecord) == 32, "FrameRecord layout");
 
 // records -> the frames and their meta words in HBM: frame k = row records[k].shape of the shape table with parameters 0 and 46 from
-// the record; silence = zeros, flagged.  One thread per DOUBLE written (consecutive threads write consecutive doubles: the 376-byte
-// frames go out as whole cache lines; the shape table is a few hundred rows and stays in L2), the thread that writes a frame's first
-// double also writes its 16-byte meta word.  HBM-bound: 32 B read, 392 B written per frame.
+// the record; silence = zeros, flagged.  A workgroup takes TILES of 64 frames: their records go through LDS once (one 32-byte record per
+// thread, which also writes the frame's 16-byte meta word), then the tile's 3008 doubles leave as 16-byte stores, consecutive threads on
+// consecutive addresses (a tile starts on a 16-byte boundary: 64 x 376 bytes); the shape table is a few hundred rows and stays in L2.
+// HBM-bound: 32 B read, 392 B written per frame (1.58 M frames: 0.30 ms as one thread per double with a 64-bit division each, round 6's
+// first form; this form: see profiles/r6_set_kernels.txt).
 __global__ void __launch_bounds__(256) klatt_expand_frames(const FrameRecord* __restrict__ records, const double* __restrict__ shapes,
                                                            double* __restrict__ frames, FrameMeta* __restrict__ meta, long long nFrames)
 {
-    const long long n = nFrames * kNumParams;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const long long k = i / kNumParams;
-        const int j = (int)(i - k * kNumParams);
-        const FrameRecord r = records[k];
-        const bool silence = r.shape == kRecordSilence;
-        double v = 0.0;
-        if (!silence) v = j == 0 ? r.voicePitch : (j == kNumParams - 1 ? r.endVoicePitch : shapes[(long long)r.shape * kNumParams + j]);
-        frames[i] = v;
-        if (j == 0) {
+    constexpr int kTileFrames = 64, kTilePairs = kTileFrames * kNumParams / 2;
+    __shared__ FrameRecord rec[kTileFrames];
+    const long long nTiles = (nFrames + kTileFrames - 1) / kTileFrames;
+    for (long long tile = blockIdx.x; tile < nTiles; tile += gridDim.x) {
+        const long long k0 = tile * kTileFrames;
+        const int n = (int)((nFrames - k0) < (long long)kTileFrames ? (nFrames - k0) : (long long)kTileFrames);
+        __syncthreads();      // (the previous tile's readers are done with `rec`)
+        if ((int)threadIdx.x < n) {
+            const FrameRecord r = records[k0 + threadIdx.x];
+            rec[threadIdx.x] = r;
             FrameMeta m;
             m.minSamples = r.minSamples;
             m.fadeSamples = r.fadeSamples > 1u ? r.fadeSamples : 1u;      // reference src/speechPlayer.cpp:36
             m.userIndex = r.userIndex;
-            m.flags = silence ? FRAME_NULL : 0u;
-            meta[k] = m;
+            m.flags = r.shape == kRecordSilence ? FRAME_NULL : 0u;
+            meta[k0 + threadIdx.x] = m;
+        }
+        __syncthreads();
+        auto value = [&](int j) -> double {      // double j of the tile
+            const int f = j / kNumParams, p = j - f * kNumParams;
+            if (f >= n) return 0.0;
+            const uint32_t shape = rec[f].shape;
+            if (shape == kRecordSilence) return 0.0;
+            return p == 0 ? rec[f].voicePitch : (p == kNumParams - 1 ? rec[f].endVoicePitch : shapes[(long long)shape * kNumParams + p]);
+        };
+        double2* const out = reinterpret_cast<double2*>(frames + k0 * kNumParams);
+        const int pairs = (n * kNumParams + 1) / 2;
+        for (int j = (int)threadIdx.x; j < kTilePairs && j < pairs; j += (int)blockDim.x) {
+            const double x = value(2 * j), y = value(2 * j + 1);
+            if (2 * j + 1 < n * kNumParams) out[j] = make_double2(x, y);
+            else frames[k0 * kNumParams + 2 * j] = x;      // (the odd last double of a short last tile)
         }
     }
 }

@@ -44,6 +44,8 @@ void speechPlayer_batch_destroy(speechPlayer_batch_t batch);
  * track per output sample: 1, default: the direct stages (every fade sample's coefficients computed in place from per-frame
  * seeds, eight wavefronts per 64 utterances) unless -- in MODE_EXACT -- the utterances are time-aligned copies of few sentences,
  * which the stages with the frame state machine run faster; 2: the direct stages always; 0: never).
+ * "quiet_last" (1, default: a launch queues the quiet groups' kernels behind the noisy groups', whose few long workgroups then start first;
+ * 0: in front; read by every launch).
  * "tracks", "track_budget_mb" and "direct" are read by speechPlayer_batch_setUtterances: set them before it.  No option changes the
  * PCM of MODE_EXACT; MODE_FAST stays within its tolerance whichever kernel runs (the direct stages advance the coefficients of a
  * fade by recurrences, re-seeded exactly at every fade's first sample: relative error <= 4 F 2^-53 after F fade samples). */

@@ -459,6 +459,7 @@ struct Batch {
     long long trackBudgetMB = 4096;        // the tracks of a batch may take this much device memory (at most 4 GB: the flat stages address them with 32-bit byte offsets); utterances beyond it run untracked
     hipStream_t side[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // the other groups run beside the last one (batch_launch)
     hipEvent_t forkEvent = nullptr, join[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int quietLast = 1;                     // option "quiet_last": the quiet groups are launched after the noisy ones (batch_launch)
     long long nUtt = 0, nFrames = 0, nSlots = 0;   // nFrames: frames resident in HBM (the lists')
     long long nLists = 0, nFramesSpoken = 0;       // frame lists of the batch; frames the utterances queue (sum over utterances of their list's)
     std::vector<long long> uttFrameStart;          // [nUtt] first frame of the utterance's list
@@ -1086,33 +1087,41 @@ int batch_launch(Batch* b)
     const bool fork = parts > 1;
     if (fork) HIP_TRY(hipEventRecord(b->forkEvent, b->stream));
     int sideUsed = 0, seen = 0;
-    // the last non-empty group runs on the main stream, the others beside it
-    auto next_stream = [&]() -> hipStream_t {
+    // The last group launched runs on the main stream, the others beside it.  The QUIET groups are launched AFTER the noisy ones (option
+    // "quiet_last", default 1): the noisy workgroups are few, long jobs (configs[2]: 896 workgroups of 8 273 .. 41 238 steps on 512
+    // slots, whose best schedule ends with half the chip idle), the quiet ones cost a third per step -- dispatched behind the noisy
+    // grid they take the slots it leaves free instead of delaying its longest jobs: configs[2] 8.44 -> 8.39 ms, MODE_FAST 7.88 -> 7.68,
+    // configs[4]'s share 62.6 -> 62.2 (tools/quiet_priority_probe.py; low-PRIORITY streams for them were measured too and lost: 8.9 ms).
+    auto next_stream = [&](bool = false) -> hipStream_t {
         if (!fork || ++seen == parts) return b->stream;
         hipStream_t st = b->side[sideUsed++];
         (void)hipStreamWaitEvent(st, b->forkEvent, 0);
         return st;
     };
     const GroupPlan plq = plan_group(b->layout, false, b->nSlots, nNoisy, b->cus);
+    auto launch_quiet = [&]() -> int {
     if (nLp > 0) {
-        hipStream_t st = next_stream();
+        hipStream_t st = next_stream(true);
         a.order = b->dOrder.ptr; a.nSlots = nLp;
         const long long g = (nLp + kLpUPG - 1) / kLpUPG;
         if (g <= b->cus ? launch_lanepipe<KLATT_LP_CH, 1>(a, b->mode, g, st) : launch_lanepipe<16, 2>(a, b->mode, g, st)) return -1;
     }
     if (nNn > 0) {
-        hipStream_t st = next_stream();
+        hipStream_t st = next_stream(true);
         a.order = b->dOrder.ptr + nLp; a.nSlots = nNn;
         const long long g = (nNn + kLanes - 1) / kLanes;
         if (plq.chunk == 32 ? launch_systolic<false, 32, 1, false>(a, b->mode, g, st) : launch_systolic<false, 16, 2, false>(a, b->mode, g, st)) return -1;
     }
     if (nQ > 0) {
-        hipStream_t st = next_stream();
+        hipStream_t st = next_stream(true);
         a.order = b->dOrder.ptr + nLp + nNn; a.nSlots = nQ;
         const long long g = (nQ + kLanes - 1) / kLanes;
         if (plq.systolic ? (plq.chunk == 32 ? launch_systolic<false, 32>(a, b->mode, g, st) : launch_systolic<false, 16>(a, b->mode, g, st))
                          : launch<false, false>(a, b->mode, g, st)) return -1;
     }
+        return 0;
+    };
+    if (!b->quietLast && launch_quiet()) return -1;
     if (nTr > 0) {
         hipStream_t st = next_stream();
         TrackArgs t;
@@ -1159,6 +1168,7 @@ int batch_launch(Batch* b)
         if (pl.systolic ? (pl.chunk == 8 ? launch_systolic<true, KLATT_NOISY_CH, 2>(a, b->mode, g, st) : launch_systolic<true, 16>(a, b->mode, g, st))
                         : launch<false, true>(a, b->mode, g, st)) return -1;
     }
+    if (b->quietLast && launch_quiet()) return -1;
     for (int i = 0; i < sideUsed; ++i) {
         HIP_TRY(hipEventRecord(b->join[i], b->side[i]));
         HIP_TRY(hipStreamWaitEvent(b->stream, b->join[i], 0));
@@ -1889,6 +1899,7 @@ speechPlayer_batch_t speechPlayer_batch_create(int sampleRate, int device)
     for (int i = 0; i < 6 && ok; ++i)
         ok = hipStreamCreateWithFlags(&b->side[i], hipStreamNonBlocking) == hipSuccess &&
              hipEventCreateWithFlags(&b->join[i], hipEventDisableTiming) == hipSuccess;
+    { const char* e = getenv("SPEECHPLAYER_QUIET_LAST"); if (e) b->quietLast = atoi(e) ? 1 : 0; }
     if (!ok) {
         set_error("cannot create a stream on device %d", dev);
         speechPlayer_batch_destroy(b);
@@ -1931,6 +1942,7 @@ int speechPlayer_batch_setOption(speechPlayer_batch_t batch, const char* name, i
         return 0;
     }
     if (!strcmp(name, "sort")) { b->sortByLength = value ? 1 : 0; return 0; }
+    if (!strcmp(name, "quiet_last")) { b->quietLast = value ? 1 : 0; return 0; }      // read by every launch (batch_launch)
     if (!strcmp(name, "layout")) { b->layout = value < 0 ? -1 : (value > 2 ? 1 : value); return 0; }
     // tracks: planned by setUtterances (set the option before it), used by the stage-parallel layouts
     if (!strcmp(name, "tracks")) { b->tracks = value ? 1 : 0; return 0; }

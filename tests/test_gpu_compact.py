@@ -356,3 +356,46 @@ def test_live_trim_releases_and_rebuilds_the_arena(ref):
             d.close()
     finally:
         L.speechPlayer_setGlobalOption(b"live_trim", 0)
+
+
+@pytest.mark.parametrize("options", [dict(tracks=0, direct=2), dict(tracks=0, direct=0), dict(tracks=1, direct=1, track_budget_mb=1)])
+def test_shared_lists_on_every_noisy_path(options):
+    """Shared frame lists on the direct stages (their per-frame seeds and headers are shared like the frames: one record run per LIST),
+    on the stages with the frame state machine, and with a track budget that runs out: the PCM of the plain batch, utterance by
+    utterance, and the oracle's on a sample; marks included."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    n, first = 1536, 200
+    plain = workloads.jittered(workloads.make("cfg2", n, first=first), seed=3)
+    k = np.arange(len(plain["index"]))
+    plain["index"] = np.where(k % 7 == 3, (k % 9973).astype(np.int32), -1).astype(np.int32)
+    # 96 jittered lists, each spoken by 16 utterances with seeds of their own
+    lists = plain.slice(0, 96)
+    list_of = (np.arange(n) % 96).astype(np.uint32)
+    seeds = (np.arange(n) * 7 + 1).astype(np.uint32)
+    fs = lists["frame_start"]
+    rows = np.concatenate([np.arange(fs[l], fs[l + 1]) for l in list_of])
+    same = workloads.Batch(frames=lists["frames"][rows], min=lists["min"][rows], fade=lists["fade"][rows], index=lists["index"][rows], isnull=lists["isnull"][rows],
+                           frame_start=np.concatenate([[0], np.cumsum((fs[1:] - fs[:-1])[list_of])]).astype(np.int64), seeds=seeds, name="same", sr=22050)
+    a = eng.BatchPlayer(22050); b = eng.BatchPlayer(22050)
+    for name, value in options.items():
+        a.setOption(name, value); b.setOption(name, value)
+    a.setUtterances(same["frame_start"], same["frames"], same["min"], same["fade"], same["index"], same["isnull"], same["seeds"])
+    b.setUtterancesShared(lists["frame_start"], lists["frames"], lists["min"], lists["fade"], list_of, lists["index"], lists["isnull"], seeds)
+    ia, ib = a.kernelInfo(), b.kernelInfo()
+    # (the budget of 1 MB holds no jittered batch's tracks: all or nothing, so that case runs on the direct stages too -- whose seeds are per LIST)
+    assert ia["direct_utterances"] == ib["direct_utterances"] and (ia["direct_utterances"] > 0) == (options["direct"] != 0), (ia, ib)
+    assert ia["tracked_utterances"] == ib["tracked_utterances"] == 0
+    if options["direct"]:
+        assert ib["direct_mbytes"] * 8 < ia["direct_mbytes"]
+    a.synthesize(); b.synthesize()
+    da, db = a.digest(per_utterance=True)[1], b.digest(per_utterance=True)[1]
+    assert np.array_equal(da, db)
+    assert [a.getLastIndex(u) for u in range(0, n, 37)] == [b.getLastIndex(u) for u in range(0, n, 37)]
+    for u in (0, 95, 96, n - 1):
+        exp, _, _ = oracle.batch_synthesize(22050, same.slice(u, 1), threads=1)
+        got = b.read(u)
+        d = got.astype(np.int32) - exp.astype(np.int32)
+        assert len(got) == len(exp) and np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1, u
+        assert b.getLastIndex(u) == int(oracle.batch_last_index(22050, same.slice(u, 1))[0])
+    a.close(); b.close()

@@ -1476,7 +1476,10 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     // the kernel's LONE instantiation, whose fade chunks are computed side by side across the identical lanes (klatt_systolic.h,
     // stage_loop: 2.04 -> 1.84 ms); control bit 1 marks the entries.
     const bool replicate = n == 1 && g_liveLayout != 0 && g_liveReplicate;
-    const int nCtl = replicate ? kLanes : n;
+    // (a FEW handles pulled together -- fewer than half a wavefront -- get their empty lanes filled with replicas of themselves too, on the
+    // ordinary kernel: the same effect, and the same remedy as for the sparse wavefronts of a batch)
+    const bool fillSparse = !replicate && n > 1 && n < kLanes / 2 && g_liveLayout != 0 && g_liveReplicate;
+    const int nCtl = (replicate || fillSparse) ? kLanes : n;
     const size_t ctlBytes = (size_t)nCtl * (sizeof(UttDesc) + sizeof(double*) + sizeof(uint32_t));
     if (c->hCtl.reserve(ctlBytes) || c->dCtl.reserve(c->hCtl.cap) || c->hResult.reserve(nCtl) || c->dResult.reserve(c->hResult.cap) ||
         c->dPcm.reserve(padded * n))
@@ -1547,6 +1550,8 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         if (replicate) {
             hControl[0] |= 2u;               // every lane of the wavefront advances THIS handle
             for (int i = 1; i < nCtl; ++i) { hUtt[i] = hUtt[0]; hState[i] = hState[0]; hControl[i] = hControl[0]; }
+        } else if (fillSparse) {
+            for (int i = n; i < nCtl; ++i) { hUtt[i] = hUtt[i % n]; hState[i] = hState[i % n]; hControl[i] = hControl[i % n]; }
         }
         const auto tb = now();
         tFill += ms(ta, tb);

@@ -399,3 +399,43 @@ def test_shared_lists_on_every_noisy_path(options):
         assert len(got) == len(exp) and np.abs(d).max() <= 1 and np.count_nonzero(d) <= 1, u
         assert b.getLastIndex(u) == int(oracle.batch_last_index(22050, same.slice(u, 1))[0])
     a.close(); b.close()
+
+
+def test_a_few_handles_pulled_together_fill_their_wavefront(ref):
+    """Fewer than 32 live handles in a pull: the empty lanes of their wavefront advance replicas of them (streams_synthesize, option
+    "live_replicate").  Five handles with different sentences, seeds and queue lengths, pulled together in ragged pulls until the
+    last one has drained: the same samples, counts and marks as with the option off."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    pulls = [4096, 100, 8192, 1, 3000, 8192]
+
+    def run(replicate):
+        assert L.speechPlayer_setGlobalOption(b"live_replicate", replicate) == 0
+        players = []
+        for j in range(5):
+            p = eng.SpeechPlayer(22050, noiseSeed=100 + j)
+            for k, (fr, m, f) in enumerate(ref.ipa_case(ref.find_ipa(j))):
+                p.queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, userIndex=(k if k % 4 == 1 else -1))
+            players.append(p)
+        got = [[] for _ in players]
+        marks = []
+        for i in range(40):
+            n = pulls[i % len(pulls)]
+            out = np.zeros((5, n), np.int16)
+            produced = eng.SpeechPlayer.synthesizeMany(players, n, out=out)
+            for j in range(5):
+                got[j].append(out[j, :produced[j]].copy())
+            marks.append([p.getLastIndex() for p in players])
+            if not produced.any():
+                break
+        for p in players:
+            p.close()
+        return [np.concatenate(g) for g in got], marks
+    try:
+        off, marks_off = run(0)
+        on, marks_on = run(1)
+        assert marks_on == marks_off and [len(x) for x in on] == [len(x) for x in off] and min(len(x) for x in off) > 8000
+        assert all(np.array_equal(a, b) for a, b in zip(on, off))
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_replicate", 1)

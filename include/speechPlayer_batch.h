@@ -202,6 +202,15 @@ int speechPlayer_node_setOption(speechPlayer_node_t node, const char* name, int 
 int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtterances, const long long* frameStart,
 	const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration, const unsigned int* fadeDuration,
 	const int* userIndex, const unsigned char* isNull, const unsigned int* noiseSeed);
+/* The node's batch in compact form (speechPlayer_batch_setRecords, speechPlayer_batch_setIpa / _setIpaVoices): lists, records and the shape
+ * table go to every shard, the deal decides which utterances each shard speaks.  sampleRate: the node's (as given to speechPlayer_node_create);
+ * voiceOf NULL: voiceName for every text (NULL / "": none). */
+int speechPlayer_node_setRecords(speechPlayer_node_t node, long long nShapes, const speechPlayer_frame_t* shapes, long long nLists,
+	const long long* listStart, const speechPlayer_frameRecord_t* records, long long nUtterances, const unsigned int* listOf,
+	const unsigned int* noiseSeed);
+int speechPlayer_node_setIpa(speechPlayer_node_t node, int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed,
+	const double* basePitch, double inflection, const char* clauseTypes, const int* voiceOf, const char* voiceName,
+	double trailingSilenceMs, const unsigned int* noiseSeed);
 int speechPlayer_node_synthesize(speechPlayer_node_t node);   /* asynchronous on every device */
 int speechPlayer_node_wait(speechPlayer_node_t node);
 long long speechPlayer_node_totalSamples(speechPlayer_node_t node);

@@ -47,7 +47,7 @@ EXPORTS = [
     "speechPlayer_ipa_phonemeCount", "speechPlayer_ipa_phoneme",
     "speechPlayer_node_create", "speechPlayer_node_destroy", "speechPlayer_node_devices", "speechPlayer_node_setOption",
     "speechPlayer_node_setUtterances", "speechPlayer_node_synthesize", "speechPlayer_node_wait", "speechPlayer_node_totalSamples",
-    "speechPlayer_node_read", "speechPlayer_node_getLastIndex", "speechPlayer_node_shardInfo", "speechPlayer_node_shardUtterances", "speechPlayer_node_part",
+    "speechPlayer_node_read", "speechPlayer_node_getLastIndex", "speechPlayer_node_shardInfo", "speechPlayer_node_shardUtterances", "speechPlayer_node_part", "speechPlayer_node_setRecords", "speechPlayer_node_setIpa",
     "speechPlayer_node_time", "speechPlayer_planTracks", "speechPlayer_planDirect", "speechPlayer_frameFacts", "speechPlayer_planTracksFacts",
     "speechPlayer_batch_setUtterancesShared", "speechPlayer_batch_setRecords", "speechPlayer_batch_frames", "speechPlayer_batch_setIpaVoices",
     "speechPlayer_ipa_records", "speechPlayer_records_view", "speechPlayer_records_free", "speechPlayer_voiceIndex", "speechPlayer_voiceDefine", "speechPlayer_voicePresetCount",
@@ -267,6 +267,10 @@ def load():
     L.speechPlayer_node_shardInfo.argtypes = [vp, i32, vp, vp, vp, vp]
     L.speechPlayer_node_shardUtterances.restype = i64
     L.speechPlayer_node_shardUtterances.argtypes = [vp, i32, vp, i64]
+    L.speechPlayer_node_setRecords.restype = i32
+    L.speechPlayer_node_setRecords.argtypes = [vp, i64, vp, i64, vp, vp, i64, vp, vp]
+    L.speechPlayer_node_setIpa.restype = i32
+    L.speechPlayer_node_setIpa.argtypes = [vp, i32, i64, vp, f64, vp, f64, ctypes.c_char_p, vp, ctypes.c_char_p, f64, vp]
     L.speechPlayer_node_part.restype = vp
     L.speechPlayer_node_part.argtypes = [vp, i32]
     L.speechPlayer_node_time.restype = i32

@@ -883,6 +883,25 @@ int speechPlayer_batch_setIpa(speechPlayer_batch_t batch, long long nTexts, cons
     return set_ipa("speechPlayer_batch_setIpa", batch, nTexts, ipaUtf8, speed, basePitch, inflection, clauseTypes, nullptr, voiceName, trailingSilenceMs, noiseSeed);
 }
 
+int speechPlayer_node_setIpa(speechPlayer_node_t node, int sampleRate, long long nTexts, const char* const* ipaUtf8, double speed,
+                             const double* basePitch, double inflection, const char* clauseTypes, const int* voiceOf, const char* voiceName,
+                             double trailingSilenceMs, const unsigned int* noiseSeed)
+{
+    return producer_call<int>("speechPlayer_node_setIpa", -1, [&]() -> int {
+        PackArgs a;
+        if (sampleRate <= 0 || check_pack_args(nTexts, ipaUtf8, clauseTypes, voiceOf, voiceName, &a.voiceAll)) {
+            set_producer_error("speechPlayer_node_setIpa: bad sample rate, text array, voice or clause type");
+            return -1;
+        }
+        a.sampleRate = sampleRate; a.nTexts = nTexts; a.texts = ipaUtf8; a.speed = speed; a.basePitch = basePitch; a.inflection = inflection;
+        a.clauseTypes = clauseTypes; a.voiceOf = voiceOf; a.tailMs = trailingSilenceMs;
+        Compact c;
+        if (build_compact(a, false, false, c)) { set_producer_error("speechPlayer_node_setIpa: voice index out of range"); return -1; }
+        return speechPlayer_node_setRecords(node, (long long)c.shapes.size(), c.shapes.data(), (long long)c.listStart.size() - 1, c.listStart.data(),
+                                            c.records.data(), nTexts, c.listOf.data(), noiseSeed);
+    });
+}
+
 int speechPlayer_batch_setIpaVoices(speechPlayer_batch_t batch, long long nTexts, const char* const* ipaUtf8, double speed,
                                     const double* basePitch, double inflection, const char* clauseTypes, const int* voiceOf,
                                     double trailingSilenceMs, const unsigned int* noiseSeed)

@@ -3006,28 +3006,11 @@ int speechPlayer_node_setOption(speechPlayer_node_t node, const char* name, int 
     return 0;
 }
 
-int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtterances, const long long* frameStart,
-                                    const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
-                                    const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
-                                    const unsigned int* noiseSeed)
+// The deal of a node's batch: before[u] = samples before utterance u (closed-form lengths).  Contiguous shards of near-equal
+// sample count, or -- option "deal" -- the sorted deal: longest first (ties in the batch's order), blocks of 64 dealt round-robin
+// (nvspeechplayer_amd.sharding.shard_deal states the same rules).
+static void node_deal(Node* n, long long nUtterances, const std::vector<unsigned long long>& before)
 {
-    begin_call();
-    Node* n = static_cast<Node*>(node);
-    if (!n || nUtterances < 0 || !frameStart) { set_error("node_setUtterances: bad arguments"); return -1; }
-    if (frameStart[0] != 0) { set_error("node_setUtterances: frameStart[0] must be 0"); return -1; }
-    for (long long u = 0; u < nUtterances; ++u)
-        if (frameStart[u + 1] < frameStart[u]) { set_error("node_setUtterances: frameStart not monotone at %lld", u); return -1; }
-    if (frameStart[nUtterances] > 0 && (!minFrameDuration || !fadeDuration)) { set_error("node_setUtterances: bad frame arrays"); return -1; }
-    // samples before each utterance (closed form: a request spans max(M, F + 1) + 1 samples, F clamped to >= 1)
-    std::vector<unsigned long long> before((size_t)nUtterances + 1, 0);
-    for (long long u = 0; u < nUtterances; ++u) {
-        unsigned long long len = 0;
-        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
-            const unsigned long long m = minFrameDuration[k], f = std::max(fadeDuration[k], 1u);
-            len += std::max(m, f + 1) + 1;
-        }
-        before[u + 1] = before[u] + len;
-    }
     const int nd = (int)n->parts.size();
     const unsigned long long total = before[nUtterances];
     n->nUtt = nUtterances;
@@ -3055,6 +3038,32 @@ int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtteran
             n->members[(size_t)d].push_back(order[i]);
         }
     }
+}
+
+int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtterances, const long long* frameStart,
+                                    const speechPlayer_frame_t* frames, const unsigned int* minFrameDuration,
+                                    const unsigned int* fadeDuration, const int* userIndex, const unsigned char* isNull,
+                                    const unsigned int* noiseSeed)
+{
+    begin_call();
+    Node* n = static_cast<Node*>(node);
+    if (!n || nUtterances < 0 || !frameStart) { set_error("node_setUtterances: bad arguments"); return -1; }
+    if (frameStart[0] != 0) { set_error("node_setUtterances: frameStart[0] must be 0"); return -1; }
+    for (long long u = 0; u < nUtterances; ++u)
+        if (frameStart[u + 1] < frameStart[u]) { set_error("node_setUtterances: frameStart not monotone at %lld", u); return -1; }
+    if (frameStart[nUtterances] > 0 && (!minFrameDuration || !fadeDuration)) { set_error("node_setUtterances: bad frame arrays"); return -1; }
+    // samples before each utterance (closed form: a request spans max(M, F + 1) + 1 samples, F clamped to >= 1)
+    std::vector<unsigned long long> before((size_t)nUtterances + 1, 0);
+    for (long long u = 0; u < nUtterances; ++u) {
+        unsigned long long len = 0;
+        for (long long k = frameStart[u]; k < frameStart[u + 1]; ++k) {
+            const unsigned long long m = minFrameDuration[k], f = std::max(fadeDuration[k], 1u);
+            len += std::max(m, f + 1) + 1;
+        }
+        before[u + 1] = before[u] + len;
+    }
+    node_deal(n, nUtterances, before);
+    const int nd = (int)n->parts.size();
     // one host thread per device: rebase the shard's index array, give every utterance its GLOBAL default seed, upload
     std::vector<int> rc((size_t)nd, 0), codes((size_t)nd, 0);
     std::vector<std::string> errors((size_t)nd);
@@ -3108,6 +3117,59 @@ int speechPlayer_node_setUtterances(speechPlayer_node_t node, long long nUtteran
     }
     for (int d = 0; d < nd; ++d)
         if (rc[d]) { set_error_code(codes[d]); set_error("node_setUtterances: shard %d: %s", d, errors[d].c_str()); return -1; }
+    return 0;
+}
+
+// The node's batch in compact form (speechPlayer_batch_setRecords): the lists, their records and the shape table go to EVERY shard (they
+// are small), each shard gets the utterances the deal gives it -- their list numbers and noise seeds.
+int speechPlayer_node_setRecords(speechPlayer_node_t node, long long nShapes, const speechPlayer_frame_t* shapes, long long nLists,
+                                 const long long* listStart, const speechPlayer_frameRecord_t* records, long long nUtterances,
+                                 const unsigned int* listOf, const unsigned int* noiseSeed)
+{
+    begin_call();
+    Node* n = static_cast<Node*>(node);
+    if (!n || nUtterances < 0 || nLists < 0 || !listStart) { set_error("node_setRecords: bad arguments"); return -1; }
+    if (!listOf && nUtterances != nLists) { set_error("node_setRecords: %lld utterances for %lld lists and no listOf", nUtterances, nLists); return -1; }
+    if (listStart[0] != 0) { set_error("node_setRecords: listStart[0] must be 0"); return -1; }
+    for (long long l = 0; l < nLists; ++l)
+        if (listStart[l + 1] < listStart[l]) { set_error("node_setRecords: listStart not monotone at %lld", l); return -1; }
+    if (listStart[nLists] > 0 && !records) { set_error("node_setRecords: no records"); return -1; }
+    for (long long u = 0; listOf && u < nUtterances; ++u)
+        if ((long long)listOf[u] >= nLists) { set_error("node_setRecords: listOf[%lld] is not a list", u); return -1; }
+    try {
+        std::vector<unsigned long long> lenL((size_t)nLists, 0), before((size_t)nUtterances + 1, 0);
+        for (long long l = 0; l < nLists; ++l)
+            for (long long k = listStart[l]; k < listStart[l + 1]; ++k) {
+                const unsigned long long m = records[k].minFrameDuration, f = std::max(records[k].fadeDuration, 1u);
+                lenL[(size_t)l] += std::max(m, f + 1) + 1;
+            }
+        for (long long u = 0; u < nUtterances; ++u) before[(size_t)u + 1] = before[(size_t)u] + lenL[listOf ? listOf[u] : (size_t)u];
+        node_deal(n, nUtterances, before);
+        const int nd = (int)n->parts.size();
+        std::vector<int> rc((size_t)nd, 0), codes((size_t)nd, 0);
+        std::vector<std::string> errors((size_t)nd);
+        run_parts((unsigned)nd, [&](unsigned ud) {
+            const int d = (int)ud;
+            try {
+                const long long cnt = n->sorted ? (long long)n->members[(size_t)d].size() : n->bounds[d + 1] - n->bounds[d];
+                std::vector<unsigned int> lo((size_t)cnt), seeds((size_t)cnt);
+                for (long long j = 0; j < cnt; ++j) {
+                    const long long u = n->sorted ? n->members[(size_t)d][(size_t)j] : n->bounds[d] + j;
+                    lo[(size_t)j] = listOf ? listOf[u] : (unsigned int)u;
+                    seeds[(size_t)j] = noiseSeed ? noiseSeed[u] : (unsigned int)u;
+                }
+                rc[d] = speechPlayer_batch_setRecords(n->parts[d], nShapes, shapes, nLists, listStart, records, cnt, lo.data(), seeds.data());
+                if (rc[d]) { errors[d] = g_lastError; codes[d] = g_lastErrorCode; }
+            } catch (const std::exception& e) {
+                rc[d] = -1; errors[d] = e.what(); codes[d] = SPEECHPLAYER_ERR_ARGUMENT;
+            }
+        });
+        for (int d = 0; d < nd; ++d)
+            if (rc[d]) { set_error_code(codes[d]); set_error("node_setRecords: shard %d: %s", d, errors[d].c_str()); return -1; }
+    } catch (const std::exception& e) {
+        set_error("node_setRecords: %s", e.what());
+        return -1;
+    }
     return 0;
 }
 

@@ -500,6 +500,33 @@ class NodePlayer(object):
         c = np.concatenate([[0], np.cumsum(per)])
         self._lens = c[fs[1:]] - c[fs[:-1]]
 
+    def setIpa(self, texts, speed=1, basePitch=100, inflection=0.5, clauseType=None, noiseSeed=None, voice=None,
+               trailing_silence_ms=150.0, textOf=None):
+        """The node's batch from IPA text (speechPlayer_node_setIpa): arguments as BatchPlayer.setIpa; the producer's compact form goes to
+        every shard, the deal decides which utterances each shard speaks."""
+        from .ipa import _text_pointers, _clauses
+        ptrs, n, keep = _text_pointers(texts, textOf)
+        pitch = np.ascontiguousarray(np.broadcast_to(np.asarray(basePitch, dtype=np.float64), (n,)))
+        sd = None if noiseSeed is None else np.ascontiguousarray(noiseSeed, dtype=np.uint32)
+        by_name = voice is None or isinstance(voice, str)
+        vo = None if by_name else np.ascontiguousarray(np.broadcast_to(np.asarray(voice, dtype=np.int32), (n,)))
+        self._check(self._dll.speechPlayer_node_setIpa(self._h, int(self.sampleRate), n, ptrs.ctypes.data, float(speed), pitch.ctypes.data, float(inflection),
+                                                       _clauses(clauseType, n), None if vo is None else vo.ctypes.data,
+                                                       (voice.encode("utf8") if (by_name and voice) else None),
+                                                       -1.0 if trailing_silence_ms is None else float(trailing_silence_ms), None if sd is None else sd.ctypes.data))
+        del keep
+        self.nUtterances = n
+        self._lens = None
+
+    def utteranceSamples(self, u):
+        """Samples utterance u produces (from the shard that holds it)."""
+        for d in range(self._dll.speechPlayer_node_devices(self._h)):
+            mem = self.shardUtterances(d)
+            at = np.flatnonzero(mem == u)
+            if len(at):
+                return self._dll.speechPlayer_batch_utteranceSamples(self._dll.speechPlayer_node_part(self._h, d), int(at[0]))
+        raise RuntimeError("NodePlayer.utteranceSamples: utterance %d out of range" % u)
+
     @property
     def totalSamples(self):
         return self._dll.speechPlayer_node_totalSamples(self._h)
@@ -522,7 +549,7 @@ class NodePlayer(object):
     def read(self, u):
         if not 0 <= u < self.nUtterances:
             raise RuntimeError("NodePlayer.read: utterance %d out of range" % u)
-        n = int(self._lens[u])
+        n = int(self._lens[u]) if self._lens is not None else int(self.utteranceSamples(u))
         buf = np.zeros(max(n, 1), dtype=np.int16)
         got = self._check(self._dll.speechPlayer_node_read(self._h, u, buf.ctypes.data, n))
         return buf[:got]

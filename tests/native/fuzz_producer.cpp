@@ -20,6 +20,8 @@ extern "C" int speechPlayer_batch_setRecords(speechPlayer_batch_t, long long nSh
     for (long long k = 0; k < listStart[nLists]; ++k) if (rec[k].shape != SPEECHPLAYER_RECORD_SILENCE && (long long)rec[k].shape >= nShapes) return -1;
     return 0;
 }
+extern "C" int speechPlayer_node_setRecords(speechPlayer_node_t, long long, const speechPlayer_frame_t*, long long, const long long*, const speechPlayer_frameRecord_t*,
+                                            long long, const unsigned int*, const unsigned int*) { return 0; }
 extern "C" void speechPlayer_internal_parallel(long long n, long long, void (*fn)(void*, long long, long long), void* ctx)
 {
     if (n > 0) { fn(ctx, 0, n / 2); fn(ctx, n / 2, n); }

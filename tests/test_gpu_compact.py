@@ -439,3 +439,32 @@ def test_a_few_handles_pulled_together_fill_their_wavefront(ref):
         assert all(np.array_equal(a, b) for a, b in zip(on, off))
     finally:
         L.speechPlayer_setGlobalOption(b"live_replicate", 1)
+
+
+@pytest.mark.parametrize("deal", [0, 1])
+def test_node_batch_from_ipa_text(deal):
+    """speechPlayer_node_setIpa: the compact form over the devices of a node (three shards on this box's one GPU), under the contiguous
+    and the sorted deal: every utterance's digest, a sample of PCM and lengths equal the single-device batch set from the same text;
+    configs[4]'s recipe with a voice per utterance."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads
+    from nvspeechplayer_amd.sharding import shard_bounds, shard_deal
+    n = 3000
+    for spec in (workloads.cfg2_spec(n, first=77), workloads.cfg4_spec(n, first=512, per=1024)):
+        one = eng.BatchPlayer(22050)
+        one.setIpa(**spec)
+        one.synthesize()
+        want = one.digest(per_utterance=True)[1]
+        lens = np.array([one.utteranceSamples(u) for u in range(n)])
+        node = eng.NodePlayer(22050, [0, 0, 0])
+        node.setOption("deal", deal)
+        node.setIpa(**spec)
+        assert node.totalSamples == one.totalSamples
+        parts = shard_deal(lens, 3, "sorted") if deal else [np.arange(a, b) for a, b in zip(shard_bounds(lens, 3)[:-1], shard_bounds(lens, 3)[1:])]
+        for d in range(3):
+            assert np.array_equal(node.shardUtterances(d), parts[d])
+        node.synthesize()
+        assert np.array_equal(node.digests(), want)
+        for u in (0, 1, n // 2, n - 1):
+            assert np.array_equal(node.read(u), one.read(u))
+        node.close(); one.close()

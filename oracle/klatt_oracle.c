@@ -3,8 +3,9 @@
  *
  * TEST INFRASTRUCTURE ONLY.  This file is the parity checker ("oracle") for the
  * HIP engine in nvspeechplayer_amd/csrc.  Only tests/, __graft_entry__.smoke()
- * and bench.py's cpu_baseline leg may load it; the product library never links
- * or calls it.
+ * and bench.py's CPU-baseline legs (cpu_baseline; since round 6 also cfg0_cpu --
+ * BASELINE configs[0] -- and the oracle column of single_stream) may load it; the
+ * product library never links or calls it.
  *
  * It restates, in plain C and double precision, what the reference computes in
  *   src/frame.cpp:41-80      (per-sample frame state machine: fade, dequeue, glide)

@@ -311,7 +311,8 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = SysLds<NOISE, CH, FLAT>::kBytes;
+    constexpr int ldsBytes = SysLds<NOISE, CH, FLAT>::kBytes + (LONE ? kStages * kLoneLdsPerStage : 0);     // LONE: a stage's fade chunks pass through LDS
+    static_assert(ldsBytes <= 160 * 1024, "a workgroup's LDS");
     auto go = [&](auto kernel) -> int {
         if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;
         hipLaunchKernelGGL(kernel, dim3((unsigned)nGroups), dim3(kLanes * kStages), ldsBytes, stream, a);
@@ -1447,6 +1448,10 @@ void ring_drop(LiveContext* c, Stream* s)
 // refilling the rings in between -- a pull is the same as several shorter pulls, reference src/speechPlayer.cpp:39-42).
 // The callers hold every stream's mutex.  produced[i] receives speechPlayer_synthesize's return value.
 // outs == nullptr: the PCM stays on the device (row i at devicePcm + i * stride), for consumers on the GPU.
+#ifdef KLATT_STAMPS
+unsigned long long g_streamStamps[32];
+extern "C" __attribute__((visibility("default"))) void speechPlayer_debugStreamStamps(unsigned long long* out) { for (int k = 0; k < 32; ++k) { out[k] = g_streamStamps[k]; g_streamStamps[k] = 0; } }
+#endif
 int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* const* outs, int* produced,
                        const int16_t** devicePcm = nullptr, long long* deviceStride = nullptr)
 {
@@ -1561,6 +1566,12 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         }
         HIP_TRY(hipMemcpyAsync(c->dCtl.ptr, c->hCtl.ptr, ctlBytes, hipMemcpyHostToDevice, c->stream));
         a.maxSamples = piece;
+#ifdef KLATT_STAMPS
+        static unsigned long long* dStamps = nullptr;
+        if (!dStamps) HIP_TRY(hipMalloc(&dStamps, 32 * 8));
+        HIP_TRY(hipMemsetAsync(dStamps, 0, 32 * 8, c->stream));
+        a.debug = groups == 1 ? dStamps : nullptr;
+#endif
         HIP_TRY(hipEventRecord(c->kernelStart, c->stream));
         if (g_liveLayout == 0) {
             if (launch<true, true>(a, mode, groups, c->stream)) return -1;
@@ -1571,6 +1582,14 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
                                        : launch_systolic<true, KLATT_NOISY_CH, 2, true, true>(a, mode, groups, c->stream))) return -1;
         }
         HIP_TRY(hipEventRecord(c->kernelStop, c->stream));
+#ifdef KLATT_STAMPS
+        if (a.debug) {
+            unsigned long long h[32];
+            HIP_TRY(hipMemcpyAsync(h, dStamps, sizeof h, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(hipStreamSynchronize(c->stream));
+            for (int k = 0; k < 32; ++k) g_streamStamps[k] += h[k];
+        }
+#endif
         HIP_TRY(hipMemcpyAsync(c->hResult.ptr, c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
         if (piece < count || joined) {       // a call in pieces: this piece's columns into the joined rows
             if (c->dPcmJoin.reserve(padded * n)) return -1;

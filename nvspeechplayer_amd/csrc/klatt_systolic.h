@@ -147,7 +147,9 @@ struct StageCtx {          // what every stage needs from the launch
     const FlatRef* myFlat;     // flat launches: the utterance's per-frame track references, loaded ahead by the stages (klatt_device.h)
     const SourceRef* mySrc;    // flat launches: what the source stage loads ahead
     bool lone = false;         // live handles: every lane of the wavefront advances ONE handle (streams_synthesize's replicas); wave-uniform
+    double* loneLds = nullptr;   // ... and this stage's 11 KB of LDS behind the kernel's own (kLoneLdsPerStage): the values of a fade's next 64 samples, [slot][sample]
 };
+constexpr int kLoneLdsPerStage = 11264;
 
 // OR over the wavefront of the low NBITS bits of a per-lane mask, as a wave-uniform (scalar) value.
 // One ballot per bit: a handful of instructions, no LDS round trips (a shuffle reduction costs 6).
@@ -551,6 +553,83 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
             steadyDone(CH);
         }
     };
+    // A handle pulled ALONE fills its wavefront with 64 identical lanes (streams_synthesize).  What a fade sample costs beyond a steady
+    // one -- the interpolation of the stage's parameters and exp / cos per moving resonator, 1700 cycles against 280 in the cascade and
+    // parallel stages (KLATT_STAMPS build) -- depends on the fade position alone, not on the filter memories: lane i computes it for
+    // sample i of the fade's NEXT 64 (`span` of them are wanted; a lane past those repeats the last), all side by side (loneEval), and
+    // the recurrence then takes each sample's values from LDS, [slot][sample] (loneTake): one ds_read_b64 of a wave-uniform address
+    // hands a value to all lanes (two v_readlane per double and the scalar-operand hazards behind them cost ~450 cycles a sample more).
+    // Same expressions on the same operands as stage_fade, sample for sample.  Slots: a resonator's frequency and bandwidth feed its
+    // coefficients alone -- of those only the values a stretch ends on are kept, as the state ([parameter][chunk], behind the slots;
+    // `whole`: the stretch is whole chunks of a fade run, else `span` samples inside a chunk with an event).
+    constexpr int kLoneG = kLanes / CH;
+    constexpr int NP_ = D::NPARAM > 0 ? D::NPARAM : 1;
+    static_assert(!K::LONE || (D::NPARAM + D::NRES + 1) * kLanes * 8 + D::NPARAM * kLoneG * 8 <= kLoneLdsPerStage, "a stage's fade values fit its LDS scratch");
+    auto loneOfRes = [&](int k) __attribute__((always_inline)) { bool y = false;
+#pragma unroll
+        for (int r = 0; r < D::NRES; ++r) y = y || RF[r] == k || RB[r] == k;
+        return y; };
+    auto loneSlot = [&](int k) __attribute__((always_inline)) { int n = 0;      // parameters below k with a slot of their own
+#pragma unroll
+        for (int j = 0; j < D::NPARAM; ++j) n += (j < k && !loneOfRes(j)) ? 1 : 0;
+        return n; };
+    auto loneEval = [&](uint32_t span, bool whole, bool lerp, uint32_t wRes, bool gainOnly, uint32_t coefCls) __attribute__((always_inline)) {
+        double* const S = X.loneLds;
+        double* const SL = S + (D::NPARAM + D::NRES + 1) * kLanes;
+        const int coef0 = loneSlot(D::NPARAM), pitchSlot = coef0 + 3 * D::NRES;
+        const bool gainAlone = D::GAIN >= 0 && lerp && gainOnly;
+        const uint32_t me = threadIdx.x & (kLanes - 1);
+        const double ratio = div_by((double)(f.cnt + 1u + (me < span ? me : span - 1u)), (double)f.newFade, f.invFade);
+        const bool ends = whole ? (me & (uint32_t)(CH - 1)) == (uint32_t)(CH - 1) : me == span - 1u;
+        const int endsAt = whole ? (int)(me / (uint32_t)CH) : 0;
+        double cv[NP_];
+#pragma unroll
+        for (int k = 0; k < D::NPARAM; ++k) cv[k] = f.cur[k];
+        if (gainAlone) cv[GI] = fade_value(f.oldL[GI * kLanes], f.getNew(GI), ratio);
+        else if (lerp) {
+#pragma unroll
+            for (int k = 0; k < D::NPARAM; ++k) { const double o = f.oldL[k * kLanes], n = f.getNew(k); cv[k] = o + ((n - o) * ratio); }
+        }
+        if (D::PITCH) S[pitchSlot * kLanes + me] = fade_value(ps->old0, ps->new0, ratio);
+        if (gainAlone) S[loneSlot(GI) * kLanes + me] = cv[GI];
+        else if (lerp) {
+#pragma unroll
+            for (int k = 0; k < D::NPARAM; ++k) {
+                if (!loneOfRes(k)) S[loneSlot(k) * kLanes + me] = cv[k];
+                else if (ends) SL[k * kLoneG + endsAt] = cv[k];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < D::NRES; ++r) {
+            if (wRes & (1u << r)) {
+                const Coef k = D::INLINE_COEF
+                    ? resonator_coefficients_inline<MODE>(cv[RF[r]], cv[RB[r]], D::ANTI0 && r == 0, X.A.negPiOverSr, X.A.twoPiOverSr, (int)((coefCls >> (2 * r)) & 3u))
+                    : resonator_coefficients<MODE>(cv[RF[r]], cv[RB[r]], D::ANTI0 && r == 0, X.A.negPiOverSr, X.A.twoPiOverSr);
+                S[(coef0 + 3 * r) * kLanes + me] = k.a; S[(coef0 + 3 * r + 1) * kLanes + me] = k.b; S[(coef0 + 3 * r + 2) * kLanes + me] = k.c;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    // sample `at` of the last loneEval becomes the stage's current values (`last`: the stretch ends on it, chunk `endsAt` of the evaluation)
+    auto loneTake = [&](int at, bool last, int endsAt, bool lerp, uint32_t wRes, bool gainOnly) __attribute__((always_inline)) {
+        const double* const S = X.loneLds;
+        const double* const SL = S + (D::NPARAM + D::NRES + 1) * kLanes;
+        const int coef0 = loneSlot(D::NPARAM), pitchSlot = coef0 + 3 * D::NRES;
+        if (D::PITCH) ps->cur0 = S[pitchSlot * kLanes + at];
+        if (D::GAIN >= 0 && lerp && gainOnly) f.cur[GI] = S[loneSlot(GI) * kLanes + at];
+        else if (lerp) {
+#pragma unroll
+            for (int k = 0; k < D::NPARAM; ++k) {
+                if (!loneOfRes(k)) f.cur[k] = S[loneSlot(k) * kLanes + at];
+                else if (last) f.cur[k] = SL[k * kLoneG + endsAt];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < D::NRES; ++r)
+            if (wRes & (1u << r)) { f.ra[r] = S[(coef0 + 3 * r) * kLanes + at]; f.rb[r] = S[(coef0 + 3 * r + 1) * kLanes + at]; f.rc[r] = S[(coef0 + 3 * r + 2) * kLanes + at]; }
+    };
     for (int iter = 0; iter < nIter; ++iter) {
         STAMP_BEGIN();
         STAMP_IDLE();
@@ -592,55 +671,21 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 (void)begin(1);
                 const uint32_t coefCls = fade_classes<D>(f, X.A, RF, RB, wRes);   // once per fade stretch
                 // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
+                uint32_t loneQ = 0;     // LONE: chunks of this run so far
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {
                     if (K::LONE) {
-                        // A handle pulled ALONE fills its wavefront with 64 identical lanes (streams_synthesize).  What a fade sample costs
-                        // beyond a steady one -- the interpolation of the stage's parameters and exp / cos per moving resonator, 1700 cycles
-                        // against 280 in the cascade and parallel stages (KLATT_STAMPS build, tools/stamps_lone.py) -- depends on the fade
-                        // position alone, not on the filter memories: lane i computes it for sample i of the chunk, all CH samples side by
-                        // side, and the recurrence then takes each sample's values out of its lane.  Same expressions on the same operands
-                        // as stage_fade, sample for sample.
+                        // every fourth chunk of the run evaluates the fade's next 64 samples (lone_eval above)
                         if (!f.done) {
-                            const int mine = (int)(threadIdx.x & (CH - 1));
-                            const double ratio = div_by((double)(f.cnt + 1u + (uint32_t)mine), (double)f.newFade, f.invFade);
-                            double pitchMine = 0.0;
-                            if (D::PITCH) pitchMine = fade_value(ps->old0, ps->new0, ratio);
-                            constexpr int NP_ = D::NPARAM > 0 ? D::NPARAM : 1, NR_ = D::NRES > 0 ? D::NRES : 1;
-                            double cv[NP_];
-#pragma unroll
-                            for (int k = 0; k < D::NPARAM; ++k) cv[k] = f.cur[k];
-                            const bool gainAlone = D::GAIN >= 0 && lerp && gainOnly;
-                            if (gainAlone) cv[GI] = fade_value(f.oldL[GI * kLanes], f.getNew(GI), ratio);
-                            else if (lerp) {
-#pragma unroll
-                                for (int k = 0; k < D::NPARAM; ++k) { const double o = f.oldL[k * kLanes], n = f.getNew(k); cv[k] = o + ((n - o) * ratio); }
-                            }
-                            double ka[NR_], kb[NR_], kc[NR_];
-#pragma unroll
-                            for (int r = 0; r < D::NRES; ++r) {
-                                ka[r] = f.ra[r]; kb[r] = f.rb[r]; kc[r] = f.rc[r];
-                                if (wRes & (1u << r)) {
-                                    const Coef k = D::INLINE_COEF
-                                        ? resonator_coefficients_inline<MODE>(cv[RF[r]], cv[RB[r]], D::ANTI0 && r == 0, X.A.negPiOverSr, X.A.twoPiOverSr, (int)((coefCls >> (2 * r)) & 3u))
-                                        : resonator_coefficients<MODE>(cv[RF[r]], cv[RB[r]], D::ANTI0 && r == 0, X.A.negPiOverSr, X.A.twoPiOverSr);
-                                    ka[r] = k.a; kb[r] = k.b; kc[r] = k.c;
-                                }
-                            }
+                            const int q0 = (int)(loneQ & (uint32_t)(kLoneG - 1));
+                            if (q0 == 0) loneEval(f.newFade - f.cnt, true, lerp, wRes, gainOnly, coefCls);
 #pragma unroll
                             for (int i = 0; i < CH; ++i) {
                                 f.cnt++;
-                                if (D::PITCH) ps->cur0 = lane_read(pitchMine, i);
-                                if (gainAlone) f.cur[GI] = lane_read(cv[GI], i);
-                                else if (lerp) {
-#pragma unroll
-                                    for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = lane_read(cv[k], i);
-                                }
-#pragma unroll
-                                for (int r = 0; r < D::NRES; ++r)
-                                    if (wRes & (1u << r)) { f.ra[r] = lane_read(ka[r], i); f.rb[r] = lane_read(kb[r], i); f.rc[r] = lane_read(kc[r], i); }
+                                loneTake(q0 * CH + i, i == CH - 1, q0, lerp, wRes, gainOnly);
                                 body(c, i, false, 0.0);
                             }
                             fadeDone(CH);
+                            ++loneQ;
                         }
                     } else
                     if (!f.done) {
@@ -676,7 +721,44 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 int i = 0;
 #pragma nounroll
                 while (i < lim) {
-                    if (K::RUNS && !forceGeneral()) {
+                    if (K::LONE && !forceGeneral()) {
+                        // a chunk with an event in it, 64 identical lanes: [uniform run][the event's steps][uniform run] -- only the event's
+                        // steps need the state machine sample by sample (16 such chunks in a pull of 8192 samples cost a third of it,
+                        // 27000 cycles each against 4900 for a steady one); a fading run is evaluated side by side like a fade chunk
+                        const bool fad = f.hasNew;
+                        const uint32_t rem = f.done ? 0u : (fad ? f.newFade - f.cnt : (f.oldMin > f.cnt ? f.oldMin - f.cnt : 0u));
+                        const bool runs = !f.done && !(fad && (f.cnt == 0u || nan_target_live(f)));
+                        const uint32_t cap = (uint32_t)(lim - i);
+                        const int n = runs ? (int)__builtin_amdgcn_readfirstlane(rem < cap ? rem : cap) : 0;
+                        if (n >= 2) {
+                            bool lerpR = false, gainOnlyR = false, moves = fad;
+                            uint32_t wResR = 0;
+                            if (fad) {
+                                lerpR = __any(f.parMask != 0u);
+                                gainOnlyR = !K::NOISE && D::GAIN >= 0 && !__any((f.parMask & ~(1u << GI)) != 0u);
+                                wResR = wave_or_bits<(D::NRES > 0 ? D::NRES : 1)>(f.resMask);
+                                if (!D::PITCH && !lerpR && wResR == 0u) moves = false;
+                            }
+                            if (!moves) {
+#pragma nounroll
+                                for (int j = i; j < i + n; ++j) body(c, j, true, K::PRE ? preIn(c, j) : 0.0);
+                                f.cnt += (uint32_t)n;
+                                steadyDone(n);
+                            } else {
+                                loneEval((uint32_t)n, false, lerpR, wResR, gainOnlyR, kCoefAllUnknown);
+#pragma nounroll
+                                for (int j = i; j < i + n; ++j) {
+                                    f.cnt++;
+                                    loneTake(j - i, j == i + n - 1, 0, lerpR, wResR, gainOnlyR);
+                                    body(c, j, false, 0.0);
+                                }
+                                fadeDone(n);
+                            }
+                            i += n;
+                            continue;
+                        }
+                    }
+                    if (K::RUNS && !K::LONE && !forceGeneral()) {
                         // whenever every live lane is inside a steady stretch (or every one inside a fade, past its first sample, no
                         // NaN target) the next n = min over the lanes of samples left in the stretch run as a rolled loop
                         const bool fad = f.hasNew;
@@ -1096,7 +1178,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     if (live) d = A.utt[u];
     const FrameWindow fw = frame_window(A, d);
     const StageCtx X{A, d, A.frames + fw.base * kNumParams, A.meta + fw.base, fw.off, fw.mask,
-                     FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr, LONE};
+                     FLAT ? A.flatRef + d.frameStart : nullptr, FLAT ? A.sourceRef + d.frameStart : nullptr, LONE,
+                     LONE ? reinterpret_cast<double*>(lds + L::kBytes + wave * kLoneLdsPerStage) : nullptr};
     const uint32_t nkey = noise_key(d.seed), ninc = noise_inc(d.seed), ninc2 = noise_inc2(ninc);
     constexpr int FINAL = NOISE ? 2 : 3;
     // quiet launches read a steady chunk's inputs from the pipe up front (the loads of all CH samples go out

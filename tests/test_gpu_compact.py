@@ -279,7 +279,8 @@ def test_read_all_async_needs_a_launch():
 
 def test_a_handle_pulled_alone_fills_its_wavefront_and_changes_nothing(ref):
     """A lone handle is advanced in all 64 lanes of its wavefront (64 identical control entries) on the kernel's LONE instantiation,
-    whose fade chunks are computed side by side across those lanes (speechPlayer_setGlobalOption("live_replicate")): the same PCM,
+    whose fade stretches -- whole chunks, and the runs either side of an event inside a chunk -- are computed side by side across those
+    lanes and handed out through LDS (speechPlayer_setGlobalOption("live_replicate")): the same PCM,
     call lengths and index marks as in one lane, pull by pull -- ragged pulls through speech with fades, silences, marks and a purge
     in the middle of a fade; and the same when the option changes between pulls of one handle."""
     import nvspeechplayer_amd as eng

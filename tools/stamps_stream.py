@@ -1,7 +1,8 @@
-"""KLATT_STAMPS build with the stream hook of tools/variants (speechPlayer_debugStreamStamps): where the four stages of ONE live handle
+"""KLATT_STAMPS build (its stream hook: speechPlayer_debugStreamStamps, klatt_engine.hip): where the four stages of ONE live handle
 spend their cycles over the pulls of bench.py's single_stream extra -- per stage: chunks decided steady / fade / sample by sample and the
 cycles (s_memtime, 100 MHz) spent in each kind, work against barrier wait.
 
+    python tools/ab_probe.py build stamps=-DKLATT_STAMPS=1
     SPEECHPLAYER_LIB=nvspeechplayer_amd/lib/variants/libspeechPlayer_stamps.so python tools/stamps_stream.py [pulls]
 """
 import ctypes, json, os, sys

@@ -262,6 +262,9 @@ int speechPlayer_lastLiveLaunches(int device);
  * at 16 384 slots), and speechPlayer_initialize fails with SPEECHPLAYER_ERR_HIP when the device cannot hold it.  It does not shrink while
  * a handle lives; "live_trim" = 1 releases a device's arena (and the pull buffers) when the LAST handle on that device is terminated --
  * and at once on devices where none lives; 0 (default) keeps it for the next handles.
+ * "live_replicate" (default 1): a pull of fewer than 32 handles fills the empty lanes of their wavefront with replicas of them (a sparse
+ * wavefront runs up to 1.7 times slower), and ONE handle pulled alone is advanced in all 64 lanes by a kernel instantiation of its own that
+ * computes its fades side by side across the lanes; 0: one lane per handle.  Same PCM, marks and counts either way.
  * "plan_hash_bits" (tests): how many bits of a frame's 128-bit shape hash the track planner looks at (default 128). */
 int speechPlayer_setGlobalOption(const char* name, int value);
 /* Choose a handle's noise stream (default 0); see DESIGN.md "Noise". */

@@ -71,7 +71,9 @@ constexpr int kStages = 4;
 
 // LDS per workgroup: pipes [2 buffers][CH][64 lanes] f64 (4 noisy / 3 quiet), the PCM tile and row
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
-template <bool NOISE, int CH, bool FLAT = false>
+// MOVED: cascade resonators (r3, then r2) that the cascade's head stage takes over from the final stage; 3: all three, and the nasal pair
+// N0, NP goes from the head stage to the source stage (stream_moved below)
+template <bool NOISE, int CH, bool FLAT = false, int MOVED = 0>
 struct SysLds {
     static constexpr int kBufs = 2;                                        // buffers of a pipe (the barrier keeps the stages within one chunk of each other)
     static constexpr int kBufsX = 2;                                       // ... of pipe X (S0 -> S1), the first in memory
@@ -87,7 +89,7 @@ struct SysLds {
     static constexpr int kFrames = kSync + 32;
     // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
     // flat launches (FLAT): the stages take everything from the tracks and keep no fade end points: 0, 0, 0, 0
-    static constexpr int kParams0 = (FLAT && KLATT_FLAT_SOURCE) ? 0 : 7, kParams1 = FLAT ? 0 : (NOISE ? 11 : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
+    static constexpr int kParams0 = (FLAT && KLATT_FLAT_SOURCE) ? 0 : (MOVED == 3 ? 12 : 7), kParams1 = FLAT ? 0 : (NOISE ? (MOVED == 3 ? 12 : 11 + 2 * MOVED) : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 - 2 * MOVED : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
     static constexpr int kFrames1 = kFrames + 1 * kParams0 * kLanes * 8;    // S0 keeps its target values in registers
     static constexpr int kFrames2 = kFrames1 + 2 * kParams1 * kLanes * 8;
     static constexpr int kFrames3 = kFrames2 + 2 * kParams2 * kLanes * 8;
@@ -147,9 +149,23 @@ struct StageCtx {          // what every stage needs from the launch
     const FlatRef* myFlat;     // flat launches: the utterance's per-frame track references, loaded ahead by the stages (klatt_device.h)
     const SourceRef* mySrc;    // flat launches: what the source stage loads ahead
     bool lone = false;         // live handles: every lane of the wavefront advances ONE handle (streams_synthesize's replicas); wave-uniform
-    double* loneLds = nullptr;   // ... and this stage's 11 KB of LDS behind the kernel's own (kLoneLdsPerStage): the values of a fade's next 64 samples, [slot][sample]
+    double* loneLds = nullptr;   // ... and this stage's 12 KB of LDS behind the kernel's own (kLoneLdsPerStage): the values of a fade's next 64 samples, [slot][sample]
 };
-constexpr int kLoneLdsPerStage = 11264;
+constexpr int kLoneLdsPerStage = 12288;
+// Live handles with one workgroup per CU (up to 16 384 of them; one pulled alone): a launch's pace is its slowest stage's, not a SIMD's
+// load, and the batch launches' split -- source | N0, NP, r6..r4 | r3..r1, parallel 5, 6, mix, PCM | frication, parallel 1..4: a lone
+// handle's steady chunk 2570 | 3360 | 4960 | 3970 ticks -- is balanced for pairs of stages on a SIMD.  Of the final stage's three cascade
+// resonators this many go to the cascade's head stage; 3: all of them, and the nasal pair N0, NP goes from the head stage to the source
+// stage: source, N0, NP | r6..r1 | parallel 5, 6, mix, PCM | frication, parallel 1..4 = 3530 | 3310 | 3930 | 3850 (one pull of a lone
+// handle 1.46 -> 1.37 (1) -> 1.33 (2) -> 1.30 ms (3); 8192 handles 2.53 -> 2.48 ms).  Same arithmetic in the same order; a handle's
+// saved state is numbered by resonator, not by stage, so pulls may alternate between the layouts.
+#ifndef KLATT_STREAM_MOVED
+#define KLATT_STREAM_MOVED 3
+#endif
+// the noisy final stage's parameters and resonators (block numbering) once `moved` cascade resonators have left it
+__device__ constexpr int final_param(int moved, int k) { constexpr int L0[14] = {9, 17, 8, 16, 7, 15, 29, 35, 30, 36, 41, 42, 43, 45}; return L0[k + 2 * moved < 13 ? k + 2 * moved : 13]; }
+__device__ constexpr int final_res(int moved, int r) { constexpr int G0[5] = {5, 6, 7, 12, 13}; return G0[r + moved < 4 ? r + moved : 4]; }
+template <bool STREAM, int WPS> constexpr int stream_moved() { return (STREAM && WPS == 1) ? KLATT_STREAM_MOVED : 0; }
 
 // OR over the wavefront of the low NBITS bits of a per-lane mask, as a wave-uniform (scalar) value.
 // One ballot per bit: a handful of instructions, no LDS round trips (a shuffle reduction costs 6).
@@ -1152,7 +1168,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
     static_assert(NOISE || !STREAM, "live handles take the noisy instantiation");
     static_assert(!FLAT || (NOISE && !STREAM), "tracks: noisy batch launches");
-    using L = SysLds<NOISE, CH, FLAT>;
+    constexpr int MOVED = stream_moved<STREAM, WPS>();
+    using L = SysLds<NOISE, CH, FLAT, MOVED>;
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     using PipeT = typename std::conditional<FLAT, sig_t, double>::type;                // what the stages hand over
@@ -1432,10 +1449,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // ================= S0: frame + glottal source (+ aspiration noise) =================
         // tracked: 1 vibratoPitchOffset, 2 vibratoSpeed, 3 turbulence, 4 openQuotient, 5 voiceAmplitude,
         //          6 aspirationAmplitude, 44 preFormantGain (quiet launches never read 3, 4, 6)
-        using D = StageDesc<7, 0, 6, true, false>;
-        constexpr int P[7] = {1, 2, 3, 4, 5, 6, 44};
-        constexpr int RF[1] = {0}, RB[1] = {0};
-        StageFrame<7, 0, true> f;         // 7 target values in registers: S0 has the room, the workgroup's LDS does not
+        // MOVED == 3 (live handles, one workgroup per CU): and the nasal pair N0 (anti), NP mixed in by caNP, behind the source
+        constexpr bool NP0 = MOVED == 3;
+        using D = StageDesc<NP0 ? 12 : 7, NP0 ? 2 : 0, 6, true, NP0, NP0>;
+        constexpr int P[12] = {1, 2, 3, 4, 5, 6, 44, 13, 21, 14, 22, 23};
+        constexpr int RF[2] = {7, 9}, RB[2] = {8, 10};
+        StageFrame<D::NPARAM, D::NRES, true> f;         // the target values in registers: S0 has the room, the workgroup's LDS does not
         PitchState ps;
         stage_frame_init(f, live, lds + L::kFrames, lane);
         ps.cur0 = 0.0; ps.old0 = 0.0; ps.new0 = 0.0; ps.oldInc = 0.0; ps.newInc = 0.0;
@@ -1443,7 +1462,7 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         uint32_t noiseSt = noise_first(nkey, ninc);     // the state of this stage's next noise value (aspiration: values 0, 2, 4, ...)
         int32_t lastIndex = -1;
         bool vibFrames = false;
-        constexpr int GR0[1] = {0};
+        constexpr int GR0[2] = {0, 1};
         if (STREAM && live) {
             if (streamState[239] != 0.0) {
                 pitchPhase = streamState[208]; vibPhase = streamState[209]; aspNoise = streamState[210];
@@ -1477,7 +1496,12 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             } else {
                 src = voice * f.cur[4];
             }
-            return (src * f.cur[6]) * 0.5;
+            const double x = (src * f.cur[6]) * 0.5;
+            if (!NP0) return x;
+            const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
+            f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
+            const double np = resonate<MODE>(f.z1[NP0 ? 1 : 0], f.z2[NP0 ? 1 : 0], f.ra[NP0 ? 1 : 0], f.rb[NP0 ? 1 : 0], f.rc[NP0 ? 1 : 0], n0);
+            return fade_value(x, np, f.cur[NP0 ? 11 : 0]);
         };
         auto vib_live_now = [&]() __attribute__((always_inline)) -> bool {
             return vibFrames || f.cur[0] != 0.0 || f.cur[1] != 0.0 || vibPhase != vibPhase;
@@ -1751,24 +1775,29 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         if (s1) run(1); else run(2);
     } else if (stage == 1) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
-        constexpr int NR = NOISE ? 5 : 3;
-        using D = StageDesc<2 * NR + 1, NR, -1, false, true, NOISE>;
-        // parameter list: (f, bw) of N0, NP, r6 [, r5, r4], then caNP
-        constexpr int P[11] = {13, 21, 14, 22, 12, 20, NOISE ? 11 : 23, 19, 10, 18, 23};
-        constexpr int RF[5] = {0, 2, 4, 6, 8};
-        constexpr int RB[5] = {1, 3, 5, 7, 9};
-        constexpr int CANP = 2 * NR;
-        StageFrame<2 * NR + 1, NR> f;
+        constexpr bool HEAD = MOVED != 3;                  // N0 and NP are here (MOVED == 3: in the source stage; this stage is r6 .. r1)
+        constexpr int NR = NOISE ? (HEAD ? 5 + MOVED : 6) : 3;
+        using D = StageDesc<HEAD ? 2 * NR + 1 : 2 * NR, NR, -1, false, HEAD, NOISE>;
+        // parameter list: (f, bw) of N0, NP, r6 [, r5, r4 [, r3 [, r2]]], then caNP
+        constexpr int P[15] = {HEAD ? 13 : 12, HEAD ? 21 : 20, HEAD ? 14 : 11, HEAD ? 22 : 19, HEAD ? 12 : 10, HEAD ? 20 : 18, HEAD ? (NOISE ? 11 : 23) : 9, HEAD ? 19 : 17,
+                               HEAD ? 10 : 8, HEAD ? 18 : 16, HEAD ? (MOVED >= 1 ? 9 : 23) : 7, HEAD ? 17 : 15, MOVED >= 2 ? 8 : 23, 16, 23};
+        constexpr int RF[7] = {0, 2, 4, 6, 8, 10, 12};
+        constexpr int RB[7] = {1, 3, 5, 7, 9, 11, 13};
+        constexpr int CANP = HEAD ? 2 * NR : 0;
+        StageFrame<D::NPARAM, NR> f;
         stage_frame_init(f, live, lds + L::kFrames1, lane);
-        constexpr int GR1[5] = {0, 1, 2, 3, 4};
+        constexpr int GR1[7] = {HEAD ? 0 : 2, HEAD ? 1 : 3, HEAD ? 2 : 4, HEAD ? 3 : 5, HEAD ? 4 : 6, HEAD ? 5 : 7, 6};
         if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GR1, streamPurge);
         auto dsp = [&](double x) __attribute__((always_inline)) -> double {
-            const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
-            f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
-            const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
-            double o = fade_value(x, np, f.cur[CANP]);
+            double o = x;
+            if (HEAD) {
+                const double n0 = dot3<MODE>(f.ra[0], x, f.rb[0], f.z1[0], f.rc[0], f.z2[0]);
+                f.z2[0] = f.z1[0]; f.z1[0] = x;                       // anti-resonator remembers its INPUT (:133)
+                const double np = resonate<MODE>(f.z1[1], f.z2[1], f.ra[1], f.rb[1], f.rc[1], n0);
+                o = fade_value(x, np, f.cur[CANP]);
+            }
 #pragma unroll
-            for (int r = 2; r < NR; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
+            for (int r = HEAD ? 2 : 0; r < NR; ++r) o = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], o);
             return o;
         };
         stage_loop<D, MODE, CH, KFil>(1, nIter, nChunks, fullChunks, stage, f, nullptr, nullptr, noDelay, P, RF, RB, X, never, noBegin, noAlt, noAltSample,
@@ -1835,18 +1864,21 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // ================= final stage: rest of the cascade, (parallel r5, r6 + bypass), gain, clip, PCM ===
         // noisy (stage 2): r3, r2, r1 | parallel 5, 6 | pa5, pa6, parallelBypass, outputGain
         // quiet (stage 3): r2, r1 | outputGain          quiet, nasal-free (stage 3): outputGain only
-        constexpr int NC = NOISE ? 3 : (NASAL ? 2 : 0);   // cascade resonators here
-        constexpr int NR = NOISE ? 5 : NC;
-        constexpr int NPAR = NOISE ? 14 : (NASAL ? 5 : 1);
+        constexpr int NC = NOISE ? 3 - MOVED : (NASAL ? 2 : 0);   // cascade resonators here
+        constexpr int NR = NOISE ? NC + 2 : NC;
+        constexpr int NPAR = NOISE ? 2 * NC + 8 : (NASAL ? 5 : 1);
         using D = StageDesc<NPAR, NR, -1, false, false, NOISE>;
-        constexpr int P[14] = {NOISE ? 9 : (NASAL ? 8 : 45), NOISE ? 17 : 16, NOISE ? 8 : 7, NOISE ? 16 : 15, NOISE ? 7 : 45, 15,
-                               29, 35, 30, 36, 41, 42, 43, 45};
+        // noisy: (f, bw) of the cascade resonators left here, of parallel 5, 6, then pa5, pa6, parallelBypass, outputGain
+        constexpr int P[14] = {NOISE ? final_param(MOVED, 0) : (NASAL ? 8 : 45), NOISE ? final_param(MOVED, 1) : 16, NOISE ? final_param(MOVED, 2) : 7,
+                               NOISE ? final_param(MOVED, 3) : 15, NOISE ? final_param(MOVED, 4) : 45, final_param(MOVED, 5), final_param(MOVED, 6), final_param(MOVED, 7),
+                               final_param(MOVED, 8), final_param(MOVED, 9), final_param(MOVED, 10), final_param(MOVED, 11), final_param(MOVED, 12), 45};
         constexpr int RF[5] = {0, 2, NOISE ? 4 : 0, 6, 8};
         constexpr int RB[5] = {1, 3, NOISE ? 5 : 0, 7, 9};
-        constexpr int OUTGAIN = NOISE ? 13 : (NASAL ? 4 : 0);
+        constexpr int PA = 2 * NC + 4;                    // noisy: pa5, pa6, parallelBypass follow the resonators' parameters
+        constexpr int OUTGAIN = NOISE ? 2 * NC + 7 : (NASAL ? 4 : 0);
         StageFrame<NPAR, NR> f;
         stage_frame_init(f, live, lds + (NOISE ? L::kFrames2 : L::kFrames3), lane);
-        constexpr int GRF[5] = {5, 6, 7, 12, 13};
+        constexpr int GRF[5] = {final_res(MOVED, 0), final_res(MOVED, 1), final_res(MOVED, 2), final_res(MOVED, 3), 13};
         if (STREAM && live) stage_state_load<D>(f, nullptr, streamState, P, RF, RB, GRF, streamPurge);
         int16_t* const myRow = reinterpret_cast<int16_t*>(tile + lane * kTileStride);
 
@@ -1857,11 +1889,11 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
             if (NOISE) {
                 double par = part;
 #pragma unroll
-                for (int r = 3; r < 5; ++r) {
+                for (int r = NC; r < NC + 2; ++r) {
                     const double w = resonate<MODE>(f.z1[r], f.z2[r], f.ra[r], f.rb[r], f.rc[r], y);
-                    par += (w - y) * f.cur[10 + (r - 3)];
+                    par += (w - y) * f.cur[PA + (r - NC)];
                 }
-                par = fade_value(par, y, f.cur[12]);
+                par = fade_value(par, y, f.cur[PA + 2]);
                 mix = o + par;
             }
             const double v = (mix * f.cur[OUTGAIN]) * 4000.0;

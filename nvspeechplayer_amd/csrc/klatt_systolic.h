@@ -298,7 +298,8 @@ __device__ __forceinline__ double lane_read(double v, int srcLane)
 
 template <class D, int MODE, bool PLAIN = false, class SF>
 __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelArgs& A, const int* RF, const int* RB,
-                                           bool lerp, uint32_t wRes, bool gainOnly = false, uint32_t coefCls = kCoefAllUnknown)
+                                           bool lerp, uint32_t wRes, bool gainOnly = false, uint32_t coefCls = kCoefAllUnknown,
+                                           const double* co = nullptr, const double* cn = nullptr)
 {
     if (!D::PITCH && !lerp) return;
     const double ratio = div_by((double)f.cnt, (double)f.newFade, f.invFade);
@@ -310,7 +311,7 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
     } else if (lerp) {
         double o[D::NPARAM > 0 ? D::NPARAM : 1], n[D::NPARAM > 0 ? D::NPARAM : 1];
 #pragma unroll
-        for (int k = 0; k < D::NPARAM; ++k) { o[k] = f.oldL[k * kLanes]; n[k] = f.getNew(k); }
+        for (int k = 0; k < D::NPARAM; ++k) { o[k] = co ? co[k] : f.oldL[k * kLanes]; n[k] = cn ? cn[k] : f.getNew(k); }
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) f.cur[k] = PLAIN ? o[k] + ((n[k] - o[k]) * ratio) : fade_value(o[k], n[k], ratio);   // PLAIN: no NaN target in any live lane
     }
@@ -331,9 +332,9 @@ __device__ __forceinline__ void stage_fade(SF& f, PitchState* ps, const KernelAr
 // advance the state machine by one sample (any mix of lanes); returns true when a sample is emitted
 template <class D, int MODE, class SF>
 __device__ __forceinline__ bool stage_advance(SF& f, PitchState* ps, int32_t* lastIndex, const int* P, const int* RF, const int* RB,
-                                              const StageCtx& X)
+                                              const StageCtx& X, const double* co = nullptr, const double* cn = nullptr, bool* anyEvent = nullptr)
 {
-    bool emit = false;
+    bool emit = false, ev = false;
     bool fading = false;
     if (!f.done) {
         f.cnt++;
@@ -343,13 +344,15 @@ __device__ __forceinline__ bool stage_advance(SF& f, PitchState* ps, int32_t* la
             emit = true;
         } else {
             emit = stage_event<D>(f, ps, lastIndex, P, RF, RB, X);
+            ev = true;
         }
     }
+    if (anyEvent) *anyEvent = __any(ev);
     if (__any(fading)) {
         // first fade sample of a lane: everything; later: what moves in some fading lane
         const bool lerp = __any(fading && (f.cnt == 1 || f.parMask != 0u));
         const uint32_t wRes = wave_or_bits<D::NRES>(fading ? ((f.cnt == 1) ? 0xFFFFFFFFu : f.resMask) : 0u);
-        if (fading) stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes);
+        if (fading) stage_fade<D, MODE>(f, ps, X.A, RF, RB, lerp, wRes, false, kCoefAllUnknown, co, cn);
     }
     return emit;
 }
@@ -528,9 +531,9 @@ struct Stamps {
 // the noisy kernels: the extra code costs them more than the runs save, cfg2 15.8 -> 16.8 ms.)  DELAY: lanes start `delay`
 // steps late (the lane-pipelined kernel's skew).  STREAM: the launch runs exactly A.maxSamples steps (live handles).
 #define STAGE_SYNC() __syncthreads()
-template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_, bool LONE_ = false>
+template <bool PRE_, bool RUNS_, bool DELAY_, bool STREAM_, bool NOISE_, int UNROLL_, bool LONE_ = false, bool CACHE_ = false>
 struct LoopKnobs {
-    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_, LONE = LONE_;
+    static constexpr bool PRE = PRE_, RUNS = RUNS_, DELAY = DELAY_, STREAM = STREAM_, NOISE = NOISE_, LONE = LONE_, CACHE = CACHE_;
     static constexpr int UNROLL = UNROLL_;
 };
 
@@ -735,6 +738,9 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
             } else {
                 (void)begin(-1);
                 int i = 0;
+                // live handles with registers to spare: the fades' end points of the lanes are kept in registers between events (24-28 LDS reads a sample otherwise)
+                double co[NP_], cn[NP_];
+                bool cached = false;
 #pragma nounroll
                 while (i < lim) {
                     if (K::LONE && !forceGeneral()) {
@@ -824,6 +830,16 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                         if (hold) { delay--; f.done = true; }
                         const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
                         if (hold) f.done = wasDone;
+                        gen(c, i, emit);
+                    } else if (K::CACHE) {
+                        if (!cached) {
+#pragma unroll
+                            for (int k = 0; k < D::NPARAM; ++k) { co[k] = f.oldL[k * kLanes]; cn[k] = f.getNew(k); }
+                            cached = true;
+                        }
+                        bool anyEvent = false;
+                        const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X, co, cn, &anyEvent);
+                        if (anyEvent) cached = false;
                         gen(c, i, emit);
                     } else {
                         const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
@@ -1239,8 +1255,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     // pipe slot of sample i of chunk c
 #define PIPE(p, c, i) (p)[(((nbuf_##p) == 2 ? ((c) & 1) : ((c) % (nbuf_##p))) * kChunk + (i)) * kLanes + lane]
     // the chunk loop's knobs: quiet launches preload a steady chunk's inputs and run uniform stretches inside event chunks
-    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, LONE>;      // stages without a pipe input
-    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, LONE>;       // stages that read a pipe
+    using KSrc = LoopKnobs<false, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, LONE, (STREAM && WPS == 1 && !LONE)>;      // stages without a pipe input
+    using KFil = LoopKnobs<kPre, (!NOISE || KLATT_NOISY_RUNS), false, STREAM, NOISE, KLATT_UNROLL, LONE, (STREAM && WPS == 1 && !LONE)>;       // stages that read a pipe
     uint32_t noDelay = 0;
     auto never = [&]() __attribute__((always_inline)) { return false; };
     auto noBegin = [&](int) __attribute__((always_inline)) { return false; };

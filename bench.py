@@ -234,6 +234,45 @@ def single_stream_extra(pulls=50, pull=8192):
             "oracle_ms_per_pull_median": float(np.median(t_cpu)) * 1e3, "real_time_ms_per_pull": pull / 22050.0 * 1e3, "pcm_equal": bool(same)}
 
 
+def live_handles_extra(n=1024, pull=8192, pulls=4):
+    """Many live handles advanced together (speechPlayer_synthesizeMany, PCM left in HBM): kernel ms per 8192-sample pull when the
+    handles speak IN STEP (one sentence, same sample: a wavefront's chunks are steady or fading as a whole) and when they are
+    UNRELATED (the eight sampleIpa sentences, every handle skewed by a pull of its own first: every chunk runs sample by sample).
+    Up to 16 384 handles a pull lasts as long as one workgroup's, so 1024 handles stand for the larger pulls too."""
+    import numpy as np
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import workloads, _native
+    L = _native.load()
+    b = workloads.make("cfg2", 8)
+    fs = b["frame_start"]
+    lines = [[(b["frames"][k], int(b["min"][k]), int(b["fade"][k]), bool(b["isnull"][k])) for k in range(int(fs[u]), int(fs[u + 1]))] for u in range(8)]
+    rng = np.random.default_rng(3)
+    out = {"handles": n, "samples_per_pull": pull, "what": "kernel ms per pull of all handles together (speechPlayer_lastLiveKernelMs), median of %d" % pulls}
+    for key, unrelated in (("in_step", False), ("unrelated", True)):
+        players = [eng.SpeechPlayer(22050, noiseSeed=k) for k in range(n)]
+        for k, p in enumerate(players):
+            rows = lines[k % 8] if unrelated else lines[5]
+            queued = 0
+            while queued < (pulls + 2) * pull + 4096:
+                for fr, m, f, nul in rows:
+                    p.queueFrameSamples(None if nul else eng.Frame.from_array(fr), m, f)
+                    queued += max(m, max(f, 1) + 1) + 1
+            if unrelated:
+                p.synthesize(int(rng.integers(1, 4000)))
+        group = eng.LiveGroup(players)
+        group.pullDevice(64)
+        kms = []
+        for _ in range(pulls):
+            _, _, produced = group.pullDevice(pull)
+            kms.append(float(L.speechPlayer_lastLiveKernelMs(0)))
+        ms = float(np.median(kms))
+        out[key] = {"kernel_ms": ms, "samples_per_s": float(produced.sum()) / (ms * 1e-3), "all_handles_full": bool((produced == pull).all())}
+        for p in players:
+            p.close()
+        del group, players
+    return out
+
+
 def cfg0_cpu_extra():
     """BASELINE configs[0]: a single steady /a/ at 120 Hz, 1 s at 22.05 kHz, on the CPU (the oracle on one core; SURVEY 8c's recipe,
     test_playVowelchart path): samples/s and multiples of real time."""
@@ -703,7 +742,7 @@ def main():
                 out["pipeline"]["pageable_host_buffers"] = dict(extra(pinned=False, **same), with_pcm_to_host=extra(n_batches=8, players=6, workers=4, copy_out=True, pinned=False))
                 batch = batch_keep
             if world == 1 and not args.no_extras:
-                for key, fn in (("single_stream", single_stream_extra), ("cfg0_cpu", cfg0_cpu_extra)):
+                for key, fn in (("single_stream", single_stream_extra), ("live_handles", live_handles_extra), ("cfg0_cpu", cfg0_cpu_extra)):
                     try:
                         out[key] = fn()
                     except Exception as e:      # noqa: BLE001

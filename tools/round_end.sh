@@ -39,8 +39,8 @@ for f in ("r6_bench", "r6_bench_steps20", "r6_bench_fast", "r6_bench_cfg1", "r6_
     for k, v in d.items():
         if isinstance(v, dict) and "kernel_ms" in v:
             print("    %-34s %8.3f ms" % (k, v["kernel_ms"]))
-        elif k in ("pipeline", "pipeline_from_ipa", "single_stream", "cfg0_cpu") and isinstance(v, dict):
-            print("    %-34s %s" % (k, {a: b for a, b in v.items() if not isinstance(b, (list, dict))}))
+        elif k in ("pipeline", "pipeline_from_ipa", "single_stream", "live_handles", "cfg0_cpu") and isinstance(v, dict):
+            print("    %-34s %s" % (k, {a: b for a, b in v.items() if not isinstance(b, list) and (k == "live_handles" or not isinstance(b, dict))}))
     if "config" in d and "host" in d["config"]:
         print("    host:", d["config"]["host"])
 PY

@@ -236,9 +236,10 @@ def single_stream_extra(pulls=50, pull=8192):
 
 def live_handles_extra(n=1024, pull=8192, pulls=4):
     """Many live handles advanced together (speechPlayer_synthesizeMany, PCM left in HBM): kernel ms per 8192-sample pull when the
-    handles speak IN STEP (one sentence, same sample: a wavefront's chunks are steady or fading as a whole) and when they are
-    UNRELATED (the eight sampleIpa sentences, every handle skewed by a pull of its own first: every chunk runs sample by sample).
-    Up to 16 384 handles a pull lasts as long as one workgroup's, so 1024 handles stand for the larger pulls too."""
+    handles speak IN STEP (one sentence, same sample: a shared wavefront's chunks are steady or fading as a whole) and when they are
+    UNRELATED (the eight sampleIpa sentences, every handle skewed by a pull of its own first: every chunk of a shared wavefront runs
+    sample by sample) -- with a wavefront per handle (the default up to 1024 handles, option "live_alone") and with 64 handles per
+    wavefront ("live_alone" 1: what larger pulls get; up to 16 384 handles such a pull lasts as long as one workgroup's)."""
     import numpy as np
     import nvspeechplayer_amd as eng
     from nvspeechplayer_amd import workloads, _native
@@ -246,30 +247,36 @@ def live_handles_extra(n=1024, pull=8192, pulls=4):
     b = workloads.make("cfg2", 8)
     fs = b["frame_start"]
     lines = [[(b["frames"][k], int(b["min"][k]), int(b["fade"][k]), bool(b["isnull"][k])) for k in range(int(fs[u]), int(fs[u + 1]))] for u in range(8)]
-    rng = np.random.default_rng(3)
     out = {"handles": n, "samples_per_pull": pull, "what": "kernel ms per pull of all handles together (speechPlayer_lastLiveKernelMs), median of %d" % pulls}
-    for key, unrelated in (("in_step", False), ("unrelated", True)):
-        players = [eng.SpeechPlayer(22050, noiseSeed=k) for k in range(n)]
-        for k, p in enumerate(players):
-            rows = lines[k % 8] if unrelated else lines[5]
-            queued = 0
-            while queued < (pulls + 2) * pull + 4096:
-                for fr, m, f, nul in rows:
-                    p.queueFrameSamples(None if nul else eng.Frame.from_array(fr), m, f)
-                    queued += max(m, max(f, 1) + 1) + 1
-            if unrelated:
-                p.synthesize(int(rng.integers(1, 4000)))
-        group = eng.LiveGroup(players)
-        group.pullDevice(64)
-        kms = []
-        for _ in range(pulls):
-            _, _, produced = group.pullDevice(pull)
-            kms.append(float(L.speechPlayer_lastLiveKernelMs(0)))
-        ms = float(np.median(kms))
-        out[key] = {"kernel_ms": ms, "samples_per_s": float(produced.sum()) / (ms * 1e-3), "all_handles_full": bool((produced == pull).all())}
-        for p in players:
-            p.close()
-        del group, players
+    try:
+        for key, unrelated in (("in_step", False), ("unrelated", True)):
+            out[key] = {}
+            for policy, alone in (("a_wavefront_per_handle", 1024), ("64_handles_per_wavefront", 1)):
+                assert L.speechPlayer_setGlobalOption(b"live_alone", alone) == 0
+                rng = np.random.default_rng(3)
+                players = [eng.SpeechPlayer(22050, noiseSeed=k) for k in range(n)]
+                for k, p in enumerate(players):
+                    rows = lines[k % 8] if unrelated else lines[5]
+                    queued = 0
+                    while queued < (pulls + 2) * pull + 4096:
+                        for fr, m, f, nul in rows:
+                            p.queueFrameSamples(None if nul else eng.Frame.from_array(fr), m, f)
+                            queued += max(m, max(f, 1) + 1) + 1
+                    if unrelated:
+                        p.synthesize(int(rng.integers(1, 4000)))
+                group = eng.LiveGroup(players)
+                group.pullDevice(64)
+                kms = []
+                for _ in range(pulls):
+                    _, _, produced = group.pullDevice(pull)
+                    kms.append(float(L.speechPlayer_lastLiveKernelMs(0)))
+                ms = float(np.median(kms))
+                out[key][policy] = {"kernel_ms": ms, "samples_per_s": float(produced.sum()) / (ms * 1e-3), "all_handles_full": bool((produced == pull).all())}
+                for p in players:
+                    p.close()
+                del group, players
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
     return out
 
 

@@ -1316,6 +1316,7 @@ int g_liveLayout = [] { const char* e = getenv("SPEECHPLAYER_LIVE_LAYOUT"); retu
 int g_liveCus = 0;
 bool g_liveCusForced = false;
 int g_liveReplicate = [] { const char* e = getenv("SPEECHPLAYER_LIVE_REPLICATE"); return e ? atoi(e) : 1; }();   // a lone handle fills its wavefront (streams_synthesize)
+int g_liveAlone = [] { const char* e = getenv("SPEECHPLAYER_LIVE_ALONE"); return e ? atoi(e) : 1024; }();   // pulls of up to this many handles: a wavefront per handle (streams_synthesize)
 int g_liveTrim = 0;                 // speechPlayer_setGlobalOption("live_trim"): release a device's arena when its last handle is terminated
 
 // c->mu held.  No handle lives on this device: give its arena (state blocks, rings) and the pull buffers back.  The next
@@ -1480,17 +1481,22 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     // thirty 8192-sample pulls of one handle 3.05 -> 2.04 ms of kernel time on average (tools/single_stream_ab.sh).  The launch then takes
     // the kernel's LONE instantiation, whose fade chunks are computed side by side across the identical lanes (klatt_systolic.h,
     // stage_loop: 2.04 -> 1.84 ms); control bit 1 marks the entries.
-    const bool replicate = n == 1 && g_liveLayout != 0 && g_liveReplicate;
+    // The same goes for a pull of SEVERAL handles, up to "live_alone" of them (default 1024): a workgroup per handle, 64 replicas each.  Handles
+    // that share a wavefront pay for one another -- with unrelated handles every chunk has some lane at an event or in a fade and runs sample
+    // by sample: 11.7 ms per 8192-sample pull however few they are -- while a handle alone in its wavefront costs 1.3-1.7 ms and 256 of them
+    // run side by side, one per CU (the LONE instantiation's LDS allows one workgroup per CU): n handles take ceil(n / CUs) rounds of that.
+    const bool replicate = n >= 1 && n <= std::max(1, g_liveAlone) && g_liveLayout != 0 && g_liveReplicate;
+    const int rep = replicate ? kLanes : 1;              // control entries (lanes) per handle
     // (a FEW handles pulled together -- fewer than half a wavefront -- get their empty lanes filled with replicas of themselves too, on the
     // ordinary kernel: the same effect, and the same remedy as for the sparse wavefronts of a batch)
     const bool fillSparse = !replicate && n > 1 && n < kLanes / 2 && g_liveLayout != 0 && g_liveReplicate;
-    const int nCtl = (replicate || fillSparse) ? kLanes : n;
+    const int nCtl = replicate ? n * kLanes : (fillSparse ? kLanes : n);
     const size_t ctlBytes = (size_t)nCtl * (sizeof(UttDesc) + sizeof(double*) + sizeof(uint32_t));
     if (c->hCtl.reserve(ctlBytes) || c->dCtl.reserve(c->hCtl.cap) || c->hResult.reserve(nCtl) || c->dResult.reserve(c->hResult.cap) ||
         c->dPcm.reserve(padded * n))
         return -1;
-    if (c->orderFilled < (size_t)n) {
-        const size_t m = std::max<size_t>(n, 1024);
+    if (c->orderFilled < (size_t)nCtl) {
+        const size_t m = std::max<size_t>(nCtl, 1024);
         std::vector<uint32_t> iota(m);
         std::iota(iota.begin(), iota.end(), 0u);
         if (c->dOrder.reserve(m)) return -1;
@@ -1543,18 +1549,21 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         }
         for (int i = 0; i < n; ++i) {
             const Stream* s = ss[i];
-            UttDesc& d = hUtt[i];
+            UttDesc& d = hUtt[(size_t)i * rep];
             d.frameStart = (long long)s->slot * kRing + s->ringHead;
             d.outStart = (long long)(i * padded);
             d.nFrames = s->ringCount;
             d.seed = s->seed; d.flags = UTT_NEEDS_NOISE;
             d.length = piece;                // the stage-parallel kernel runs exactly `piece` steps (klatt_systolic.h, STREAM)
-            hState[i] = c->dState.ptr + (size_t)s->slot * kStateDoubles;
-            hControl[i] = s->purgePending ? 1u : 0u;
+            hState[(size_t)i * rep] = c->dState.ptr + (size_t)s->slot * kStateDoubles;
+            hControl[(size_t)i * rep] = s->purgePending ? 1u : 0u;
         }
         if (replicate) {
-            hControl[0] |= 2u;               // every lane of the wavefront advances THIS handle
-            for (int i = 1; i < nCtl; ++i) { hUtt[i] = hUtt[0]; hState[i] = hState[0]; hControl[i] = hControl[0]; }
+            for (int i = 0; i < n; ++i) {
+                const size_t j0 = (size_t)i * kLanes;
+                hControl[j0] |= 2u;              // every lane of the wavefront advances THIS handle
+                for (size_t j = j0 + 1; j < j0 + kLanes; ++j) { hUtt[j] = hUtt[j0]; hState[j] = hState[j0]; hControl[j] = hControl[j0]; }
+            }
         } else if (fillSparse) {
             for (int i = n; i < nCtl; ++i) { hUtt[i] = hUtt[i % n]; hState[i] = hState[i % n]; hControl[i] = hControl[i % n]; }
         }
@@ -1590,7 +1599,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
             for (int k = 0; k < 32; ++k) g_streamStamps[k] += h[k];
         }
 #endif
-        HIP_TRY(hipMemcpyAsync(c->hResult.ptr, c->dResult.ptr, n * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipMemcpyAsync(c->hResult.ptr, c->dResult.ptr, (size_t)(replicate ? nCtl : n) * sizeof(UttResult), hipMemcpyDeviceToHost, c->stream));
         if (piece < count || joined) {       // a call in pieces: this piece's columns into the joined rows
             if (c->dPcmJoin.reserve(padded * n)) return -1;
             HIP_TRY(hipMemcpy2DAsync(c->dPcmJoin.ptr + at, padded * sizeof(int16_t), c->dPcm.ptr, padded * sizeof(int16_t), (size_t)piece * sizeof(int16_t), n,
@@ -1607,7 +1616,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
         c->lastKernelMs += kms; c->lastLaunches++;
         for (int i = 0; i < n; ++i) {
             Stream* s = ss[i];
-            const UttResult& r = c->hResult.ptr[i];
+            const UttResult& r = c->hResult.ptr[(size_t)i * rep];
             if (r.produced > piece || r.framesTaken > s->ringCount) { set_error("kernel produced %u > %u (took %u frames of %u)", r.produced, piece, r.framesTaken, s->ringCount); return -1; }
             s->purgePending = false;
             s->ringHead = (s->ringHead + r.framesTaken) & (kRing - 1);
@@ -1813,6 +1822,8 @@ int speechPlayer_setGlobalOption(const char* name, int value)
     if (name && !strcmp(name, "live_cus")) { g_liveCus = value < 0 ? 0 : value; g_liveCusForced = value > 0; return 0; }
     // "live_replicate": 1 (default) a handle pulled alone is advanced in all 64 lanes of its wavefront (streams_synthesize); 0: in one lane
     if (name && !strcmp(name, "live_replicate")) { g_liveReplicate = value ? 1 : 0; return 0; }
+    // "live_alone": pulls of up to this many handles give every handle a wavefront of its own (default 1024; 1: only a handle pulled alone)
+    if (name && !strcmp(name, "live_alone")) { g_liveAlone = value < 1 ? 1 : value; return 0; }
     // "live_trim": 1 = a device's arena of live handles (~100 KB of HBM per slot, grown by doubling) is released when the last handle on
     // that device is terminated -- and now, on devices where none lives; 0 (default): it stays for the next handles.
     if (name && !strcmp(name, "live_trim")) {

@@ -403,16 +403,17 @@ def test_shared_lists_on_every_noisy_path(options):
 
 
 def test_a_few_handles_pulled_together_fill_their_wavefront(ref):
-    """Fewer than 32 live handles in a pull: the empty lanes of their wavefront advance replicas of them (streams_synthesize, option
-    "live_replicate").  Five handles with different sentences, seeds and queue lengths, pulled together in ragged pulls until the
-    last one has drained: the same samples, counts and marks as with the option off."""
+    """A few live handles in a pull: every one in a wavefront of its own (the default: option "live_alone"); or, sharing one wavefront
+    ("live_alone" 1), its empty lanes advance replicas of them (fewer than 32 handles; option "live_replicate").  Five handles with
+    different sentences, seeds and queue lengths, pulled together in ragged pulls until the last one has drained: the same samples,
+    counts and marks as in one lane each of one wavefront."""
     import nvspeechplayer_amd as eng
     from nvspeechplayer_amd import _native
     L = _native.load()
     pulls = [4096, 100, 8192, 1, 3000, 8192]
 
-    def run(replicate):
-        assert L.speechPlayer_setGlobalOption(b"live_replicate", replicate) == 0
+    def run(replicate, alone=1):
+        assert L.speechPlayer_setGlobalOption(b"live_replicate", replicate) == 0 and L.speechPlayer_setGlobalOption(b"live_alone", alone) == 0
         players = []
         for j in range(5):
             p = eng.SpeechPlayer(22050, noiseSeed=100 + j)
@@ -435,11 +436,12 @@ def test_a_few_handles_pulled_together_fill_their_wavefront(ref):
         return [np.concatenate(g) for g in got], marks
     try:
         off, marks_off = run(0)
-        on, marks_on = run(1)
-        assert marks_on == marks_off and [len(x) for x in on] == [len(x) for x in off] and min(len(x) for x in off) > 8000
-        assert all(np.array_equal(a, b) for a, b in zip(on, off))
+        for on, marks_on in (run(1), run(1, alone=1024)):
+            assert marks_on == marks_off and [len(x) for x in on] == [len(x) for x in off] and min(len(x) for x in off) > 8000
+            assert all(np.array_equal(a, b) for a, b in zip(on, off))
     finally:
         L.speechPlayer_setGlobalOption(b"live_replicate", 1)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
 
 
 @pytest.mark.parametrize("deal", [0, 1])

@@ -608,11 +608,15 @@ def test_limits_are_reported_not_wrapped(ref):
     bp.close()
 
 
-def test_many_live_streams_one_launch(ref, all_scenarios):
-    """speechPlayer_synthesizeMany: 130 live handles (3 wavefronts) at unrelated points of unrelated streams,
-    pulled together in uneven chunks, one of them purged on the way, frames queued between pulls --
-    each handle's PCM, call lengths and index marks equal its own oracle player's."""
+@pytest.mark.parametrize("policy", ["alone", "shared", "alternate"])
+def test_many_live_streams_one_launch(ref, all_scenarios, policy):
+    """speechPlayer_synthesizeMany: 130 live handles at unrelated points of unrelated streams, pulled together in uneven chunks, one
+    of them purged on the way, frames queued between pulls -- each handle's PCM, call lengths and index marks equal its own oracle
+    player's.  "alone": every handle in a wavefront of its own (the default up to 1024 handles, option "live_alone"); "shared": 64
+    handles per wavefront (3 wavefronts; "live_alone" 1); "alternate": the policy changes from pull to pull of the same handles."""
     import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    L = _native.load()
     rng = np.random.default_rng(5)
     cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=130)]
     players = [eng.SpeechPlayer(22050, noiseSeed=300 + k) for k in range(len(cases))]
@@ -635,7 +639,11 @@ def test_many_live_streams_one_launch(ref, all_scenarios):
                     for j, (fr, m, f) in enumerate(case[len(case) // 2:]):
                         players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, 1000 + j)
                         oracles[k].queue(fr, m, f, 1000 + j)
-        bufs = eng.SpeechPlayer.synthesizeMany(players, n)
+        assert L.speechPlayer_setGlobalOption(b"live_alone", {"alone": 1024, "shared": 1, "alternate": 1024 if step % 2 else 1}[policy]) == 0
+        try:
+            bufs = eng.SpeechPlayer.synthesizeMany(players, n)
+        finally:
+            L.speechPlayer_setGlobalOption(b"live_alone", 1024)
         for k, b in enumerate(bufs):
             e = oracles[k].synthesize(n)
             g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
@@ -1110,6 +1118,7 @@ def test_live_handles_on_both_kernels(all_scenarios, ref):
     L = _native.load()
     names = ("cfg0_a_1s", "stream_chunks", "purge_resume", "vowelchart_pairs", "hannah_vibrato", "nan_hold", "duration_edges")
     try:
+        assert L.speechPlayer_setGlobalOption(b"live_alone", 1) == 0      # (the 200 handles share wavefronts: the kernels this test is about)
         for policy in ("stage", "lane", "alternate"):
             pulls = [0]
 
@@ -1167,6 +1176,7 @@ def test_live_handles_on_both_kernels(all_scenarios, ref):
             p.close()
     finally:
         L.speechPlayer_setGlobalOption(b"live_layout", 1)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
 
 
 def test_large_live_pulls_take_the_two_per_cu_stream_kernel(all_scenarios, ref):
@@ -1180,6 +1190,7 @@ def test_large_live_pulls_take_the_two_per_cu_stream_kernel(all_scenarios, ref):
     from nvspeechplayer_amd import _native
     L = _native.load()
     try:
+        assert L.speechPlayer_setGlobalOption(b"live_alone", 1) == 0      # (64 handles per wavefront: the kernels this test is about)
         rng = np.random.default_rng(23)
         cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=330)]
         players = [eng.SpeechPlayer(22050, noiseSeed=5000 + k) for k in range(len(cases))]
@@ -1238,6 +1249,7 @@ def test_large_live_pulls_take_the_two_per_cu_stream_kernel(all_scenarios, ref):
     finally:
         L.speechPlayer_setGlobalOption(b"live_cus", 0)
         L.speechPlayer_setGlobalOption(b"live_layout", 1)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
 
 
 def test_quiet_classification_needs_finite_parallel_coefficients(ref):

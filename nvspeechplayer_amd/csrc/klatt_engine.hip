@@ -1823,7 +1823,7 @@ int speechPlayer_setGlobalOption(const char* name, int value)
     // "live_replicate": 1 (default) a handle pulled alone is advanced in all 64 lanes of its wavefront (streams_synthesize); 0: in one lane
     if (name && !strcmp(name, "live_replicate")) { g_liveReplicate = value ? 1 : 0; return 0; }
     // "live_alone": pulls of up to this many handles give every handle a wavefront of its own (default 1024; 1: only a handle pulled alone)
-    if (name && !strcmp(name, "live_alone")) { g_liveAlone = value < 1 ? 1 : value; return 0; }
+    if (name && !strcmp(name, "live_alone")) { g_liveAlone = value < 1 ? 1 : (value > 65536 ? 65536 : value); return 0; }
     // "live_trim": 1 = a device's arena of live handles (~100 KB of HBM per slot, grown by doubling) is released when the last handle on
     // that device is terminated -- and now, on devices where none lives; 0 (default): it stays for the next handles.
     if (name && !strcmp(name, "live_trim")) {

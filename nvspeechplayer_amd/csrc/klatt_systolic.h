@@ -583,7 +583,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
     // `whole`: the stretch is whole chunks of a fade run, else `span` samples inside a chunk with an event).
     constexpr int kLoneG = kLanes / CH;
     constexpr int NP_ = D::NPARAM > 0 ? D::NPARAM : 1;
-    static_assert(!K::LONE || (D::NPARAM + D::NRES + 1) * kLanes * 8 + D::NPARAM * kLoneG * 8 <= kLoneLdsPerStage, "a stage's fade values fit its LDS scratch");
+    static_assert(!K::LONE || (D::NPARAM + D::NRES + 1) * kLanes * 8 + D::NPARAM * kLoneG * 8 <= kLoneLdsPerStage, "a stage's fade values fit its LDS scratch (every resonator's frequency and bandwidth are parameters of their own, without slots)");
     auto loneOfRes = [&](int k) __attribute__((always_inline)) { bool y = false;
 #pragma unroll
         for (int r = 0; r < D::NRES; ++r) y = y || RF[r] == k || RB[r] == k;
@@ -594,8 +594,8 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
         return n; };
     auto loneEval = [&](uint32_t span, bool whole, bool lerp, uint32_t wRes, bool gainOnly, uint32_t coefCls) __attribute__((always_inline)) {
         double* const S = X.loneLds;
-        double* const SL = S + (D::NPARAM + D::NRES + 1) * kLanes;
         const int coef0 = loneSlot(D::NPARAM), pitchSlot = coef0 + 3 * D::NRES;
+        double* const SL = S + (pitchSlot + 1) * kLanes;
         const bool gainAlone = D::GAIN >= 0 && lerp && gainOnly;
         const uint32_t me = threadIdx.x & (kLanes - 1);
         const double ratio = div_by((double)(f.cnt + 1u + (me < span ? me : span - 1u)), (double)f.newFade, f.invFade);
@@ -634,8 +634,8 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
     // sample `at` of the last loneEval becomes the stage's current values (`last`: the stretch ends on it, chunk `endsAt` of the evaluation)
     auto loneTake = [&](int at, bool last, int endsAt, bool lerp, uint32_t wRes, bool gainOnly) __attribute__((always_inline)) {
         const double* const S = X.loneLds;
-        const double* const SL = S + (D::NPARAM + D::NRES + 1) * kLanes;
         const int coef0 = loneSlot(D::NPARAM), pitchSlot = coef0 + 3 * D::NRES;
+        const double* const SL = S + (pitchSlot + 1) * kLanes;
         if (D::PITCH) ps->cur0 = S[pitchSlot * kLanes + at];
         if (D::GAIN >= 0 && lerp && gainOnly) f.cur[GI] = S[loneSlot(GI) * kLanes + at];
         else if (lerp) {

@@ -311,7 +311,7 @@ int launch_systolic(const KernelArgs& a, int mode, long long nGroups, hipStream_
 {
     if (nGroups <= 0) return 0;
     if (nGroups > 0x7FFFFFFF) { set_error("too many workgroups: %lld", nGroups); return -1; }
-    constexpr int ldsBytes = SysLds<NOISE, CH, FLAT, stream_moved<STREAM, WPS>()>::kBytes + (LONE ? kStages * kLoneLdsPerStage : 0);     // LONE: a stage's fade chunks pass through LDS
+    constexpr int ldsBytes = SysLds<NOISE, CH, FLAT, stream_split<STREAM, WPS, LONE>()>::kBytes + (LONE ? kStages * kLoneLdsPerStage : 0);     // LONE: a stage's fade chunks pass through LDS
     static_assert(ldsBytes <= 160 * 1024, "a workgroup's LDS");
     auto go = [&](auto kernel) -> int {
         if (ensure_lds_limit(reinterpret_cast<const void*>(kernel), ldsBytes)) return -1;

@@ -71,10 +71,12 @@ constexpr int kStages = 4;
 
 // LDS per workgroup: pipes [2 buffers][CH][64 lanes] f64 (4 noisy / 3 quiet), the PCM tile and row
 // info of the final stage, then each stage's old/new parameter region.  CH = samples per pipeline hand-over.
-// MOVED: cascade resonators (r3, then r2) that the cascade's head stage takes over from the final stage; 3: all three, and the nasal pair
-// N0, NP goes from the head stage to the source stage (stream_moved below)
-template <bool NOISE, int CH, bool FLAT = false, int MOVED = 0>
+// SPLIT: which stage runs what (stream_split below): bits 0-1 cascade resonators (r3, then r2, then r1) that the cascade's head stage takes
+// over from the final stage, bit 2 the nasal pair N0, NP in the source stage instead of the head stage
+template <bool NOISE, int CH, bool FLAT = false, int SPLIT = 0>
 struct SysLds {
+    static constexpr int MOVED = SPLIT & 3;
+    static constexpr bool NP0 = (SPLIT >> 2) != 0;
     static constexpr int kBufs = 2;                                        // buffers of a pipe (the barrier keeps the stages within one chunk of each other)
     static constexpr int kBufsX = 2;                                       // ... of pipe X (S0 -> S1), the first in memory
     static constexpr int kBufBytes = CH * kLanes * (FLAT ? (int)sizeof(sig_t) : 8);
@@ -89,7 +91,7 @@ struct SysLds {
     static constexpr int kFrames = kSync + 32;
     // parameters per stage (S0, S1, S2, S3): noisy 7, 11, 14, 14; quiet 7, 7, 6, 5
     // flat launches (FLAT): the stages take everything from the tracks and keep no fade end points: 0, 0, 0, 0
-    static constexpr int kParams0 = (FLAT && KLATT_FLAT_SOURCE) ? 0 : (MOVED == 3 ? 12 : 7), kParams1 = FLAT ? 0 : (NOISE ? (MOVED == 3 ? 12 : 11 + 2 * MOVED) : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 - 2 * MOVED : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
+    static constexpr int kParams0 = (FLAT && KLATT_FLAT_SOURCE) ? 0 : (NP0 ? 12 : 7), kParams1 = FLAT ? 0 : (NOISE ? (NP0 ? 0 : 5) + 2 * (3 + MOVED) : 7), kParams2 = FLAT ? 0 : (NOISE ? 14 - 2 * MOVED : 6), kParams3 = FLAT ? 0 : (NOISE ? 14 : 5);
     static constexpr int kFrames1 = kFrames + 1 * kParams0 * kLanes * 8;    // S0 keeps its target values in registers
     static constexpr int kFrames2 = kFrames1 + 2 * kParams1 * kLanes * 8;
     static constexpr int kFrames3 = kFrames2 + 2 * kParams2 * kLanes * 8;
@@ -152,20 +154,34 @@ struct StageCtx {          // what every stage needs from the launch
     double* loneLds = nullptr;   // ... and this stage's 12 KB of LDS behind the kernel's own (kLoneLdsPerStage): the values of a fade's next 64 samples, [slot][sample]
 };
 constexpr int kLoneLdsPerStage = 12288;
-// Live handles with one workgroup per CU (up to 16 384 of them; one pulled alone): a launch's pace is its slowest stage's, not a SIMD's
-// load, and the batch launches' split -- source | N0, NP, r6..r4 | r3..r1, parallel 5, 6, mix, PCM | frication, parallel 1..4: a lone
-// handle's steady chunk 2570 | 3360 | 4960 | 3970 ticks -- is balanced for pairs of stages on a SIMD.  Of the final stage's three cascade
-// resonators this many go to the cascade's head stage; 3: all of them, and the nasal pair N0, NP goes from the head stage to the source
-// stage: source, N0, NP | r6..r1 | parallel 5, 6, mix, PCM | frication, parallel 1..4 = 3530 | 3310 | 3930 | 3850 (one pull of a lone
-// handle 1.46 -> 1.37 (1) -> 1.33 (2) -> 1.30 ms (3); 8192 handles 2.53 -> 2.48 ms).  Same arithmetic in the same order; a handle's
-// saved state is numbered by resonator, not by stage, so pulls may alternate between the layouts.
-#ifndef KLATT_STREAM_MOVED
-#define KLATT_STREAM_MOVED 3
+// Live handles with one workgroup per CU (up to 16 384 of them; one alone in its wavefront): a launch's pace is its slowest stage's, not a
+// SIMD's load, and the batch launches' split -- source | N0, NP, r6..r4 | r3..r1, parallel 5, 6, mix, PCM | frication, parallel 1..4: a lone
+// handle's steady chunk 2570 | 3360 | 4960 | 3970 ticks -- is balanced for pairs of stages on a SIMD.  SPLIT (SysLds above): of the final
+// stage's three cascade resonators bits 0-1 go to the cascade's head stage; bit 2: the nasal pair N0, NP goes from the head stage to the
+// source stage.  7: source, N0, NP | r6..r1 | parallel 5, 6, mix, PCM | frication, parallel 1..4 = 3530 | 3310 | 3930 | 3850 (one pull of a
+// lone handle 1.46 -> 1.37 (split 1) -> 1.33 (2) -> 1.30 ms (7); 8192 handles in step 2.53 -> 2.48 ms; unrelated 13.3 -> 12.3).  Same
+// arithmetic in the same order; a handle's saved state is numbered by resonator, not by stage, so pulls may alternate between splits.
+// Unrelated handles that share wavefronts run every chunk sample by sample, where a stage's cost follows the resonators it evaluates:
+// split 5 -- source, N0, NP | r6..r3 | r2, r1, parallel 5, 6, mix, PCM | frication, parallel 1..4 -- 11.2 ms per pull of 8192 handles
+// against 11.6 with split 7, 11.3 with 6, 12.7 with 4.
+#ifndef KLATT_STREAM_SPLIT
+#define KLATT_STREAM_SPLIT 5      // live handles sharing wavefronts (one workgroup per CU), see below
+#endif
+#ifndef KLATT_LONE_SPLIT
+#define KLATT_LONE_SPLIT 7        // a handle alone in its wavefront
 #endif
 // the noisy final stage's parameters and resonators (block numbering) once `moved` cascade resonators have left it
 __device__ constexpr int final_param(int moved, int k) { constexpr int L0[14] = {9, 17, 8, 16, 7, 15, 29, 35, 30, 36, 41, 42, 43, 45}; return L0[k + 2 * moved < 13 ? k + 2 * moved : 13]; }
 __device__ constexpr int final_res(int moved, int r) { constexpr int G0[5] = {5, 6, 7, 12, 13}; return G0[r + moved < 4 ? r + moved : 4]; }
-template <bool STREAM, int WPS> constexpr int stream_moved() { return (STREAM && WPS == 1) ? KLATT_STREAM_MOVED : 0; }
+template <bool STREAM, int WPS, bool LONE> constexpr int stream_split() { return (STREAM && WPS == 1) ? (LONE ? KLATT_LONE_SPLIT : KLATT_STREAM_SPLIT) : 0; }
+// the parameters of the cascade's head stage: (f, bw) of [N0, NP,] r6 .. (ncasc resonators), [then caNP]
+__device__ constexpr int head_param(bool nasal, int ncasc, int k)
+{
+    constexpr int N[4] = {13, 21, 14, 22}, C[12] = {12, 20, 11, 19, 10, 18, 9, 17, 8, 16, 7, 15};
+    if (nasal && k < 4) return N[k];
+    const int j = nasal ? k - 4 : k;
+    return j < 2 * ncasc ? C[j] : 23;
+}
 
 // OR over the wavefront of the low NBITS bits of a per-lane mask, as a wave-uniform (scalar) value.
 // One ballot per bit: a handful of instructions, no LDS round trips (a shuffle reduction costs 6).
@@ -1184,8 +1200,10 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
     static_assert(NASAL || !NOISE, "only quiet launches have a nasal-free instantiation");
     static_assert(NOISE || !STREAM, "live handles take the noisy instantiation");
     static_assert(!FLAT || (NOISE && !STREAM), "tracks: noisy batch launches");
-    constexpr int MOVED = stream_moved<STREAM, WPS>();
-    using L = SysLds<NOISE, CH, FLAT, MOVED>;
+    constexpr int SPLIT = stream_split<STREAM, WPS, LONE>();
+    constexpr int MOVED = SPLIT & 3;
+    using L = SysLds<NOISE, CH, FLAT, SPLIT>;
+    static_assert(SPLIT != 3, "eight resonators in the head stage: not built");
     constexpr int kChunk = CH;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     using PipeT = typename std::conditional<FLAT, sig_t, double>::type;                // what the stages hand over
@@ -1465,8 +1483,8 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         // ================= S0: frame + glottal source (+ aspiration noise) =================
         // tracked: 1 vibratoPitchOffset, 2 vibratoSpeed, 3 turbulence, 4 openQuotient, 5 voiceAmplitude,
         //          6 aspirationAmplitude, 44 preFormantGain (quiet launches never read 3, 4, 6)
-        // MOVED == 3 (live handles, one workgroup per CU): and the nasal pair N0 (anti), NP mixed in by caNP, behind the source
-        constexpr bool NP0 = MOVED == 3;
+        // SPLIT bit 2 (live handles, one workgroup per CU): and the nasal pair N0 (anti), NP mixed in by caNP, behind the source
+        constexpr bool NP0 = (SPLIT >> 2) != 0;
         using D = StageDesc<NP0 ? 12 : 7, NP0 ? 2 : 0, 6, true, NP0, NP0>;
         constexpr int P[12] = {1, 2, 3, 4, 5, 6, 44, 13, 21, 14, 22, 23};
         constexpr int RF[2] = {7, 9}, RB[2] = {8, 10};
@@ -1791,12 +1809,14 @@ __global__ void __launch_bounds__(kLanes * kStages, WPS) klatt_systolic(const Ke
         if (s1) run(1); else run(2);
     } else if (stage == 1) {
         // ================= S1: N0 (anti), NP mixed by caNP, r6 [, r5, r4] =================
-        constexpr bool HEAD = MOVED != 3;                  // N0 and NP are here (MOVED == 3: in the source stage; this stage is r6 .. r1)
-        constexpr int NR = NOISE ? (HEAD ? 5 + MOVED : 6) : 3;
+        constexpr bool HEAD = (SPLIT >> 2) == 0;           // N0 and NP are here (else in the source stage, and this stage is r6 ..)
+        constexpr int NCASC = NOISE ? 3 + MOVED : 1;       // cascade resonators here: r6 [, r5, r4 [, r3 [, r2 [, r1]]]]
+        constexpr int NR = (HEAD ? 2 : 0) + NCASC;
         using D = StageDesc<HEAD ? 2 * NR + 1 : 2 * NR, NR, -1, false, HEAD, NOISE>;
-        // parameter list: (f, bw) of N0, NP, r6 [, r5, r4 [, r3 [, r2]]], then caNP
-        constexpr int P[15] = {HEAD ? 13 : 12, HEAD ? 21 : 20, HEAD ? 14 : 11, HEAD ? 22 : 19, HEAD ? 12 : 10, HEAD ? 20 : 18, HEAD ? (NOISE ? 11 : 23) : 9, HEAD ? 19 : 17,
-                               HEAD ? 10 : 8, HEAD ? 18 : 16, HEAD ? (MOVED >= 1 ? 9 : 23) : 7, HEAD ? 17 : 15, MOVED >= 2 ? 8 : 23, 16, 23};
+        // parameter list: (f, bw) of [N0, NP,] r6 .., [then caNP]
+        constexpr int P[15] = {head_param(HEAD, NCASC, 0), head_param(HEAD, NCASC, 1), head_param(HEAD, NCASC, 2), head_param(HEAD, NCASC, 3), head_param(HEAD, NCASC, 4),
+                               head_param(HEAD, NCASC, 5), head_param(HEAD, NCASC, 6), head_param(HEAD, NCASC, 7), head_param(HEAD, NCASC, 8), head_param(HEAD, NCASC, 9),
+                               head_param(HEAD, NCASC, 10), head_param(HEAD, NCASC, 11), head_param(HEAD, NCASC, 12), head_param(HEAD, NCASC, 13), head_param(HEAD, NCASC, 14)};
         constexpr int RF[7] = {0, 2, 4, 6, 8, 10, 12};
         constexpr int RB[7] = {1, 3, 5, 7, 9, 11, 13};
         constexpr int CANP = HEAD ? 2 * NR : 0;

@@ -267,7 +267,7 @@ int speechPlayer_lastLiveLaunches(int device);
  * computes its fades side by side across the lanes; 0: one lane per handle.  Same PCM, marks and counts either way.
  * "live_alone" (default 1024; 1: only a handle pulled alone): a pull of up to this many handles gives EVERY handle a wavefront of its own
  * (one workgroup per handle, 256 side by side on MI355X, further ones in rounds): handles that share a wavefront pay for one another --
- * unrelated handles 11.7 ms per 8192-sample pull however few they are -- while 2 .. 256 handles alone in their wavefronts take 1.4-1.7 ms
+ * unrelated handles 11.2 ms per 8192-sample pull however few they are -- while 2 .. 256 handles alone in their wavefronts take 1.4-1.7 ms
  * and 1024 take 6.4.  Handles that speak IN STEP (same frames from the same sample) are the exception: beyond 256 of them sharing
  * wavefronts is faster (2.5 ms) -- set 1 for those.  Needs "live_replicate" 1 and "live_layout" 1.
  * "plan_hash_bits" (tests): how many bits of a frame's 128-bit shape hash the track planner looks at (default 128). */

@@ -588,18 +588,16 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
             steadyDone(CH);
         }
     };
-    // A handle pulled ALONE fills its wavefront with 64 identical lanes (streams_synthesize).  What a fade sample costs beyond a steady
-    // one -- the interpolation of the stage's parameters and exp / cos per moving resonator, 1700 cycles against 280 in the cascade and
-    // parallel stages (KLATT_STAMPS build) -- depends on the fade position alone, not on the filter memories: lane i computes it for
-    // sample i of the fade's NEXT 64 (`span` of them are wanted; a lane past those repeats the last), all side by side (loneEval), and
-    // the recurrence then takes each sample's values from LDS, [slot][sample] (loneTake): one ds_read_b64 of a wave-uniform address
-    // hands a value to all lanes (two v_readlane per double and the scalar-operand hazards behind them cost ~450 cycles a sample more).
-    // Same expressions on the same operands as stage_fade, sample for sample.  Slots: a resonator's frequency and bandwidth feed its
-    // coefficients alone -- of those only the values a stretch ends on are kept, as the state ([parameter][chunk], behind the slots;
-    // `whole`: the stretch is whole chunks of a fade run, else `span` samples inside a chunk with an event).
-    constexpr int kLoneG = kLanes / CH;
+    // A handle ALONE in its wavefront fills it with 64 identical lanes (streams_synthesize).  What a fade sample costs beyond a steady one --
+    // the interpolation of the stage's parameters and exp / cos per moving resonator, 1700 cycles against 280 in the cascade and parallel
+    // stages (KLATT_STAMPS build) -- depends on the fade position alone, not on the filter memories: lane i computes it for sample i of
+    // the fade's NEXT 64 (a lane past the fade's end repeats the last), all side by side (loneEval), and the recurrence then takes each
+    // sample's values from LDS, [slot][sample] (loneTake): one ds_read_b64 of a wave-uniform address hands a value to all lanes (two
+    // v_readlane per double and the scalar-operand hazards behind them cost ~450 cycles a sample more).  Same expressions on the same
+    // operands as stage_fade, sample for sample.  Slots: a resonator's frequency and bandwidth feed its coefficients alone and have
+    // none; where a stretch ends they are interpolated for that one sample, as the state (loneEnd).
     constexpr int NP_ = D::NPARAM > 0 ? D::NPARAM : 1;
-    static_assert(!K::LONE || (D::NPARAM + D::NRES + 1) * kLanes * 8 + D::NPARAM * kLoneG * 8 <= kLoneLdsPerStage, "a stage's fade values fit its LDS scratch (every resonator's frequency and bandwidth are parameters of their own, without slots)");
+    static_assert(!K::LONE || (D::NPARAM + D::NRES + 1) * kLanes * 8 <= kLoneLdsPerStage, "a stage's fade values fit its LDS scratch (every resonator's frequency and bandwidth are parameters of their own, without slots)");
     auto loneOfRes = [&](int k) __attribute__((always_inline)) { bool y = false;
 #pragma unroll
         for (int r = 0; r < D::NRES; ++r) y = y || RF[r] == k || RB[r] == k;
@@ -608,15 +606,12 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
 #pragma unroll
         for (int j = 0; j < D::NPARAM; ++j) n += (j < k && !loneOfRes(j)) ? 1 : 0;
         return n; };
-    auto loneEval = [&](uint32_t span, bool whole, bool lerp, uint32_t wRes, bool gainOnly, uint32_t coefCls) __attribute__((always_inline)) {
+    auto loneEval = [&](bool lerp, uint32_t wRes, bool gainOnly, uint32_t coefCls) __attribute__((always_inline)) {
         double* const S = X.loneLds;
         const int coef0 = loneSlot(D::NPARAM), pitchSlot = coef0 + 3 * D::NRES;
-        double* const SL = S + (pitchSlot + 1) * kLanes;
         const bool gainAlone = D::GAIN >= 0 && lerp && gainOnly;
-        const uint32_t me = threadIdx.x & (kLanes - 1);
+        const uint32_t me = threadIdx.x & (kLanes - 1), span = f.newFade - f.cnt;      // (>= 1: the callers are inside the fade)
         const double ratio = div_by((double)(f.cnt + 1u + (me < span ? me : span - 1u)), (double)f.newFade, f.invFade);
-        const bool ends = whole ? (me & (uint32_t)(CH - 1)) == (uint32_t)(CH - 1) : me == span - 1u;
-        const int endsAt = whole ? (int)(me / (uint32_t)CH) : 0;
         double cv[NP_];
 #pragma unroll
         for (int k = 0; k < D::NPARAM; ++k) cv[k] = f.cur[k];
@@ -629,10 +624,8 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
         if (gainAlone) S[loneSlot(GI) * kLanes + me] = cv[GI];
         else if (lerp) {
 #pragma unroll
-            for (int k = 0; k < D::NPARAM; ++k) {
+            for (int k = 0; k < D::NPARAM; ++k)
                 if (!loneOfRes(k)) S[loneSlot(k) * kLanes + me] = cv[k];
-                else if (ends) SL[k * kLoneG + endsAt] = cv[k];
-            }
         }
 #pragma unroll
         for (int r = 0; r < D::NRES; ++r) {
@@ -647,23 +640,40 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     };
-    // sample `at` of the last loneEval becomes the stage's current values (`last`: the stretch ends on it, chunk `endsAt` of the evaluation)
-    auto loneTake = [&](int at, bool last, int endsAt, bool lerp, uint32_t wRes, bool gainOnly) __attribute__((always_inline)) {
+    // One evaluation serves the fade's next 64 samples wherever they fall -- the rest of the chunk in which the fade began, whole chunks, the
+    // chunk in which it ends: `loneBase` is the sample count the evaluation started from; any step of the state machine ends its validity.
+    uint32_t loneBase = 0;
+    bool loneValid = false;
+    // the values of samples f.cnt + 1 .. f.cnt + n of the running fade are in LDS from here on; returns the first one's place
+    auto loneNeed = [&](uint32_t n, bool lerp, uint32_t wRes, bool gainOnly, uint32_t coefCls) __attribute__((always_inline)) -> int {
+        if (!(loneValid && f.cnt >= loneBase && f.cnt - loneBase + n <= (uint32_t)kLanes)) {
+            loneEval(lerp, wRes, gainOnly, coefCls);
+            loneBase = f.cnt; loneValid = true;
+        }
+        return (int)(f.cnt - loneBase);
+    };
+    // sample `at` of the evaluation becomes the stage's current values
+    auto loneTake = [&](int at, bool lerp, uint32_t wRes, bool gainOnly) __attribute__((always_inline)) {
         const double* const S = X.loneLds;
         const int coef0 = loneSlot(D::NPARAM), pitchSlot = coef0 + 3 * D::NRES;
-        const double* const SL = S + (pitchSlot + 1) * kLanes;
         if (D::PITCH) ps->cur0 = S[pitchSlot * kLanes + at];
         if (D::GAIN >= 0 && lerp && gainOnly) f.cur[GI] = S[loneSlot(GI) * kLanes + at];
         else if (lerp) {
 #pragma unroll
-            for (int k = 0; k < D::NPARAM; ++k) {
+            for (int k = 0; k < D::NPARAM; ++k)
                 if (!loneOfRes(k)) f.cur[k] = S[loneSlot(k) * kLanes + at];
-                else if (last) f.cur[k] = SL[k * kLoneG + endsAt];
-            }
         }
 #pragma unroll
         for (int r = 0; r < D::NRES; ++r)
             if (wRes & (1u << r)) { f.ra[r] = S[(coef0 + 3 * r) * kLanes + at]; f.rb[r] = S[(coef0 + 3 * r + 1) * kLanes + at]; f.rc[r] = S[(coef0 + 3 * r + 2) * kLanes + at]; }
+    };
+    // a stretch ends on the sample just taken: the resonators' frequencies and bandwidths (which have no slots) take its values, as the state
+    auto loneEnd = [&](bool lerp, bool gainOnly) __attribute__((always_inline)) {
+        if (!lerp || (D::GAIN >= 0 && gainOnly) || D::NRES == 0) return;
+        const double ratio = div_by((double)f.cnt, (double)f.newFade, f.invFade);
+#pragma unroll
+        for (int k = 0; k < D::NPARAM; ++k)
+            if (loneOfRes(k)) { const double o = f.oldL[k * kLanes], n = f.getNew(k); f.cur[k] = o + ((n - o) * ratio); }
     };
     for (int iter = 0; iter < nIter; ++iter) {
         STAMP_BEGIN();
@@ -706,21 +716,19 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                 (void)begin(1);
                 const uint32_t coefCls = fade_classes<D>(f, X.A, RF, RB, wRes);   // once per fade stretch
                 // what moves in a fade (lerp, wRes, gainOnly) is fixed for the fade: its chunks run in a tight loop too
-                uint32_t loneQ = 0;     // LONE: chunks of this run so far
                 auto fadeChunk = [&](int c) __attribute__((always_inline)) {
                     if (K::LONE) {
-                        // every fourth chunk of the run evaluates the fade's next 64 samples (lone_eval above)
+                        // (an evaluation serves four chunks: loneNeed above)
                         if (!f.done) {
-                            const int q0 = (int)(loneQ & (uint32_t)(kLoneG - 1));
-                            if (q0 == 0) loneEval(f.newFade - f.cnt, true, lerp, wRes, gainOnly, coefCls);
+                            const int at = loneNeed((uint32_t)CH, lerp, wRes, gainOnly, coefCls);
 #pragma unroll
                             for (int i = 0; i < CH; ++i) {
                                 f.cnt++;
-                                loneTake(q0 * CH + i, i == CH - 1, q0, lerp, wRes, gainOnly);
+                                loneTake(at + i, lerp, wRes, gainOnly);
                                 body(c, i, false, 0.0);
                             }
+                            loneEnd(lerp, gainOnly);
                             fadeDone(CH);
-                            ++loneQ;
                         }
                     } else
                     if (!f.done) {
@@ -783,13 +791,14 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                                 f.cnt += (uint32_t)n;
                                 steadyDone(n);
                             } else {
-                                loneEval((uint32_t)n, false, lerpR, wResR, gainOnlyR, kCoefAllUnknown);
+                                const int at = loneNeed((uint32_t)n, lerpR, wResR, gainOnlyR, kCoefAllUnknown);
 #pragma nounroll
                                 for (int j = i; j < i + n; ++j) {
                                     f.cnt++;
-                                    loneTake(j - i, j == i + n - 1, 0, lerpR, wResR, gainOnlyR);
+                                    loneTake(at + (j - i), lerpR, wResR, gainOnlyR);
                                     body(c, j, false, 0.0);
                                 }
+                                loneEnd(lerpR, gainOnlyR);
                                 fadeDone(n);
                             }
                             i += n;
@@ -859,6 +868,7 @@ __device__ __forceinline__ void stage_loop(int depth, int nIter, int nChunks, in
                         gen(c, i, emit);
                     } else {
                         const bool emit = stage_advance<D, MODE>(f, ps, lastIndex, P, RF, RB, X);
+                        if (K::LONE) loneValid = false;
                         gen(c, i, emit);
                     }
                     ++i;

@@ -229,8 +229,27 @@ def single_stream_extra(pulls=50, pull=8192):
         t = time.perf_counter(); exp = o.synthesize(pull); t_cpu.append(time.perf_counter() - t)
         same = same and buf is not None and buf.length == pull and np.array_equal(np.frombuffer(buf, dtype=np.int16)[:pull], exp)
     p.close()
+    # the same pulls of a MODE_FAST handle (speechPlayer_setGlobalOption("live_mode", 1): fused multiply-adds in the filters)
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    t_fast = []
+    try:
+        if L.speechPlayer_setGlobalOption(b"live_mode", 1) == 0:
+            pf = eng.SpeechPlayer(22050, noiseSeed=1)
+            queued = 0
+            while queued < need:
+                for fr, m, f, nul in rows:
+                    pf.queueFrameSamples(None if nul else eng.Frame.from_array(fr), m, f)
+                    queued += max(m, max(f, 1) + 1) + 1
+            pf.synthesize(pull)
+            for _ in range(pulls):
+                t = time.perf_counter(); pf.synthesize(pull); t_fast.append(time.perf_counter() - t)
+            pf.close()
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_mode", 0)
     return {"what": "one live handle, %d pulls of %d samples (speechPlayer_synthesize); the same pulls of the oracle on one host core" % (pulls, pull),
             "ms_per_pull_median": float(np.median(t_gpu)) * 1e3, "ms_per_pull_min": float(np.min(t_gpu)) * 1e3,
+            "mode_fast_ms_per_pull_median": float(np.median(t_fast)) * 1e3 if t_fast else None,
             "oracle_ms_per_pull_median": float(np.median(t_cpu)) * 1e3, "real_time_ms_per_pull": pull / 22050.0 * 1e3, "pcm_equal": bool(same)}
 
 

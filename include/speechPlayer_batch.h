@@ -265,6 +265,9 @@ int speechPlayer_lastLiveLaunches(int device);
  * "live_replicate" (default 1): a pull of fewer than 32 handles fills the empty lanes of their wavefront with replicas of them (a sparse
  * wavefront runs up to 1.7 times slower), and ONE handle pulled alone is advanced in all 64 lanes by a kernel instantiation of its own that
  * computes its fades side by side across the lanes; 0: one lane per handle.  Same PCM, marks and counts either way.
+ * "live_mode" (default 0): the arithmetic mode of handles created FROM NOW ON -- 0 MODE_EXACT (the reference's rounding, sample for sample),
+ * 1 MODE_FAST (the filters' multiply-adds fused; within north_star's tolerance, held to <= 1 LSB and <= 5 one-LSB differences per million
+ * samples against the oracle like the batches' MODE_FAST; one stream 1.27 -> 1.18 ms per 8192-sample pull).  Handles pulled together must share it.
  * "live_alone" (default 1024; 1: only a handle pulled alone): a pull of up to this many handles gives EVERY handle a wavefront of its own
  * (one workgroup per handle, 256 side by side on MI355X, further ones in rounds): handles that share a wavefront pay for one another --
  * unrelated handles 11.2 ms per 8192-sample pull however few they are -- while 2 .. 256 handles alone in their wavefronts take 1.4-1.7 ms

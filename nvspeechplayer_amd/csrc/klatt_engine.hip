@@ -1316,6 +1316,7 @@ int g_liveLayout = [] { const char* e = getenv("SPEECHPLAYER_LIVE_LAYOUT"); retu
 int g_liveCus = 0;
 bool g_liveCusForced = false;
 int g_liveReplicate = [] { const char* e = getenv("SPEECHPLAYER_LIVE_REPLICATE"); return e ? atoi(e) : 1; }();   // a lone handle fills its wavefront (streams_synthesize)
+int g_liveMode = [] { const char* e = getenv("SPEECHPLAYER_LIVE_MODE"); return e && atoi(e) == 1 ? MODE_FAST : MODE_EXACT; }();   // arithmetic mode of handles created from now on
 int g_liveAlone = [] { const char* e = getenv("SPEECHPLAYER_LIVE_ALONE"); return e ? atoi(e) : 1024; }();   // pulls of up to this many handles: a wavefront per handle (streams_synthesize)
 int g_liveTrim = 0;                 // speechPlayer_setGlobalOption("live_trim"): release a device's arena when its last handle is terminated
 
@@ -1711,6 +1712,7 @@ speechPlayer_handle_t speechPlayer_initialize(int sampleRate)
     if (dev < 0) return nullptr;
     Stream* s = new Stream;
     s->sampleRate = sampleRate;
+    s->mode = g_liveMode;
     s->device = dev;
     if (stream_init_device(s)) { delete s; return nullptr; }
     std::lock_guard<std::mutex> g(g_tableMutex);
@@ -1821,6 +1823,8 @@ int speechPlayer_setGlobalOption(const char* name, int value)
     // lets a test (or a small device) reach that kernel with a few hundred handles.
     if (name && !strcmp(name, "live_cus")) { g_liveCus = value < 0 ? 0 : value; g_liveCusForced = value > 0; return 0; }
     // "live_replicate": 1 (default) a handle pulled alone is advanced in all 64 lanes of its wavefront (streams_synthesize); 0: in one lane
+    // "live_mode": the arithmetic mode of handles created from now on -- 0 (default) MODE_EXACT, 1 MODE_FAST (fused multiply-adds in the filters)
+    if (name && !strcmp(name, "live_mode")) { if (value != MODE_EXACT && value != MODE_FAST) { set_error("live_mode: 0 or 1"); return -1; } g_liveMode = value; return 0; }
     if (name && !strcmp(name, "live_replicate")) { g_liveReplicate = value ? 1 : 0; return 0; }
     // "live_alone": pulls of up to this many handles give every handle a wavefront of its own (default 1024; 1: only a handle pulled alone)
     if (name && !strcmp(name, "live_alone")) { g_liveAlone = value < 1 ? 1 : (value > 65536 ? 65536 : value); return 0; }

@@ -89,6 +89,55 @@ def test_streaming_abi_scenarios(all_scenarios):
     print("streaming scenarios: %d one-LSB differences in total" % flips)
 
 
+def test_live_handles_in_mode_fast(all_scenarios, ref):
+    """speechPlayer_setGlobalOption("live_mode", 1): handles created afterwards run the stream kernels' MODE_FAST instantiations (fused
+    multiply-adds in the filters).  Every scenario through the five reference entry points, and 100 unrelated handles pulled together
+    under both wavefront policies: call lengths and index marks exactly, PCM to MODE_FAST's bar (<= 1 LSB, <= 5 one-LSB differences per
+    million samples, RMS < 1e-5 of full scale); a handle created after the option went back is bit-exact again."""
+    import nvspeechplayer_amd as eng
+    from nvspeechplayer_amd import _native
+    L = _native.load()
+    try:
+        assert L.speechPlayer_setGlobalOption(b"live_mode", 2) != 0 and L.speechPlayer_setGlobalOption(b"live_mode", 1) == 0
+        flips = 0
+        for scn in all_scenarios:
+            exp_pcm, exp_marks = scenarios.play_oracle(scn)
+            got_pcm, got_marks = play_engine(scn)
+            assert [len(x) for x in got_pcm] == [len(x) for x in exp_pcm], scn.name
+            assert got_marks == exp_marks, scn.name
+            flips += compare(np.concatenate(got_pcm), np.concatenate(exp_pcm), scn.name)
+        rng = np.random.default_rng(41)
+        cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=100)]
+        for alone in (1024, 1):
+            assert L.speechPlayer_setGlobalOption(b"live_alone", alone) == 0
+            players = [eng.SpeechPlayer(22050, noiseSeed=70 + k) for k in range(len(cases))]
+            oracles = [oracle.OraclePlayer(22050, seed=70 + k) for k in range(len(cases))]
+            for k, case in enumerate(cases):
+                for j, (fr, m, f) in enumerate(case):
+                    players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, j)
+                    oracles[k].queue(fr, m, f, j)
+            got = [[] for _ in cases]; exp = [[] for _ in cases]
+            for n in (5000, 33, 8192, 8192, 8192, 8192):
+                bufs = eng.SpeechPlayer.synthesizeMany(players, n)
+                for k, b in enumerate(bufs):
+                    e = oracles[k].synthesize(n)
+                    g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
+                    assert len(g) == len(e) and players[k].getLastIndex() == oracles[k].last_index(), (alone, k)
+                    got[k].append(g); exp[k].append(e)
+            for k in range(len(cases)):
+                flips += compare(np.concatenate(got[k]), np.concatenate(exp[k]), "fast live handle %d" % k)
+                players[k].close()
+        print("MODE_FAST live handles: %d one-LSB differences in total" % flips)
+        assert L.speechPlayer_setGlobalOption(b"live_mode", 0) == 0
+        scn = next(s for s in all_scenarios if s.name == "stream_chunks")
+        exp_pcm, _ = scenarios.play_oracle(scn)
+        got_pcm, _ = play_engine(scn)
+        assert np.array_equal(np.concatenate(got_pcm), np.concatenate(exp_pcm))
+    finally:
+        L.speechPlayer_setGlobalOption(b"live_mode", 0)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
+
+
 def make_batch(sel):
     frames, mins, fades, idx, nul, start, seeds = [], [], [], [], [], [0], []
     for s in sel:

@@ -257,7 +257,7 @@ def live_handles_extra(n=1024, pull=8192, pulls=4):
     """Many live handles advanced together (speechPlayer_synthesizeMany, PCM left in HBM): kernel ms per 8192-sample pull when the
     handles speak IN STEP (one sentence, same sample: a shared wavefront's chunks are steady or fading as a whole) and when they are
     UNRELATED (the eight sampleIpa sentences, every handle skewed by a pull of its own first: every chunk of a shared wavefront runs
-    sample by sample) -- with a wavefront per handle (the default up to 1024 handles, option "live_alone") and with 64 handles per
+    sample by sample) -- with a wavefront per handle (the default up to 1536 handles, option "live_alone") and with 64 handles per
     wavefront ("live_alone" 1: what larger pulls get; up to 16 384 handles such a pull lasts as long as one workgroup's)."""
     import numpy as np
     import nvspeechplayer_amd as eng
@@ -270,7 +270,7 @@ def live_handles_extra(n=1024, pull=8192, pulls=4):
     try:
         for key, unrelated in (("in_step", False), ("unrelated", True)):
             out[key] = {}
-            for policy, alone in (("a_wavefront_per_handle", 1024), ("64_handles_per_wavefront", 1)):
+            for policy, alone in (("a_wavefront_per_handle", 1536), ("64_handles_per_wavefront", 1)):
                 assert L.speechPlayer_setGlobalOption(b"live_alone", alone) == 0
                 rng = np.random.default_rng(3)
                 players = [eng.SpeechPlayer(22050, noiseSeed=k) for k in range(n)]
@@ -295,7 +295,7 @@ def live_handles_extra(n=1024, pull=8192, pulls=4):
                     p.close()
                 del group, players
     finally:
-        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1536)
     return out
 
 

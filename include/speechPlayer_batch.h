@@ -268,10 +268,10 @@ int speechPlayer_lastLiveLaunches(int device);
  * "live_mode" (default 0): the arithmetic mode of handles created FROM NOW ON -- 0 MODE_EXACT (the reference's rounding, sample for sample),
  * 1 MODE_FAST (the filters' multiply-adds fused; within north_star's tolerance, held to <= 1 LSB and <= 5 one-LSB differences per million
  * samples against the oracle like the batches' MODE_FAST; one stream 1.27 -> 1.18 ms per 8192-sample pull).  Handles pulled together must share it.
- * "live_alone" (default 1024; 1: only a handle pulled alone): a pull of up to this many handles gives EVERY handle a wavefront of its own
+ * "live_alone" (default 1536; 1: only a handle pulled alone): a pull of up to this many handles gives EVERY handle a wavefront of its own
  * (one workgroup per handle, 256 side by side on MI355X, further ones in rounds): handles that share a wavefront pay for one another --
  * unrelated handles 11.2 ms per 8192-sample pull however few they are -- while 2 .. 256 handles alone in their wavefronts take 1.4-1.7 ms
- * and 1024 take 6.4.  Handles that speak IN STEP (same frames from the same sample) are the exception: beyond 256 of them sharing
+ * and 1024 take 6.2, 1536 9.3 (the two policies meet near 1850 handles).  Handles that speak IN STEP (same frames from the same sample) are the exception: beyond 256 of them sharing
  * wavefronts is faster (2.5 ms) -- set 1 for those.  Needs "live_replicate" 1 and "live_layout" 1.
  * "plan_hash_bits" (tests): how many bits of a frame's 128-bit shape hash the track planner looks at (default 128). */
 int speechPlayer_setGlobalOption(const char* name, int value);

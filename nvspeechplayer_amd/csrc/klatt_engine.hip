@@ -1317,7 +1317,7 @@ int g_liveCus = 0;
 bool g_liveCusForced = false;
 int g_liveReplicate = [] { const char* e = getenv("SPEECHPLAYER_LIVE_REPLICATE"); return e ? atoi(e) : 1; }();   // a lone handle fills its wavefront (streams_synthesize)
 int g_liveMode = [] { const char* e = getenv("SPEECHPLAYER_LIVE_MODE"); return e && atoi(e) == 1 ? MODE_FAST : MODE_EXACT; }();   // arithmetic mode of handles created from now on
-int g_liveAlone = [] { const char* e = getenv("SPEECHPLAYER_LIVE_ALONE"); return e ? atoi(e) : 1024; }();   // pulls of up to this many handles: a wavefront per handle (streams_synthesize)
+int g_liveAlone = [] { const char* e = getenv("SPEECHPLAYER_LIVE_ALONE"); return e ? atoi(e) : 1536; }();   // pulls of up to this many handles: a wavefront per handle (streams_synthesize)
 int g_liveTrim = 0;                 // speechPlayer_setGlobalOption("live_trim"): release a device's arena when its last handle is terminated
 
 // c->mu held.  No handle lives on this device: give its arena (state blocks, rings) and the pull buffers back.  The next
@@ -1482,7 +1482,7 @@ int streams_synthesize(Stream* const* ss, int n, unsigned int count, sample* con
     // thirty 8192-sample pulls of one handle 3.05 -> 2.04 ms of kernel time on average (tools/single_stream_ab.sh).  The launch then takes
     // the kernel's LONE instantiation, whose fade chunks are computed side by side across the identical lanes (klatt_systolic.h,
     // stage_loop: 2.04 -> 1.84 ms); control bit 1 marks the entries.
-    // The same goes for a pull of SEVERAL handles, up to "live_alone" of them (default 1024): a workgroup per handle, 64 replicas each.  Handles
+    // The same goes for a pull of SEVERAL handles, up to "live_alone" of them (default 1536: six rounds of 256 workgroups; the two policies meet near 1850 unrelated handles): a workgroup per handle, 64 replicas each.  Handles
     // that share a wavefront pay for one another -- with unrelated handles every chunk has some lane at an event or in a fade and runs sample
     // by sample: 11.7 ms per 8192-sample pull however few they are -- while a handle alone in its wavefront costs 1.3-1.7 ms and 256 of them
     // run side by side, one per CU (the LONE instantiation's LDS allows one workgroup per CU): n handles take ceil(n / CUs) rounds of that.
@@ -1826,7 +1826,7 @@ int speechPlayer_setGlobalOption(const char* name, int value)
     // "live_mode": the arithmetic mode of handles created from now on -- 0 (default) MODE_EXACT, 1 MODE_FAST (fused multiply-adds in the filters)
     if (name && !strcmp(name, "live_mode")) { if (value != MODE_EXACT && value != MODE_FAST) { set_error("live_mode: 0 or 1"); return -1; } g_liveMode = value; return 0; }
     if (name && !strcmp(name, "live_replicate")) { g_liveReplicate = value ? 1 : 0; return 0; }
-    // "live_alone": pulls of up to this many handles give every handle a wavefront of its own (default 1024; 1: only a handle pulled alone)
+    // "live_alone": pulls of up to this many handles give every handle a wavefront of its own (default 1536; 1: only a handle pulled alone)
     if (name && !strcmp(name, "live_alone")) { g_liveAlone = value < 1 ? 1 : (value > 65536 ? 65536 : value); return 0; }
     // "live_trim": 1 = a device's arena of live handles (~100 KB of HBM per slot, grown by doubling) is released when the last handle on
     // that device is terminated -- and now, on devices where none lives; 0 (default): it stays for the next handles.

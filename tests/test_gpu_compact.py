@@ -436,12 +436,12 @@ def test_a_few_handles_pulled_together_fill_their_wavefront(ref):
         return [np.concatenate(g) for g in got], marks
     try:
         off, marks_off = run(0)
-        for on, marks_on in (run(1), run(1, alone=1024)):
+        for on, marks_on in (run(1), run(1, alone=1536)):
             assert marks_on == marks_off and [len(x) for x in on] == [len(x) for x in off] and min(len(x) for x in off) > 8000
             assert all(np.array_equal(a, b) for a, b in zip(on, off))
     finally:
         L.speechPlayer_setGlobalOption(b"live_replicate", 1)
-        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1536)
 
 
 @pytest.mark.parametrize("deal", [0, 1])

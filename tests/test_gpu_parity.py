@@ -108,7 +108,7 @@ def test_live_handles_in_mode_fast(all_scenarios, ref):
             flips += compare(np.concatenate(got_pcm), np.concatenate(exp_pcm), scn.name)
         rng = np.random.default_rng(41)
         cases = [ref.ipa_case(int(i)) for i in rng.integers(0, len(ref.ipa_meta), size=100)]
-        for alone in (1024, 1):
+        for alone in (1536, 1):
             assert L.speechPlayer_setGlobalOption(b"live_alone", alone) == 0
             players = [eng.SpeechPlayer(22050, noiseSeed=70 + k) for k in range(len(cases))]
             oracles = [oracle.OraclePlayer(22050, seed=70 + k) for k in range(len(cases))]
@@ -135,7 +135,7 @@ def test_live_handles_in_mode_fast(all_scenarios, ref):
         assert np.array_equal(np.concatenate(got_pcm), np.concatenate(exp_pcm))
     finally:
         L.speechPlayer_setGlobalOption(b"live_mode", 0)
-        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1536)
 
 
 def make_batch(sel):
@@ -661,7 +661,7 @@ def test_limits_are_reported_not_wrapped(ref):
 def test_many_live_streams_one_launch(ref, all_scenarios, policy):
     """speechPlayer_synthesizeMany: 130 (300) live handles at unrelated points of unrelated streams, pulled together in uneven chunks, one
     of them purged on the way, frames queued between pulls -- each handle's PCM, call lengths and index marks equal its own oracle
-    player's.  "alone": every handle in a wavefront of its own (the default up to 1024 handles, option "live_alone"); "shared": 64
+    player's.  "alone": every handle in a wavefront of its own (the default up to 1536 handles, option "live_alone"); "shared": 64
     handles per wavefront (3 wavefronts; "live_alone" 1); "alternate": the policy changes from pull to pull of the same handles."""
     import nvspeechplayer_amd as eng
     from nvspeechplayer_amd import _native
@@ -689,11 +689,11 @@ def test_many_live_streams_one_launch(ref, all_scenarios, policy):
                     for j, (fr, m, f) in enumerate(case[len(case) // 2:]):
                         players[k].queueFrameSamples(None if fr is None else eng.Frame.from_array(fr), m, f, 1000 + j)
                         oracles[k].queue(fr, m, f, 1000 + j)
-        assert L.speechPlayer_setGlobalOption(b"live_alone", {"alone": 1024, "shared": 1, "alternate": 1024 if step % 2 else 1}[policy]) == 0
+        assert L.speechPlayer_setGlobalOption(b"live_alone", {"alone": 1536, "shared": 1, "alternate": 1536 if step % 2 else 1}[policy]) == 0
         try:
             bufs = eng.SpeechPlayer.synthesizeMany(players, n)
         finally:
-            L.speechPlayer_setGlobalOption(b"live_alone", 1024)
+            L.speechPlayer_setGlobalOption(b"live_alone", 1536)
         for k, b in enumerate(bufs):
             e = oracles[k].synthesize(n)
             g = np.zeros(0, np.int16) if b is None else np.frombuffer(b, dtype=np.int16)[:b.length].copy()
@@ -1226,7 +1226,7 @@ def test_live_handles_on_both_kernels(all_scenarios, ref):
             p.close()
     finally:
         L.speechPlayer_setGlobalOption(b"live_layout", 1)
-        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1536)
 
 
 def test_large_live_pulls_take_the_two_per_cu_stream_kernel(all_scenarios, ref):
@@ -1299,7 +1299,7 @@ def test_large_live_pulls_take_the_two_per_cu_stream_kernel(all_scenarios, ref):
     finally:
         L.speechPlayer_setGlobalOption(b"live_cus", 0)
         L.speechPlayer_setGlobalOption(b"live_layout", 1)
-        L.speechPlayer_setGlobalOption(b"live_alone", 1024)
+        L.speechPlayer_setGlobalOption(b"live_alone", 1536)
 
 
 def test_quiet_classification_needs_finite_parallel_coefficients(ref):

@@ -16,7 +16,7 @@ pulls = 6
 text = "mɑɪ næɪm ɪz mɑɪkʊl dæɪmɪən kɑɹən"
 frames = list(ipa.generateFramesAndTiming(text, clauseType="."))
 L = _native.load()
-L.speechPlayer_setGlobalOption(b"live_alone", 1)      # 64 handles per wavefront, as measured since round 3 (default since round 6: up to 1024 handles a wavefront each)
+L.speechPlayer_setGlobalOption(b"live_alone", 1)      # 64 handles per wavefront, as measured since round 3 (default since round 6: up to 1536 handles a wavefront each)
 
 
 def fresh():

@@ -1,6 +1,6 @@
 """Live handles that are NOT aligned: the eight sampleIpa sentences at different pitches, every handle skewed by a pull of its own length
 first, so that no two lanes of a wavefront dequeue or fade on the same sample -- against the same handles aligned (tools/live_bench.py's case).
-Kernel ms per 8192-sample pull of all handles together, with 64 handles per wavefront ("live_alone" 1) and, up to 1024 handles, with a
+Kernel ms per 8192-sample pull of all handles together, with 64 handles per wavefront ("live_alone" 1) and, up to 1536 handles, with a
 wavefront per handle (the default).
     python tools/live_unaligned.py [handles]"""
 import os
@@ -17,7 +17,7 @@ d = np.load(os.path.join(os.path.dirname(eng.__file__), "data", "workload_inputs
 lines = [x.decode("utf-8") if isinstance(x, bytes) else str(x) for x in d["ipa_lines"]]
 rng = np.random.default_rng(3)
 cases = [(label, skew, varied, alone) for label, skew, varied in (("in step, one sentence", False, False), ("eight sentences x pitches, aligned starts", False, True), ("eight sentences x pitches, skewed starts", True, True))
-         for alone in ((1, 1024) if n <= 1024 else (1,))]
+         for alone in ((1, 1536) if n <= 1536 else (1,))]
 for label, skew, varied, alone in cases:
     assert L.speechPlayer_setGlobalOption(b"live_alone", alone) == 0
     players = [eng.SpeechPlayer(22050, noiseSeed=k) for k in range(n)]

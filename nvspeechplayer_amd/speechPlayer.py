@@ -193,6 +193,14 @@ class LiveGroup(object):
         return self.produced
 
 
+def setGlobalOption(name, value):
+    """speechPlayer_setGlobalOption (include/speechPlayer_batch.h): process-wide options of the live handles -- "live_mode" (arithmetic mode
+    of handles created from now on), "live_alone" (up to how many handles of a pull get a wavefront each), "live_layout", "live_cus",
+    "live_replicate", "live_trim"."""
+    if _native.load().speechPlayer_setGlobalOption(name.encode() if isinstance(name, str) else name, int(value)) != 0:
+        raise ValueError("speechPlayer_setGlobalOption(%r, %r) refused" % (name, value))
+
+
 def pcm_digest(pcm):
     """speechPlayer_batch_digest's per-utterance value for a host int16 array (uint64 arithmetic wraps)."""
     v = np.asarray(pcm, dtype=np.int16).view(np.uint16).astype(np.uint64)

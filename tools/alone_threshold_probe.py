@@ -1,5 +1,7 @@
+"""Unrelated live handles beyond 1024: a wavefront per handle ("live_alone" large) against 64 handles per wavefront ("live_alone" 1), kernel ms of three
+8192-sample pulls -- where the two policies meet (profiles/r6_live_alone.txt: near 1850 handles; the default is 1536)."""
 import os, sys
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 import nvspeechplayer_amd as eng
 from nvspeechplayer_amd import ipa, _native

@@ -197,3 +197,19 @@ def test_forged_shape_hashes_are_refused():
     one[1, 2] = 123.0                                                        # its partner in that product
     assert L.speechPlayer_frameFacts(one.ctypes.data, 2, 22050, 0, out.ctypes.data) == 2
     assert out["h0"][0] != out["h0"][1] and out["h1"][0] != out["h1"][1]
+
+
+def test_global_options_are_checked():
+    """speechPlayer_setGlobalOption (no GPU needed): known options take their values, "live_mode" takes 0 or 1 only, an unknown name is
+    refused -- and the Python wrapper raises where the C call returns non-zero."""
+    import nvspeechplayer_amd as eng
+    try:
+        eng.setGlobalOption("live_mode", 1)
+        eng.setGlobalOption("live_alone", 7)
+        with pytest.raises(ValueError):
+            eng.setGlobalOption("live_mode", 2)
+        with pytest.raises(ValueError):
+            eng.setGlobalOption("no_such_option", 1)
+    finally:
+        eng.setGlobalOption("live_mode", 0)
+        eng.setGlobalOption("live_alone", 1536)
